@@ -1,0 +1,82 @@
+"""ctypes binding of include/o3dsot.h (libo3dsot_hip.so).
+
+The library is the product's only compute path: if it is missing or fails to load this
+module raises -- there is NO CPU or PyTorch fallback.  `import torch` happens first on
+purpose: torch brings its own ROCm runtime (libamdhip64.so.7) and the kernels must run on
+the same runtime instance that owns torch's device pointers and streams.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be loaded before the HIP library, see above)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SO_PATH = os.path.join(_HERE, "_lib", "libo3dsot_hip.so")
+
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+
+# name -> argtypes (every function returns int except o3d_version)
+SIGNATURES = {
+    "o3d_furthest_point_sampling": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "o3d_furthest_point_sampling_shfl": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "o3d_gather_points": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "o3d_gather_points_grad": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "o3d_ball_query": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
+    "o3d_group_points": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "o3d_group_points_grad": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+    "o3d_three_nn": [_vp, _vp, _i, _i, _i, _vp, _vp, _vp],
+    "o3d_three_interpolate": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "o3d_three_interpolate_grad": [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "o3d_knn": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
+}
+
+_lib = None
+
+
+class O3DError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises O3DError when it is absent -- by design."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise O3DError(
+            "open3dsot_amd: %s is missing. Build it with `python -m open3dsot_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % SO_PATH)
+    try:
+        lib = ctypes.CDLL(SO_PATH)
+    except OSError as e:  # pragma: no cover
+        raise O3DError("open3dsot_amd: cannot load %s: %s" % (SO_PATH, e))
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+    lib.o3d_version.restype = ctypes.c_char_p
+    lib.o3d_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def register(name, argtypes):
+    """Declare one more entry point (used by the fused-layer modules)."""
+    SIGNATURES[name] = argtypes
+    if _lib is not None:
+        fn = getattr(_lib, name)
+        fn.argtypes = argtypes
+        fn.restype = ctypes.c_int
+
+
+_ERR = {-1: "invalid argument (shape / null pointer / unsupported size)",
+        -2: "HIP launch failed"}
+
+
+def check(rc, what):
+    if rc != 0:
+        raise O3DError("%s failed: %s (code %d)" % (what, _ERR.get(rc, "unknown"), rc))
+
+
+def version():
+    return load().o3d_version().decode()

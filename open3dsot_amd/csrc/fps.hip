@@ -1,0 +1,239 @@
+// fps.hip -- furthest point sampling for gfx950 (wave64).
+//
+// Replaces _ext.furthest_point_sampling (pointnet2/utils/pointnet2_utils.py:56; upstream
+// sampling_gpu.cu, semantics restated in oracle/pointnet2_oracle.c and SURVEY.md A.1).
+//
+// Design (MI355X-first, not the upstream block-of-512 + shared-memory tree):
+//   * the op is LATENCY bound: npoint-1 strictly serial arg-max rounds per cloud, a few
+//     KB of data.  One workgroup owns one cloud and keeps the whole cloud -- coordinates
+//     and the running min-distance -- in VGPRs for all rounds (PPT points per lane), so a
+//     round touches no memory except one uniform 12-byte LDS read of the new centre.
+//   * N <= 2048: ONE wave per cloud, no barrier anywhere in the round loop; the arg-max
+//     is a DPP row reduction (quad_perm / row_half_mirror / row_mirror) + 4 v_readlane.
+//     2048 < N <= 16384: 8 waves per cloud, two LDS hand-offs per round.
+//     N > 16384: generic strided kernel with the min-distance array in caller scratch.
+//   * bit-identical indices: the upstream winner among equal maxima is decided by its
+//     thread-strided scan + tree reduction, i.e. by
+//         rank(k) = bitrev_L(k mod bs) * ceil(N/bs) + (k div bs),  bs = opt_n_threads(N),
+//     lowest rank wins (L = log2 bs).  The reduction here is two-phase: wave/block max of
+//     the distance, then max of ((0xFFFF - rank) << 16 | k) over the lanes that hold that
+//     maximum -- independent of how points are laid over lanes.
+#include "o3d_common.hpp"
+
+namespace {
+
+__device__ __forceinline__ unsigned dpp_max_row_u32(unsigned v) {
+    // all-reduce max inside each row of 16 lanes
+    unsigned t;
+    t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false);  // quad_perm [1,0,3,2]
+    v = v > t ? v : t;
+    t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false);  // quad_perm [2,3,0,1]
+    v = v > t ? v : t;
+    t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false); // row_half_mirror
+    v = v > t ? v : t;
+    t = (unsigned)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false); // row_mirror
+    v = v > t ? v : t;
+    return v;
+}
+
+template <bool USE_DPP>
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) {
+    if (USE_DPP) {
+        v = dpp_max_row_u32(v);
+        const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0);
+        const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)v, 16);
+        const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)v, 32);
+        const unsigned d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+        const unsigned ab = a > b ? a : b, cd = c > d ? c : d;
+        return ab > cd ? ab : cd;
+    } else {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned t = (unsigned)__shfl_xor((int)v, off, 64);
+            v = v > t ? v : t;
+        }
+        return (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    }
+}
+
+__device__ __forceinline__ unsigned fps_rank(unsigned k, int bs_log2, unsigned cpb) {
+    const unsigned tid = k & ((1u << bs_log2) - 1u);
+    const unsigned rev = bs_log2 == 0 ? 0u : (__brev(tid) >> (32 - bs_log2));
+    return rev * cpb + (k >> bs_log2);
+}
+
+// One workgroup (NW waves) per cloud, PPT points per lane in registers.  N <= 64*NW*PPT,
+// N < 65535.  LDS: N*3 floats (cloud copy) + 2*NW words (cross-wave exchange).
+template <int PPT, int NW, bool USE_DPP>
+__global__ __launch_bounds__(64 * NW) void fps_reg_kernel(const float* __restrict__ xyz, int N,
+                                                          int npoint, int bs_log2, int cpb,
+                                                          int32_t* __restrict__ idx) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* s_xyz = smem;
+    unsigned* s_x = reinterpret_cast<unsigned*>(smem + (size_t)N * 3);  // [2][NW]
+    constexpr int T = 64 * NW;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const float* p = xyz + (size_t)blockIdx.x * N * 3;
+    int32_t* out = idx + (size_t)blockIdx.x * npoint;
+
+    for (int t = tid; t < N * 3; t += T) s_xyz[t] = p[t];
+    __syncthreads();
+
+    float px[PPT], py[PPT], pz[PPT], tmp[PPT];
+    unsigned lo[PPT];
+#pragma unroll
+    for (int i = 0; i < PPT; ++i) {
+        const int k = tid + T * i;
+        const bool in = k < N;
+        const float x = in ? s_xyz[3 * k + 0] : 0.f;
+        const float y = in ? s_xyz[3 * k + 1] : 0.f;
+        const float z = in ? s_xyz[3 * k + 2] : 0.f;
+        const float mag = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
+        const bool valid = in && !(mag <= 1e-3f);
+        // skipped / padded slots: min-distance pinned at +0 and key 0 => never a winner
+        px[i] = x; py[i] = y; pz[i] = z;
+        tmp[i] = valid ? 1e10f : 0.f;
+        lo[i] = valid ? (((0xFFFFu - fps_rank((unsigned)k, bs_log2, (unsigned)cpb)) << 16) | (unsigned)k) : 0u;
+    }
+
+    if (tid == 0) out[0] = 0;
+    int old = 0;
+    for (int j = 1; j < npoint; ++j) {
+        const float x1 = s_xyz[3 * old + 0], y1 = s_xyz[3 * old + 1], z1 = s_xyz[3 * old + 2];
+        float hb = 0.f;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const float d = o3d_sqdist3(px[i], py[i], pz[i], x1, y1, z1);
+            const float d2 = fminf(d, tmp[i]);
+            tmp[i] = d2;
+            hb = fmaxf(hb, d2);
+        }
+        // phase 1: maximum distance over the cloud (non-negative floats order like u32)
+        unsigned M = wave_max_u32<USE_DPP>(__float_as_uint(hb));
+        if (NW > 1) {
+            unsigned* ex = s_x + ((j & 1) ? NW : 0);
+            if ((tid & 63) == 0) ex[wave] = M;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { const unsigned t = ex[w]; M = M > t ? M : t; }
+            __syncthreads();
+        }
+        // phase 2: lowest upstream rank among the points at that distance
+        unsigned c = 0u;
+#pragma unroll
+        for (int i = 0; i < PPT; ++i) {
+            const unsigned cand = (__float_as_uint(tmp[i]) == M) ? lo[i] : 0u;
+            c = c > cand ? c : cand;
+        }
+        unsigned L = wave_max_u32<USE_DPP>(c);
+        if (NW > 1) {
+            unsigned* ex = s_x + ((j & 1) ? NW : 0);
+            if ((tid & 63) == 0) ex[wave] = L;
+            __syncthreads();
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { const unsigned t = ex[w]; L = L > t ? L : t; }
+            __syncthreads();
+        }
+        old = (int)(L & 0xFFFFu);  // L == 0 (nothing selectable) -> index 0, as upstream
+        if (tid == 0) out[j] = old;
+    }
+}
+
+// Generic fallback, any N: 1024 threads per cloud, min-distance array in global scratch.
+__global__ __launch_bounds__(1024) void fps_generic_kernel(const float* __restrict__ xyz, int N,
+                                                           int npoint, int bs_log2, int cpb,
+                                                           float* __restrict__ temp,
+                                                           int32_t* __restrict__ idx) {
+    __shared__ unsigned long long s_key[2][16];
+    const int tid = threadIdx.x, wave = tid >> 6;
+    const float* p = xyz + (size_t)blockIdx.x * N * 3;
+    float* tmp = temp + (size_t)blockIdx.x * N;
+    int32_t* out = idx + (size_t)blockIdx.x * npoint;
+    for (int k = tid; k < N; k += 1024) tmp[k] = 1e10f;
+    if (tid == 0) out[0] = 0;
+    __syncthreads();
+    int old = 0;
+    for (int j = 1; j < npoint; ++j) {
+        const float x1 = p[3 * old], y1 = p[3 * old + 1], z1 = p[3 * old + 2];
+        unsigned long long best = 0ull;
+        for (int k = tid; k < N; k += 1024) {
+            const float x = p[3 * k], y = p[3 * k + 1], z = p[3 * k + 2];
+            const float mag = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
+            if (mag <= 1e-3f) continue;
+            const float d2 = fminf(o3d_sqdist3(x, y, z, x1, y1, z1), tmp[k]);
+            tmp[k] = d2;
+            // key: distance bits, then inverted rank (rank < 2^31 so the low word is never 0)
+            const unsigned long long key = ((unsigned long long)__float_as_uint(d2) << 32) |
+                                           (0xFFFFFFFFu - fps_rank((unsigned)k, bs_log2, (unsigned)cpb));
+            best = key > best ? key : best;
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const unsigned long long t = __shfl_xor(best, off, 64);
+            best = t > best ? t : best;
+        }
+        if ((tid & 63) == 0) s_key[j & 1][wave] = best;
+        __syncthreads();
+#pragma unroll
+        for (int w = 0; w < 16; ++w) { const unsigned long long t = s_key[j & 1][w]; best = t > best ? t : best; }
+        if (best == 0ull) {
+            old = 0;
+        } else {
+            const unsigned r = 0xFFFFFFFFu - (unsigned)(best & 0xFFFFFFFFull);
+            const unsigned t = r / (unsigned)cpb, q = r % (unsigned)cpb;
+            const unsigned rev = bs_log2 == 0 ? 0u : (__brev(t) >> (32 - bs_log2));
+            old = (int)(rev + (q << bs_log2));
+        }
+        if (tid == 0) out[j] = old;
+        __syncthreads();  // temp[] writes of this round visible before the next one reads them
+    }
+}
+
+template <int PPT, int NW, bool USE_DPP>
+int launch_reg(const float* xyz, int B, int N, int npoint, int bs_log2, int cpb, int32_t* idx,
+               hipStream_t s) {
+    const size_t lds = (size_t)N * 3 * sizeof(float) + 2 * NW * sizeof(unsigned);
+    hipLaunchKernelGGL((fps_reg_kernel<PPT, NW, USE_DPP>), dim3(B), dim3(64 * NW), lds, s, xyz, N,
+                       npoint, bs_log2, cpb, idx);
+    return o3d_launch_status();
+}
+
+template <bool USE_DPP>
+int fps_dispatch(const float* xyz, int B, int N, int npoint, float* temp, int32_t* idx,
+                 hipStream_t s) {
+    int bs_log2 = 0;
+    while ((2 << bs_log2) <= N && bs_log2 < 9) ++bs_log2;  // bs = opt_n_threads(N)
+    const int bs = 1 << bs_log2;
+    const int cpb = (N + bs - 1) / bs;
+    if (N <= 64) return launch_reg<1, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
+    if (N <= 128) return launch_reg<2, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
+    if (N <= 256) return launch_reg<4, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
+    if (N <= 512) return launch_reg<8, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
+    if (N <= 1024) return launch_reg<16, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
+    if (N <= 2048) return launch_reg<32, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
+    if (N <= 4096) return launch_reg<8, 8, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
+    if (N <= 8192) return launch_reg<16, 8, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
+    if (N <= 16384) return launch_reg<32, 8, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
+    if (!temp) return O3D_EINVAL;
+    hipLaunchKernelGGL(fps_generic_kernel, dim3(B), dim3(1024), 0, s, xyz, N, npoint, bs_log2, cpb,
+                       temp, idx);
+    return o3d_launch_status();
+}
+
+}  // namespace
+
+extern "C" int o3d_furthest_point_sampling(const float* xyz, int B, int N, int npoint, float* temp,
+                                           int32_t* idx, void* stream) {
+    if (B < 0 || N <= 0 || npoint < 0 || (B > 0 && npoint > 0 && (!xyz || !idx))) return O3D_EINVAL;
+    if (B == 0 || npoint == 0) return O3D_OK;
+    return fps_dispatch<true>(xyz, B, N, npoint, temp, idx, o3d_stream(stream));
+}
+
+// Test hook: same op through the ds_bpermute (__shfl_xor) reduction instead of DPP.
+extern "C" int o3d_furthest_point_sampling_shfl(const float* xyz, int B, int N, int npoint,
+                                                float* temp, int32_t* idx, void* stream) {
+    if (B < 0 || N <= 0 || npoint < 0 || (B > 0 && npoint > 0 && (!xyz || !idx))) return O3D_EINVAL;
+    if (B == 0 || npoint == 0) return O3D_OK;
+    return fps_dispatch<false>(xyz, B, N, npoint, temp, idx, o3d_stream(stream));
+}

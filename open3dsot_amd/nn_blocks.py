@@ -1,0 +1,189 @@
+"""Conv/BN/ReLU building blocks with the reference's module tree (state_dict compatible).
+
+Mirror of pointnet2/utils/pytorch_utils.py: `SharedMLP` :12 (stack of 1x1 Conv2d ->
+BatchNorm2d -> ReLU), `Conv1d/2d/3d` :124-223 (bias dropped when bn=True :88, kaiming_normal
+weights :97, module order conv->bn->activation or the pre-activation order :101-121),
+`BatchNorm1d/2d/3d` :50-65 (weight 1, bias 0, nested as `<name>bn.bn`), `FC` :226, `Seq`
+:300 (fluent builder with children "0","1",...), `BNMomentumScheduler` :272.
+
+Checkpoint keys are therefore identical to the reference's, e.g.
+`SA_modules.0.mlps.0.layer0.conv.weight`, `...layer0.bn.bn.running_mean`.
+The fused MI355X path (open3dsot_amd.fused) reads parameters out of these modules; it
+never changes the tree.
+"""
+import torch.nn as nn
+
+_CONV = {1: nn.Conv1d, 2: nn.Conv2d, 3: nn.Conv3d}
+_BN = {1: nn.BatchNorm1d, 2: nn.BatchNorm2d, 3: nn.BatchNorm3d}
+
+
+class _BNWrap(nn.Sequential):
+    """BatchNorm nested one level down (`bn`) with gamma=1, beta=0."""
+
+    def __init__(self, channels, dims, name=""):
+        super().__init__()
+        norm = _BN[dims](channels)
+        nn.init.constant_(norm.weight, 1.0)
+        nn.init.constant_(norm.bias, 0.0)
+        self.add_module(name + "bn", norm)
+
+
+class BatchNorm1d(_BNWrap):
+    def __init__(self, in_size, *, name=""):
+        super().__init__(in_size, 1, name)
+
+
+class BatchNorm2d(_BNWrap):
+    def __init__(self, in_size, name=""):
+        super().__init__(in_size, 2, name)
+
+
+class BatchNorm3d(_BNWrap):
+    def __init__(self, in_size, name=""):
+        super().__init__(in_size, 3, name)
+
+
+_BN_WRAP = {1: BatchNorm1d, 2: BatchNorm2d, 3: BatchNorm3d}
+
+
+class _ConvUnit(nn.Sequential):
+    """conv (+bn) (+activation); `preact` puts bn/activation in front of the conv."""
+
+    DIMS = 2
+
+    def __init__(self, in_size, out_size, *, kernel_size=None, stride=None, padding=None,
+                 activation=nn.ReLU(inplace=True), bn=False, init=nn.init.kaiming_normal_,
+                 bias=True, preact=False, name=""):
+        super().__init__()
+        d = self.DIMS
+        one, zero = (1,) * d, (0,) * d
+        if d == 1:
+            one, zero = 1, 0
+        conv = _CONV[d](in_size, out_size,
+                        kernel_size=one if kernel_size is None else kernel_size,
+                        stride=one if stride is None else stride,
+                        padding=zero if padding is None else padding,
+                        bias=bias and not bn)
+        init(conv.weight)
+        if conv.bias is not None:
+            nn.init.constant_(conv.bias, 0)
+        norm = None
+        if bn:
+            norm = _BN_WRAP[d](in_size if preact else out_size)
+        head = []
+        if norm is not None:
+            head.append(("bn", norm))
+        if activation is not None:
+            head.append(("activation", activation))
+        order = head + [("conv", conv)] if preact else [("conv", conv)] + head
+        for key, mod in order:
+            self.add_module(name + key, mod)
+
+
+class Conv1d(_ConvUnit):
+    DIMS = 1
+
+
+class Conv2d(_ConvUnit):
+    DIMS = 2
+
+
+class Conv3d(_ConvUnit):
+    DIMS = 3
+
+
+class SharedMLP(nn.Sequential):
+    """Pointwise MLP over a (B,C,npoint,nsample) tensor: children `layer0`, `layer1`, ..."""
+
+    def __init__(self, args, *, bn=False, activation=nn.ReLU(inplace=True), preact=False,
+                 first=False, name=""):
+        super().__init__()
+        for i in range(len(args) - 1):
+            plain = first and preact and i == 0  # first pre-activation layer: conv only
+            self.add_module(
+                name + "layer{}".format(i),
+                Conv2d(args[i], args[i + 1], bn=bn and not plain,
+                       activation=None if plain else activation, preact=preact))
+
+
+class FC(nn.Sequential):
+    def __init__(self, in_size, out_size, *, activation=nn.ReLU(inplace=True), bn=False,
+                 init=None, preact=False, name=""):
+        super().__init__()
+        fc = nn.Linear(in_size, out_size, bias=not bn)
+        if init is not None:
+            init(fc.weight)
+        if not bn:
+            nn.init.constant_(fc.bias, 0)
+        head = []
+        if bn:
+            head.append(("bn", BatchNorm1d(in_size if preact else out_size)))
+        if activation is not None:
+            head.append(("activation", activation))
+        order = head + [("fc", fc)] if preact else [("fc", fc)] + head
+        for key, mod in order:
+            self.add_module(name + key, mod)
+
+
+def set_bn_momentum_default(bn_momentum):
+    def fn(m):
+        if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):
+            m.momentum = bn_momentum
+    return fn
+
+
+class BNMomentumScheduler(object):
+    def __init__(self, model, bn_lambda, last_epoch=-1, setter=set_bn_momentum_default):
+        if not isinstance(model, nn.Module):
+            raise RuntimeError("Class '{}' is not a PyTorch nn Module".format(type(model).__name__))
+        self.model, self.setter, self.lmbd = model, setter, bn_lambda
+        self.step(last_epoch + 1)
+        self.last_epoch = last_epoch
+
+    def step(self, epoch=None):
+        if epoch is None:
+            epoch = self.last_epoch + 1
+        self.last_epoch = epoch
+        self.model.apply(self.setter(self.lmbd(epoch)))
+
+
+class Seq(nn.Sequential):
+    """Fluent builder: Seq(c).conv1d(c2, bn=True).conv1d(c3, activation=None) ..."""
+
+    def __init__(self, input_channels):
+        super().__init__()
+        self.count = 0
+        self.current_channels = input_channels
+
+    def _push(self, module, out_size=None):
+        self.add_module(str(self.count), module)
+        self.count += 1
+        if out_size is not None:
+            self.current_channels = out_size
+        return self
+
+    def _conv(self, cls, out_size, kw):
+        kw.pop("dilation", None)
+        kw.pop("norm_layer", None)
+        return self._push(cls(self.current_channels, out_size, **kw), out_size)
+
+    def conv1d(self, out_size, **kw):
+        return self._conv(Conv1d, out_size, kw)
+
+    def conv2d(self, out_size, **kw):
+        return self._conv(Conv2d, out_size, kw)
+
+    def conv3d(self, out_size, **kw):
+        return self._conv(Conv3d, out_size, kw)
+
+    def fc(self, out_size, **kw):
+        return self._push(FC(self.current_channels, out_size, **kw), out_size)
+
+    def dropout(self, p=0.5):
+        return self._push(nn.Dropout(p=0.5))  # the reference ignores p as well (:431)
+
+    def maxpool2d(self, kernel_size, stride=None, padding=0, dilation=1, return_indices=False,
+                  ceil_mode=False):
+        return self._push(nn.MaxPool2d(kernel_size=kernel_size, stride=stride, padding=padding,
+                                       dilation=dilation, return_indices=return_indices,
+                                       ceil_mode=ceil_mode))

@@ -1,0 +1,42 @@
+"""VoteNet-style region proposal head shared by BAT and P2B.
+
+Mirror of models/head/rpn.py::P2BVoteNetRPN (:12-67): per-seed classification MLP, vote MLP
+(xyz + feature offsets, residual), vote aggregation = set abstraction (radius 0.3,
+nsample 16, MLP [1+f -> +3, v, v, v], no FPS, first `num_proposal` votes as centres),
+proposal MLP -> (B, num_proposal, 5) = (x, y, z, theta, objectness).
+"""
+import torch
+from torch import nn
+
+from . import nn_blocks as pt_utils
+from .sa_modules import PointnetSAModule
+
+
+class P2BVoteNetRPN(nn.Module):
+    def __init__(self, feature_channel, vote_channel=256, num_proposal=64, normalize_xyz=False):
+        super().__init__()
+        self.num_proposal = num_proposal
+        f = feature_channel
+        self.FC_layer_cla = (pt_utils.Seq(f).conv1d(f, bn=True).conv1d(f, bn=True)
+                             .conv1d(1, activation=None))
+        self.vote_layer = (pt_utils.Seq(3 + f).conv1d(f, bn=True).conv1d(f, bn=True)
+                           .conv1d(3 + f, activation=None))
+        self.vote_aggregation = PointnetSAModule(
+            radius=0.3, nsample=16, mlp=[1 + f, vote_channel, vote_channel, vote_channel],
+            use_xyz=True, normalize_xyz=normalize_xyz)
+        self.FC_proposal = (pt_utils.Seq(vote_channel).conv1d(vote_channel, bn=True)
+                            .conv1d(vote_channel, bn=True).conv1d(3 + 1 + 1, activation=None))
+
+    def forward(self, xyz, feature):
+        """xyz (B,N,3), feature (B,f,N) -> boxes (B,P,5), cla (B,N), vote_xyz (B,N,3), centres (B,P,3)"""
+        estimation_cla = self.FC_layer_cla(feature).squeeze(1)
+        score = estimation_cla.sigmoid()
+        seeds = torch.cat((xyz.transpose(1, 2).contiguous(), feature), dim=1)   # (B,3+f,N)
+        vote = seeds + self.vote_layer(seeds)
+        vote_xyz = vote[:, 0:3, :].transpose(1, 2).contiguous()
+        vote_feature = torch.cat((score.unsqueeze(1), vote[:, 3:, :]), dim=1).contiguous()
+        center_xyzs, proposal_features = self.vote_aggregation(vote_xyz, vote_feature, self.num_proposal)
+        offsets = self.FC_proposal(proposal_features)
+        boxes = torch.cat((offsets[:, 0:3, :] + center_xyzs.transpose(1, 2).contiguous(),
+                           offsets[:, 3:5, :]), dim=1)
+        return boxes.transpose(1, 2).contiguous(), estimation_cla, vote_xyz, center_xyzs

@@ -1,0 +1,115 @@
+"""PointNet++ set-abstraction / feature-propagation modules on the MI355X operator set.
+
+Mirror of pointnet2/utils/pointnet2_modules.py: `_PointnetSAModuleBase.forward` :31-79
+(sample -> gather centres -> ball-query group -> SharedMLP -> max over nsample; returns
+`(new_xyz, features[, sample_idxs])`), `PointnetSAModuleMSG` :82, `PointnetSAModule` :120,
+`PointnetFPModule` :152.  Module / parameter names equal the reference's, so its
+checkpoints load.
+
+Two execution paths produce the same numbers (tests/test_fused_gpu.py):
+  * fused (default on GPU): grouping gather + 1x1-conv + BatchNorm + ReLU + max-pool run as
+    the fp32-MFMA kernels of csrc/mlp.hip through open3dsot_amd.fused -- the grouped
+    (B,3+C,npoint,nsample) tensor is never materialised;
+  * composed: the operator-by-operator graph exactly as the reference composes it
+    (QueryAndGroup -> SharedMLP -> max_pool2d), kept as the fp32 reference of the fused path.
+Differences from the reference, by design: no `.cuda()` H2D copy for the non-FPS prefix
+indices (:56 builds them on the host) -- they are created on the device.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import nn_blocks as pt_utils
+from . import ops as pointnet2_utils
+
+_FUSED = {"enabled": True}
+
+
+def set_fused(enabled):
+    """Globally enable/disable the fused grouped-MLP kernels (default: enabled)."""
+    _FUSED["enabled"] = bool(enabled)
+
+
+def fused_enabled():
+    return _FUSED["enabled"]
+
+
+class _PointnetSAModuleBase(nn.Module):
+    def __init__(self, use_fps=False):
+        super().__init__()
+        self.groupers = None
+        self.mlps = None
+        self.use_fps = use_fps
+
+    def _group_mlp_pool(self, i, xyz, new_xyz, features):
+        grouper, mlp = self.groupers[i], self.mlps[i]
+        if _FUSED["enabled"] and xyz.is_cuda:
+            from . import fused
+            if fused.supports(grouper, mlp, features):
+                return fused.sa_group_mlp_pool(grouper, mlp, xyz, new_xyz, features)
+        x = grouper(xyz, new_xyz, features)              # (B, 3+C, npoint, nsample)
+        x = mlp(x)                                       # (B, mlp[-1], npoint, nsample)
+        x = F.max_pool2d(x, kernel_size=[1, x.size(3)])  # (B, mlp[-1], npoint, 1)
+        return x.squeeze(-1)
+
+    def forward(self, xyz, features, npoint, return_idx=False):
+        """xyz (B,N,3), features (B,C,N) | None -> new_xyz (B,npoint,3), (B,sum(mlp[-1]),npoint)"""
+        self.npoint = npoint
+        if self.use_fps:
+            sample_idxs = pointnet2_utils.furthest_point_sample(xyz, npoint)
+            new_xyz = pointnet2_utils.gather_operation(
+                xyz.transpose(1, 2).contiguous(), sample_idxs).transpose(1, 2).contiguous()
+        else:
+            # reference: arange(npoint) indices, i.e. the first npoint points (:56-62)
+            sample_idxs = torch.arange(npoint, dtype=torch.int32, device=xyz.device).repeat(xyz.size(0), 1)
+            new_xyz = xyz[:, :npoint, :].contiguous()
+        outs = [self._group_mlp_pool(i, xyz, new_xyz, features) for i in range(len(self.groupers))]
+        feats = torch.cat(outs, dim=1) if len(outs) > 1 else outs[0]
+        if return_idx:
+            return new_xyz, feats, sample_idxs
+        return new_xyz, feats
+
+
+class PointnetSAModuleMSG(_PointnetSAModuleBase):
+    """Multi-scale grouping: one (radius, nsample, mlp) branch per scale."""
+
+    def __init__(self, radii, nsamples, mlps, bn=True, use_xyz=True, use_fps=False,
+                 normalize_xyz=False):
+        super().__init__(use_fps=use_fps)
+        assert len(radii) == len(nsamples) == len(mlps)
+        self.groupers = nn.ModuleList()
+        self.mlps = nn.ModuleList()
+        for radius, nsample, spec in zip(radii, nsamples, mlps):
+            self.groupers.append(pointnet2_utils.QueryAndGroup(
+                radius, nsample, use_xyz=use_xyz, normalize_xyz=normalize_xyz))
+            if use_xyz:
+                spec[0] += 3  # in place, like the reference (:114): callers see the +3
+            self.mlps.append(pt_utils.SharedMLP(spec, bn=bn))
+
+
+class PointnetSAModule(PointnetSAModuleMSG):
+    """Single-scale set abstraction."""
+
+    def __init__(self, mlp, radius=None, nsample=None, bn=True, use_xyz=True, use_fps=False,
+                 normalize_xyz=False):
+        super().__init__(mlps=[mlp], radii=[radius], nsamples=[nsample], bn=bn, use_xyz=use_xyz,
+                         use_fps=use_fps, normalize_xyz=normalize_xyz)
+
+
+class PointnetFPModule(nn.Module):
+    """Feature propagation: 3-NN inverse-distance interpolation + SharedMLP (:152-212)."""
+
+    def __init__(self, mlp, bn=True):
+        super().__init__()
+        self.mlp = pt_utils.SharedMLP(mlp, bn=bn)
+
+    def forward(self, unknown, known, unknow_feats, known_feats):
+        if known is not None:
+            dist, idx = pointnet2_utils.three_nn(unknown, known)
+            recip = 1.0 / (dist + 1e-8)
+            weight = recip / torch.sum(recip, dim=2, keepdim=True)
+            interpolated = pointnet2_utils.three_interpolate(known_feats, idx, weight)
+        else:
+            interpolated = known_feats.expand(*(list(known_feats.size()[0:2]) + [unknown.size(1)]))
+        x = interpolated if unknow_feats is None else torch.cat([interpolated, unknow_feats], dim=1)
+        return self.mlp(x.unsqueeze(-1)).squeeze(-1)

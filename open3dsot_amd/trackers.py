@@ -1,0 +1,185 @@
+"""BAT and P2B siamese trackers: forward graph, losses and the training-step arithmetic.
+
+Host-side mirror (plain nn.Module, no Lightning) of
+  models/bat.py   BAT.__init__ :18-38, forward :67-112, compute_loss :57-65, training_step :114-143
+  models/p2b.py   P2B.__init__ :13-26, forward :28-59, training_step :61-78
+  models/base_model.py  MatchingBaseModel.compute_loss :122-164, configure_optimizers :28-36
+Submodule names (`backbone`, `conv_final`, `mlp_bc`, `xcorr`, `rpn`) and therefore
+state_dict keys equal the reference's.  What is deliberately absent: the six `.item()`
+host synchronisations per step that the reference spends on logging (bat.py:146-164) --
+`training_loss` returns device tensors only.
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import nn_blocks as pt_utils
+from .backbone import Pointnet_Backbone
+from .rpn import P2BVoteNetRPN
+from .xcorr import BoxAwareXCorr, P2B_XCorr
+
+# cfgs/BAT_Car.yaml :9-10,27-37,40-44,53-61 and cfgs/P2B_Car.yaml (model/loss/optimizer keys)
+BAT_CAR = dict(net_model="BAT", template_size=512, search_size=1024, use_fps=True, normalize_xyz=False,
+               feature_channel=256, hidden_channel=256, out_channel=256, vote_channel=256,
+               num_proposal=64, k=4, use_search_bc=False, use_search_feature=False, bc_channel=9,
+               objectiveness_weight=1.5, box_weight=0.2, vote_weight=1.0, seg_weight=0.2, bc_weight=1.0,
+               optimizer="Adam", lr=0.001, wd=0, lr_decay_step=12, lr_decay_rate=0.2, batch_size=50)
+P2B_CAR = dict(net_model="P2B", template_size=512, search_size=1024, use_fps=False, normalize_xyz=False,
+               feature_channel=256, hidden_channel=256, out_channel=256, vote_channel=256,
+               num_proposal=64, objectiveness_weight=1.5, box_weight=0.2, vote_weight=1.0,
+               seg_weight=0.2, optimizer="Adam", lr=0.001, wd=0, lr_decay_step=12,
+               lr_decay_rate=0.2, batch_size=50)
+
+
+def make_config(base, **overrides):
+    cfg = dict(base)
+    cfg.update(overrides)
+    return SimpleNamespace(**cfg)
+
+
+class MatchingBaseModel(nn.Module):
+    def __init__(self, config=None, **kwargs):
+        super().__init__()
+        self.config = config if config is not None else SimpleNamespace(**kwargs)
+
+    def configure_optimizers(self):
+        c = self.config
+        if str(c.optimizer).lower() == "sgd":
+            opt = torch.optim.SGD(self.parameters(), lr=c.lr, momentum=0.9, weight_decay=c.wd)
+        else:
+            opt = torch.optim.Adam(self.parameters(), lr=c.lr, weight_decay=c.wd, betas=(0.5, 0.999), eps=1e-06)
+        sched = torch.optim.lr_scheduler.StepLR(opt, step_size=c.lr_decay_step, gamma=c.lr_decay_rate)
+        return {"optimizer": opt, "lr_scheduler": sched}
+
+    def compute_loss(self, data, output):
+        """Siamese matching losses  [models/base_model.py:122-164]."""
+        boxes = output["estimation_boxes"]          # (B,P,5)
+        cla = output["estimation_cla"]              # (B,N)
+        seg_label = data["seg_label"]               # (B,N)
+        box_label = data["box_label"]               # (B,4)
+        centers = output["center_xyz"]              # (B,P,3)
+        vote_xyz = output["vote_xyz"]               # (B,N,3)
+
+        loss_seg = F.binary_cross_entropy_with_logits(cla, seg_label)
+
+        loss_vote = F.smooth_l1_loss(vote_xyz, box_label[:, None, :3].expand_as(vote_xyz), reduction="none")
+        loss_vote = (loss_vote.mean(2) * seg_label).sum() / (seg_label.sum() + 1e-06)
+
+        dist = torch.sqrt(torch.sum((centers - box_label[:, None, :3]) ** 2, dim=-1) + 1e-6)  # (B,P)
+        near = (dist < 0.3).float()
+        objectness_label = near
+        objectness_mask = torch.clamp(near + (dist > 0.6).float(), max=1.0)
+        pos_weight = torch.tensor([2.0], device=dist.device, dtype=dist.dtype)
+        # NB the reference leaves the default reduction ('mean') here (base_model.py:149-152), so
+        # the mask only rescales a scalar; mirrored as is.
+        loss_objective = F.binary_cross_entropy_with_logits(boxes[:, :, 4], objectness_label,
+                                                            pos_weight=pos_weight)
+        loss_objective = torch.sum(loss_objective * objectness_mask) / (torch.sum(objectness_mask) + 1e-6)
+
+        loss_box = F.smooth_l1_loss(boxes[:, :, :4], box_label[:, None, :4].expand_as(boxes[:, :, :4]),
+                                    reduction="none")
+        loss_box = torch.sum(loss_box.mean(2) * objectness_label) / (objectness_label.sum() + 1e-6)
+        return {"loss_objective": loss_objective, "loss_box": loss_box, "loss_seg": loss_seg,
+                "loss_vote": loss_vote}
+
+
+class P2B(MatchingBaseModel):
+    def __init__(self, config=None, **kwargs):
+        super().__init__(config if config is not None else make_config(P2B_CAR, **kwargs))
+        c = self.config
+        self.backbone = Pointnet_Backbone(c.use_fps, c.normalize_xyz, return_intermediate=False)
+        self.conv_final = nn.Conv1d(256, c.feature_channel, kernel_size=1)
+        self.xcorr = P2B_XCorr(feature_channel=c.feature_channel, hidden_channel=c.hidden_channel,
+                               out_channel=c.out_channel)
+        self.rpn = P2BVoteNetRPN(c.feature_channel, vote_channel=c.vote_channel,
+                                 num_proposal=c.num_proposal, normalize_xyz=c.normalize_xyz)
+
+    def forward(self, input_dict):
+        template, search = input_dict["template_points"], input_dict["search_points"]
+        M, N = template.shape[1], search.shape[1]
+        template_xyz, template_feature, _ = self.backbone(template, [M // 2, M // 4, M // 8])
+        search_xyz, search_feature, sample_idxs = self.backbone(search, [N // 2, N // 4, N // 8])
+        template_feature = self.conv_final(template_feature)
+        search_feature = self.conv_final(search_feature)
+        fusion = self.xcorr(template_feature, search_feature, template_xyz)
+        boxes, cla, vote_xyz, centers = self.rpn(search_xyz, fusion)
+        return {"estimation_boxes": boxes, "vote_center": vote_xyz, "pred_seg_score": cla,
+                "center_xyz": centers, "sample_idxs": sample_idxs, "estimation_cla": cla,
+                "vote_xyz": vote_xyz}
+
+    def training_loss(self, batch):
+        """forward + label re-indexing + weighted loss (p2b.py:61-78); returns (loss, loss_dict)."""
+        end_points = self(batch)
+        n_seed = end_points["estimation_cla"].shape[1]
+        data = dict(batch)
+        data["seg_label"] = batch["seg_label"].gather(1, end_points["sample_idxs"][:, :n_seed].long())
+        ld = self.compute_loss(data, end_points)
+        c = self.config
+        loss = (ld["loss_objective"] * c.objectiveness_weight + ld["loss_box"] * c.box_weight
+                + ld["loss_seg"] * c.seg_weight + ld["loss_vote"] * c.vote_weight)
+        return loss, ld
+
+
+class BAT(MatchingBaseModel):
+    def __init__(self, config=None, **kwargs):
+        super().__init__(config if config is not None else make_config(BAT_CAR, **kwargs))
+        c = self.config
+        self.backbone = Pointnet_Backbone(c.use_fps, c.normalize_xyz, return_intermediate=False)
+        self.conv_final = nn.Conv1d(256, c.feature_channel, kernel_size=1)
+        self.mlp_bc = (pt_utils.Seq(3 + c.feature_channel)
+                       .conv1d(c.feature_channel, bn=True)
+                       .conv1d(c.feature_channel, bn=True)
+                       .conv1d(c.bc_channel, activation=None))
+        self.xcorr = BoxAwareXCorr(feature_channel=c.feature_channel, hidden_channel=c.hidden_channel,
+                                   out_channel=c.out_channel, k=c.k, use_search_bc=c.use_search_bc,
+                                   use_search_feature=c.use_search_feature, bc_channel=c.bc_channel)
+        self.rpn = P2BVoteNetRPN(c.feature_channel, vote_channel=c.vote_channel,
+                                 num_proposal=c.num_proposal, normalize_xyz=c.normalize_xyz)
+
+    def compute_loss(self, data, output):
+        out = super().compute_loss(data, output)
+        loss_bc = F.smooth_l1_loss(output["pred_search_bc"], data["points2cc_dist_s"], reduction="none")
+        seg_label = data["seg_label"]
+        out["loss_bc"] = torch.sum(loss_bc.mean(2) * seg_label) / (seg_label.sum() + 1e-6)
+        return out
+
+    def forward(self, input_dict):
+        template, search = input_dict["template_points"], input_dict["search_points"]
+        template_bc = input_dict["points2cc_dist_t"]
+        M, N = template.shape[1], search.shape[1]
+        template_xyz, template_feature, sample_idxs_t = self.backbone(template, [M // 2, M // 4, M // 8])
+        search_xyz, search_feature, sample_idxs = self.backbone(search, [N // 2, N // 4, N // 8])
+        template_feature = self.conv_final(template_feature)
+        search_feature = self.conv_final(search_feature)
+        pred_search_bc = self.mlp_bc(torch.cat([search_xyz.transpose(1, 2), search_feature], dim=1))
+        pred_search_bc = pred_search_bc.transpose(1, 2)                                    # (B,N/8,9)
+        t_idx = sample_idxs_t[:, :M // 8, None].long().expand(-1, -1, self.config.bc_channel)
+        template_bc = template_bc.gather(dim=1, index=t_idx)                               # (B,M/8,9)
+        fusion = self.xcorr(template_feature, search_feature, template_xyz, search_xyz, template_bc,
+                            pred_search_bc)
+        boxes, cla, vote_xyz, centers = self.rpn(search_xyz, fusion)
+        return {"estimation_boxes": boxes, "vote_center": vote_xyz, "pred_seg_score": cla,
+                "center_xyz": centers, "sample_idxs": sample_idxs, "estimation_cla": cla,
+                "vote_xyz": vote_xyz, "pred_search_bc": pred_search_bc}
+
+    def training_loss(self, batch):
+        """forward + label re-indexing + weighted loss (bat.py:114-143); returns (loss, loss_dict)."""
+        end_points = self(batch)
+        n_seed = end_points["estimation_cla"].shape[1]
+        sidx = end_points["sample_idxs"][:, :n_seed].long()
+        data = dict(batch)
+        data["seg_label"] = batch["seg_label"].gather(1, sidx)
+        data["points2cc_dist_s"] = batch["points2cc_dist_s"].gather(
+            1, sidx[:, :, None].expand(-1, -1, self.config.bc_channel))
+        ld = self.compute_loss(data, end_points)
+        c = self.config
+        loss = (ld["loss_objective"] * c.objectiveness_weight + ld["loss_box"] * c.box_weight
+                + ld["loss_seg"] * c.seg_weight + ld["loss_vote"] * c.vote_weight
+                + ld["loss_bc"] * c.bc_weight)
+        return loss, ld
+
+
+def get_model(name):
+    return {"BAT": BAT, "P2B": P2B}[name.upper()]

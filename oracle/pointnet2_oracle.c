@@ -1,0 +1,258 @@
+/*
+ * oracle/pointnet2_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * Plain-C CPU restatement of the nine `pointnet2_ops._ext` operators that the
+ * reference calls at pointnet2/utils/pointnet2_utils.py:56,92,98,125,162,184,217,237,268
+ * (reference tree: Ghostish/Open3DSOT), plus the stable top-k used to pin the
+ * tie order of models/head/xcorr.py:87 and pointnet2_utils.py:400.
+ *
+ * PARITY UNPINNED at this boundary: the arithmetic lives in the un-vendored
+ * third-party package `pointnet2_ops` (erikwijmans/Pointnet2_PyTorch,
+ * pointnet2_ops_lib, installed from git HEAD by requirement.txt:5, package
+ * version 3.0.0); its CUDA source is absent from the reference tree and the
+ * reference ships no test or golden vector for it.  What is restated here is
+ * the published algorithm of those kernels:
+ *   - FPS:  sampling_gpu.cu  furthest_point_sampling_kernel<block_size>
+ *   - ball: ball_query_gpu.cu query_ball_point_kernel
+ *   - group/gather (+grad): group_points_gpu.cu / sampling_gpu.cu
+ *   - 3-NN / interpolate (+grad): interpolate_gpu.cu
+ * The FPS restatement SIMULATES the upstream thread block (block_size =
+ * opt_n_threads(N), strided per-thread scan, shared-memory tree reduction) so
+ * that its tie-breaking order is the upstream one, not an approximation.
+ *
+ * Canonical arithmetic: squared distances are fmaf(dz,dz,fmaf(dy,dy,dx*dx)),
+ * i.e. the FMA contraction nvcc (-fmad=true) and hipcc emit for the
+ * left-associated upstream expression.  Compile with -ffp-contract=off so no
+ * other contraction is introduced.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+static inline float sqdist3(float ax, float ay, float az, float bx, float by, float bz) {
+    const float dx = ax - bx, dy = ay - by, dz = az - bz;
+    return fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+}
+
+/* upstream cuda_utils.h: opt_n_threads(w) = max(min(1 << int(log2(w)), 512), 1) */
+int o3d_oracle_opt_n_threads(int work) {
+    int p = 1;
+    while ((p << 1) <= work && (p << 1) <= 512) p <<= 1;
+    return p < 1 ? 1 : p;
+}
+
+/* ---- A.1 furthest point sampling ------------------------------------------------
+ * xyz (B,N,3) f32 -> idx (B,npoint) i32.  temp (B,N) scratch is internal. */
+int o3d_oracle_furthest_point_sampling(const float* xyz, int B, int N, int npoint, int32_t* idx) {
+    if (B < 0 || N <= 0 || npoint < 0) return -1;
+    if (npoint == 0 || B == 0) return 0;
+    const int bs = o3d_oracle_opt_n_threads(N);
+    float* temp = (float*)malloc(sizeof(float) * (size_t)N);
+    float* dists = (float*)malloc(sizeof(float) * (size_t)bs);
+    int* dists_i = (int*)malloc(sizeof(int) * (size_t)bs);
+    if (!temp || !dists || !dists_i) { free(temp); free(dists); free(dists_i); return -2; }
+    for (int b = 0; b < B; ++b) {
+        const float* p = xyz + (size_t)b * N * 3;
+        int32_t* out = idx + (size_t)b * npoint;
+        for (int k = 0; k < N; ++k) temp[k] = 1e10f;
+        for (int j = 0; j < npoint; ++j) out[j] = 0; /* upstream output is zeros() */
+        int old = 0;
+        out[0] = 0;
+        for (int j = 1; j < npoint; ++j) {
+            const float x1 = p[old * 3 + 0], y1 = p[old * 3 + 1], z1 = p[old * 3 + 2];
+            for (int tid = 0; tid < bs; ++tid) { /* one simulated thread each */
+                int besti = 0;
+                float best = -1.0f;
+                for (int k = tid; k < N; k += bs) {
+                    const float x2 = p[k * 3 + 0], y2 = p[k * 3 + 1], z2 = p[k * 3 + 2];
+                    const float mag = fmaf(z2, z2, fmaf(y2, y2, x2 * x2));
+                    if (mag <= 1e-3f) continue; /* near-origin points: never selected, temp untouched */
+                    const float d = sqdist3(x2, y2, z2, x1, y1, z1);
+                    const float d2 = fminf(d, temp[k]);
+                    temp[k] = d2;
+                    if (d2 > best) { besti = k; best = d2; }
+                }
+                dists[tid] = best;
+                dists_i[tid] = besti;
+            }
+            for (int s = bs >> 1; s >= 1; s >>= 1) { /* shared-memory tree */
+                for (int tid = 0; tid < s; ++tid) {
+                    const float v1 = dists[tid], v2 = dists[tid + s];
+                    const int i1 = dists_i[tid], i2 = dists_i[tid + s];
+                    dists[tid] = v1 > v2 ? v1 : v2;
+                    dists_i[tid] = v2 > v1 ? i2 : i1; /* tie keeps the lower slot */
+                }
+            }
+            old = dists_i[0];
+            out[j] = old;
+        }
+    }
+    free(temp); free(dists); free(dists_i);
+    return 0;
+}
+
+/* ---- A.2 ball query ---------------------------------------------------------------
+ * new_xyz (B,npoint,3), xyz (B,N,3) -> idx (B,npoint,nsample) i32 */
+int o3d_oracle_ball_query(const float* new_xyz, const float* xyz, int B, int N, int npoint,
+                          float radius, int nsample, int32_t* idx) {
+    if (B < 0 || N < 0 || npoint < 0 || nsample < 0) return -1;
+    const float r2 = radius * radius;
+    for (int b = 0; b < B; ++b) {
+        const float* p = xyz + (size_t)b * N * 3;
+        for (int j = 0; j < npoint; ++j) {
+            const float* c = new_xyz + ((size_t)b * npoint + j) * 3;
+            int32_t* out = idx + ((size_t)b * npoint + j) * nsample;
+            for (int l = 0; l < nsample; ++l) out[l] = 0; /* output pre-zeroed */
+            int cnt = 0;
+            for (int k = 0; k < N && cnt < nsample; ++k) {
+                const float d2 = sqdist3(c[0], c[1], c[2], p[k * 3], p[k * 3 + 1], p[k * 3 + 2]);
+                if (d2 < r2) {
+                    if (cnt == 0) for (int l = 0; l < nsample; ++l) out[l] = k;
+                    out[cnt] = k;
+                    ++cnt;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
+/* ---- A.3 group points (+grad) ---------------------------------------------------- */
+int o3d_oracle_group_points(const float* feats, const int32_t* idx, int B, int C, int N,
+                            int npoint, int nsample, float* out) {
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            const float* src = feats + ((size_t)b * C + c) * N;
+            float* dst = out + ((size_t)b * C + c) * npoint * nsample;
+            const int32_t* id = idx + (size_t)b * npoint * nsample;
+            for (int q = 0; q < npoint * nsample; ++q) dst[q] = src[id[q]];
+        }
+    return 0;
+}
+
+int o3d_oracle_group_points_grad(const float* grad_out, const int32_t* idx, int B, int C, int N,
+                                 int npoint, int nsample, float* grad_feats) {
+    memset(grad_feats, 0, sizeof(float) * (size_t)B * C * N);
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < C; ++c) {
+            float* dst = grad_feats + ((size_t)b * C + c) * N;
+            const float* src = grad_out + ((size_t)b * C + c) * npoint * nsample;
+            const int32_t* id = idx + (size_t)b * npoint * nsample;
+            for (int q = 0; q < npoint * nsample; ++q) dst[id[q]] += src[q];
+        }
+    return 0;
+}
+
+/* ---- A.4 gather points (+grad) --------------------------------------------------- */
+int o3d_oracle_gather_points(const float* feats, const int32_t* idx, int B, int C, int N,
+                             int npoint, float* out) {
+    return o3d_oracle_group_points(feats, idx, B, C, N, npoint, 1, out);
+}
+
+int o3d_oracle_gather_points_grad(const float* grad_out, const int32_t* idx, int B, int C, int N,
+                                  int npoint, float* grad_feats) {
+    return o3d_oracle_group_points_grad(grad_out, idx, B, C, N, npoint, 1, grad_feats);
+}
+
+/* ---- A.5 three nearest neighbours -------------------------------------------------
+ * unknown (B,n,3), known (B,m,3) -> dist2 (B,n,3) f32 (SQUARED), idx (B,n,3) i32 */
+int o3d_oracle_three_nn(const float* unknown, const float* known, int B, int n, int m,
+                        float* dist2, int32_t* idx) {
+    for (int b = 0; b < B; ++b)
+        for (int j = 0; j < n; ++j) {
+            const float* u = unknown + ((size_t)b * n + j) * 3;
+            double best1 = 1e40, best2 = 1e40, best3 = 1e40; /* upstream literal is a double */
+            int besti1 = 0, besti2 = 0, besti3 = 0;
+            for (int k = 0; k < m; ++k) {
+                const float* q = known + ((size_t)b * m + k) * 3;
+                const float d = sqdist3(u[0], u[1], u[2], q[0], q[1], q[2]);
+                if (d < best1) {
+                    best3 = best2; besti3 = besti2;
+                    best2 = best1; besti2 = besti1;
+                    best1 = d; besti1 = k;
+                } else if (d < best2) {
+                    best3 = best2; besti3 = besti2;
+                    best2 = d; besti2 = k;
+                } else if (d < best3) {
+                    best3 = d; besti3 = k;
+                }
+            }
+            float* dd = dist2 + ((size_t)b * n + j) * 3;
+            int32_t* ii = idx + ((size_t)b * n + j) * 3;
+            dd[0] = (float)best1; dd[1] = (float)best2; dd[2] = (float)best3;
+            ii[0] = besti1; ii[1] = besti2; ii[2] = besti3;
+        }
+    return 0;
+}
+
+/* ---- A.6 three interpolate (+grad) ----------------------------------------------- */
+int o3d_oracle_three_interpolate(const float* feats, const int32_t* idx, const float* weight,
+                                 int B, int c, int m, int n, float* out) {
+    for (int b = 0; b < B; ++b)
+        for (int ch = 0; ch < c; ++ch) {
+            const float* src = feats + ((size_t)b * c + ch) * m;
+            float* dst = out + ((size_t)b * c + ch) * n;
+            for (int j = 0; j < n; ++j) {
+                const int32_t* ii = idx + ((size_t)b * n + j) * 3;
+                const float* w = weight + ((size_t)b * n + j) * 3;
+                /* upstream: p[i1]*w1 + p[i2]*w2 + p[i3]*w3, contracted left to right */
+                dst[j] = fmaf(src[ii[2]], w[2], fmaf(src[ii[1]], w[1], src[ii[0]] * w[0]));
+            }
+        }
+    return 0;
+}
+
+int o3d_oracle_three_interpolate_grad(const float* grad_out, const int32_t* idx, const float* weight,
+                                      int B, int c, int n, int m, float* grad_feats) {
+    memset(grad_feats, 0, sizeof(float) * (size_t)B * c * m);
+    for (int b = 0; b < B; ++b)
+        for (int ch = 0; ch < c; ++ch) {
+            float* dst = grad_feats + ((size_t)b * c + ch) * m;
+            const float* src = grad_out + ((size_t)b * c + ch) * n;
+            for (int j = 0; j < n; ++j) {
+                const int32_t* ii = idx + ((size_t)b * n + j) * 3;
+                const float* w = weight + ((size_t)b * n + j) * 3;
+                dst[ii[0]] += src[j] * w[0];
+                dst[ii[1]] += src[j] * w[1];
+                dst[ii[2]] += src[j] * w[2];
+            }
+        }
+    return 0;
+}
+
+/* ---- stable k-smallest selection ---------------------------------------------------
+ * For every query q of (B,Q,D) pick the k rows of ref (B,R,D) with the smallest squared
+ * Euclidean distance, ascending, ties -> lowest row index first.  Pins the tie order that
+ * torch.argsort (unstable) leaves open at models/head/xcorr.py:87 / pointnet2_utils.py:400.
+ * The squared distance is accumulated as a left-to-right fmaf chain over D. */
+int o3d_oracle_knn(const float* query, const float* ref, int B, int Q, int R, int D, int k,
+                   int32_t* idx) {
+    if (k > R) return -1;
+    float* best = (float*)malloc(sizeof(float) * (size_t)(k > 0 ? k : 1));
+    if (!best) return -2;
+    for (int b = 0; b < B; ++b)
+        for (int q = 0; q < Q; ++q) {
+            const float* qq = query + ((size_t)b * Q + q) * D;
+            int32_t* out = idx + ((size_t)b * Q + q) * k;
+            int cnt = 0;
+            for (int r = 0; r < R; ++r) {
+                const float* rr = ref + ((size_t)b * R + r) * D;
+                float d = 0.0f;
+                for (int t = 0; t < D; ++t) { const float df = qq[t] - rr[t]; d = fmaf(df, df, d); }
+                /* insertion keeping ascending (d, r); strict < keeps earlier r on ties */
+                int pos = cnt;
+                while (pos > 0 && d < best[pos - 1]) --pos;
+                if (pos >= k) continue;
+                const int last = cnt < k ? cnt : k - 1;
+                for (int t = last; t > pos; --t) { best[t] = best[t - 1]; out[t] = out[t - 1]; }
+                best[pos] = d; out[pos] = r;
+                if (cnt < k) ++cnt;
+            }
+        }
+    free(best);
+    return 0;
+}
