@@ -1,0 +1,184 @@
+#!/usr/bin/env python
+"""bench.py -- template/search pairs per second (forward + backward + Adam) of the BAT tracker
+at KITTI-Car shapes (template 512 / search 1024 points), BASELINE.json's metric.
+
+    python bench.py --gpus 1 --steps K --warmup W          (one MI355X)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full training step of the hot path on one synthetic batch of `--batch`
+pairs PER GPU (weak scaling; default 48 = BASELINE config 2): FPS, ball queries, the fused
+grouped-MLP stack, BoxCloud xcorr, vote heads, losses, backward, the one-message RCCL
+gradient all-reduce and the Adam update.  Inputs are resident in HBM before the timed
+region.  Rank 0 prints ONE JSON line (contract in the task statement) that also carries
+  "roofline"     -- the dominant kernel family (fp32-MFMA grouped-MLP GEMMs) measured live
+                    with HIP events on the launch stream: algorithmic FLOPs / time vs the
+                    157.3 TFLOP/s dense fp32 matrix peak of gfx950;
+  "cpu_baseline" -- the oracle's PyTorch restatement of the same step timed on this host's
+                    cores on a bounded sample (kind "port": the reference has no CPU path).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+from open3dsot_amd import dist as D  # noqa: E402
+from open3dsot_amd import synth, trackers  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: dense fp32 matrix peak (= vector peak)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=48, help="pairs per GPU (BASELINE config 2: 48)")
+    ap.add_argument("--model", default="BAT", choices=["BAT", "P2B"])
+    ap.add_argument("--pool", type=int, default=4, help="distinct resident synthetic batches cycled through")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--composed", action="store_true", help="disable the fused kernels (debug A/B only)")
+    return ap.parse_args()
+
+
+def mlp_flops_per_pair(model_name):
+    """Algorithmic forward FLOPs per pair of every 1x1-conv layer: 2*Cin*Cout*positions
+    (BAT 5.462 GFLOP, P2B 8.462 GFLOP)."""
+    def mlp(spec, pos):
+        return sum(2 * a * b * pos for a, b in zip(spec[:-1], spec[1:]))
+    total = 0
+    for M in (512, 1024):
+        total += mlp([3, 64, 64, 128], (M // 2) * 32)
+        total += mlp([131, 128, 128, 256], (M // 4) * 32)
+        total += mlp([259, 256, 256, 256], (M // 8) * 32)
+        total += mlp([256, 256], M // 8)                      # conv_final
+    total += mlp([260, 256, 256, 256], 64 * 16)               # vote aggregation SA
+    total += mlp([256, 256, 256, 1], 128) + mlp([259, 256, 256, 259], 128) + mlp([256, 256, 256, 5], 64)
+    if model_name == "BAT":
+        total += mlp([259, 256, 256, 9], 128)                 # mlp_bc
+        total += mlp([268, 256, 256, 256], 128 * 4) + mlp([256, 256, 256], 128)
+    else:
+        total += mlp([260, 256, 256, 256], 64 * 128) + mlp([256, 256, 256], 128)
+    return total
+
+
+def cpu_baseline(model_name, sd, batch_size, iters):
+    """Oracle restatement (oracle/torch_ref.py) of the same training step on the host cores."""
+    from oracle import torch_ref
+    torch.set_num_threads(os.cpu_count() or 1)
+    w = {k: v for k, v in (trackers.BAT_CAR if model_name == "BAT" else trackers.P2B_CAR).items() if k.endswith("_weight")}
+    params = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
+    leafs = [v for v in params.values() if v.requires_grad]
+    opt = torch.optim.Adam(leafs, lr=1e-3, betas=(0.5, 0.999), eps=1e-6)
+    times = []
+    for it in range(iters + 1):
+        batch = synth.to_torch(synth.make_batch(5000 + it * batch_size, batch_size))
+        t0 = time.perf_counter()
+        opt.zero_grad()
+        if model_name == "BAT":
+            out = torch_ref.bat_forward(params, batch, True)
+        else:
+            out = torch_ref.p2b_forward(params, batch, True)
+        loss, _ = torch_ref.matching_loss(batch, out, w, bat=model_name == "BAT")
+        loss.backward()
+        opt.step()
+        times.append(time.perf_counter() - t0)
+    t = sorted(times[1:])[len(times[1:]) // 2]       # median, first iteration is warm-up
+    return {"value": round(batch_size / t, 3), "unit": "pairs/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": "%s fwd+bwd+Adam, batch %d, median of %d iterations after 1 warm-up, oracle/torch_ref.py "
+                      "(C index ops + PyTorch fp32 CPU convs)" % (model_name, batch_size, iters)}
+
+
+def main():
+    args = parse()
+    rank, local_rank, world = D.init_distributed()
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library is the only compute path (no CPU fallback)")
+    dev = torch.device("cuda", local_rank)
+    from open3dsot_amd import capi, sa_modules
+    capi.load()
+    if args.composed:
+        sa_modules.set_fused(False)
+
+    torch.manual_seed(1234)
+    model = trackers.get_model(args.model)().to(dev).train()
+    sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    trainer = D.DataParallelStep(model, world=world)
+
+    # resident synthetic batches (distinct per rank and per pool slot)
+    pool = []
+    for s in range(args.pool):
+        first, n = D.shard_indices(s, rank, world, args.batch)
+        pool.append(synth.to_torch(synth.make_batch(first, n), dev))
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for i in range(args.warmup):
+        trainer.step(pool[i % len(pool)])
+    torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        trainer.step(pool[i % len(pool)])
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel family, measured live with HIP events ------------
+    roofline = None
+    try:
+        from open3dsot_amd import fused
+        if sa_modules.fused_enabled() and hasattr(fused, "profile_step"):
+            roofline = fused.profile_step(lambda: trainer.step(pool[0]), PEAK_FP32_MFMA_TFLOPS)
+    except ImportError:
+        roofline = None
+    if roofline is None:  # no instrumented kernels yet: whole-step algorithmic rate (labelled as such)
+        flops = 3.0 * mlp_flops_per_pair(args.model) * args.batch
+        ach = flops / (elapsed / args.steps) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "kernel": "whole training step (3x forward conv FLOPs / step time)"}
+
+    if rank == 0:
+        pairs = world * args.batch * args.steps
+        line = {
+            "metric": "template/search pairs/sec (fwd+bwd), BAT KITTI-Car 512/1024 pts" if args.model == "BAT"
+                      else "template/search pairs/sec (fwd+bwd), P2B KITTI-Car 512/1024 pts",
+            "value": round(pairs / elapsed, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic KITTI-Car-like pairs (open3dsot_amd/synth.py, seed 1234+index), random-init weights",
+            "config": {"workload": "%s_Car.yaml KITTI-Car, template 512 / search 1024 pts, batch %d per GPU, "
+                                   "fwd+bwd+Adam, fp32" % (args.model, args.batch),
+                       "global_batch": world * args.batch, "parallelism": "dp%d" % world,
+                       "fused_kernels": bool(sa_modules.fused_enabled())},
+            "roofline": roofline,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            line["cpu_baseline"] = cpu_baseline(args.model, sd_cpu, args.cpu_batch, args.cpu_iters)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

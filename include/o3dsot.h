@@ -88,33 +88,6 @@ int o3d_three_interpolate_grad(const float* grad_out, const int32_t* idx, const 
 int o3d_knn(const float* query, const float* ref, int B, int Q, int R, int D, int k,
             int32_t* idx, void* stream);
 
-/* ---- fused grouped-MLP layer (1x1 conv as an fp32-MFMA GEMM) -----------------------
- * replaces, per layer, Conv2d(1x1,bias=False)+BatchNorm2d+ReLU of SharedMLP
- *                                   pointnet2/utils/pytorch_utils.py:12-37,68-121
- * and the QueryAndGroup gather that feeds layer 0    pointnet2_utils.py:299-339.
- * See open3dsot_amd/csrc/mlp.hip for the contract of each argument.                  */
-
-/* Y[b,co,p] = sum_ci W[co,ci] * f(X[b,ci,p]),  p in [0,P)
- *   f(x) = x                                  when in_scale == NULL
- *   f(x) = max(x*in_scale[ci]+in_shift[ci],0) otherwise (BN+ReLU of the producer folded in)
- * X (B,Cin,P), W (Cout,Cin), Y (B,Cout,P).  If stats != NULL it must hold 2*Cout zeros on
- * entry and receives sum_y[co] at stats[co], sum_y2[co] at stats[Cout+co] (fp32 atomics of
- * per-workgroup partials).  P must be a multiple of 32. */
-int o3d_conv1x1_fwd(const float* X, const float* W, const float* in_scale, const float* in_shift,
-                    int B, int Cin, int Cout, int P, float* Y, float* stats, void* stream);
-
-/* Grouped layer-0 variant: X is gathered on the fly,
- *   X[b,ci,j*ns+k] = ci<3 ? xyz[b,idx[b,j,k],ci]-new_xyz[b,j,ci] : feats[b,ci-3,idx[b,j,k]]
- * xyz (B,N,3), new_xyz (B,npoint,3), feats (B,C,N) or NULL (C=0), idx (B,npoint,ns).      */
-int o3d_conv1x1_grouped_fwd(const float* xyz, const float* new_xyz, const float* feats,
-                            const int32_t* idx, const float* W, int B, int N, int C, int npoint,
-                            int ns, int Cout, float* Y, float* stats, void* stream);
-
-/* BN(train)+ReLU+max over the `ns` neighbours of the last layer's pre-BN output:
- * Y (B,C,npoint*ns), scale/shift (C) -> out (B,C,npoint), arg (B,C,npoint) i32 (k of max). */
-int o3d_bn_relu_maxpool_fwd(const float* Y, const float* scale, const float* shift, int B, int C,
-                            int npoint, int ns, float* out, int32_t* arg, void* stream);
-
 #ifdef __cplusplus
 }
 #endif

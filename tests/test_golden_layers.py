@@ -1,0 +1,130 @@
+"""The oracle's PyTorch restatement (oracle/torch_ref.py) and the product's host-side mirror
+(open3dsot_amd, run on the CPU through the oracle operator shim) must reproduce the outputs
+of the REFERENCE'S OWN Python layers, frozen in tests/golden/ref_python_layers.npz by
+tests/golden/make_golden.py.  Tolerance: 1e-4 absolute on fp32
+features (north_star), exact on indices."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import torch_ref
+
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def sd_from(golden, prefix, add=""):
+    out = {}
+    for k in golden.files:
+        if k.startswith(prefix):
+            out[add + k[len(prefix):]] = torch.from_numpy(golden[k].copy())
+    return out
+
+
+@pytest.mark.parametrize("use_fps", [True, False])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_torch_ref_backbone(golden, use_fps, mode):
+    tag = "backbone_fps%d" % int(use_fps)
+    sd = sd_from(golden, tag + ".sd.", "backbone.")
+    st = torch_ref.State(sd, mode == "train")
+    pc = torch.from_numpy(golden["search_points"])
+    N = pc.shape[1]
+    xyz, feat, idx0 = torch_ref.backbone(st, pc, [N // 2, N // 4, N // 8], use_fps)
+    assert np.array_equal(idx0.numpy(), golden["%s.%s.idx0" % (tag, mode)])
+    np.testing.assert_allclose(xyz.numpy(), golden["%s.%s.xyz" % (tag, mode)], **TOL)
+    np.testing.assert_allclose(feat.numpy(), golden["%s.%s.feat" % (tag, mode)], **TOL)
+    if mode == "train":  # running statistics updated like the reference's BatchNorm
+        for k in golden.files:
+            pre = tag + ".train.sd_after."
+            if k.startswith(pre):
+                np.testing.assert_allclose(sd["backbone." + k[len(pre):]].numpy(), golden[k], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_torch_ref_xcorr_and_rpn(golden, mode):
+    gi = {k.split(".")[-1]: torch.from_numpy(golden[k]) for k in golden.files if k.startswith("xcorr.in.")}
+    st = torch_ref.State(sd_from(golden, "bat_xcorr.sd.", "xcorr."), mode == "train")
+    out = torch_ref.box_aware_xcorr(st, gi["t_feat"], gi["s_feat"], gi["t_xyz"], gi["t_bc"], gi["s_bc"], 4)
+    np.testing.assert_allclose(out.detach().numpy(), golden["bat_xcorr.%s.out" % mode], **TOL)
+    st = torch_ref.State(sd_from(golden, "p2b_xcorr.sd.", "xcorr."), mode == "train")
+    out = torch_ref.p2b_xcorr(st, gi["t_feat"], gi["s_feat"], gi["t_xyz"])
+    np.testing.assert_allclose(out.detach().numpy(), golden["p2b_xcorr.%s.out" % mode], **TOL)
+    st = torch_ref.State(sd_from(golden, "rpn.sd.", "rpn."), mode == "train")
+    boxes, cla, vote_xyz, centers = torch_ref.rpn(st, torch.from_numpy(golden["rpn.in.xyz"]),
+                                                  torch.from_numpy(golden["rpn.in.feat"]), 16)
+    for nm, t in (("boxes", boxes), ("cla", cla), ("vote_xyz", vote_xyz), ("centers", centers)):
+        np.testing.assert_allclose(t.detach().numpy(), golden["rpn.%s.%s" % (mode, nm)], **TOL)
+
+
+@pytest.mark.parametrize("use_fps", [True, False])
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_host_mirror_backbone_loads_reference_state_dict(golden, cpu_ext, use_fps, mode):
+    from open3dsot_amd.backbone import Pointnet_Backbone
+    tag = "backbone_fps%d" % int(use_fps)
+    net = Pointnet_Backbone(use_fps=use_fps, normalize_xyz=False, return_intermediate=True)
+    missing = net.load_state_dict(sd_from(golden, tag + ".sd."), strict=True)   # identical key set
+    assert not missing.missing_keys and not missing.unexpected_keys
+    net.train(mode == "train")
+    pc = torch.from_numpy(golden["search_points"])
+    N = pc.shape[1]
+    xyzs, feats, idx0 = net(pc, [N // 2, N // 4, N // 8])
+    assert np.array_equal(idx0.numpy(), golden["%s.%s.idx0" % (tag, mode)])
+    np.testing.assert_allclose(feats[0].detach().numpy(), golden["%s.%s.feat0" % (tag, mode)], **TOL)
+    np.testing.assert_allclose(feats[-1].detach().numpy(), golden["%s.%s.feat" % (tag, mode)], **TOL)
+    np.testing.assert_allclose(xyzs[-1].detach().numpy(), golden["%s.%s.xyz" % (tag, mode)], **TOL)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_host_mirror_heads(golden, cpu_ext, mode):
+    from open3dsot_amd.rpn import P2BVoteNetRPN
+    from open3dsot_amd.xcorr import BoxAwareXCorr, P2B_XCorr
+    gi = {k.split(".")[-1]: torch.from_numpy(golden[k]) for k in golden.files if k.startswith("xcorr.in.")}
+    m = BoxAwareXCorr(256, 256, 256, k=4)
+    m.load_state_dict(sd_from(golden, "bat_xcorr.sd."), strict=True)
+    m.train(mode == "train")
+    out = m(gi["t_feat"], gi["s_feat"], gi["t_xyz"], gi["s_xyz"], gi["t_bc"], gi["s_bc"])
+    np.testing.assert_allclose(out.detach().numpy(), golden["bat_xcorr.%s.out" % mode], **TOL)
+    m = P2B_XCorr(256, 256, 256)
+    m.load_state_dict(sd_from(golden, "p2b_xcorr.sd."), strict=True)
+    m.train(mode == "train")
+    out = m(gi["t_feat"], gi["s_feat"], gi["t_xyz"])
+    np.testing.assert_allclose(out.detach().numpy(), golden["p2b_xcorr.%s.out" % mode], **TOL)
+    m = P2BVoteNetRPN(256, vote_channel=256, num_proposal=16)
+    m.load_state_dict(sd_from(golden, "rpn.sd."), strict=True)
+    m.train(mode == "train")
+    outs = m(torch.from_numpy(golden["rpn.in.xyz"]), torch.from_numpy(golden["rpn.in.feat"]))
+    for nm, t in zip(("boxes", "cla", "vote_xyz", "centers"), outs):
+        np.testing.assert_allclose(t.detach().numpy(), golden["rpn.%s.%s" % (mode, nm)], **TOL)
+
+
+def test_bat_host_mirror_matches_torch_ref_end_to_end(cpu_ext):
+    """full BAT forward + loss + backward: product host graph (CPU shim) == oracle restatement"""
+    from open3dsot_amd import synth, trackers
+    torch.manual_seed(3)
+    model = trackers.BAT()
+    model.train()
+    batch = synth.to_torch(synth.make_batch(40, 2, 256, 512))
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    for k in list(sd):
+        if sd[k].dtype.is_floating_point and "running" not in k:
+            sd[k].requires_grad_(True)
+    loss, ld = model.training_loss(batch)
+    loss.backward()
+    out = torch_ref.bat_forward(sd, batch, True)
+    w = {k: getattr(model.config, k) for k in ("objectiveness_weight", "box_weight", "seg_weight", "vote_weight", "bc_weight")}
+    loss2, ld2 = torch_ref.matching_loss(batch, out, w, bat=True)
+    loss2.backward()
+    assert abs(loss.item() - loss2.item()) < 1e-4 * (1 + abs(loss2.item()))
+    for k in ld2:
+        assert abs(ld[k].item() - ld2[k].item()) < 1e-4 * (1 + abs(ld2[k].item())), k
+    named = dict(model.named_parameters())
+    worst = 0.0
+    for k, p in named.items():
+        g2 = sd[k].grad
+        assert g2 is not None, k
+        denom = g2.abs().max().item() + 1e-6
+        worst = max(worst, (p.grad - g2).abs().max().item() / denom)
+    assert worst < 2e-3, worst
+    # BatchNorm running statistics advanced identically
+    for k, v in model.state_dict().items():
+        if "running" in k:
+            np.testing.assert_allclose(v.numpy(), sd[k].detach().numpy(), rtol=1e-4, atol=1e-5)

@@ -1,0 +1,181 @@
+"""GPU parity: every HIP index operator vs the CPU oracle -- BIT-EXACT for indices, exact for
+gathers, fp32 summation-order tolerance for the atomic scatter-adds.  Called through the
+C-ABI (open3dsot_amd.ext -> ctypes -> libo3dsot_hip.so).  Covers the committed golden
+vectors, the BASELINE config-2 shapes (B=48, 512/1024 points), ragged / edge sizes, ties,
+duplicates, all-zero clouds, and size-independent properties at full size."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import ops as O
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def cloud(seed, B, N, kind="normal"):
+    rng = np.random.default_rng(seed)
+    p = rng.normal(0, 1.2, (B, N, 3)).astype(f32)
+    if kind == "dup":
+        src = rng.integers(0, min(N, max(2, N // 4)), (B, N))
+        p = np.take_along_axis(p, src[:, :, None], 1)
+    elif kind == "grid":
+        p = (np.round(p * 2) / 2).astype(f32)
+    elif kind == "zero":
+        p[:] = 0
+    elif kind == "origin":
+        p[:, ::3] *= 0.01
+    return p
+
+
+def explain(got, exp, name):
+    bad = np.argwhere(got != exp)
+    return "%s: %d/%d mismatches, first at %s got %s exp %s" % (
+        name, len(bad), got.size, bad[:3].tolist(), got[tuple(bad[0])] if len(bad) else None,
+        exp[tuple(bad[0])] if len(bad) else None)
+
+
+@pytest.fixture(scope="module")
+def ext():
+    import pointnet2_ops._ext as e
+    from open3dsot_amd import ext as full
+    e.knn = full.knn
+    e.fps_variant = full.furthest_point_sampling
+    return e
+
+
+@pytest.mark.parametrize("variant", ["dpp", "shfl"])
+def test_fps_golden(ext, golden_index, variant):
+    g = golden_index
+    for key, n in (("t", 256), ("s", 512)):
+        got = ext.fps_variant(dev(g["xyz_" + key]), n, _variant=variant).cpu().numpy()
+        assert got.dtype == np.int32
+        assert np.array_equal(got, g["fps_" + key]), explain(got, g["fps_" + key], "fps_" + key)
+
+
+@pytest.mark.parametrize("variant", ["dpp", "shfl"])
+@pytest.mark.parametrize("N,npoint", [(1, 1), (2, 2), (5, 3), (63, 40), (64, 64), (65, 10), (100, 100), (255, 128),
+                                      (512, 256), (777, 300), (1024, 512), (1500, 200), (2048, 1024),
+                                      (3000, 64), (5000, 100), (9000, 50), (20000, 40)])
+def test_fps_sizes_and_ties(ext, variant, N, npoint):
+    for kind in ("normal", "dup", "grid", "origin", "zero"):
+        B = 3 if N <= 2048 else 2
+        xyz = cloud(N * 7 + len(kind), B, N, kind)
+        exp = O.furthest_point_sampling(xyz, npoint)
+        got = ext.fps_variant(dev(xyz), npoint, _variant=variant).cpu().numpy()
+        assert np.array_equal(got, exp), explain(got, exp, "fps N=%d %s %s" % (N, kind, variant))
+
+
+def test_fps_full_size_batch48(ext):
+    from open3dsot_amd import synth
+    b = synth.make_batch(100, 48)
+    for key, n in (("template_points", 256), ("search_points", 512)):
+        got = ext.furthest_point_sampling(dev(b[key]), n).cpu().numpy()
+        exp = O.furthest_point_sampling(b[key], n)
+        assert np.array_equal(got, exp), explain(got, exp, key)
+        assert (got[:, 0] == 0).all()
+
+
+def test_ball_query_golden_and_edges(ext, golden_index):
+    g = golden_index
+    new_s = np.take_along_axis(g["xyz_s"], g["fps_s"][:, :, None].astype(np.int64), 1)
+    cases = [("ball_s_r03", new_s, g["xyz_s"], 0.3, 32), ("ball_s_r05", new_s[:, :256], new_s, 0.5, 32),
+             ("ball_s_r07", new_s[:, :128], new_s[:, :256], 0.7, 32), ("ball_rpn", new_s[:, :64], new_s[:, :128], 0.3, 16)]
+    for name, c, p, r, ns in cases:
+        got = ext.ball_query(dev(c), dev(p), r, ns).cpu().numpy()
+        assert np.array_equal(got, g[name]), explain(got, g[name], name)
+    for (B, N, npnt, r, ns) in [(1, 1, 1, 0.5, 1), (2, 7, 3, 0.8, 4), (2, 64, 64, 0.5, 16), (3, 65, 9, 3.0, 70),
+                                (2, 200, 33, 0.05, 8), (2, 1000, 100, 10.0, 32), (1, 130, 5, 1.0, 129)]:
+        for kind in ("normal", "dup", "grid", "zero"):
+            p = cloud(N + npnt, B, N, kind)
+            c = cloud(N + npnt + 1, B, npnt, "grid" if kind == "grid" else "normal")
+            exp = O.ball_query(c, p, r, ns)
+            got = ext.ball_query(dev(c), dev(p), r, ns).cpu().numpy()
+            assert np.array_equal(got, exp), explain(got, exp, "ball %s %s" % ((B, N, npnt, r, ns), kind))
+    # boundary: d2 == r2 is excluded (strict <)
+    p = np.array([[[0, 0, 0], [0.5, 0, 0]]], f32)
+    assert ext.ball_query(dev(np.zeros((1, 1, 3), f32)), dev(p), 0.5, 2).cpu().numpy().tolist() == [[[0, 0]]]
+
+
+def test_ball_query_full_size_batch48(ext):
+    from open3dsot_amd import synth
+    b = synth.make_batch(200, 48)
+    xyz = b["search_points"]
+    fps = O.furthest_point_sampling(xyz, 512)
+    new = np.take_along_axis(xyz, fps[:, :, None].astype(np.int64), 1)
+    got = ext.ball_query(dev(new), dev(xyz), 0.3, 32).cpu().numpy()
+    exp = O.ball_query(new, xyz, 0.3, 32)
+    assert np.array_equal(got, exp), explain(got, exp, "ball full")
+    # property at full size: rows ascending until the padding starts, all indices valid
+    assert (got >= 0).all() and (got < 1024).all()
+
+
+def test_group_gather_exact_and_grads(ext):
+    rng = np.random.default_rng(5)
+    for (B, C, N, npnt, ns) in [(1, 1, 1, 1, 1), (2, 3, 17, 5, 4), (3, 19, 100, 33, 7), (48, 131, 512, 256, 32),
+                                (4, 268, 64, 128, 4), (2, 257, 128, 64, 16)]:
+        feats = rng.normal(size=(B, C, N)).astype(f32)
+        idx = rng.integers(0, N, (B, npnt, ns)).astype(np.int32)
+        got = ext.group_points(dev(feats), dev(idx)).cpu().numpy()
+        assert np.array_equal(got, O.group_points(feats, idx)), "group %s" % ((B, C, N, npnt, ns),)
+        go = rng.normal(size=got.shape).astype(f32)
+        gg = ext.group_points_grad(dev(go), dev(idx), N).cpu().numpy()
+        np.testing.assert_allclose(gg, O.group_points_grad(go, idx, N), rtol=1e-4, atol=1e-4)
+        gi = idx[:, :, 0].copy()
+        ga = ext.gather_points(dev(feats), dev(gi)).cpu().numpy()
+        assert np.array_equal(ga, O.gather_points(feats, gi))
+        g2 = rng.normal(size=ga.shape).astype(f32)
+        np.testing.assert_allclose(ext.gather_points_grad(dev(g2), dev(gi), N).cpu().numpy(),
+                                   O.gather_points_grad(g2, gi, N), rtol=1e-4, atol=1e-4)
+
+
+def test_three_nn_interpolate(ext, golden_index):
+    g = golden_index
+    new_s = np.take_along_axis(g["xyz_s"], g["fps_s"][:, :, None].astype(np.int64), 1)
+    d2, idx = ext.three_nn(dev(g["xyz_s"][:, :200]), dev(new_s[:, :77]))
+    assert np.array_equal(idx.cpu().numpy(), g["three_nn_idx"])
+    assert np.array_equal(d2.cpu().numpy(), g["three_nn_d2"])
+    rng = np.random.default_rng(9)
+    for (B, n, m, c) in [(1, 1, 1, 1), (2, 5, 2, 3), (2, 300, 77, 20), (3, 64, 64, 33)]:
+        u, k = cloud(n + m, B, n, "dup"), cloud(n + m + 1, B, m, "dup")
+        d2e, ie = O.three_nn(u, k)
+        d2g, ig = ext.three_nn(dev(u), dev(k))
+        assert np.array_equal(ig.cpu().numpy(), ie) and np.array_equal(d2g.cpu().numpy(), d2e)
+        feats = rng.normal(size=(B, c, m)).astype(f32)
+        w = rng.uniform(size=(B, n, 3)).astype(f32)
+        out = ext.three_interpolate(dev(feats), dev(ie), dev(w)).cpu().numpy()
+        assert np.array_equal(out, O.three_interpolate(feats, ie, w))
+        go = rng.normal(size=out.shape).astype(f32)
+        np.testing.assert_allclose(ext.three_interpolate_grad(dev(go), dev(ie), dev(w), m).cpu().numpy(),
+                                   O.three_interpolate_grad(go, ie, w, m), rtol=1e-4, atol=1e-4)
+
+
+def test_knn_stable(ext, golden_index):
+    g = golden_index
+    from open3dsot_amd import synth
+    b = synth.make_batch(0, 12, 512, 1024)
+    bc_s, bc_t = b["points2cc_dist_s"][:, :128], b["points2cc_dist_t"][:, :64]
+    got = ext.knn(dev(bc_s), dev(bc_t), 4).cpu().numpy()
+    assert np.array_equal(got, g["knn_k4"]), explain(got, g["knn_k4"], "knn golden")
+    rng = np.random.default_rng(11)
+    for (B, Q, R, D, k) in [(1, 1, 1, 1, 1), (2, 9, 5, 3, 5), (2, 130, 64, 9, 4), (2, 50, 40, 9, 8), (1, 33, 70, 2, 16),
+                            (1, 20, 64, 9, 32)]:
+        q = (np.round(rng.normal(size=(B, Q, D)) * 2) / 2).astype(f32)   # exact ties
+        r = (np.round(rng.normal(size=(B, R, D)) * 2) / 2).astype(f32)
+        exp = O.knn(q, r, k)
+        got = ext.knn(dev(q), dev(r), k).cpu().numpy()
+        assert np.array_equal(got, exp), explain(got, exp, "knn %s" % ((B, Q, R, D, k),))
+
+
+def test_error_behaviour(ext):
+    x = torch.zeros(2, 8, 3).cuda()
+    with pytest.raises(RuntimeError):
+        ext.furthest_point_sampling(x.transpose(0, 1), 4)          # non-contiguous
+    with pytest.raises(RuntimeError):
+        ext.group_points(torch.zeros(1, 2, 8).cuda(), torch.zeros(1, 2, 2).cuda())  # idx not int32
+    with pytest.raises(RuntimeError):
+        ext.ball_query(x.double(), x, 0.3, 4)                      # wrong dtype
