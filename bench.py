@@ -75,13 +75,21 @@ def mlp_flops_per_pair(model_name):
 def cpu_baseline(model_name, sd, batch_size, iters):
     """Oracle restatement (oracle/torch_ref.py) of the same training step on the host cores."""
     from oracle import torch_ref
-    torch.set_num_threads(os.cpu_count() or 1)
+    try:
+        import psutil
+        cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
+    except ImportError:
+        cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)      # one thread per physical core
     w = {k: v for k, v in (trackers.BAT_CAR if model_name == "BAT" else trackers.P2B_CAR).items() if k.endswith("_weight")}
     params = {k: v.clone().requires_grad_(v.dtype.is_floating_point and "running" not in k) for k, v in sd.items()}
     leafs = [v for v in params.values() if v.requires_grad]
     opt = torch.optim.Adam(leafs, lr=1e-3, betas=(0.5, 0.999), eps=1e-6)
     times = []
+    t_start = time.perf_counter()
     for it in range(iters + 1):
+        if it >= 2 and time.perf_counter() - t_start > 45.0:   # bounded sample
+            break
         batch = synth.to_torch(synth.make_batch(5000 + it * batch_size, batch_size))
         t0 = time.perf_counter()
         opt.zero_grad()
@@ -97,7 +105,7 @@ def cpu_baseline(model_name, sd, batch_size, iters):
     return {"value": round(batch_size / t, 3), "unit": "pairs/s", "cores": torch.get_num_threads(),
             "kind": "port",
             "sample": "%s fwd+bwd+Adam, batch %d, median of %d iterations after 1 warm-up, oracle/torch_ref.py "
-                      "(C index ops + PyTorch fp32 CPU convs)" % (model_name, batch_size, iters)}
+                      "(C index ops + PyTorch fp32 CPU convs)" % (model_name, batch_size, len(times) - 1)}
 
 
 def main():
@@ -128,9 +136,15 @@ def main():
         if world > 1:
             dist.barrier()
 
+    def log(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    tw = time.perf_counter()
     for i in range(args.warmup):
         trainer.step(pool[i % len(pool)])
     torch.cuda.synchronize()
+    log("warm-up %d steps: %.2f s" % (args.warmup, time.perf_counter() - tw))
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -138,6 +152,7 @@ def main():
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
+    log("timed %d steps: %.3f s" % (args.steps, elapsed))
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -1,0 +1,945 @@
+// mlp.hip -- the grouped-MLP hot loop of the set-abstraction / xcorr stacks as fp32-MFMA
+// GEMMs for gfx950, with everything around the contraction fused into its prologue/epilogue.
+//
+// Replaces, per SharedMLP layer (pointnet2/utils/pytorch_utils.py:12-37,68-121):
+//   Conv2d(1x1, bias=False) -> BatchNorm2d (batch statistics in training) -> ReLU
+// plus the QueryAndGroup gather that feeds layer 0 (pointnet2_utils.py:299-339), the
+// max-pool over nsample (pointnet2_modules.py:70-73) and the whole backward of that chain.
+//
+// Why per-layer kernels: training-mode BatchNorm needs the per-channel mean/variance over
+// ALL B*npoint*nsample positions of a layer before the next layer may consume it, so a layer
+// boundary is a grid-wide dependency.  Each boundary is cut into
+//     GEMM (raw conv output Y + per-tile partial statistics)  ->  tiny finalize kernel
+// and BN+ReLU is applied by the CONSUMER while it stages its operand ("transform on load"),
+// so a normalised activation is never written to HBM.  The grouped (B,3+C,npoint,nsample)
+// tensor is never materialised either: layer 0 gathers straight from (B,C,N) while staging.
+//
+// Contraction: v_mfma_f32_32x32x2_f32 (exact fp32 FMA chain, 157.3 TFLOP/s dense peak).
+//   wave tile 64x64 = 2x2 MFMA tiles (64 accumulator VGPRs), workgroup = 2..8 waves,
+//   operands staged global -> registers (prefetch of chunk t+1 issued before the MFMAs of
+//   chunk t) -> LDS double buffer -> one ds_read per fragment; one barrier per K chunk.
+//   fp32 MFMA is slow relative to LDS/HBM (64 cycles per instruction), so a plain
+//   double-buffered pipeline keeps the matrix pipe busy; occupancy 2 workgroups/CU lets one
+//   workgroup's epilogue (VALU/stores) overlap the other's MFMA stream.
+// K index permutation: inside each group of 8 k's, MFMA step s (0..3) consumes k = 8g+s on
+// lanes 0-31 and k = 8g+4+s on lanes 32-63, so an operand stored [row][k] is fetched with one
+// ds_read_b128 per 4 steps; an operand stored [k][row] uses ds_read_b32 with the same mapping.
+#include "o3d_common.hpp"
+
+#include <mutex>
+#include <unordered_set>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BN_POS = 128;  // positions per workgroup tile (forward / dgrad)
+constexpr int BK = 16;       // channel chunk (forward / dgrad)
+constexpr int LDMK = BK + 4; // [row][k] LDS stride (conflict-free ds_read_b128)
+constexpr int WBK = 32;      // position chunk of the weight-gradient kernel
+constexpr int WLD = WBK + 4;
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+// accumulator register r of a 32x32 tile holds row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// One K chunk of CH k's for a 64x64 wave tile.  A_MK: A stored [m][k] (stride lda) else [k][m].
+template <int CH, bool A_MK, bool B_MK>
+__device__ __forceinline__ void mma_chunk(const float* __restrict__ As, int lda,
+                                          const float* __restrict__ Bs, int ldb, int wm0, int wn0,
+                                          int l31, int h, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int g = 0; g < CH / 8; ++g) {
+        float a[2][4], b[2][4];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            if (A_MK) {
+                const float4 v = *reinterpret_cast<const float4*>(&As[(wm0 + 32 * t + l31) * lda + 8 * g + 4 * h]);
+                a[t][0] = v.x; a[t][1] = v.y; a[t][2] = v.z; a[t][3] = v.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) a[t][s] = As[(8 * g + 4 * h + s) * lda + wm0 + 32 * t + l31];
+            }
+            if (B_MK) {
+                const float4 v = *reinterpret_cast<const float4*>(&Bs[(wn0 + 32 * t + l31) * ldb + 8 * g + 4 * h]);
+                b[t][0] = v.x; b[t][1] = v.y; b[t][2] = v.z; b[t][3] = v.w;
+            } else {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) b[t][s] = Bs[(8 * g + 4 * h + s) * ldb + wn0 + 32 * t + l31];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = mfma32(a[tm][s], b[tn][s], acc[tm][tn]);
+    }
+}
+
+// Reduce-scatter of 32 per-lane values over the 32 lanes of each half-wave: afterwards lane
+// (l&31) holds in x[0] the sum over those 32 lanes of the value with index (l&31).
+__device__ __forceinline__ void reduce_scatter32(float (&x)[32], int l31) {
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {
+        const bool up = (l31 & m) != 0;
+#pragma unroll
+        for (int v = 0; v < m; ++v) {
+            const float keep = up ? x[v + m] : x[v];
+            const float send = up ? x[v] : x[v + m];
+            x[v] = keep + __shfl_xor(send, m, 64);
+        }
+    }
+}
+
+// ======================================================================================
+// K1: forward layer   Y[b,co,p] = sum_ci W[co,ci] * f(X[b,ci,p])
+// ======================================================================================
+struct FwdArgs {
+    const float* X;         // (B,Cin,P) pre-activation of the producer layer, or NULL (GATHER)
+    const float* W;         // (Cout,Cin)
+    float* Y;               // (B,Cout,P) raw conv output
+    const float* in_scale;  // (Cin) f(x) = max(x*scale+shift,0) when XFORM
+    const float* in_shift;
+    float* part;            // [B*P/128][2][Cout] per-tile {sum y, sum (y-c)^2} or NULL
+    const float* stat_c;    // (Cout) shift c of the second moment (running_mean) or NULL (=0)
+    // GATHER mode (layer 0 of a grouped MLP):
+    //   X[b,ci,j*ns+k] = ci < nxyz ? xyz[b,idx[b,j,k],ci] - new_xyz[b,j,ci] : feats[b,ci-nxyz,idx[b,j,k]]
+    const float* xyz;       // (B,N,3) or NULL when nxyz == 0
+    const float* new_xyz;   // (B,npoint,3)
+    const float* feats;     // (B,C,N) or NULL
+    const int32_t* idx;     // (B,npoint*ns)
+    int N, C, ns, nxyz;
+    float inv_radius;       // grouped xyz is multiplied by this (1 unless normalize_xyz)
+    int B, Cin, Cout, P;
+};
+
+template <int BM, bool GATHER, bool XFORM>
+__global__ __launch_bounds__(BM * 2) void conv_fwd_kernel(FwdArgs a) {
+    constexpr int T = BM * 2;            // threads
+    constexpr int NB4 = 512 / T;         // float4 of the X tile per thread (16x128 floats)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    auto As = [&](int buf) -> float* { return smem + buf * (BM * LDMK); };                     // [m][k]
+    auto Bs = [&](int buf) -> float* { return smem + 2 * BM * LDMK + buf * (BK * BN_POS); };  // [k][p]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int tiles_per_b = a.P / BN_POS;
+    const int tile = blockIdx.x;
+    const int b = tile / tiles_per_b;
+    const int p0 = (tile - b * tiles_per_b) * BN_POS;
+    const int co0 = blockIdx.y * BM;
+    const bool w_vec = (a.Cin & 3) == 0;
+
+    // fixed per-thread staging coordinates
+    const int bc4 = tid & 31;            // float4 column of the X tile (positions 4*bc4..+3)
+    const int br0 = tid >> 5;            // first k row; further rows at +T/32
+    int gid[4] = {0, 0, 0, 0};
+    int gj = 0;
+    if (GATHER) {
+        const int4 v = *reinterpret_cast<const int4*>(&a.idx[(long)b * a.P + p0 + 4 * bc4]);
+        gid[0] = v.x; gid[1] = v.y; gid[2] = v.z; gid[3] = v.w;
+        gj = (p0 + 4 * bc4) / a.ns;      // ns % 4 == 0: the four positions share one centre
+    }
+
+    float4 ra[2], rb[NB4];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {    // W tile: BM rows x 16 k  ([m][k] image)
+            const int f = tid + T * i, m = f >> 2, c4 = f & 3;
+            const int co = co0 + m, k = k0 + 4 * c4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < a.Cout) {
+                const float* src = a.W + (long)co * a.Cin + k;
+                if (w_vec && k + 3 < a.Cin) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (k + 0 < a.Cin) v.x = src[0];
+                    if (k + 1 < a.Cin) v.y = src[1];
+                    if (k + 2 < a.Cin) v.z = src[2];
+                    if (k + 3 < a.Cin) v.w = src[3];
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB4; ++i) {  // X tile: 16 k rows x 128 positions ([k][p] image)
+            const int ci = k0 + br0 + (T / 32) * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci < a.Cin) {
+                if (GATHER) {
+                    if (ci < a.nxyz) {
+                        const float c = a.new_xyz[((long)b * (a.P / a.ns) + gj) * 3 + ci];
+                        const float* px = a.xyz + (long)b * a.N * 3 + ci;
+                        v.x = (px[3 * gid[0]] - c) * a.inv_radius;
+                        v.y = (px[3 * gid[1]] - c) * a.inv_radius;
+                        v.z = (px[3 * gid[2]] - c) * a.inv_radius;
+                        v.w = (px[3 * gid[3]] - c) * a.inv_radius;
+                    } else {
+                        const float* pf = a.feats + ((long)b * a.C + (ci - a.nxyz)) * a.N;
+                        v.x = pf[gid[0]]; v.y = pf[gid[1]]; v.z = pf[gid[2]]; v.w = pf[gid[3]];
+                    }
+                } else {
+                    v = *reinterpret_cast<const float4*>(&a.X[((long)b * a.Cin + ci) * a.P + p0 + 4 * bc4]);
+                    if (XFORM) {
+                        const float sc = a.in_scale[ci], sh = a.in_shift[ci];
+                        v.x = fmaxf(fmaf(v.x, sc, sh), 0.f); v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
+                        v.z = fmaxf(fmaf(v.z, sc, sh), 0.f); v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
+                    }
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + T * i, m = f >> 2, c4 = f & 3;
+            *reinterpret_cast<float4*>(&As(buf)[m * LDMK + 4 * c4]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB4; ++i) {
+            const int r = br0 + (T / 32) * i;
+            *reinterpret_cast<float4*>(&Bs(buf)[r * BN_POS + 4 * bc4]) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = (a.Cin + BK - 1) / BK;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int t = 0; t < nchunks; ++t) {
+        if (t + 1 < nchunks) load_chunk((t + 1) * BK);
+        mma_chunk<BK, true, false>(As(t & 1), LDMK, Bs(t & 1), BN_POS, wm0, wn0, l31, h, acc);
+        if (t + 1 < nchunks) store_chunk((t + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: raw output
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm0 + 32 * tm + acc_row(r, h);
+            if (co < a.Cout) {
+                float* dst = a.Y + ((long)b * a.Cout + co) * a.P + p0 + wn0 + l31;
+                dst[0] = acc[tm][0][r];
+                dst[32] = acc[tm][1][r];
+            }
+        }
+    // ---- epilogue: per-tile BatchNorm statistics
+    if (a.part) {
+        float s[32], q[32];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wm0 + 32 * tm + acc_row(r, h);
+                const float c = (a.stat_c && co < a.Cout) ? a.stat_c[co] : 0.f;
+                const float y0 = acc[tm][0][r], y1 = acc[tm][1][r];
+                s[tm * 16 + r] = y0 + y1;
+                q[tm * 16 + r] = (y0 - c) * (y0 - c) + (y1 - c) * (y1 - c);
+            }
+        reduce_scatter32(s, l31);
+        reduce_scatter32(q, l31);
+        // lane l31 now owns value index l31 -> (tm = l31>>4, r = l31&15)
+        float* red = smem;  // [2 (wn)][BM][2]; the staging buffers are free after the last barrier
+        const int row = wm0 + 32 * (l31 >> 4) + acc_row(l31 & 15, h);
+        red[((wave & 1) * BM + row) * 2 + 0] = s[0];
+        red[((wave & 1) * BM + row) * 2 + 1] = q[0];
+        __syncthreads();
+        if (tid < BM && co0 + tid < a.Cout) {
+            float* dst = a.part + (long)tile * 2 * a.Cout + co0 + tid;
+            dst[0] = red[tid * 2 + 0] + red[(BM + tid) * 2 + 0];
+            dst[a.Cout] = red[tid * 2 + 1] + red[(BM + tid) * 2 + 1];
+        }
+    }
+}
+
+// ======================================================================================
+// BatchNorm statistics finalize: partials -> mean / invstd / scale / shift (+ running stats)
+// ======================================================================================
+struct BnFinArgs {
+    const float* part;  // [nparts][2][C]
+    int nparts, C;
+    double count;       // positions reduced (B*P)
+    const float* stat_c; // shift used by the producer for the second moment, or NULL
+    const float* gamma; const float* beta;
+    float* running_mean; float* running_var;  // updated in place when momentum >= 0 (may be NULL)
+    float momentum, eps;
+    float* mean; float* invstd; float* scale; float* shift;  // outputs (C each)
+};
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
+    __shared__ double sh[2][16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < a.C)
+        for (int t = sl; t < a.nparts; t += 16) {
+            s += (double)a.part[((long)t * 2 + 0) * a.C + c];
+            q += (double)a.part[((long)t * 2 + 1) * a.C + c];
+        }
+    sh[0][sl][cl] = s;
+    sh[1][sl][cl] = q;
+    __syncthreads();
+    if (sl == 0 && c < a.C) {
+        s = 0.0; q = 0.0;
+        for (int i = 0; i < 16; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
+        const double cs = a.stat_c ? (double)a.stat_c[c] : 0.0;
+        const double mean = s / a.count;
+        double var = q / a.count - (mean - cs) * (mean - cs);
+        if (var < 0.0) var = 0.0;
+        const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+        const float g = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
+        a.mean[c] = (float)mean;
+        a.invstd[c] = invstd;
+        const float sc = g * invstd;
+        a.scale[c] = sc;
+        a.shift[c] = bt - (float)mean * sc;
+        if (a.running_mean && a.momentum >= 0.f) {
+            const double unbiased = a.count > 1.0 ? var * a.count / (a.count - 1.0) : var;
+            a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+            a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+        }
+    }
+}
+
+// ======================================================================================
+// BN + ReLU + max over the ns neighbours (forward of the pooling that ends a grouped MLP)
+// ======================================================================================
+__global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__ Y,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int C,
+                                                       int npoint, int ns, long total,
+                                                       float* __restrict__ out, int32_t* __restrict__ arg,
+                                                       float* __restrict__ yarg) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // over (b, c, j)
+    if (i >= total) return;
+    const int c = (int)((i / npoint) % C);
+    const float sc = scale[c], sf = shift[c];
+    const float4* src = reinterpret_cast<const float4*>(Y + i * ns);
+    float best = -INFINITY, ybest = 0.f;
+    int bk = 0;
+    for (int k4 = 0; k4 < ns / 4; ++k4) {
+        const float4 v = src[k4];
+        const float y[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float n = fmaf(y[e], sc, sf);
+            if (n > best) { best = n; bk = 4 * k4 + e; ybest = y[e]; }
+        }
+    }
+    out[i] = fmaxf(best, 0.f);
+    if (arg) { arg[i] = bk; yarg[i] = ybest; }
+}
+
+// Backward statistics of the pooled layer: per (b,c) partial {sum g, sum g*(yarg-mean)} with
+// g = dOut where the pooled activation is positive.  One wave per (b,c).
+__global__ __launch_bounds__(256) void pool_bwd_partials_kernel(const float* __restrict__ dOut,
+                                                                const float* __restrict__ out,
+                                                                const float* __restrict__ yarg,
+                                                                const float* __restrict__ mean, int B,
+                                                                int C, int npoint,
+                                                                float* __restrict__ part) {
+    const int lane = threadIdx.x & 63;
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b,c)
+    if (w >= (long)B * C) return;
+    const int b = (int)(w / C), c = (int)(w % C);
+    const float mu = mean[c];
+    float s = 0.f, q = 0.f;
+    for (int j = lane; j < npoint; j += 64) {
+        const long i = w * npoint + j;
+        const float g = out[i] > 0.f ? dOut[i] : 0.f;
+        s += g;
+        q += g * (yarg[i] - mu);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { s += __shfl_xor(s, off, 64); q += __shfl_xor(q, off, 64); }
+    if (lane == 0) {
+        part[((long)b * 2 + 0) * C + c] = s;
+        part[((long)b * 2 + 1) * C + c] = q;
+    }
+}
+
+// BatchNorm backward finalize: partials {sum dN, sum dN*(Y-mean)} -> dgamma, dbeta and the
+// coefficients of dY = A1*dN + A2*Y + A3 (per channel).
+struct BnBwdFinArgs {
+    const float* part; int nparts, C; double count;
+    const float* gamma; const float* mean; const float* invstd;
+    float* dgamma; float* dbeta; float* A1; float* A2; float* A3;
+};
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFinArgs a) {
+    __shared__ double sh[2][16][17];
+    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double s = 0.0, q = 0.0;
+    if (c < a.C)
+        for (int t = sl; t < a.nparts; t += 16) {
+            s += (double)a.part[((long)t * 2 + 0) * a.C + c];
+            q += (double)a.part[((long)t * 2 + 1) * a.C + c];
+        }
+    sh[0][sl][cl] = s;
+    sh[1][sl][cl] = q;
+    __syncthreads();
+    if (sl == 0 && c < a.C) {
+        s = 0.0; q = 0.0;
+        for (int i = 0; i < 16; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
+        const double g = a.gamma ? (double)a.gamma[c] : 1.0;
+        const double is = (double)a.invstd[c], mu = (double)a.mean[c];
+        a.dbeta[c] = (float)s;
+        a.dgamma[c] = (float)(q * is);
+        const double a1 = g * is;
+        const double a2 = -a1 * is * is * q / a.count;
+        const double a3 = -a1 * s / a.count - a2 * mu;
+        a.A1[c] = (float)a1; a.A2[c] = (float)a2; a.A3[c] = (float)a3;
+    }
+}
+
+// ======================================================================================
+// dY operand loader shared by the dgrad and wgrad kernels
+//   dense : dN (B,Cout,P) stored by the consumer layer's dgrad epilogue
+//   pooled: dN[b,co,j*ns+k] = (k == arg[b,co,j] && out[b,co,j] > 0) ? dOut[b,co,j] : 0
+//   dY = A1[co]*dN + A2[co]*Y + A3[co]
+// ======================================================================================
+struct DyArgs {
+    const float* dN;      // dense source or NULL
+    const float* dOut;    // pooled source (B,Cout,npoint)
+    const float* out;     // pooled activation (B,Cout,npoint)
+    const int32_t* arg;   // (B,Cout,npoint)
+    const float* Y;       // (B,Cout,P)
+    const float* A1; const float* A2; const float* A3;
+    int ns;
+};
+
+template <bool POOLED>
+__device__ __forceinline__ float4 load_dy4(const DyArgs& d, long b, int co, int Cout, int P, int p) {
+    const long row = b * Cout + co;
+    const float4 y = *reinterpret_cast<const float4*>(&d.Y[row * P + p]);
+    float4 g;
+    if (POOLED) {
+        const int np = P / d.ns;
+        const int j = p / d.ns, k = p - j * d.ns;
+        const long pi = row * np + j;
+        const int ak = d.arg[pi];
+        const float go = d.out[pi] > 0.f ? d.dOut[pi] : 0.f;
+        g.x = (k + 0 == ak) ? go : 0.f; g.y = (k + 1 == ak) ? go : 0.f;
+        g.z = (k + 2 == ak) ? go : 0.f; g.w = (k + 3 == ak) ? go : 0.f;
+    } else {
+        g = *reinterpret_cast<const float4*>(&d.dN[row * P + p]);
+    }
+    const float a1 = d.A1[co], a2 = d.A2[co], a3 = d.A3[co];
+    float4 r;
+    r.x = fmaf(a1, g.x, fmaf(a2, y.x, a3)); r.y = fmaf(a1, g.y, fmaf(a2, y.y, a3));
+    r.z = fmaf(a1, g.z, fmaf(a2, y.z, a3)); r.w = fmaf(a1, g.w, fmaf(a2, y.w, a3));
+    return r;
+}
+
+// ======================================================================================
+// K2: data gradient   G[b,ci,p] = sum_co W[co,c_lo+ci] * dY[b,co,p],  ci in [0,M)
+//   EPI 0 (MASK):    dNprev = G * [Yprev*scale_p+shift_p > 0] -> store (B,M,P)
+//                    + per-tile partials {sum dNprev, sum dNprev*(Yprev-mean_p)}
+//   EPI 1 (SCATTER): layer 0 of a grouped MLP: scatter-add G through idx into
+//                    dfeats (B,C,N) [channels >= nxyz] and dxyz / dnew_xyz [channels < nxyz]
+// ======================================================================================
+struct DgradArgs {
+    DyArgs dy;
+    const float* W;        // (Cout,Cin)
+    int B, Cin, Cout, P, c_lo, M;
+    // EPI 0
+    const float* Yprev; const float* scale_p; const float* shift_p; const float* mean_p;
+    float* dNprev; float* part;
+    // EPI 1
+    const int32_t* idx; int N, C, nxyz, ns; float inv_radius;
+    float* dfeats; float* dxyz; float* dnew_xyz;
+};
+
+template <int BM, bool POOLED, int EPI>
+__global__ __launch_bounds__(BM * 2) void conv_dgrad_kernel(DgradArgs a) {
+    constexpr int T = BM * 2;
+    constexpr int NB4 = 512 / T;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    auto As = [&](int buf) -> float* { return smem + buf * (BK * BM); };                     // [k][m]
+    auto Bs = [&](int buf) -> float* { return smem + 2 * BK * BM + buf * (BK * BN_POS); };  // [k][p]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int tiles_per_b = a.P / BN_POS;
+    const int tile = blockIdx.x;
+    const int b = tile / tiles_per_b;
+    const int p0 = (tile - b * tiles_per_b) * BN_POS;
+    const int m0 = blockIdx.y * BM;
+    const bool w_vec = ((a.Cin & 3) == 0) && ((a.c_lo & 3) == 0);
+    const int bc4 = tid & 31, br0 = tid >> 5;
+
+    float4 ra[2], rb[NB4];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {     // W^T tile: 16 k(co) rows x BM m(ci)
+            const int f = tid + T * i, r = f / (BM / 4), m4 = f - r * (BM / 4);
+            const int co = k0 + r, m = m0 + 4 * m4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < a.Cout) {
+                const float* src = a.W + (long)co * a.Cin + a.c_lo + m;
+                if (w_vec && m + 3 < a.M) {
+                    v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (m + 0 < a.M) v.x = src[0];
+                    if (m + 1 < a.M) v.y = src[1];
+                    if (m + 2 < a.M) v.z = src[2];
+                    if (m + 3 < a.M) v.w = src[3];
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < NB4; ++i) {   // dY tile: 16 k(co) rows x 128 positions
+            const int co = k0 + br0 + (T / 32) * i;
+            rb[i] = co < a.Cout ? load_dy4<POOLED>(a.dy, b, co, a.Cout, a.P, p0 + 4 * bc4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int f = tid + T * i, r = f / (BM / 4), m4 = f - r * (BM / 4);
+            *reinterpret_cast<float4*>(&As(buf)[r * BM + 4 * m4]) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NB4; ++i) {
+            const int r = br0 + (T / 32) * i;
+            *reinterpret_cast<float4*>(&Bs(buf)[r * BN_POS + 4 * bc4]) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks = (a.Cout + BK - 1) / BK;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    for (int t = 0; t < nchunks; ++t) {
+        if (t + 1 < nchunks) load_chunk((t + 1) * BK);
+        mma_chunk<BK, false, false>(As(t & 1), BM, Bs(t & 1), BN_POS, wm0, wn0, l31, h, acc);
+        if (t + 1 < nchunks) store_chunk((t + 1) & 1);
+        __syncthreads();
+    }
+
+    if (EPI == 0) {
+        float s[32], q[32];
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + 32 * tm + acc_row(r, h);
+                float s_ = 0.f, q_ = 0.f;
+                if (m < a.M) {
+                    const float sc = a.scale_p[m], sf = a.shift_p[m], mu = a.mean_p[m];
+                    const long o = ((long)b * a.M + m) * a.P + p0 + wn0 + l31;
+#pragma unroll
+                    for (int tn = 0; tn < 2; ++tn) {
+                        const float yp = a.Yprev[o + 32 * tn];
+                        const float g = fmaf(yp, sc, sf) > 0.f ? acc[tm][tn][r] : 0.f;
+                        a.dNprev[o + 32 * tn] = g;
+                        s_ += g;
+                        q_ += g * (yp - mu);
+                    }
+                }
+                s[tm * 16 + r] = s_;
+                q[tm * 16 + r] = q_;
+            }
+        reduce_scatter32(s, l31);
+        reduce_scatter32(q, l31);
+        float* red = smem;
+        const int row = wm0 + 32 * (l31 >> 4) + acc_row(l31 & 15, h);
+        red[((wave & 1) * BM + row) * 2 + 0] = s[0];
+        red[((wave & 1) * BM + row) * 2 + 1] = q[0];
+        __syncthreads();
+        if (tid < BM && m0 + tid < a.M) {
+            float* dst = a.part + (long)tile * 2 * a.M + m0 + tid;
+            dst[0] = red[tid * 2 + 0] + red[(BM + tid) * 2 + 0];
+            dst[a.M] = red[tid * 2 + 1] + red[(BM + tid) * 2 + 1];
+        }
+    } else {
+        // scatter through the grouping indices (two positions per lane: tn = 0,1)
+        const int np = a.P / a.ns;
+#pragma unroll
+        for (int tn = 0; tn < 2; ++tn) {
+            const int p = p0 + wn0 + 32 * tn + l31;
+            const int id = a.idx[(long)b * a.P + p];
+            const int j = p / a.ns;
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm0 + 32 * tm + acc_row(r, h);
+                    if (m >= a.M) continue;
+                    const int ci = a.c_lo + m;
+                    const float g = acc[tm][tn][r];
+                    if (ci >= a.nxyz) {
+                        if (a.dfeats) unsafeAtomicAdd(a.dfeats + ((long)b * a.C + (ci - a.nxyz)) * a.N + id, g);
+                    } else if (a.dxyz) {
+                        const float gx = g * a.inv_radius;
+                        unsafeAtomicAdd(a.dxyz + ((long)b * a.N + id) * 3 + ci, gx);
+                        unsafeAtomicAdd(a.dnew_xyz + ((long)b * np + j) * 3 + ci, -gx);
+                    }
+                }
+        }
+    }
+}
+
+// ======================================================================================
+// K3: weight gradient   dW[co,ci] = sum_{b,p} dY[b,co,p] * X[b,ci,p]   (split over positions)
+//   X: transform-on-load of the producer's raw output, or the layer-0 gather.
+//   Each workgroup reduces `chunks_per_block` chunks of 32 positions into a 128x128 tile of
+//   partial dW and writes it to part[z][Cout][Cin]; wgrad_reduce_kernel sums the slices.
+// ======================================================================================
+struct WgradArgs {
+    DyArgs dy;
+    const float* X; const float* in_scale; const float* in_shift;  // non-gather source
+    const float* xyz; const float* new_xyz; const float* feats; const int32_t* idx;  // gather
+    int N, C, ns, nxyz; float inv_radius;
+    int B, Cin, Cout, P;
+    int chunks_per_block, total_chunks;
+    float* part;   // [gridDim.z][Cout][Cin]
+};
+
+template <bool POOLED, bool GATHER, bool XFORM>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    auto As = [&](int buf) -> float* { return smem + buf * (128 * WLD); };        // dY^T  [co][pos]
+    auto Bs = [&](int buf) -> float* { return smem + (2 + buf) * (128 * WLD); };  // X^T   [ci][pos]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
+    const int ci0 = blockIdx.x * 128, co0 = blockIdx.y * 128;
+    const int c_begin = blockIdx.z * a.chunks_per_block;
+    int c_end = c_begin + a.chunks_per_block;
+    if (c_end > a.total_chunks) c_end = a.total_chunks;
+    const int chunks_per_b = a.P / WBK;
+    const int r0 = tid >> 3, c4 = tid & 7;   // row (+32*i) and float4 column inside a chunk
+
+    float4 ra[4], rb[4];
+    auto load_chunk = [&](int ch) {
+        const long b = ch / chunks_per_b;
+        const int p = (ch - (int)b * chunks_per_b) * WBK + 4 * c4;
+        int gid[4] = {0, 0, 0, 0};
+        int gj = 0;
+        if (GATHER) {
+            const int4 v = *reinterpret_cast<const int4*>(&a.idx[b * a.P + p]);
+            gid[0] = v.x; gid[1] = v.y; gid[2] = v.z; gid[3] = v.w;
+            gj = p / a.ns;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = co0 + r0 + 32 * i;
+            ra[i] = co < a.Cout ? load_dy4<POOLED>(a.dy, b, co, a.Cout, a.P, p)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int ci = ci0 + r0 + 32 * i;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ci < a.Cin) {
+                if (GATHER) {
+                    if (ci < a.nxyz) {
+                        const float c = a.new_xyz[(b * (a.P / a.ns) + gj) * 3 + ci];
+                        const float* px = a.xyz + b * a.N * 3 + ci;
+                        v.x = (px[3 * gid[0]] - c) * a.inv_radius; v.y = (px[3 * gid[1]] - c) * a.inv_radius;
+                        v.z = (px[3 * gid[2]] - c) * a.inv_radius; v.w = (px[3 * gid[3]] - c) * a.inv_radius;
+                    } else {
+                        const float* pf = a.feats + (b * a.C + (ci - a.nxyz)) * a.N;
+                        v.x = pf[gid[0]]; v.y = pf[gid[1]]; v.z = pf[gid[2]]; v.w = pf[gid[3]];
+                    }
+                } else {
+                    v = *reinterpret_cast<const float4*>(&a.X[(b * a.Cin + ci) * a.P + p]);
+                    if (XFORM) {
+                        const float sc = a.in_scale[ci], sh = a.in_shift[ci];
+                        v.x = fmaxf(fmaf(v.x, sc, sh), 0.f); v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
+                        v.z = fmaxf(fmaf(v.z, sc, sh), 0.f); v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
+                    }
+                }
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<float4*>(&As(buf)[(r0 + 32 * i) * WLD + 4 * c4]) = ra[i];
+            *reinterpret_cast<float4*>(&Bs(buf)[(r0 + 32 * i) * WLD + 4 * c4]) = rb[i];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
+        store_chunk(0);
+        __syncthreads();
+        for (int ch = c_begin; ch < c_end; ++ch) {
+            const int t = ch - c_begin;
+            if (ch + 1 < c_end) load_chunk(ch + 1);
+            mma_chunk<WBK, true, true>(As(t & 1), WLD, Bs(t & 1), WLD, wm0, wn0, l31, h, acc);
+            if (ch + 1 < c_end) store_chunk((t + 1) & 1);
+            __syncthreads();
+        }
+    }
+    float* dst = a.part + (long)blockIdx.z * a.Cout * a.Cin;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm0 + 32 * tm + acc_row(r, h);
+            if (co >= a.Cout) continue;
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) {
+                const int ci = ci0 + wn0 + 32 * tn + l31;
+                if (ci < a.Cin) dst[(long)co * a.Cin + ci] = acc[tm][tn][r];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nslices,
+                                                           long n, float* __restrict__ dW) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int z = 0; z < nslices; ++z) s += part[(long)z * n + i];
+    dW[i] = s;
+}
+
+template <typename K, typename A>
+int launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, const A& args) {
+    if (lds > 48 * 1024) {  // dynamic LDS beyond the default window must be opted into, once per kernel
+        static std::mutex mu;
+        static std::unordered_set<const void*> done;
+        std::lock_guard<std::mutex> lock(mu);
+        const void* key = reinterpret_cast<const void*>(kernel);
+        if (!done.count(key)) {
+            if (hipFuncSetAttribute(key, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return O3D_ELAUNCH;
+            done.insert(key);
+        }
+    }
+    hipLaunchKernelGGL(kernel, grid, block, lds, s, args);
+    return o3d_launch_status();
+}
+
+inline size_t fwd_lds(int BM) { return sizeof(float) * (2 * BM * LDMK + 2 * BK * BN_POS); }
+inline size_t dgrad_lds(int BM) {
+    size_t stage = sizeof(float) * (2 * BK * BM + 2 * BK * BN_POS), red = sizeof(float) * 4 * BM;
+    return stage > red ? stage : red;
+}
+
+template <bool GATHER, bool XFORM>
+int launch_fwd(const FwdArgs& a, hipStream_t s) {
+    const int tiles = a.B * (a.P / BN_POS);
+    if (a.Cout > 128) {
+        return launch(conv_fwd_kernel<256, GATHER, XFORM>, dim3(tiles, o3d_cdiv(a.Cout, 256)), dim3(512),
+                      fwd_lds(256), s, a);
+    } else if (a.Cout > 64) {
+        return launch(conv_fwd_kernel<128, GATHER, XFORM>, dim3(tiles, 1), dim3(256), fwd_lds(128), s, a);
+    }
+    return launch(conv_fwd_kernel<64, GATHER, XFORM>, dim3(tiles, 1), dim3(128), fwd_lds(64), s, a);
+}
+
+template <bool POOLED, int EPI>
+int launch_dgrad(const DgradArgs& a, hipStream_t s) {
+    const int tiles = a.B * (a.P / BN_POS);
+    if (a.M > 128) {
+        return launch(conv_dgrad_kernel<256, POOLED, EPI>, dim3(tiles, o3d_cdiv(a.M, 256)), dim3(512),
+                      dgrad_lds(256), s, a);
+    } else if (a.M > 64) {
+        return launch(conv_dgrad_kernel<128, POOLED, EPI>, dim3(tiles, 1), dim3(256), dgrad_lds(128), s, a);
+    }
+    return launch(conv_dgrad_kernel<64, POOLED, EPI>, dim3(tiles, 1), dim3(128), dgrad_lds(64), s, a);
+}
+
+}  // namespace
+
+// --------------------------------------------------------------------------------------
+// C-ABI
+// --------------------------------------------------------------------------------------
+extern "C" int o3d_mlp_conv_fwd(const float* X, const float* W, const float* in_scale,
+                                const float* in_shift, int B, int Cin, int Cout, int P, float* Y,
+                                float* part, const float* stat_c, void* stream) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || P <= 0 || P % BN_POS != 0 || !X || !W || !Y) return O3D_EINVAL;
+    FwdArgs a = {};
+    a.X = X; a.W = W; a.Y = Y; a.in_scale = in_scale; a.in_shift = in_shift; a.part = part; a.stat_c = stat_c;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = P; a.ns = 4; a.inv_radius = 1.f;
+    return in_scale ? launch_fwd<false, true>(a, o3d_stream(stream)) : launch_fwd<false, false>(a, o3d_stream(stream));
+}
+
+extern "C" int o3d_mlp_conv_grouped_fwd(const float* xyz, const float* new_xyz, const float* feats,
+                                        const int32_t* idx, const float* W, int B, int N, int C,
+                                        int npoint, int ns, int nxyz, float inv_radius, int Cout,
+                                        float* Y, float* part, const float* stat_c, void* stream) {
+    const long P = (long)npoint * ns;
+    if (B <= 0 || N <= 0 || C < 0 || npoint <= 0 || ns <= 0 || ns % 4 != 0 || P % BN_POS != 0 ||
+        (nxyz != 0 && nxyz != 3) || nxyz + C <= 0 || !idx || !W || !Y || (nxyz && (!xyz || !new_xyz)) ||
+        (C && !feats))
+        return O3D_EINVAL;
+    FwdArgs a = {};
+    a.W = W; a.Y = Y; a.part = part; a.stat_c = stat_c;
+    a.xyz = xyz; a.new_xyz = new_xyz; a.feats = feats; a.idx = idx;
+    a.N = N; a.C = C; a.ns = ns; a.nxyz = nxyz; a.inv_radius = inv_radius;
+    a.B = B; a.Cin = nxyz + C; a.Cout = Cout; a.P = (int)P;
+    return launch_fwd<true, false>(a, o3d_stream(stream));
+}
+
+extern "C" int o3d_bn_finalize(const float* part, int nparts, int C, double count, const float* stat_c,
+                               const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, float momentum, float eps, float* mean,
+                               float* invstd, float* scale, float* shift, void* stream) {
+    if (!part || nparts <= 0 || C <= 0 || !mean || !invstd || !scale || !shift) return O3D_EINVAL;
+    BnFinArgs a = {part, nparts, C, count, stat_c, gamma, beta, running_mean, running_var, momentum, eps,
+                   mean, invstd, scale, shift};
+    return launch(bn_finalize_kernel, dim3(o3d_cdiv(C, 16)), dim3(256), 0, o3d_stream(stream), a);
+}
+
+extern "C" int o3d_bn_relu_maxpool_fwd(const float* Y, const float* scale, const float* shift, int B,
+                                       int C, int npoint, int ns, float* out, int32_t* arg,
+                                       float* yarg, void* stream) {
+    if (B <= 0 || C <= 0 || npoint <= 0 || ns <= 0 || ns % 4 != 0 || !Y || !scale || !shift || !out ||
+        (arg && !yarg))
+        return O3D_EINVAL;
+    const long total = (long)B * C * npoint;
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(o3d_cdiv(total, 256)), dim3(256), 0, o3d_stream(stream), Y,
+                       scale, shift, C, npoint, ns, total, out, arg, yarg);
+    return o3d_launch_status();
+}
+
+extern "C" int o3d_pool_bwd_partials(const float* dOut, const float* out, const float* yarg,
+                                     const float* mean, int B, int C, int npoint, float* part,
+                                     void* stream) {
+    if (B <= 0 || C <= 0 || npoint <= 0 || !dOut || !out || !yarg || !mean || !part) return O3D_EINVAL;
+    hipLaunchKernelGGL(pool_bwd_partials_kernel, dim3(o3d_cdiv((long)B * C, 4)), dim3(256), 0,
+                       o3d_stream(stream), dOut, out, yarg, mean, B, C, npoint, part);
+    return o3d_launch_status();
+}
+
+extern "C" int o3d_bn_bwd_finalize(const float* part, int nparts, int C, double count, const float* gamma,
+                                   const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                   float* A1, float* A2, float* A3, void* stream) {
+    if (!part || nparts <= 0 || C <= 0 || !mean || !invstd || !dgamma || !dbeta || !A1 || !A2 || !A3)
+        return O3D_EINVAL;
+    BnBwdFinArgs a = {part, nparts, C, count, gamma, mean, invstd, dgamma, dbeta, A1, A2, A3};
+    return launch(bn_bwd_finalize_kernel, dim3(o3d_cdiv(C, 16)), dim3(256), 0, o3d_stream(stream), a);
+}
+
+static int fill_dy(DyArgs& d, const float* dN, const float* dOut, const float* out, const int32_t* arg,
+                   const float* Y, const float* A1, const float* A2, const float* A3, int ns) {
+    if (!Y || !A1 || !A2 || !A3) return O3D_EINVAL;
+    if (!dN && (!dOut || !out || !arg || ns <= 0 || ns % 4 != 0)) return O3D_EINVAL;
+    d.dN = dN; d.dOut = dOut; d.out = out; d.arg = arg; d.Y = Y; d.A1 = A1; d.A2 = A2; d.A3 = A3;
+    d.ns = ns > 0 ? ns : 4;
+    return O3D_OK;
+}
+
+// data gradient w.r.t. the (BN+ReLU'd) input of a layer; see DgradArgs for the two epilogues
+extern "C" int o3d_mlp_conv_dgrad(const float* dN, const float* dOut, const float* out, const int32_t* arg,
+                                  int ns, const float* Y, const float* A1, const float* A2, const float* A3,
+                                  const float* W, int B, int Cin, int Cout, int P,
+                                  const float* Yprev, const float* scale_p, const float* shift_p,
+                                  const float* mean_p, float* dNprev, float* part, void* stream) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || P <= 0 || P % BN_POS != 0 || !W || !Yprev || !scale_p ||
+        !shift_p || !mean_p || !dNprev || !part)
+        return O3D_EINVAL;
+    DgradArgs a = {};
+    if (fill_dy(a.dy, dN, dOut, out, arg, Y, A1, A2, A3, ns) != O3D_OK) return O3D_EINVAL;
+    a.W = W; a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = P; a.c_lo = 0; a.M = Cin;
+    a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p; a.dNprev = dNprev; a.part = part;
+    a.ns = 4; a.inv_radius = 1.f;
+    return dN ? launch_dgrad<false, 0>(a, o3d_stream(stream)) : launch_dgrad<true, 0>(a, o3d_stream(stream));
+}
+
+// data gradient of grouped layer 0, scattered through idx.  Channels [c_lo, Cin) of the grouped
+// input are differentiated; dfeats (B,C,N) / dxyz (B,N,3) / dnew_xyz (B,npoint,3) must be
+// zero-initialised by the caller and receive atomic adds.  dxyz/dnew_xyz may be NULL.
+extern "C" int o3d_mlp_conv_grouped_dgrad(const float* dN, const float* dOut, const float* out,
+                                          const int32_t* arg, const float* Y, const float* A1,
+                                          const float* A2, const float* A3, const float* W,
+                                          const int32_t* idx, int B, int N, int C, int npoint, int ns,
+                                          int nxyz, float inv_radius, int Cout, int c_lo, float* dfeats,
+                                          float* dxyz, float* dnew_xyz, void* stream) {
+    const long P = (long)npoint * ns;
+    const int Cin = nxyz + C;
+    if (B <= 0 || N <= 0 || C < 0 || npoint <= 0 || ns <= 0 || ns % 4 != 0 || P % BN_POS != 0 || Cout <= 0 ||
+        c_lo < 0 || c_lo >= Cin || !W || !idx || (dxyz && !dnew_xyz))
+        return O3D_EINVAL;
+    DgradArgs a = {};
+    if (fill_dy(a.dy, dN, dOut, out, arg, Y, A1, A2, A3, ns) != O3D_OK) return O3D_EINVAL;
+    a.W = W; a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = (int)P; a.c_lo = c_lo; a.M = Cin - c_lo;
+    a.idx = idx; a.N = N; a.C = C; a.nxyz = nxyz; a.ns = ns; a.inv_radius = inv_radius;
+    a.dfeats = dfeats; a.dxyz = dxyz; a.dnew_xyz = dnew_xyz;
+    return dN ? launch_dgrad<false, 1>(a, o3d_stream(stream)) : launch_dgrad<true, 1>(a, o3d_stream(stream));
+}
+
+// weight gradient.  `part` is scratch of nslices*Cout*Cin floats; dW (Cout,Cin) is overwritten.
+// X source: (X, in_scale, in_shift) for inner layers (in_scale NULL = identity), or the layer-0
+// gather (xyz,new_xyz,feats,idx,N,C,nxyz) when X == NULL.
+extern "C" int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const float* out, const int32_t* arg,
+                                  int ns, const float* Y, const float* A1, const float* A2, const float* A3,
+                                  const float* X, const float* in_scale, const float* in_shift,
+                                  const float* xyz, const float* new_xyz, const float* feats,
+                                  const int32_t* idx, int N, int C, int nxyz, float inv_radius,
+                                  int B, int Cin, int Cout, int P, int nslices, float* part, float* dW,
+                                  void* stream) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || P <= 0 || P % WBK != 0 || nslices <= 0 || !part || !dW)
+        return O3D_EINVAL;
+    const bool gather = X == nullptr;
+    if (gather && (!idx || ns <= 0 || ns % 4 != 0 || nxyz + C != Cin || (nxyz && (!xyz || !new_xyz)) || (C && !feats)))
+        return O3D_EINVAL;
+    WgradArgs a = {};
+    if (fill_dy(a.dy, dN, dOut, out, arg, Y, A1, A2, A3, ns) != O3D_OK) return O3D_EINVAL;
+    a.X = X; a.in_scale = in_scale; a.in_shift = in_shift;
+    a.xyz = xyz; a.new_xyz = new_xyz; a.feats = feats; a.idx = idx;
+    a.N = N; a.C = C; a.ns = ns > 0 ? ns : 4; a.nxyz = nxyz; a.inv_radius = inv_radius;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = P;
+    a.total_chunks = B * (P / WBK);
+    a.chunks_per_block = (a.total_chunks + nslices - 1) / nslices;
+    a.part = part;
+    const dim3 grid(o3d_cdiv(Cin, 128), o3d_cdiv(Cout, 128), nslices), block(256);
+    const size_t lds = sizeof(float) * 4 * 128 * WLD;
+    hipStream_t s = o3d_stream(stream);
+    int rc;
+    const bool pooled = dN == nullptr;
+    if (gather) {
+        rc = pooled ? launch(conv_wgrad_kernel<true, true, false>, grid, block, lds, s, a)
+                    : launch(conv_wgrad_kernel<false, true, false>, grid, block, lds, s, a);
+    } else if (in_scale) {
+        rc = pooled ? launch(conv_wgrad_kernel<true, false, true>, grid, block, lds, s, a)
+                    : launch(conv_wgrad_kernel<false, false, true>, grid, block, lds, s, a);
+    } else {
+        rc = pooled ? launch(conv_wgrad_kernel<true, false, false>, grid, block, lds, s, a)
+                    : launch(conv_wgrad_kernel<false, false, false>, grid, block, lds, s, a);
+    }
+    if (rc != O3D_OK) return rc;
+    const long n = (long)Cout * Cin;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(o3d_cdiv(n, 256)), dim3(256), 0, s, part, nslices, n, dW);
+    return o3d_launch_status();
+}

@@ -1,10 +1,330 @@
-"""Fused grouped-MLP path (gather + 1x1 conv + BatchNorm + ReLU + max-pool on fp32 MFMA).
-Placeholder until csrc/mlp.hip lands: reports 'unsupported' so callers use the composed path."""
+"""Fused grouped-MLP path: gather + 1x1 conv + BatchNorm + ReLU + max-pool (+ full backward)
+on the fp32-MFMA kernels of csrc/mlp.hip, behind the reference's module boundary.
+
+What it replaces, numerically identical within fp32 rounding (tests/test_fused_gpu.py):
+  QueryAndGroup.forward            pointnet2/utils/pointnet2_utils.py:299-339
+  SharedMLP (Conv2d+BN2d+ReLU x L) pointnet2/utils/pytorch_utils.py:12-37,68-121
+  F.max_pool2d over nsample        pointnet2/utils/pointnet2_modules.py:69-73
+  BoxAwareXCorr's group+mlp+max    models/head/xcorr.py:89-100
+Parameters stay in the reference's module tree (state_dict keys unchanged); this module only
+reads `conv.weight`, `bn.bn.{weight,bias,running_mean,running_var,num_batches_tracked}`.
+
+Data flow per layer (training): GEMM writes the raw conv output Y_l and per-tile partial
+statistics; `bn_finalize` turns them into mean/invstd/scale/shift and updates the running
+statistics exactly like torch.nn.BatchNorm2d (biased variance to normalise, unbiased into
+running_var, momentum 0.1); the NEXT kernel applies BN+ReLU while loading.  Saved for
+backward: Y_l and four per-channel vectors per layer, plus arg-max of the pool.
+"""
+import ctypes
+import math
+
+import torch
+from torch import nn
+
+from . import capi
+from .ops import QueryAndGroup
+
+_vp, _i, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double
+capi.register("o3d_mlp_conv_fwd", [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_grouped_fwd", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp])
+capi.register("o3d_bn_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_bn_relu_maxpool_fwd", [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
+capi.register("o3d_pool_bwd_partials", [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp])
+capi.register("o3d_bn_bwd_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_dgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
+                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_grouped_dgrad", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
+                                             _i, _f, _i, _i, _vp, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_wgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                     _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp])
+
+TILE = 128  # positions per workgroup tile of the GEMM kernels (csrc/mlp.hip BN_POS)
+
+# ---- optional per-kernel timing (bench.py's roofline leg) ---------------------------------
+_PROF = {"on": False, "events": []}
 
 
-def supports(grouper, mlp, features):
-    return False
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _call(name, flops, fn, *args):
+    """Launch one C-ABI entry; when profiling, bracket it with HIP events on the launch stream."""
+    if _PROF["on"]:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn(*args)
+        e1.record()
+        _PROF["events"].append((name, flops, e0, e1))
+    else:
+        rc = fn(*args)
+    capi.check(rc, name)
+
+
+def profile_step(step_fn, peak_tflops, repeats=3):
+    """Run `step_fn` with every fused launch bracketed by HIP events; returns the roofline dict
+    of the dominant kernel family (the three MFMA GEMM kernels: forward / dgrad / wgrad)."""
+    torch.cuda.synchronize()
+    _PROF["events"] = []
+    _PROF["on"] = True
+    try:
+        for _ in range(repeats):
+            step_fn()
+        torch.cuda.synchronize()
+    finally:
+        _PROF["on"] = False
+    agg = {}
+    for name, flops, e0, e1 in _PROF["events"]:
+        a = agg.setdefault(name, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += flops
+        a[2] += e0.elapsed_time(e1)
+    _PROF["events"] = []
+    gemm = {k: v for k, v in agg.items() if k in ("conv_fwd", "conv_grouped_fwd", "conv_dgrad",
+                                                    "conv_grouped_dgrad", "conv_wgrad")}
+    if not gemm:
+        return None
+    launches = sum(v[0] for v in gemm.values())
+    flops = sum(v[1] for v in gemm.values())
+    ms = sum(v[2] for v in gemm.values())
+    ach = flops / (ms * 1e-3) / 1e12
+    per_kernel = {k: {"launches": v[0] // repeats, "ms_per_step": round(v[2] / repeats, 4),
+                      "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2) if v[2] > 0 else None}
+                  for k, v in sorted(agg.items())}
+    return {"bound": "mfma", "achieved": round(ach, 3), "peak": peak_tflops, "unit": "TFLOP/s",
+            "frac": round(ach / peak_tflops, 4), "traffic": None,
+            "kernel": "fp32-MFMA grouped-MLP GEMMs (conv_fwd/dgrad/wgrad kernels of csrc/mlp.hip), "
+                      "algorithmic 2*Cin*Cout*positions FLOPs per launch / HIP-event time",
+            "launches_per_step": launches // repeats, "avg_launch_ms": round(ms / launches, 5),
+            "gemm_ms_per_step": round(ms / repeats, 4), "per_kernel": per_kernel}
+
+
+# ---- module introspection --------------------------------------------------------------
+def _layers(mlp):
+    """[(conv, bn)] of a SharedMLP whose layers are conv(1x1,no bias) -> BatchNorm2d -> ReLU."""
+    out = []
+    for layer in mlp.children():
+        kids = dict(layer.named_children())
+        conv, bnw, act = kids.get("conv"), kids.get("bn"), kids.get("activation")
+        if conv is None or bnw is None or not isinstance(act, nn.ReLU) or list(kids)[0] != "conv":
+            return None
+        bn = getattr(bnw, "bn", None)
+        if not isinstance(conv, nn.Conv2d) or not isinstance(bn, nn.BatchNorm2d):
+            return None
+        if conv.bias is not None or conv.kernel_size != (1, 1) or conv.stride != (1, 1) or conv.groups != 1:
+            return None
+        if not bn.affine or not bn.track_running_stats or bn.momentum is None:
+            return None
+        out.append((conv, bn))
+    return out or None
 
 
 def supports_mlp(mlp):
-    return False
+    return _layers(mlp) is not None
+
+
+def supports(grouper, mlp, features):
+    return isinstance(grouper, QueryAndGroup) and grouper.use_xyz and supports_mlp(mlp)
+
+
+def _shape_ok(npoint, ns):
+    return ns % 4 == 0 and (npoint * ns) % TILE == 0
+
+
+# ---- the autograd function ---------------------------------------------------------------
+class _Cfg:
+    __slots__ = ("nxyz", "inv_radius", "training", "bns", "eps", "momentum")
+
+
+class FusedGroupedMLP(torch.autograd.Function):
+    """(xyz, new_xyz, feats, idx, cfg, W0,g0,b0, W1,g1,b1, ...) -> pooled (B, C_last, npoint)"""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feats, idx, cfg, *params):
+        lib = capi.load()
+        L = len(params) // 3
+        Ws = [params[3 * l].detach().reshape(params[3 * l].shape[0], -1).contiguous() for l in range(L)]
+        gammas = [params[3 * l + 1].detach().contiguous() for l in range(L)]
+        betas = [params[3 * l + 2].detach().contiguous() for l in range(L)]
+        B, npoint, ns = idx.shape
+        P = npoint * ns
+        dev = idx.device
+        nxyz = cfg.nxyz
+        C = feats.shape[1] if feats is not None else 0
+        N = feats.shape[2] if feats is not None else xyz.shape[1]
+        xyz_c = xyz.detach().contiguous() if nxyz else None
+        new_c = new_xyz.detach().contiguous() if nxyz else None
+        feats_c = feats.detach().contiguous() if feats is not None else None
+        ntiles = B * (P // TILE)
+        st = _stream()
+        Ys, means, invstds, scales, shifts = [], [], [], [], []
+        for l in range(L):
+            Cout, Cin = Ws[l].shape
+            bn = cfg.bns[l]
+            Y = torch.empty((B, Cout, P), device=dev, dtype=torch.float32)
+            part = torch.empty((ntiles, 2, Cout), device=dev, dtype=torch.float32) if cfg.training else None
+            stat_c = bn.running_mean if cfg.training else None
+            flops = 2.0 * Cin * Cout * B * P
+            if l == 0:
+                _call("conv_grouped_fwd", flops, lib.o3d_mlp_conv_grouped_fwd, _ptr(xyz_c), _ptr(new_c), _ptr(feats_c),
+                      idx.data_ptr(), Ws[0].data_ptr(), B, N, C, npoint, ns, nxyz, cfg.inv_radius, Cout,
+                      Y.data_ptr(), _ptr(part), _ptr(stat_c), st)
+            else:
+                _call("conv_fwd", flops, lib.o3d_mlp_conv_fwd, Ys[-1].data_ptr(), Ws[l].data_ptr(),
+                      scales[-1].data_ptr(), shifts[-1].data_ptr(), B, Cin, Cout, P, Y.data_ptr(), _ptr(part),
+                      _ptr(stat_c), st)
+            vec = torch.empty((4, Cout), device=dev, dtype=torch.float32)
+            if cfg.training:
+                _call("bn_finalize", 0.0, lib.o3d_bn_finalize, part.data_ptr(), ntiles, Cout, float(B) * P,
+                      stat_c.data_ptr(), gammas[l].data_ptr(), betas[l].data_ptr(), bn.running_mean.data_ptr(),
+                      bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps), vec[0].data_ptr(),
+                      vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), st)
+                bn.num_batches_tracked.add_(1)
+            else:
+                vec[0].copy_(bn.running_mean)
+                vec[1].copy_(torch.rsqrt(bn.running_var + bn.eps))
+                vec[2].copy_(gammas[l] * vec[1])
+                vec[3].copy_(betas[l] - vec[0] * vec[2])
+            Ys.append(Y)
+            means.append(vec[0]); invstds.append(vec[1]); scales.append(vec[2]); shifts.append(vec[3])
+        Cl = Ws[-1].shape[0]
+        out = torch.empty((B, Cl, npoint), device=dev, dtype=torch.float32)
+        need_bwd = any(ctx.needs_input_grad)
+        arg = torch.empty((B, Cl, npoint), device=dev, dtype=torch.int32) if need_bwd else None
+        yarg = torch.empty((B, Cl, npoint), device=dev, dtype=torch.float32) if need_bwd else None
+        _call("pool_fwd", 0.0, lib.o3d_bn_relu_maxpool_fwd, Ys[-1].data_ptr(), scales[-1].data_ptr(),
+              shifts[-1].data_ptr(), B, Cl, npoint, ns, out.data_ptr(), _ptr(arg), _ptr(yarg), st)
+        if need_bwd:
+            ctx.cfg = cfg
+            ctx.dims = (B, N, C, npoint, ns, L)
+            ctx.saved = (xyz_c, new_c, feats_c, idx, Ws, gammas, Ys, means, invstds, scales, shifts, out, arg, yarg)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        lib = capi.load()
+        cfg = ctx.cfg
+        B, N, C, npoint, ns, L = ctx.dims
+        xyz_c, new_c, feats_c, idx, Ws, gammas, Ys, means, invstds, scales, shifts, out, arg, yarg = ctx.saved
+        P = npoint * ns
+        dev = idx.device
+        st = _stream()
+        dOut = dOut.contiguous()
+        nxyz = cfg.nxyz
+        count = float(B) * P
+        ntiles = B * (P // TILE)
+        grads = [None] * (3 * L)
+        want_xyz = nxyz > 0 and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        want_feats = feats_c is not None and ctx.needs_input_grad[2]
+
+        # BN-backward coefficients of the last (pooled) layer
+        Cl = Ws[-1].shape[0]
+        part = torch.empty((B, 2, Cl), device=dev, dtype=torch.float32)
+        _call("pool_bwd_partials", 0.0, lib.o3d_pool_bwd_partials, dOut.data_ptr(), out.data_ptr(), yarg.data_ptr(),
+              means[-1].data_ptr(), B, Cl, npoint, part.data_ptr(), st)
+        nparts = B
+        dN = None  # dense dN of the current layer (None = pooled source)
+        dfeats = dxyz = dnew = None
+        for l in range(L - 1, -1, -1):
+            Cout, Cin = Ws[l].shape
+            coef = torch.empty((5, Cout), device=dev, dtype=torch.float32)  # dgamma dbeta A1 A2 A3
+            _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize, part.data_ptr(), nparts, Cout, count,
+                  gammas[l].data_ptr(), means[l].data_ptr(), invstds[l].data_ptr(), coef[0].data_ptr(),
+                  coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr(), st)
+            if not cfg.training:      # eval-mode BN is a fixed affine map: dY = scale * dN
+                coef[3].zero_()
+                coef[4].zero_()
+            grads[3 * l + 1], grads[3 * l + 2] = coef[0], coef[1]
+            src = (_ptr(dN), dOut.data_ptr(), out.data_ptr(), arg.data_ptr()) if dN is None else \
+                  (dN.data_ptr(), None, None, None)
+            A = (coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr())
+            flops = 2.0 * Cin * Cout * B * P
+            # ---- weight gradient
+            tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
+            total_chunks = B * (P // 32)
+            nsl = max(1, min(total_chunks // 4 if total_chunks >= 4 else 1, 768 // tiles))
+            wpart = torch.empty((nsl, Cout, Cin), device=dev, dtype=torch.float32)
+            dW = torch.empty((Cout, Cin), device=dev, dtype=torch.float32)
+            if l == 0:
+                xsrc = (None, None, None, _ptr(xyz_c), _ptr(new_c), _ptr(feats_c), idx.data_ptr(), N, C, nxyz,
+                        cfg.inv_radius)
+            else:
+                xsrc = (Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), None, None, None,
+                        None, 0, 0, 0, 1.0)
+            _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad, src[0], src[1], src[2], src[3], ns, Ys[l].data_ptr(),
+                  A[0], A[1], A[2], *xsrc, B, Cin, Cout, P, nsl, wpart.data_ptr(), dW.data_ptr(), st)
+            grads[3 * l] = dW
+            # ---- data gradient
+            if l > 0:
+                dNp = torch.empty((B, Cin, P), device=dev, dtype=torch.float32)
+                part = torch.empty((ntiles, 2, Cin), device=dev, dtype=torch.float32)
+                _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad, src[0], src[1], src[2], src[3], ns,
+                      Ys[l].data_ptr(), A[0], A[1], A[2], Ws[l].data_ptr(), B, Cin, Cout, P, Ys[l - 1].data_ptr(),
+                      scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),
+                      part.data_ptr(), st)
+                nparts = ntiles
+                dN = dNp
+            elif want_xyz or want_feats:
+                c_lo = 0 if want_xyz else nxyz
+                if want_feats:
+                    dfeats = torch.zeros((B, C, N), device=dev, dtype=torch.float32)
+                if want_xyz:
+                    dxyz = torch.zeros((B, N, 3), device=dev, dtype=torch.float32)
+                    dnew = torch.zeros((B, npoint, 3), device=dev, dtype=torch.float32)
+                _call("conv_grouped_dgrad", 2.0 * (Cin - c_lo) * Cout * B * P, lib.o3d_mlp_conv_grouped_dgrad,
+                      src[0], src[1], src[2], src[3], Ys[0].data_ptr(), A[0], A[1], A[2], Ws[0].data_ptr(),
+                      idx.data_ptr(), B, N, C, npoint, ns, nxyz, cfg.inv_radius, Cout, c_lo, _ptr(dfeats),
+                      _ptr(dxyz), _ptr(dnew), st)
+        gw = []
+        for l in range(L):
+            shape = (Ws[l].shape[0], Ws[l].shape[1], 1, 1)
+            gw += [grads[3 * l].view(shape), grads[3 * l + 1], grads[3 * l + 2]]
+        return (dxyz if ctx.needs_input_grad[0] else None, dnew if ctx.needs_input_grad[1] else None,
+                dfeats if ctx.needs_input_grad[2] else None, None, None, *gw)
+
+
+def _run(mlp, xyz, new_xyz, feats, idx, nxyz, inv_radius):
+    layers = _layers(mlp)
+    cfg = _Cfg()
+    cfg.nxyz, cfg.inv_radius, cfg.training = nxyz, float(inv_radius), bool(mlp.training)
+    cfg.bns = [bn for _, bn in layers]
+    params = []
+    for conv, bn in layers:
+        params += [conv.weight, bn.weight, bn.bias]
+    return FusedGroupedMLP.apply(xyz, new_xyz, feats, idx, cfg, *params)
+
+
+def sa_group_mlp_pool(grouper, mlp, xyz, new_xyz, features):
+    """QueryAndGroup + SharedMLP + max over nsample -> (B, C_last, npoint)."""
+    idx = grouper.query(xyz, new_xyz)                      # ball query (B,npoint,nsample) int32
+    _, npoint, ns = idx.shape
+    if not _shape_ok(npoint, ns):
+        return _composed(grouper, mlp, xyz, new_xyz, features, idx)
+    inv_r = 1.0 / grouper.radius if grouper.normalize_xyz else 1.0
+    return _run(mlp, xyz, new_xyz, features, idx, 3, inv_r)
+
+
+def group_mlp_pool(mlp, bundle, idx):
+    """grouping_operation(bundle, idx) + SharedMLP + max over the last axis -> (B, C_last, idx.shape[1])."""
+    _, npoint, ns = idx.shape
+    if not _shape_ok(npoint, ns):
+        from . import ops
+        x = mlp(ops.grouping_operation(bundle, idx))
+        return x.max(dim=-1)[0]
+    return _run(mlp, None, None, bundle, idx, 0, 1.0)
+
+
+def _composed(grouper, mlp, xyz, new_xyz, features, idx):
+    """operator-by-operator path for shapes the tile kernels do not cover (npoint*nsample % 128 != 0)"""
+    import torch.nn.functional as F
+    from . import ops
+    rel = ops.grouping_operation(xyz.transpose(1, 2).contiguous(), idx) - new_xyz.transpose(1, 2).unsqueeze(-1)
+    if grouper.normalize_xyz:
+        rel = rel / grouper.radius
+    x = rel if features is None else torch.cat([rel, ops.grouping_operation(features, idx)], dim=1)
+    x = mlp(x)
+    return F.max_pool2d(x, kernel_size=[1, x.size(3)]).squeeze(-1)

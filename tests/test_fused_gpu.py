@@ -1,0 +1,187 @@
+"""GPU parity of the fused grouped-MLP kernels (csrc/mlp.hip) against plain PyTorch fp32
+references of the same operators (this is the floating-point kernel of the path, so a torch
+fp32 reference is the yardstick; tolerance 1e-4 relative to the tensor scale, as north_star
+states, 1e-3 on gradients which accumulate over up to 786k positions)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-20))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from open3dsot_amd import capi, fused  # noqa: F401  (registers the signatures)
+    return capi.load()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+@pytest.mark.parametrize("B,Cin,Cout,P,xform", [(2, 64, 64, 256, True), (3, 64, 128, 128, True), (2, 128, 256, 384, True),
+                                                (1, 256, 256, 128, False), (2, 16, 64, 128, True), (2, 40, 200, 256, True)])
+def test_conv_fwd_and_stats(lib, B, Cin, Cout, P, xform):
+    g = torch.Generator(device="cuda").manual_seed(B * 1000 + Cin + Cout)
+    X = torch.randn(B, Cin, P, device="cuda", generator=g)
+    W = torch.randn(Cout, Cin, device="cuda", generator=g) * 0.2
+    sc = torch.rand(Cin, device="cuda", generator=g) + 0.5
+    sh = torch.randn(Cin, device="cuda", generator=g) * 0.3
+    c = torch.randn(Cout, device="cuda", generator=g) * 0.1
+    Y = torch.full((B, Cout, P), float("nan"), device="cuda")
+    ntiles = B * (P // 128)
+    part = torch.full((ntiles, 2, Cout), float("nan"), device="cuda")
+    rc = lib.o3d_mlp_conv_fwd(X.data_ptr(), W.data_ptr(), sc.data_ptr() if xform else None,
+                              sh.data_ptr() if xform else None, B, Cin, Cout, P, Y.data_ptr(), part.data_ptr(),
+                              c.data_ptr(), st())
+    assert rc == 0
+    Xin = F.relu(X * sc[None, :, None] + sh[None, :, None]) if xform else X
+    ref = torch.einsum("oc,bcp->bop", W.double(), Xin.double())
+    assert rel(Y, ref) < 2e-6 * max(1, Cin ** 0.5), rel(Y, ref)
+    s = part[:, 0, :].double().sum(0)
+    q = part[:, 1, :].double().sum(0)
+    assert rel(s, ref.sum((0, 2))) < 1e-5
+    assert rel(q, ((ref - c.double()[None, :, None]) ** 2).sum((0, 2))) < 1e-5
+
+
+def test_bn_finalize_matches_torch(lib):
+    torch.manual_seed(0)
+    B, C, P = 4, 96, 256
+    Y = torch.randn(B, C, P, device="cuda") * 2 + 3
+    bn = torch.nn.BatchNorm2d(C).cuda().train()
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.1)
+        bn.running_mean.normal_(0, 0.5); bn.running_var.uniform_(0.5, 2)
+    rm, rv = bn.running_mean.clone(), bn.running_var.clone()
+    ntiles = B * P // 128
+    Yt = Y.view(B, C, P // 128, 128)
+    part = torch.stack([Yt.sum(3), ((Yt - rm[None, :, None, None]) ** 2).sum(3)], 0)  # (2,B,C,T)
+    part = part.permute(1, 3, 0, 2).reshape(ntiles, 2, C).contiguous()
+    vec = torch.empty(4, C, device="cuda")
+    rc = lib.o3d_bn_finalize(part.data_ptr(), ntiles, C, float(B * P), rm.data_ptr(), bn.weight.data_ptr(),
+                             bn.bias.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, vec[0].data_ptr(),
+                             vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), st())
+    assert rc == 0
+    ref = bn(Y.view(B, C, P, 1))
+    got = Y * vec[2][None, :, None] + vec[3][None, :, None]
+    assert rel(got, ref.squeeze(-1)) < 1e-5
+    assert rel(rm, bn.running_mean) < 1e-5 and rel(rv, bn.running_var) < 1e-5
+
+
+def make_case(kind, B=3, train=True, seed=0):
+    """(grouper, mlp, xyz, new_xyz, feats) on the GPU for a layer shape family of the tracker"""
+    from open3dsot_amd import nn_blocks, ops, synth
+    torch.manual_seed(seed)
+    if kind == "sa1":
+        N, npoint, ns, r, C, spec = 512, 256, 32, 0.3, 0, [3, 64, 64, 128]
+    elif kind == "sa2":
+        N, npoint, ns, r, C, spec = 256, 128, 32, 0.5, 128, [131, 128, 128, 256]
+    elif kind == "sa3":
+        N, npoint, ns, r, C, spec = 128, 64, 32, 0.7, 256, [259, 256, 256, 256]
+    elif kind == "rpn":
+        N, npoint, ns, r, C, spec = 128, 64, 16, 0.3, 257, [260, 256, 256, 256]
+    else:
+        raise ValueError(kind)
+    b = synth.make_batch(900 + seed, B, 512, 1024)
+    xyz = torch.from_numpy(b["search_points"][:, :N, :]).cuda()
+    if kind != "sa1":
+        xyz = xyz * 0.5
+    new_xyz = xyz[:, :npoint, :].contiguous()
+    feats = torch.randn(B, C, N, device="cuda") if C else None
+    grouper = ops.QueryAndGroup(r, ns, use_xyz=True)
+    mlp = nn_blocks.SharedMLP(list(spec), bn=True).cuda().train(train)
+    g = torch.Generator().manual_seed(seed + 5)
+    with torch.no_grad():
+        for m in mlp.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(torch.empty(m.weight.shape).uniform_(0.5, 1.5, generator=g))
+                m.bias.copy_(torch.empty(m.bias.shape).normal_(0, 0.2, generator=g))
+                m.running_mean.copy_(torch.empty(m.bias.shape).normal_(0, 0.2, generator=g))
+                m.running_var.copy_(torch.empty(m.bias.shape).uniform_(0.5, 1.5, generator=g))
+    return grouper, mlp, xyz, new_xyz, feats
+
+
+def composed(grouper, mlp, xyz, new_xyz, feats):
+    x = mlp(grouper(xyz, new_xyz, feats))
+    return F.max_pool2d(x, kernel_size=[1, x.size(3)]).squeeze(-1)
+
+
+@pytest.mark.parametrize("kind", ["sa1", "sa2", "sa3", "rpn"])
+@pytest.mark.parametrize("train", [True, False])
+def test_fused_sa_matches_composed(kind, train):
+    import copy
+    from open3dsot_amd import fused
+    grouper, mlp, xyz, new_xyz, feats = make_case(kind, train=train)
+    mlp_ref = copy.deepcopy(mlp)
+    want_xyz = kind == "rpn"
+    leaves = []
+    for t in (xyz, new_xyz, feats):
+        leaves.append(t.clone().requires_grad_(True) if t is not None and (t is feats or want_xyz) else t)
+    leaves_ref = [t.detach().clone().requires_grad_(t.requires_grad) if t is not None else None for t in leaves]
+    out = fused.sa_group_mlp_pool(grouper, mlp, *leaves)
+    ref = composed(grouper, mlp_ref, *leaves_ref)
+    assert out.shape == ref.shape
+    assert rel(out, ref) < 1e-4, ("forward", rel(out, ref))
+    go = torch.randn(out.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    if not train and not any(t is not None and t.requires_grad for t in leaves):
+        return
+    out.backward(go)
+    ref.backward(go)
+    for (n1, p1), (n2, p2) in zip(mlp.named_parameters(), mlp_ref.named_parameters()):
+        assert p1.grad is not None, n1
+        assert rel(p1.grad, p2.grad) < 1e-3, (n1, rel(p1.grad, p2.grad))
+    for nm, a, b_ in zip(("xyz", "new_xyz", "feats"), leaves, leaves_ref):
+        if a is not None and a.requires_grad:
+            assert rel(a.grad, b_.grad) < 1e-3, (nm, rel(a.grad, b_.grad))
+    if train:
+        for (n1, b1), (n2, b2) in zip(mlp.named_buffers(), mlp_ref.named_buffers()):
+            if b1.dtype.is_floating_point:
+                assert rel(b1, b2) < 1e-4, n1
+            else:
+                assert torch.equal(b1, b2), n1
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_fused_xcorr_group_mlp_pool(train):
+    import copy
+    from open3dsot_amd import fused, nn_blocks, ops
+    torch.manual_seed(4)
+    B, M, N, k, f = 3, 64, 128, 4, 256
+    bundle = torch.randn(B, 3 + 9 + f, M, device="cuda", requires_grad=True)
+    idx = torch.randint(0, M, (B, N, k), device="cuda", dtype=torch.int32)
+    mlp = nn_blocks.SharedMLP([3 + 9 + f, 256, 256, 256], bn=True).cuda().train(train)
+    mlp_ref = copy.deepcopy(mlp)
+    out = fused.group_mlp_pool(mlp, bundle, idx)
+    b2 = bundle.detach().clone().requires_grad_(True)
+    ref = mlp_ref(ops.grouping_operation(b2, idx)).max(dim=-1)[0]
+    assert rel(out, ref) < 1e-4
+    go = torch.randn_like(ref)
+    out.backward(go)
+    ref.backward(go)
+    assert rel(bundle.grad, b2.grad) < 1e-3
+    for (n1, p1), (n2, p2) in zip(mlp.named_parameters(), mlp_ref.named_parameters()):
+        assert rel(p1.grad, p2.grad) < 1e-3, (n1, rel(p1.grad, p2.grad))
+
+
+def test_fused_full_size_layer_properties():
+    """BASELINE config-2 size (B=48, search SA1: 512 centres x 32 neighbours): properties that do
+    not need a second implementation -- pooled output >= 0, BN statistics consistent with the
+    stored raw output, linearity of the weight gradient in dOut."""
+    from open3dsot_amd import fused
+    grouper, mlp, xyz, new_xyz, feats = make_case("sa1", B=48)
+    out = fused.sa_group_mlp_pool(grouper, mlp, xyz, new_xyz, feats)
+    assert out.shape == (48, 128, 256) and bool((out >= 0).all()) and bool(torch.isfinite(out).all())
+    g1 = torch.randn_like(out)
+    out.backward(g1, retain_graph=True)
+    w = [p.grad.clone() for p in mlp.parameters()]
+    for p in mlp.parameters():
+        p.grad = None
+    out.backward(2 * g1)
+    for a, p in zip(w, mlp.parameters()):
+        assert rel(p.grad, 2 * a) < 1e-5

@@ -61,12 +61,17 @@ def rel(a, b):
 @pytest.mark.parametrize("fused", [False, True])
 def test_training_step_matches_oracle(model_name, fused):
     model, (loss, ld), (ref_loss, ref_ld, sd) = run_pair(model_name, fused)
-    assert abs(float(loss) - float(ref_loss)) <= 1e-4 * (1 + abs(float(ref_loss))), (float(loss), float(ref_loss))
+    assert abs(float(loss.detach()) - float(ref_loss.detach())) <= 1e-4 * (1 + abs(float(ref_loss))), (float(loss), float(ref_loss))
     for k in ref_ld:
         assert abs(float(ld[k]) - float(ref_ld[k])) <= 1e-4 * (1 + abs(float(ref_ld[k]))), k
+    # error of each gradient relative to its own scale, floored at 1e-3 of the largest gradient in
+    # the model: parameters whose true gradient is ~0 (a bias in front of a training-mode
+    # BatchNorm) hold only rounding noise and must not be judged against that noise.
+    gmax = max(float(sd[k].grad.abs().max()) for k, _ in model.named_parameters())
     worst, worst_k = 0.0, None
     for k, p in model.named_parameters():
-        r = rel(p.grad, sd[k].grad)
+        a, b = p.grad.detach().cpu().double(), sd[k].grad.double()
+        r = float((a - b).abs().max() / (b.abs().max() + 1e-3 * gmax))
         if r > worst:
             worst, worst_k = r, k
     assert worst < 2e-3, (worst, worst_k)
