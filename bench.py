@@ -48,6 +48,7 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--cpu-iters", type=int, default=4)
     ap.add_argument("--composed", action="store_true", help="disable the fused kernels (debug A/B only)")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one HIP graph")
     return ap.parse_args()
 
 
@@ -123,7 +124,7 @@ def main():
     torch.manual_seed(1234)
     model = trackers.get_model(args.model)().to(dev).train()
     sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    trainer = D.DataParallelStep(model, world=world)
+    trainer = D.DataParallelStep(model, world=world, graph=not args.no_graph, graph_warmup=2)
 
     # resident synthetic batches (distinct per rank and per pool slot)
     pool = []
@@ -141,10 +142,11 @@ def main():
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
     tw = time.perf_counter()
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 4 if not args.no_graph else 0)):   # graph capture happens in here
         trainer.step(pool[i % len(pool)])
     torch.cuda.synchronize()
-    log("warm-up %d steps: %.2f s" % (args.warmup, time.perf_counter() - tw))
+    log("warm-up: %.2f s; hip graph: %s %s" % (time.perf_counter() - tw, trainer.graph is not None,
+                                              trainer.graph_error or ""))
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -163,7 +165,10 @@ def main():
     try:
         from open3dsot_amd import fused
         if sa_modules.fused_enabled() and hasattr(fused, "profile_step"):
-            roofline = fused.profile_step(lambda: trainer.step(pool[0]), PEAK_FP32_MFMA_TFLOPS)
+            def eager_step():      # event-bracketed launches cannot be replayed from a graph
+                trainer._forward_backward(pool[0])
+                trainer.grads.rebind(); trainer.reduce_gradients(); trainer.optimizer.step()
+            roofline = fused.profile_step(eager_step, PEAK_FP32_MFMA_TFLOPS)
     except ImportError:
         roofline = None
     if roofline is None:  # no instrumented kernels yet: whole-step algorithmic rate (labelled as such)
@@ -185,7 +190,8 @@ def main():
             "config": {"workload": "%s_Car.yaml KITTI-Car, template 512 / search 1024 pts, batch %d per GPU, "
                                    "fwd+bwd+Adam, fp32" % (args.model, args.batch),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
-                       "fused_kernels": bool(sa_modules.fused_enabled())},
+                       "fused_kernels": bool(sa_modules.fused_enabled()),
+                       "hip_graph": trainer.graph is not None},
             "roofline": roofline,
         }
         if not args.no_cpu_baseline and world == 1:

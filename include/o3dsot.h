@@ -152,14 +152,15 @@ int o3d_mlp_conv_dgrad(const float* dN, const float* dOut, const float* out, con
                        const float* scale_p, const float* shift_p, const float* mean_p,
                        float* dNprev, float* part, void* stream);
 
-/* Data gradient of grouped layer 0, scatter-added (fp32 atomics) through idx into
- * dfeats (B,C,N), dxyz (B,N,3), dnew_xyz (B,npoint,3) -- caller zero-fills them; channels
- * [c_lo, nxyz+C) of the grouped input are differentiated; dxyz/dnew_xyz/dfeats may be NULL. */
+/* Data gradient of grouped layer 0.  G (B,M,P), M = Cin - c_lo, receives W[:, c_lo:]^T dY (caller
+ * scratch, left filled); dgrouped (B,M,N) receives its scatter-add through idx:
+ * dgrouped[b,m,n] = sum over positions p with idx[b,p] == n of G[b,m,p]  (= group_points_grad,
+ * pointnet2_utils.py:237, accumulated in LDS instead of global atomics). */
 int o3d_mlp_conv_grouped_dgrad(const float* dN, const float* dOut, const float* out,
                                const int32_t* arg, const float* Y, const float* A1, const float* A2,
                                const float* A3, const float* W, const int32_t* idx, int B, int N,
-                               int C, int npoint, int ns, int nxyz, float inv_radius, int Cout,
-                               int c_lo, float* dfeats, float* dxyz, float* dnew_xyz, void* stream);
+                               int Cin, int npoint, int ns, int Cout, int c_lo, float* G,
+                               float* dgrouped, void* stream);
 
 /* Weight gradient dW (Cout,Cin) = sum_{b,p} dY[b,co,p] * X[b,ci,p]; X = f(X raw) as in
  * o3d_mlp_conv_fwd, or the layer-0 gather when X == NULL.  part: scratch of

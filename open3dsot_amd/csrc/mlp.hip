@@ -88,8 +88,12 @@ __device__ __forceinline__ void reduce_scatter32(float (&x)[32], int l31) {
         const bool up = (l31 & m) != 0;
 #pragma unroll
         for (int v = 0; v < m; ++v) {
-            const float keep = up ? x[v + m] : x[v];
-            const float send = up ? x[v] : x[v + m];
+            // operands made opaque first: otherwise LLVM rewrites select(up, x[v+m], x[v]) into a
+            // dynamically indexed extract of the 32-wide array (a 32-way v_cndmask chain per access)
+            float lo = x[v], hi = x[v + m];
+            asm volatile("" : "+v"(lo), "+v"(hi));
+            const float keep = up ? hi : lo;
+            const float send = up ? lo : hi;
             x[v] = keep + __shfl_xor(send, m, 64);
         }
     }
@@ -146,7 +150,11 @@ __global__ __launch_bounds__(BM * 2) void conv_fwd_kernel(FwdArgs a) {
         gj = (p0 + 4 * bc4) / a.ns;      // ns % 4 == 0: the four positions share one centre
     }
 
+    // Operand staging is split in two so that nothing waits on HBM in front of the MFMAs:
+    //   load_chunk  -- only issues the global loads of chunk t+1 (raw values + per-row constants)
+    //   store_chunk -- after the MFMAs of chunk t: applies BN+ReLU / centre subtraction, writes LDS
     float4 ra[2], rb[NB4];
+    float rc0[NB4], rc1[NB4];   // per-row constants: (scale, shift) or (centre coordinate, -)
     auto load_chunk = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {    // W tile: BM rows x 16 k  ([m][k] image)
@@ -170,32 +178,26 @@ __global__ __launch_bounds__(BM * 2) void conv_fwd_kernel(FwdArgs a) {
         for (int i = 0; i < NB4; ++i) {  // X tile: 16 k rows x 128 positions ([k][p] image)
             const int ci = k0 + br0 + (T / 32) * i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float c0 = 0.f, c1 = 0.f;
             if (ci < a.Cin) {
                 if (GATHER) {
                     if (ci < a.nxyz) {
-                        const float c = a.new_xyz[((long)b * (a.P / a.ns) + gj) * 3 + ci];
+                        c0 = a.new_xyz[((long)b * (a.P / a.ns) + gj) * 3 + ci];
                         const float* px = a.xyz + (long)b * a.N * 3 + ci;
-                        v.x = (px[3 * gid[0]] - c) * a.inv_radius;
-                        v.y = (px[3 * gid[1]] - c) * a.inv_radius;
-                        v.z = (px[3 * gid[2]] - c) * a.inv_radius;
-                        v.w = (px[3 * gid[3]] - c) * a.inv_radius;
+                        v.x = px[3 * gid[0]]; v.y = px[3 * gid[1]]; v.z = px[3 * gid[2]]; v.w = px[3 * gid[3]];
                     } else {
                         const float* pf = a.feats + ((long)b * a.C + (ci - a.nxyz)) * a.N;
                         v.x = pf[gid[0]]; v.y = pf[gid[1]]; v.z = pf[gid[2]]; v.w = pf[gid[3]];
                     }
                 } else {
                     v = *reinterpret_cast<const float4*>(&a.X[((long)b * a.Cin + ci) * a.P + p0 + 4 * bc4]);
-                    if (XFORM) {
-                        const float sc = a.in_scale[ci], sh = a.in_shift[ci];
-                        v.x = fmaxf(fmaf(v.x, sc, sh), 0.f); v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
-                        v.z = fmaxf(fmaf(v.z, sc, sh), 0.f); v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
-                    }
+                    if (XFORM) { c0 = a.in_scale[ci]; c1 = a.in_shift[ci]; }
                 }
             }
-            rb[i] = v;
+            rb[i] = v; rc0[i] = c0; rc1[i] = c1;
         }
     };
-    auto store_chunk = [&](int buf) {
+    auto store_chunk = [&](int buf, int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int f = tid + T * i, m = f >> 2, c4 = f & 3;
@@ -204,7 +206,22 @@ __global__ __launch_bounds__(BM * 2) void conv_fwd_kernel(FwdArgs a) {
 #pragma unroll
         for (int i = 0; i < NB4; ++i) {
             const int r = br0 + (T / 32) * i;
-            *reinterpret_cast<float4*>(&Bs(buf)[r * BN_POS + 4 * bc4]) = rb[i];
+            const int ci = k0 + r;
+            float4 v = rb[i];
+            if (GATHER) {
+                if (ci < a.nxyz) {
+                    const float c = rc0[i];
+                    v.x = (v.x - c) * a.inv_radius; v.y = (v.y - c) * a.inv_radius;
+                    v.z = (v.z - c) * a.inv_radius; v.w = (v.w - c) * a.inv_radius;
+                }
+            } else if (XFORM) {
+                if (ci < a.Cin) {
+                    const float sc = rc0[i], sh = rc1[i];
+                    v.x = fmaxf(fmaf(v.x, sc, sh), 0.f); v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
+                    v.z = fmaxf(fmaf(v.z, sc, sh), 0.f); v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
+                }
+            }
+            *reinterpret_cast<float4*>(&Bs(buf)[r * BN_POS + 4 * bc4]) = v;
         }
     };
 
@@ -218,12 +235,12 @@ __global__ __launch_bounds__(BM * 2) void conv_fwd_kernel(FwdArgs a) {
 
     const int nchunks = (a.Cin + BK - 1) / BK;
     load_chunk(0);
-    store_chunk(0);
+    store_chunk(0, 0);
     __syncthreads();
     for (int t = 0; t < nchunks; ++t) {
         if (t + 1 < nchunks) load_chunk((t + 1) * BK);
         mma_chunk<BK, true, false>(As(t & 1), LDMK, Bs(t & 1), BN_POS, wm0, wn0, l31, h, acc);
-        if (t + 1 < nchunks) store_chunk((t + 1) & 1);
+        if (t + 1 < nchunks) store_chunk((t + 1) & 1, (t + 1) * BK);
         __syncthreads();
     }
 
@@ -425,35 +442,55 @@ struct DyArgs {
     int ns;
 };
 
+struct RawDy {
+    float4 g;      // dense: dN;  pooled: {dOut, bits(arg), out, -}
+    float4 y;      // raw conv output Y
+    float a1, a2, a3;
+    int k;         // pooled: neighbour index of the first of the four positions
+};
+
 template <bool POOLED>
-__device__ __forceinline__ float4 load_dy4(const DyArgs& d, long b, int co, int Cout, int P, int p) {
+__device__ __forceinline__ RawDy load_dy_raw(const DyArgs& d, long b, int co, int Cout, int P, int p) {
+    RawDy r;
     const long row = b * Cout + co;
-    const float4 y = *reinterpret_cast<const float4*>(&d.Y[row * P + p]);
-    float4 g;
+    r.y = *reinterpret_cast<const float4*>(&d.Y[row * P + p]);
     if (POOLED) {
         const int np = P / d.ns;
-        const int j = p / d.ns, k = p - j * d.ns;
+        const int j = p / d.ns;
         const long pi = row * np + j;
-        const int ak = d.arg[pi];
-        const float go = d.out[pi] > 0.f ? d.dOut[pi] : 0.f;
-        g.x = (k + 0 == ak) ? go : 0.f; g.y = (k + 1 == ak) ? go : 0.f;
-        g.z = (k + 2 == ak) ? go : 0.f; g.w = (k + 3 == ak) ? go : 0.f;
+        r.k = p - j * d.ns;
+        r.g = make_float4(d.dOut[pi], __int_as_float(d.arg[pi]), d.out[pi], 0.f);
     } else {
-        g = *reinterpret_cast<const float4*>(&d.dN[row * P + p]);
+        r.k = 0;
+        r.g = *reinterpret_cast<const float4*>(&d.dN[row * P + p]);
     }
-    const float a1 = d.A1[co], a2 = d.A2[co], a3 = d.A3[co];
-    float4 r;
-    r.x = fmaf(a1, g.x, fmaf(a2, y.x, a3)); r.y = fmaf(a1, g.y, fmaf(a2, y.y, a3));
-    r.z = fmaf(a1, g.z, fmaf(a2, y.z, a3)); r.w = fmaf(a1, g.w, fmaf(a2, y.w, a3));
+    r.a1 = d.A1[co]; r.a2 = d.A2[co]; r.a3 = d.A3[co];
     return r;
+}
+
+template <bool POOLED>
+__device__ __forceinline__ float4 finish_dy(const RawDy& r) {
+    float4 g;
+    if (POOLED) {
+        const int ak = __float_as_int(r.g.y);
+        const float go = r.g.z > 0.f ? r.g.x : 0.f;
+        g.x = (r.k + 0 == ak) ? go : 0.f; g.y = (r.k + 1 == ak) ? go : 0.f;
+        g.z = (r.k + 2 == ak) ? go : 0.f; g.w = (r.k + 3 == ak) ? go : 0.f;
+    } else {
+        g = r.g;
+    }
+    float4 o;
+    o.x = fmaf(r.a1, g.x, fmaf(r.a2, r.y.x, r.a3)); o.y = fmaf(r.a1, g.y, fmaf(r.a2, r.y.y, r.a3));
+    o.z = fmaf(r.a1, g.z, fmaf(r.a2, r.y.z, r.a3)); o.w = fmaf(r.a1, g.w, fmaf(r.a2, r.y.w, r.a3));
+    return o;
 }
 
 // ======================================================================================
 // K2: data gradient   G[b,ci,p] = sum_co W[co,c_lo+ci] * dY[b,co,p],  ci in [0,M)
 //   EPI 0 (MASK):    dNprev = G * [Yprev*scale_p+shift_p > 0] -> store (B,M,P)
 //                    + per-tile partials {sum dNprev, sum dNprev*(Yprev-mean_p)}
-//   EPI 1 (SCATTER): layer 0 of a grouped MLP: scatter-add G through idx into
-//                    dfeats (B,C,N) [channels >= nxyz] and dxyz / dnew_xyz [channels < nxyz]
+//   EPI 1 (STORE):   layer 0 of a grouped MLP: store G (B,M,P); scatter_rows_kernel then adds it
+//                    through idx into (B,M,N) with LDS-privatised accumulation
 // ======================================================================================
 struct DgradArgs {
     DyArgs dy;
@@ -462,9 +499,7 @@ struct DgradArgs {
     // EPI 0
     const float* Yprev; const float* scale_p; const float* shift_p; const float* mean_p;
     float* dNprev; float* part;
-    // EPI 1
-    const int32_t* idx; int N, C, nxyz, ns; float inv_radius;
-    float* dfeats; float* dxyz; float* dnew_xyz;
+    // EPI 1: plain store of G into dNprev (B,M,P)
 };
 
 template <int BM, bool POOLED, int EPI>
@@ -486,7 +521,9 @@ __global__ __launch_bounds__(BM * 2) void conv_dgrad_kernel(DgradArgs a) {
     const bool w_vec = ((a.Cin & 3) == 0) && ((a.c_lo & 3) == 0);
     const int bc4 = tid & 31, br0 = tid >> 5;
 
-    float4 ra[2], rb[NB4];
+    float4 ra[2];
+    RawDy rb[NB4];
+    bool rbv[NB4];
     auto load_chunk = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {     // W^T tile: 16 k(co) rows x BM m(ci)
@@ -509,8 +546,8 @@ __global__ __launch_bounds__(BM * 2) void conv_dgrad_kernel(DgradArgs a) {
 #pragma unroll
         for (int i = 0; i < NB4; ++i) {   // dY tile: 16 k(co) rows x 128 positions
             const int co = k0 + br0 + (T / 32) * i;
-            rb[i] = co < a.Cout ? load_dy4<POOLED>(a.dy, b, co, a.Cout, a.P, p0 + 4 * bc4)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            rbv[i] = co < a.Cout;
+            if (rbv[i]) rb[i] = load_dy_raw<POOLED>(a.dy, b, co, a.Cout, a.P, p0 + 4 * bc4);
         }
     };
     auto store_chunk = [&](int buf) {
@@ -522,7 +559,8 @@ __global__ __launch_bounds__(BM * 2) void conv_dgrad_kernel(DgradArgs a) {
 #pragma unroll
         for (int i = 0; i < NB4; ++i) {
             const int r = br0 + (T / 32) * i;
-            *reinterpret_cast<float4*>(&Bs(buf)[r * BN_POS + 4 * bc4]) = rb[i];
+            *reinterpret_cast<float4*>(&Bs(buf)[r * BN_POS + 4 * bc4]) =
+                rbv[i] ? finish_dy<POOLED>(rb[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
 
@@ -581,31 +619,43 @@ __global__ __launch_bounds__(BM * 2) void conv_dgrad_kernel(DgradArgs a) {
             dst[a.M] = red[tid * 2 + 1] + red[(BM + tid) * 2 + 1];
         }
     } else {
-        // scatter through the grouping indices (two positions per lane: tn = 0,1)
-        const int np = a.P / a.ns;
+        // plain store of G (B,M,P); the scatter through the grouping indices is done by
+        // scatter_rows_kernel with LDS-privatised accumulation (global fp32 atomics from here
+        // ran at the L2 atomic rate: 170 M atomics = 9 ms per BAT step)
 #pragma unroll
-        for (int tn = 0; tn < 2; ++tn) {
-            const int p = p0 + wn0 + 32 * tn + l31;
-            const int id = a.idx[(long)b * a.P + p];
-            const int j = p / a.ns;
+        for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm0 + 32 * tm + acc_row(r, h);
-                    if (m >= a.M) continue;
-                    const int ci = a.c_lo + m;
-                    const float g = acc[tm][tn][r];
-                    if (ci >= a.nxyz) {
-                        if (a.dfeats) unsafeAtomicAdd(a.dfeats + ((long)b * a.C + (ci - a.nxyz)) * a.N + id, g);
-                    } else if (a.dxyz) {
-                        const float gx = g * a.inv_radius;
-                        unsafeAtomicAdd(a.dxyz + ((long)b * a.N + id) * 3 + ci, gx);
-                        unsafeAtomicAdd(a.dnew_xyz + ((long)b * np + j) * 3 + ci, -gx);
-                    }
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + 32 * tm + acc_row(r, h);
+                if (m < a.M) {
+                    float* dst = a.dNprev + ((long)b * a.M + m) * a.P + p0 + wn0 + l31;
+                    dst[0] = acc[tm][0][r];
+                    dst[32] = acc[tm][1][r];
                 }
-        }
+            }
     }
+}
+
+// Scatter-add rows of G (B,M,P) through idx (B,P) into out (B,M,N):
+//   out[b,m,n] = sum_{p : idx[b,p] == n} G[b,m,p]
+// One workgroup owns (b, CT channels): accumulates in LDS (ds_add_f32), then writes its rows once.
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ G,
+                                                           const int32_t* __restrict__ idx, int M, int P,
+                                                           int N, int CT, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x, c0 = blockIdx.y * CT;
+    const int nc = (c0 + CT <= M) ? CT : (M - c0);
+    for (int i = threadIdx.x; i < nc * N; i += 256) smem[i] = 0.f;
+    __syncthreads();
+    const int32_t* id_b = idx + (long)b * P;
+    const float* g_b = G + ((long)b * M + c0) * P;
+    for (int p = threadIdx.x; p < P; p += 256) {
+        const int id = id_b[p];
+        for (int c = 0; c < nc; ++c) atomicAdd(&smem[c * N + id], g_b[(long)c * P + p]);
+    }
+    __syncthreads();
+    float* o_b = out + ((long)b * M + c0) * N;
+    for (int i = threadIdx.x; i < nc * N; i += 256) o_b[i] = smem[i];
 }
 
 // ======================================================================================
@@ -639,53 +689,76 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int chunks_per_b = a.P / WBK;
     const int r0 = tid >> 3, c4 = tid & 7;   // row (+32*i) and float4 column inside a chunk
 
-    float4 ra[4], rb[4];
+    // staging split like the forward kernel: raw global loads before the MFMAs, transforms after;
+    // the grouping indices of chunk t+2 are fetched together with the operands of chunk t+1 so the
+    // dependent gather never waits for its index load.
+    RawDy ra[4];
+    float4 rb[4];
+    float rc0[4], rc1[4];
+    int gid[4] = {0, 0, 0, 0}, gnext[4] = {0, 0, 0, 0};
+    auto load_idx = [&](int ch, int (&dst)[4]) {
+        if (GATHER && ch < c_end) {
+            const long b = ch / chunks_per_b;
+            const int p = (ch - (int)b * chunks_per_b) * WBK + 4 * c4;
+            const int4 v = *reinterpret_cast<const int4*>(&a.idx[b * a.P + p]);
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+    };
     auto load_chunk = [&](int ch) {
         const long b = ch / chunks_per_b;
         const int p = (ch - (int)b * chunks_per_b) * WBK + 4 * c4;
-        int gid[4] = {0, 0, 0, 0};
-        int gj = 0;
-        if (GATHER) {
-            const int4 v = *reinterpret_cast<const int4*>(&a.idx[b * a.P + p]);
-            gid[0] = v.x; gid[1] = v.y; gid[2] = v.z; gid[3] = v.w;
-            gj = p / a.ns;
-        }
+        const int gj = GATHER ? p / a.ns : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int co = co0 + r0 + 32 * i;
-            ra[i] = co < a.Cout ? load_dy4<POOLED>(a.dy, b, co, a.Cout, a.P, p)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (co < a.Cout) ra[i] = load_dy_raw<POOLED>(a.dy, b, co, a.Cout, a.P, p);
             const int ci = ci0 + r0 + 32 * i;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float c0 = 0.f, c1 = 0.f;
             if (ci < a.Cin) {
                 if (GATHER) {
                     if (ci < a.nxyz) {
-                        const float c = a.new_xyz[(b * (a.P / a.ns) + gj) * 3 + ci];
+                        c0 = a.new_xyz[(b * (a.P / a.ns) + gj) * 3 + ci];
                         const float* px = a.xyz + b * a.N * 3 + ci;
-                        v.x = (px[3 * gid[0]] - c) * a.inv_radius; v.y = (px[3 * gid[1]] - c) * a.inv_radius;
-                        v.z = (px[3 * gid[2]] - c) * a.inv_radius; v.w = (px[3 * gid[3]] - c) * a.inv_radius;
+                        v.x = px[3 * gid[0]]; v.y = px[3 * gid[1]]; v.z = px[3 * gid[2]]; v.w = px[3 * gid[3]];
                     } else {
                         const float* pf = a.feats + (b * a.C + (ci - a.nxyz)) * a.N;
                         v.x = pf[gid[0]]; v.y = pf[gid[1]]; v.z = pf[gid[2]]; v.w = pf[gid[3]];
                     }
                 } else {
                     v = *reinterpret_cast<const float4*>(&a.X[(b * a.Cin + ci) * a.P + p]);
-                    if (XFORM) {
-                        const float sc = a.in_scale[ci], sh = a.in_shift[ci];
-                        v.x = fmaxf(fmaf(v.x, sc, sh), 0.f); v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
-                        v.z = fmaxf(fmaf(v.z, sc, sh), 0.f); v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
-                    }
+                    if (XFORM) { c0 = a.in_scale[ci]; c1 = a.in_shift[ci]; }
                 }
             }
-            rb[i] = v;
+            rb[i] = v; rc0[i] = c0; rc1[i] = c1;
         }
+        load_idx(ch + 1, gnext);
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<float4*>(&As(buf)[(r0 + 32 * i) * WLD + 4 * c4]) = ra[i];
-            *reinterpret_cast<float4*>(&Bs(buf)[(r0 + 32 * i) * WLD + 4 * c4]) = rb[i];
+            const int co = co0 + r0 + 32 * i;
+            *reinterpret_cast<float4*>(&As(buf)[(r0 + 32 * i) * WLD + 4 * c4]) =
+                co < a.Cout ? finish_dy<POOLED>(ra[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const int ci = ci0 + r0 + 32 * i;
+            float4 v = rb[i];
+            if (GATHER) {
+                if (ci < a.nxyz) {
+                    const float c = rc0[i];
+                    v.x = (v.x - c) * a.inv_radius; v.y = (v.y - c) * a.inv_radius;
+                    v.z = (v.z - c) * a.inv_radius; v.w = (v.w - c) * a.inv_radius;
+                }
+            } else if (XFORM) {
+                if (ci < a.Cin) {
+                    const float sc = rc0[i], sh = rc1[i];
+                    v.x = fmaxf(fmaf(v.x, sc, sh), 0.f); v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
+                    v.z = fmaxf(fmaf(v.z, sc, sh), 0.f); v.w = fmaxf(fmaf(v.w, sc, sh), 0.f);
+                }
+            }
+            *reinterpret_cast<float4*>(&Bs(buf)[(r0 + 32 * i) * WLD + 4 * c4]) = v;
         }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gid[e] = gnext[e];
     };
 
     f32x16 acc[2][2];
@@ -697,6 +770,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (c_begin < c_end) {
+        load_idx(c_begin, gid);
         load_chunk(c_begin);
         store_chunk(0);
         __syncthreads();
@@ -732,8 +806,8 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     dW[i] = s;
 }
 
-template <typename K, typename A>
-int launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, const A& args) {
+template <typename K, typename... A>
+int launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, A... args) {
     if (lds > 48 * 1024) {  // dynamic LDS beyond the default window must be opted into, once per kernel
         static std::mutex mu;
         static std::unordered_set<const void*> done;
@@ -745,7 +819,7 @@ int launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, const A& 
             done.insert(key);
         }
     }
-    hipLaunchKernelGGL(kernel, grid, block, lds, s, args);
+    hipLaunchKernelGGL(kernel, grid, block, lds, s, args...);
     return o3d_launch_status();
 }
 
@@ -873,30 +947,34 @@ extern "C" int o3d_mlp_conv_dgrad(const float* dN, const float* dOut, const floa
     if (fill_dy(a.dy, dN, dOut, out, arg, Y, A1, A2, A3, ns) != O3D_OK) return O3D_EINVAL;
     a.W = W; a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = P; a.c_lo = 0; a.M = Cin;
     a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p; a.dNprev = dNprev; a.part = part;
-    a.ns = 4; a.inv_radius = 1.f;
     return dN ? launch_dgrad<false, 0>(a, o3d_stream(stream)) : launch_dgrad<true, 0>(a, o3d_stream(stream));
 }
 
-// data gradient of grouped layer 0, scattered through idx.  Channels [c_lo, Cin) of the grouped
-// input are differentiated; dfeats (B,C,N) / dxyz (B,N,3) / dnew_xyz (B,npoint,3) must be
-// zero-initialised by the caller and receive atomic adds.  dxyz/dnew_xyz may be NULL.
+// data gradient of grouped layer 0: G (B,M,P) = W[:, c_lo:]^T dY, then scattered through idx into
+// dgrouped (B,M,N) with M = Cin - c_lo.  G is caller scratch (B*M*P floats) and is left filled
+// (the caller reads its xyz rows for the centre gradient).
 extern "C" int o3d_mlp_conv_grouped_dgrad(const float* dN, const float* dOut, const float* out,
                                           const int32_t* arg, const float* Y, const float* A1,
                                           const float* A2, const float* A3, const float* W,
-                                          const int32_t* idx, int B, int N, int C, int npoint, int ns,
-                                          int nxyz, float inv_radius, int Cout, int c_lo, float* dfeats,
-                                          float* dxyz, float* dnew_xyz, void* stream) {
+                                          const int32_t* idx, int B, int N, int Cin, int npoint, int ns,
+                                          int Cout, int c_lo, float* G, float* dgrouped, void* stream) {
     const long P = (long)npoint * ns;
-    const int Cin = nxyz + C;
-    if (B <= 0 || N <= 0 || C < 0 || npoint <= 0 || ns <= 0 || ns % 4 != 0 || P % BN_POS != 0 || Cout <= 0 ||
-        c_lo < 0 || c_lo >= Cin || !W || !idx || (dxyz && !dnew_xyz))
+    if (B <= 0 || N <= 0 || Cin <= 0 || npoint <= 0 || ns <= 0 || ns % 4 != 0 || P % BN_POS != 0 || Cout <= 0 ||
+        c_lo < 0 || c_lo >= Cin || !W || !idx || !G || !dgrouped || B > 65535)
         return O3D_EINVAL;
     DgradArgs a = {};
     if (fill_dy(a.dy, dN, dOut, out, arg, Y, A1, A2, A3, ns) != O3D_OK) return O3D_EINVAL;
     a.W = W; a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = (int)P; a.c_lo = c_lo; a.M = Cin - c_lo;
-    a.idx = idx; a.N = N; a.C = C; a.nxyz = nxyz; a.ns = ns; a.inv_radius = inv_radius;
-    a.dfeats = dfeats; a.dxyz = dxyz; a.dnew_xyz = dnew_xyz;
-    return dN ? launch_dgrad<false, 1>(a, o3d_stream(stream)) : launch_dgrad<true, 1>(a, o3d_stream(stream));
+    a.dNprev = G;
+    hipStream_t s = o3d_stream(stream);
+    int rc = dN ? launch_dgrad<false, 1>(a, s) : launch_dgrad<true, 1>(a, s);
+    if (rc != O3D_OK) return rc;
+    int CT = 16384 / N;            // CT*N*4 bytes <= 64 KiB of LDS
+    if (CT < 1) return O3D_EINVAL; // N > 16384 points per cloud is outside this kernel's LDS budget
+    if (CT > a.M) CT = a.M;
+    const size_t lds = sizeof(float) * (size_t)CT * N;
+    return launch(scatter_rows_kernel, dim3(B, o3d_cdiv(a.M, CT)), dim3(256), lds, s, G, idx, a.M, (int)P, N, CT,
+                  dgrouped);
 }
 
 // weight gradient.  `part` is scratch of nslices*Cout*Cin floats; dW (Cout,Cin) is overwritten.

@@ -75,9 +75,15 @@ class FlatGrads:
 
 class DataParallelStep:
     """model + optimizer + one-message gradient all-reduce.  `step(batch)` = forward, backward,
-    all-reduce (mean over ranks), optimizer update; returns the detached loss (device tensor)."""
+    all-reduce (mean over ranks), optimizer update; returns the detached loss (device tensor).
 
-    def __init__(self, model, optimizer=None, world=None):
+    graph=True captures forward+backward (every kernel of the hot path: FPS, ball queries, the
+    MFMA GEMMs, losses, autograd) into ONE HIP graph after `graph_warmup` eager steps and replays
+    it afterwards -- the step has no host synchronisation and fixed shapes, so a replay is the
+    same work with none of the per-launch host overhead.  The all-reduce and the optimizer stay
+    outside the graph (eagerly enqueued while the graph runs)."""
+
+    def __init__(self, model, optimizer=None, world=None, graph=False, graph_warmup=3):
         self.model = model
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         if self.world > 1:  # identical replicas: rank 0's parameters and buffers everywhere
@@ -85,17 +91,58 @@ class DataParallelStep:
                 dist.broadcast(t.data, src=0)
         self.grads = FlatGrads(model.parameters())
         self.optimizer = optimizer if optimizer is not None else model.configure_optimizers()["optimizer"]
+        self.graph_requested = bool(graph) and torch.cuda.is_available()
+        self.graph_warmup = graph_warmup
+        self.graph = None
+        self.graph_error = None
+        self._static = None
+        self._static_loss = None
+        self._eager_steps = 0
 
     def reduce_gradients(self):
         if self.world > 1:
             dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM)
             self.grads.flat.div_(self.world)
 
-    def step(self, batch):
+    def _forward_backward(self, batch):
         self.grads.zero()
         loss, _ = self.model.training_loss(batch)
         loss.backward()
+        return loss.detach()
+
+    def _capture(self, batch):
+        self._static = {k: v.clone() for k, v in batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):      # one more eager pass on the capture stream's allocator
+            self._forward_backward(self._static)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._static_loss = self._forward_backward(self._static)
+        self.graph = g
+
+    def step(self, batch):
+        if self.graph is not None:
+            for k, v in batch.items():
+                self._static[k].copy_(v, non_blocking=True)
+            self.graph.replay()
+            loss = self._static_loss
+        else:
+            if self.graph_requested and self._eager_steps >= self.graph_warmup:
+                try:
+                    self._capture(batch)
+                except Exception as e:  # capture unsupported for some op: stay eager, say so
+                    self.graph_error = "%s: %s" % (type(e).__name__, e)
+                    self.graph_requested = False
+                    self.graph = None
+                    torch.cuda.synchronize()
+            if self.graph is not None:
+                return self.step(batch)
+            loss = self._forward_backward(batch)
+            self._eager_steps += 1
         self.grads.rebind()
         self.reduce_gradients()
         self.optimizer.step()
-        return loss.detach()
+        return loss

@@ -34,7 +34,7 @@ capi.register("o3d_bn_bwd_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, 
 capi.register("o3d_mlp_conv_dgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_grouped_dgrad", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
-                                             _i, _f, _i, _i, _vp, _vp, _vp, _vp])
+                                             _i, _i, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_wgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp])
 
@@ -270,15 +270,17 @@ class FusedGroupedMLP(torch.autograd.Function):
                 dN = dNp
             elif want_xyz or want_feats:
                 c_lo = 0 if want_xyz else nxyz
-                if want_feats:
-                    dfeats = torch.zeros((B, C, N), device=dev, dtype=torch.float32)
-                if want_xyz:
-                    dxyz = torch.zeros((B, N, 3), device=dev, dtype=torch.float32)
-                    dnew = torch.zeros((B, npoint, 3), device=dev, dtype=torch.float32)
-                _call("conv_grouped_dgrad", 2.0 * (Cin - c_lo) * Cout * B * P, lib.o3d_mlp_conv_grouped_dgrad,
+                M = Cin - c_lo
+                G = torch.empty((B, M, P), device=dev, dtype=torch.float32)
+                dgrp = torch.empty((B, M, N), device=dev, dtype=torch.float32)
+                _call("conv_grouped_dgrad", 2.0 * M * Cout * B * P, lib.o3d_mlp_conv_grouped_dgrad,
                       src[0], src[1], src[2], src[3], Ys[0].data_ptr(), A[0], A[1], A[2], Ws[0].data_ptr(),
-                      idx.data_ptr(), B, N, C, npoint, ns, nxyz, cfg.inv_radius, Cout, c_lo, _ptr(dfeats),
-                      _ptr(dxyz), _ptr(dnew), st)
+                      idx.data_ptr(), B, N, Cin, npoint, ns, Cout, c_lo, G.data_ptr(), dgrp.data_ptr(), st)
+                if want_feats:
+                    dfeats = dgrp[:, nxyz - c_lo:, :]
+                if want_xyz:      # grouped_xyz = (xyz[idx] - new_xyz) * inv_radius
+                    dxyz = dgrp[:, :3, :].transpose(1, 2) * cfg.inv_radius
+                    dnew = G[:, :3, :].reshape(B, 3, npoint, ns).sum(-1).transpose(1, 2) * (-cfg.inv_radius)
         gw = []
         for l in range(L):
             shape = (Ws[l].shape[0], Ws[l].shape[1], 1, 1)

@@ -71,7 +71,7 @@ class MatchingBaseModel(nn.Module):
         near = (dist < 0.3).float()
         objectness_label = near
         objectness_mask = torch.clamp(near + (dist > 0.6).float(), max=1.0)
-        pos_weight = torch.tensor([2.0], device=dist.device, dtype=dist.dtype)
+        pos_weight = torch.full((1,), 2.0, device=dist.device, dtype=dist.dtype)  # no H2D copy: graph-capturable
         # NB the reference leaves the default reduction ('mean') here (base_model.py:149-152), so
         # the mask only rescales a scalar; mirrored as is.
         loss_objective = F.binary_cross_entropy_with_logits(boxes[:, :, 4], objectness_label,

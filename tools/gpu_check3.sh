@@ -1,0 +1,28 @@
+#!/bin/bash
+# round-1 GPU pass 3: tests, gradient diagnostic, eager vs graph bench, rocprofv3 kernel stats
+TAG=${1:-run}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_fused_gpu.py tests/test_model_gpu.py -m gpu -q --timeout=300 -p no:cacheprovider > $OUT/pytest.log 2>&1
+echo "pytest exit $?" >> $OUT/pytest.log
+grep -E "passed|failed|^E  " $OUT/pytest.log | cut -c1-250 | head -30
+timeout 300 python tools/diag_grad.py > $OUT/diag.log 2>&1; tail -34 $OUT/diag.log | cut -c1-200
+timeout 600 python bench.py --steps 10 --warmup 3 --no-graph --no-cpu-baseline > $OUT/bench_eager.json 2> $OUT/bench_eager.err; echo "bench eager exit $?"
+grep -E "bench\]|Error" $OUT/bench_eager.err | tail -4
+timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench graph exit $?"
+grep -E "bench\]|Error" $OUT/bench.err | tail -4
+python - <<PY
+import json
+for f in ("bench_eager.json","bench.json"):
+    try:
+        d=json.loads(open("$OUT/"+f).read())
+        print(f, d["value"], d["ms_per_step"], d["config"].get("hip_graph"), d["roofline"]["achieved"], d["roofline"].get("gemm_ms_per_step"))
+        for k,v in d["roofline"].get("per_kernel",{}).items(): print("   ",k,v)
+        print(d.get("cpu_baseline"))
+    except Exception as e: print(f, "ERR", e)
+PY
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $REPO/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline > $OUT/rocprof.log 2>&1; echo "rocprof exit $?"
+cd $REPO
+find $OUT/prof -name "*stats*" | head; F=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && head -40 "$F" | cut -c1-220
