@@ -152,19 +152,20 @@ int o3d_mlp_conv_dgrad(const float* dN, const float* dOut, const float* out, con
                        const float* scale_p, const float* shift_p, const float* mean_p,
                        float* dNprev, float* part, void* stream);
 
-/* Data gradient of grouped layer 0.  G (B,M,P), M = Cin - c_lo, receives W[:, c_lo:]^T dY (caller
- * scratch, left filled); dgrouped (B,M,N) receives its scatter-add through idx:
- * dgrouped[b,m,n] = sum over positions p with idx[b,p] == n of G[b,m,p]  (= group_points_grad,
- * pointnet2_utils.py:237, accumulated in LDS instead of global atomics). */
+/* Data gradient of grouped layer 0.  GT (B,P,M), M = Cin - c_lo, receives (W[:, c_lo:]^T dY)^T
+ * (caller scratch, left filled); dgrouped (B,M,N) receives its sum through the grouping map:
+ * dgrouped[b,m,n] = sum over positions p with idx[b,p] == n of GT[b,p,m]  (= group_points_grad,
+ * pointnet2_utils.py:237, as a CSR gather instead of global atomics).  offsets (B,N+1) and perm
+ * (B,P) int32 are caller scratch (the inverse grouping map).  N <= 8192. */
 int o3d_mlp_conv_grouped_dgrad(const float* dN, const float* dOut, const float* out,
                                const int32_t* arg, const float* Y, const float* A1, const float* A2,
                                const float* A3, const float* W, const int32_t* idx, int B, int N,
-                               int Cin, int npoint, int ns, int Cout, int c_lo, float* G,
-                               float* dgrouped, void* stream);
+                               int Cin, int npoint, int ns, int Cout, int c_lo, float* GT,
+                               int32_t* offsets, int32_t* perm, float* dgrouped, void* stream);
 
 /* Weight gradient dW (Cout,Cin) = sum_{b,p} dY[b,co,p] * X[b,ci,p]; X = f(X raw) as in
  * o3d_mlp_conv_fwd, or the layer-0 gather when X == NULL.  part: scratch of
- * nslices*Cout*Cin floats (split over positions, reduced in a fixed order). */
+ * (nslices+16)*Cout*Cin floats (split over positions, reduced in a fixed order). */
 int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const float* out, const int32_t* arg, int ns,
                        const float* Y, const float* A1, const float* A2, const float* A3,
                        const float* X, const float* in_scale, const float* in_shift, const float* xyz,

@@ -300,21 +300,25 @@ struct BnFinArgs {
 };
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
-    __shared__ double sh[2][16][17];
-    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    // 4 channels x 64 tile-slices per workgroup: the partial list (up to 6144 tiles) is a
+    // latency-bound strided read, so it is spread over many lanes with 8 loads in flight each
+    __shared__ double sh[2][64][5];
+    const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
     double s = 0.0, q = 0.0;
-    if (c < a.C)
-        for (int t = sl; t < a.nparts; t += 16) {
+    if (c < a.C) {
+#pragma unroll 8
+        for (int t = sl; t < a.nparts; t += 64) {
             s += (double)a.part[((long)t * 2 + 0) * a.C + c];
             q += (double)a.part[((long)t * 2 + 1) * a.C + c];
         }
+    }
     sh[0][sl][cl] = s;
     sh[1][sl][cl] = q;
     __syncthreads();
     if (sl == 0 && c < a.C) {
         s = 0.0; q = 0.0;
-        for (int i = 0; i < 16; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
+        for (int i = 0; i < 64; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
         const double cs = a.stat_c ? (double)a.stat_c[c] : 0.0;
         const double mean = s / a.count;
         double var = q / a.count - (mean - cs) * (mean - cs);
@@ -343,24 +347,36 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
                                                        int npoint, int ns, long total,
                                                        float* __restrict__ out, int32_t* __restrict__ arg,
                                                        float* __restrict__ yarg) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;  // over (b, c, j)
-    if (i >= total) return;
+    // 8 lanes share one (b, c, centre): lane e reads float4 e, e+8, ... of the ns neighbours, so a
+    // wave reads 8 x 128 contiguous bytes per instruction; first-maximum arg-max via 3 shuffles.
+    const long gi = ((long)blockIdx.x * 256 + threadIdx.x) >> 3;  // over (b, c, j)
+    const int e = threadIdx.x & 7;
+    const bool live = gi < total;
+    const long i = live ? gi : total - 1;
     const int c = (int)((i / npoint) % C);
     const float sc = scale[c], sf = shift[c];
     const float4* src = reinterpret_cast<const float4*>(Y + i * ns);
     float best = -INFINITY, ybest = 0.f;
-    int bk = 0;
-    for (int k4 = 0; k4 < ns / 4; ++k4) {
+    int bk = 0x7fffffff;
+    for (int k4 = e; k4 < ns / 4; k4 += 8) {
         const float4 v = src[k4];
         const float y[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float n = fmaf(y[e], sc, sf);
-            if (n > best) { best = n; bk = 4 * k4 + e; ybest = y[e]; }
+        for (int t = 0; t < 4; ++t) {
+            const float n = fmaf(y[t], sc, sf);
+            if (n > best) { best = n; bk = 4 * k4 + t; ybest = y[t]; }
         }
     }
-    out[i] = fmaxf(best, 0.f);
-    if (arg) { arg[i] = bk; yarg[i] = ybest; }
+#pragma unroll
+    for (int off = 4; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64), oy = __shfl_xor(ybest, off, 64);
+        const int ok = __shfl_xor(bk, off, 64);
+        if (ob > best || (ob == best && ok < bk)) { best = ob; bk = ok; ybest = oy; }
+    }
+    if (live && e == 0) {
+        out[i] = fmaxf(best, 0.f);
+        if (arg) { arg[i] = bk; yarg[i] = ybest; }
+    }
 }
 
 // Backward statistics of the pooled layer: per (b,c) partial {sum g, sum g*(yarg-mean)} with
@@ -400,21 +416,23 @@ struct BnBwdFinArgs {
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFinArgs a) {
-    __shared__ double sh[2][16][17];
-    const int cl = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ double sh[2][64][5];
+    const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
+    const int c = blockIdx.x * 4 + cl;
     double s = 0.0, q = 0.0;
-    if (c < a.C)
-        for (int t = sl; t < a.nparts; t += 16) {
+    if (c < a.C) {
+#pragma unroll 8
+        for (int t = sl; t < a.nparts; t += 64) {
             s += (double)a.part[((long)t * 2 + 0) * a.C + c];
             q += (double)a.part[((long)t * 2 + 1) * a.C + c];
         }
+    }
     sh[0][sl][cl] = s;
     sh[1][sl][cl] = q;
     __syncthreads();
     if (sl == 0 && c < a.C) {
         s = 0.0; q = 0.0;
-        for (int i = 0; i < 16; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
+        for (int i = 0; i < 64; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
         const double g = a.gamma ? (double)a.gamma[c] : 1.0;
         const double is = (double)a.invstd[c], mu = (double)a.mean[c];
         a.dbeta[c] = (float)s;
@@ -578,7 +596,8 @@ __global__ __launch_bounds__(BM * 2) void conv_dgrad_kernel(DgradArgs a) {
     __syncthreads();
     for (int t = 0; t < nchunks; ++t) {
         if (t + 1 < nchunks) load_chunk((t + 1) * BK);
-        mma_chunk<BK, false, false>(As(t & 1), BM, Bs(t & 1), BN_POS, wm0, wn0, l31, h, acc);
+        if (EPI == 0) mma_chunk<BK, false, false>(As(t & 1), BM, Bs(t & 1), BN_POS, wm0, wn0, l31, h, acc);
+        else          mma_chunk<BK, false, false>(Bs(t & 1), BN_POS, As(t & 1), BM, wn0, wm0, l31, h, acc);
         if (t + 1 < nchunks) store_chunk((t + 1) & 1);
         __syncthreads();
     }
@@ -619,43 +638,117 @@ __global__ __launch_bounds__(BM * 2) void conv_dgrad_kernel(DgradArgs a) {
             dst[a.M] = red[tid * 2 + 1] + red[(BM + tid) * 2 + 1];
         }
     } else {
-        // plain store of G (B,M,P); the scatter through the grouping indices is done by
-        // scatter_rows_kernel with LDS-privatised accumulation (global fp32 atomics from here
-        // ran at the L2 atomic rate: 170 M atomics = 9 ms per BAT step)
+        // operand roles were swapped for this epilogue: acc[tm][tn] holds positions (rows) x input
+        // channels (lane = channel), so G^T (B,P,M) is stored with 128-byte channel rows.  The
+        // scatter through the grouping indices is a separate CSR gather (scatter_gt_kernel):
+        // global fp32 atomics from here ran at the L2 atomic rate (170 M atomics = 9 ms per BAT step).
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + 32 * tm + acc_row(r, h);
-                if (m < a.M) {
-                    float* dst = a.dNprev + ((long)b * a.M + m) * a.P + p0 + wn0 + l31;
-                    dst[0] = acc[tm][0][r];
-                    dst[32] = acc[tm][1][r];
-                }
+                const int p = p0 + wn0 + 32 * tm + acc_row(r, h);
+                float* dst = a.dNprev + ((long)b * a.P + p) * a.M + m0 + wm0 + l31;
+                if (m0 + wm0 + l31 < a.M) dst[0] = acc[tm][0][r];
+                if (m0 + wm0 + 32 + l31 < a.M) dst[32] = acc[tm][1][r];
             }
     }
 }
 
-// Scatter-add rows of G (B,M,P) through idx (B,P) into out (B,M,N):
-//   out[b,m,n] = sum_{p : idx[b,p] == n} G[b,m,p]
-// One workgroup owns (b, CT channels): accumulates in LDS (ds_add_f32), then writes its rows once.
-__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ G,
-                                                           const int32_t* __restrict__ idx, int M, int P,
-                                                           int N, int CT, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x, c0 = blockIdx.y * CT;
-    const int nc = (c0 + CT <= M) ? CT : (M - c0);
-    for (int i = threadIdx.x; i < nc * N; i += 256) smem[i] = 0.f;
-    __syncthreads();
+// Inverse of the grouping map: for every source point n of cloud b the list of positions p with
+// idx[b,p] == n  (offsets (B,N+1), perm (B,P)).  One workgroup per cloud, counting sort in LDS.
+__global__ __launch_bounds__(256) void group_csr_kernel(const int32_t* __restrict__ idx, int P, int N,
+                                                        int32_t* __restrict__ offsets,
+                                                        int32_t* __restrict__ perm) {
+    extern __shared__ __attribute__((aligned(16))) int scnt[];   // [N] counts -> cursors, then [256] scan
+    int* sscan = scnt + N;
+    const int b = blockIdx.x, tid = threadIdx.x;
     const int32_t* id_b = idx + (long)b * P;
-    const float* g_b = G + ((long)b * M + c0) * P;
-    for (int p = threadIdx.x; p < P; p += 256) {
-        const int id = id_b[p];
-        for (int c = 0; c < nc; ++c) atomicAdd(&smem[c * N + id], g_b[(long)c * P + p]);
+    for (int n = tid; n < N; n += 256) scnt[n] = 0;
+    __syncthreads();
+    for (int p = tid; p < P; p += 256) atomicAdd(&scnt[id_b[p]], 1);
+    __syncthreads();
+    const int per = (N + 255) / 256;
+    const int n0 = tid * per;
+    int local = 0;
+    for (int n = n0; n < n0 + per && n < N; ++n) local += scnt[n];
+    sscan[tid] = local;
+    __syncthreads();
+    if (tid == 0) {
+        int run = 0;
+        for (int t = 0; t < 256; ++t) { const int v = sscan[t]; sscan[t] = run; run += v; }
     }
     __syncthreads();
-    float* o_b = out + ((long)b * M + c0) * N;
-    for (int i = threadIdx.x; i < nc * N; i += 256) o_b[i] = smem[i];
+    int run = sscan[tid];
+    int32_t* off_b = offsets + (long)b * (N + 1);
+    for (int n = n0; n < n0 + per && n < N; ++n) {
+        const int v = scnt[n];
+        off_b[n] = run;
+        scnt[n] = run;       // becomes the fill cursor
+        run += v;
+    }
+    if (tid == 255) off_b[N] = P;
+    __syncthreads();
+    int32_t* perm_b = perm + (long)b * P;
+    for (int p = tid; p < P; p += 256) perm_b[atomicAdd(&scnt[id_b[p]], 1)] = p;
+}
+
+// out[b,m,n] = sum over positions p in list(b,n) of GT[b,p,m]   (= group_points_grad of G).
+// One workgroup per (cloud, 32 source points); a wave walks one point's list and accumulates whole
+// channel rows (coalesced float4 per lane); the 32 x M tile is transposed through LDS so the
+// (B,M,N) output is written in 128-byte rows.  No atomics; list order = counting-sort fill order.
+constexpr int SG_NB = 32;
+__global__ __launch_bounds__(256) void scatter_gt_kernel(const float* __restrict__ GT,
+                                                         const int32_t* __restrict__ offsets,
+                                                         const int32_t* __restrict__ perm, int M, int P,
+                                                         int N, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float tile[];   // [SG_NB][Mc + 1], Mc = channel chunk
+    const int b = blockIdx.x, n0 = blockIdx.y * SG_NB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int32_t* off_b = offsets + (long)b * (N + 1);
+    const int32_t* perm_b = perm + (long)b * P;
+    const float* g_b = GT + (long)b * P * M;
+    for (int cb = 0; cb < M; cb += 256) {
+        const int mc = (M - cb) < 256 ? (M - cb) : 256;
+        const int ld = mc + 1;
+        const int c = cb + 4 * lane;
+        for (int nl = wave; nl < SG_NB; nl += 4) {
+            const int n = n0 + nl;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n < N) {
+                const int beg = off_b[n], end = off_b[n + 1];
+                for (int base = beg; base < end; base += 64) {
+                    const int cnt = (end - base) < 64 ? (end - base) : 64;
+                    const int mine = lane < cnt ? perm_b[base + lane] : 0;   // 64 list entries at once
+                    for (int i = 0; i < cnt; ++i) {
+                        const int p = __shfl(mine, i, 64);
+                        const float* row = g_b + (long)p * M + c;
+                        if (c + 3 < M) {
+                            if ((M & 3) == 0) {
+                                const float4 v = *reinterpret_cast<const float4*>(row);
+                                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+                            } else {
+                                acc.x += row[0]; acc.y += row[1]; acc.z += row[2]; acc.w += row[3];
+                            }
+                        } else {
+                            if (c + 0 < M) acc.x += row[0];
+                            if (c + 1 < M) acc.y += row[1];
+                            if (c + 2 < M) acc.z += row[2];
+                        }
+                    }
+                }
+            }
+            const int cl = 4 * lane;
+            if (cl + 0 < mc) tile[nl * ld + cl + 0] = acc.x;
+            if (cl + 1 < mc) tile[nl * ld + cl + 1] = acc.y;
+            if (cl + 2 < mc) tile[nl * ld + cl + 2] = acc.z;
+            if (cl + 3 < mc) tile[nl * ld + cl + 3] = acc.w;
+        }
+        __syncthreads();
+        const int nl = tid & 31;
+        for (int cl = tid >> 5; cl < mc; cl += 8)
+            if (n0 + nl < N) out[((long)b * M + cb + cl) * N + n0 + nl] = tile[nl * ld + cl];
+        __syncthreads();
+    }
 }
 
 // ======================================================================================
@@ -797,13 +890,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         }
 }
 
+// out[g][i] = sum over slices z in group g of part[z][i]; groups of `per` consecutive slices
+// (grid.y = number of groups).  Called twice (nslices -> 16 groups -> 1) so that no thread walks
+// hundreds of slices serially; the summation order is fixed.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, int nslices,
-                                                           long n, float* __restrict__ dW) {
+                                                           int per, long n, float* __restrict__ out) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    const int z0 = blockIdx.y * per;
+    int z1 = z0 + per;
+    if (z1 > nslices) z1 = nslices;
     float s = 0.f;
-    for (int z = 0; z < nslices; ++z) s += part[(long)z * n + i];
-    dW[i] = s;
+#pragma unroll 8
+    for (int z = z0; z < z1; ++z) s += part[(long)z * n + i];
+    out[(long)blockIdx.y * n + i] = s;
 }
 
 template <typename K, typename... A>
@@ -892,7 +992,7 @@ extern "C" int o3d_bn_finalize(const float* part, int nparts, int C, double coun
     if (!part || nparts <= 0 || C <= 0 || !mean || !invstd || !scale || !shift) return O3D_EINVAL;
     BnFinArgs a = {part, nparts, C, count, stat_c, gamma, beta, running_mean, running_var, momentum, eps,
                    mean, invstd, scale, shift};
-    return launch(bn_finalize_kernel, dim3(o3d_cdiv(C, 16)), dim3(256), 0, o3d_stream(stream), a);
+    return launch(bn_finalize_kernel, dim3(o3d_cdiv(C, 4)), dim3(256), 0, o3d_stream(stream), a);
 }
 
 extern "C" int o3d_bn_relu_maxpool_fwd(const float* Y, const float* scale, const float* shift, int B,
@@ -902,7 +1002,7 @@ extern "C" int o3d_bn_relu_maxpool_fwd(const float* Y, const float* scale, const
         (arg && !yarg))
         return O3D_EINVAL;
     const long total = (long)B * C * npoint;
-    hipLaunchKernelGGL(pool_fwd_kernel, dim3(o3d_cdiv(total, 256)), dim3(256), 0, o3d_stream(stream), Y,
+    hipLaunchKernelGGL(pool_fwd_kernel, dim3(o3d_cdiv(total * 8, 256)), dim3(256), 0, o3d_stream(stream), Y,
                        scale, shift, C, npoint, ns, total, out, arg, yarg);
     return o3d_launch_status();
 }
@@ -922,7 +1022,7 @@ extern "C" int o3d_bn_bwd_finalize(const float* part, int nparts, int C, double 
     if (!part || nparts <= 0 || C <= 0 || !mean || !invstd || !dgamma || !dbeta || !A1 || !A2 || !A3)
         return O3D_EINVAL;
     BnBwdFinArgs a = {part, nparts, C, count, gamma, mean, invstd, dgamma, dbeta, A1, A2, A3};
-    return launch(bn_bwd_finalize_kernel, dim3(o3d_cdiv(C, 16)), dim3(256), 0, o3d_stream(stream), a);
+    return launch(bn_bwd_finalize_kernel, dim3(o3d_cdiv(C, 4)), dim3(256), 0, o3d_stream(stream), a);
 }
 
 static int fill_dy(DyArgs& d, const float* dN, const float* dOut, const float* out, const int32_t* arg,
@@ -950,34 +1050,36 @@ extern "C" int o3d_mlp_conv_dgrad(const float* dN, const float* dOut, const floa
     return dN ? launch_dgrad<false, 0>(a, o3d_stream(stream)) : launch_dgrad<true, 0>(a, o3d_stream(stream));
 }
 
-// data gradient of grouped layer 0: G (B,M,P) = W[:, c_lo:]^T dY, then scattered through idx into
-// dgrouped (B,M,N) with M = Cin - c_lo.  G is caller scratch (B*M*P floats) and is left filled
-// (the caller reads its xyz rows for the centre gradient).
+// data gradient of grouped layer 0: GT (B,P,M) = (W[:, c_lo:]^T dY)^T, M = Cin - c_lo, then gathered
+// through the inverse grouping map into dgrouped (B,M,N).  GT (B*P*M floats), offsets (B*(N+1)
+// ints) and perm (B*P ints) are caller scratch; GT is left filled (the caller reads its xyz
+// columns for the centre gradient).
 extern "C" int o3d_mlp_conv_grouped_dgrad(const float* dN, const float* dOut, const float* out,
                                           const int32_t* arg, const float* Y, const float* A1,
                                           const float* A2, const float* A3, const float* W,
                                           const int32_t* idx, int B, int N, int Cin, int npoint, int ns,
-                                          int Cout, int c_lo, float* G, float* dgrouped, void* stream) {
+                                          int Cout, int c_lo, float* GT, int32_t* offsets, int32_t* perm,
+                                          float* dgrouped, void* stream) {
     const long P = (long)npoint * ns;
-    if (B <= 0 || N <= 0 || Cin <= 0 || npoint <= 0 || ns <= 0 || ns % 4 != 0 || P % BN_POS != 0 || Cout <= 0 ||
-        c_lo < 0 || c_lo >= Cin || !W || !idx || !G || !dgrouped || B > 65535)
+    if (B <= 0 || N <= 0 || N > 8192 || Cin <= 0 || npoint <= 0 || ns <= 0 || ns % 4 != 0 || P % BN_POS != 0 ||
+        Cout <= 0 || c_lo < 0 || c_lo >= Cin || !W || !idx || !GT || !offsets || !perm || !dgrouped || B > 65535)
         return O3D_EINVAL;
     DgradArgs a = {};
     if (fill_dy(a.dy, dN, dOut, out, arg, Y, A1, A2, A3, ns) != O3D_OK) return O3D_EINVAL;
     a.W = W; a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = (int)P; a.c_lo = c_lo; a.M = Cin - c_lo;
-    a.dNprev = G;
+    a.dNprev = GT;
     hipStream_t s = o3d_stream(stream);
-    int rc = dN ? launch_dgrad<false, 1>(a, s) : launch_dgrad<true, 1>(a, s);
+    int rc = launch(group_csr_kernel, dim3(B), dim3(256), sizeof(int) * (size_t)(N + 256), s, idx, (int)P, N,
+                    offsets, perm);
     if (rc != O3D_OK) return rc;
-    int CT = 16384 / N;            // CT*N*4 bytes <= 64 KiB of LDS
-    if (CT < 1) return O3D_EINVAL; // N > 16384 points per cloud is outside this kernel's LDS budget
-    if (CT > a.M) CT = a.M;
-    const size_t lds = sizeof(float) * (size_t)CT * N;
-    return launch(scatter_rows_kernel, dim3(B, o3d_cdiv(a.M, CT)), dim3(256), lds, s, G, idx, a.M, (int)P, N, CT,
-                  dgrouped);
+    rc = dN ? launch_dgrad<false, 1>(a, s) : launch_dgrad<true, 1>(a, s);
+    if (rc != O3D_OK) return rc;
+    const int mc = a.M < 256 ? a.M : 256;
+    return launch(scatter_gt_kernel, dim3(B, o3d_cdiv(N, SG_NB)), dim3(256), sizeof(float) * SG_NB * (mc + 1), s,
+                  GT, offsets, perm, a.M, (int)P, N, dgrouped);
 }
 
-// weight gradient.  `part` is scratch of nslices*Cout*Cin floats; dW (Cout,Cin) is overwritten.
+// weight gradient.  `part` is scratch of (nslices+16)*Cout*Cin floats; dW (Cout,Cin) is overwritten.
 // X source: (X, in_scale, in_shift) for inner layers (in_scale NULL = identity), or the layer-0
 // gather (xyz,new_xyz,feats,idx,N,C,nxyz) when X == NULL.
 extern "C" int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const float* out, const int32_t* arg,
@@ -1018,6 +1120,16 @@ extern "C" int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const floa
     }
     if (rc != O3D_OK) return rc;
     const long n = (long)Cout * Cin;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(o3d_cdiv(n, 256)), dim3(256), 0, s, part, nslices, n, dW);
+    if (nslices > 32) {   // stage 1: 16 groups written over the first 16 slices' worth of scratch tail
+        const int groups = 16, per = (nslices + groups - 1) / groups;
+        float* part2 = part + (long)nslices * n;   // caller provides (nslices + 16) * n floats
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(o3d_cdiv(n, 256), groups), dim3(256), 0, s, part, nslices, per,
+                           n, part2);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(o3d_cdiv(n, 256), 1), dim3(256), 0, s, part2, groups, groups,
+                           n, dW);
+    } else {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(o3d_cdiv(n, 256), 1), dim3(256), 0, s, part, nslices, nslices,
+                           n, dW);
+    }
     return o3d_launch_status();
 }

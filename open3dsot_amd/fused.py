@@ -34,7 +34,7 @@ capi.register("o3d_bn_bwd_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, 
 capi.register("o3d_mlp_conv_dgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_grouped_dgrad", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
-                                             _i, _i, _vp, _vp, _vp])
+                                             _i, _i, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_wgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp])
 
@@ -201,7 +201,10 @@ class FusedGroupedMLP(torch.autograd.Function):
         if need_bwd:
             ctx.cfg = cfg
             ctx.dims = (B, N, C, npoint, ns, L)
-            ctx.saved = (xyz_c, new_c, feats_c, idx, Ws, gammas, Ys, means, invstds, scales, shifts, out, arg, yarg)
+            # NB: `out` itself must not be stored on ctx (out.grad_fn is this node: a reference cycle
+            # that keeps the whole graph -- and last step's AccumulateGrad nodes -- alive until the GC runs)
+            ctx.saved = (xyz_c, new_c, feats_c, idx, Ws, gammas, Ys, means, invstds, scales, shifts,
+                         out.detach(), arg, yarg)
         return out
 
     @staticmethod
@@ -247,7 +250,7 @@ class FusedGroupedMLP(torch.autograd.Function):
             tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
             total_chunks = B * (P // 32)
             nsl = max(1, min(total_chunks // 4 if total_chunks >= 4 else 1, 768 // tiles))
-            wpart = torch.empty((nsl, Cout, Cin), device=dev, dtype=torch.float32)
+            wpart = torch.empty((nsl + 16, Cout, Cin), device=dev, dtype=torch.float32)
             dW = torch.empty((Cout, Cin), device=dev, dtype=torch.float32)
             if l == 0:
                 xsrc = (None, None, None, _ptr(xyz_c), _ptr(new_c), _ptr(feats_c), idx.data_ptr(), N, C, nxyz,
@@ -271,16 +274,19 @@ class FusedGroupedMLP(torch.autograd.Function):
             elif want_xyz or want_feats:
                 c_lo = 0 if want_xyz else nxyz
                 M = Cin - c_lo
-                G = torch.empty((B, M, P), device=dev, dtype=torch.float32)
+                GT = torch.empty((B, P, M), device=dev, dtype=torch.float32)
+                offs = torch.empty((B, N + 1), device=dev, dtype=torch.int32)
+                perm = torch.empty((B, P), device=dev, dtype=torch.int32)
                 dgrp = torch.empty((B, M, N), device=dev, dtype=torch.float32)
                 _call("conv_grouped_dgrad", 2.0 * M * Cout * B * P, lib.o3d_mlp_conv_grouped_dgrad,
                       src[0], src[1], src[2], src[3], Ys[0].data_ptr(), A[0], A[1], A[2], Ws[0].data_ptr(),
-                      idx.data_ptr(), B, N, Cin, npoint, ns, Cout, c_lo, G.data_ptr(), dgrp.data_ptr(), st)
+                      idx.data_ptr(), B, N, Cin, npoint, ns, Cout, c_lo, GT.data_ptr(), offs.data_ptr(),
+                      perm.data_ptr(), dgrp.data_ptr(), st)
                 if want_feats:
                     dfeats = dgrp[:, nxyz - c_lo:, :]
                 if want_xyz:      # grouped_xyz = (xyz[idx] - new_xyz) * inv_radius
                     dxyz = dgrp[:, :3, :].transpose(1, 2) * cfg.inv_radius
-                    dnew = G[:, :3, :].reshape(B, 3, npoint, ns).sum(-1).transpose(1, 2) * (-cfg.inv_radius)
+                    dnew = GT[:, :, :3].reshape(B, npoint, ns, 3).sum(2) * (-cfg.inv_radius)
         gw = []
         for l in range(L):
             shape = (Ws[l].shape[0], Ws[l].shape[1], 1, 1)

@@ -8,7 +8,7 @@ export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_fused_gpu.py tests/test_model_gpu.py -m gpu -q --timeout=300 -p no:cacheprovider > $OUT/pytest.log 2>&1
 echo "pytest exit $?" >> $OUT/pytest.log
 grep -E "passed|failed|^E  " $OUT/pytest.log | cut -c1-250 | head -30
-timeout 300 python tools/diag_grad.py > $OUT/diag.log 2>&1; tail -34 $OUT/diag.log | cut -c1-200
+timeout 300 python tools/diag_grad.py > $OUT/diag.log 2>&1; tail -16 $OUT/diag.log | cut -c1-200
 timeout 600 python bench.py --steps 10 --warmup 3 --no-graph --no-cpu-baseline > $OUT/bench_eager.json 2> $OUT/bench_eager.err; echo "bench eager exit $?"
 grep -E "bench\]|Error" $OUT/bench_eager.err | tail -4
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench graph exit $?"
@@ -23,6 +23,6 @@ for f in ("bench_eager.json","bench.json"):
         print(d.get("cpu_baseline"))
     except Exception as e: print(f, "ERR", e)
 PY
-cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/prof -o bench -- python $REPO/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline > $OUT/rocprof.log 2>&1; echo "rocprof exit $?"
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o bench -- python $REPO/bench.py --steps 5 --warmup 2 --no-graph --no-cpu-baseline > $OUT/rocprof.log 2>&1; echo "rocprof exit $?"
 cd $REPO
 find $OUT/prof -name "*stats*" | head; F=$(find $OUT/prof -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && head -40 "$F" | cut -c1-220
