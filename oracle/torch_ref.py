@@ -25,7 +25,7 @@ EPS, MOMENTUM = 1e-5, 0.1
 
 
 def _np(t):
-    return t.detach().cpu().contiguous().numpy()
+    return t.detach().cpu().float().contiguous().numpy()   # index ops are fp32 (also under an fp64 shadow run)
 
 
 def fps(xyz, npoint):
@@ -181,7 +181,7 @@ def matching_loss(batch, out, weights, bat=True):
     mask = torch.zeros_like(dist)
     mask[dist < 0.3] = 1
     mask[dist > 0.6] = 1
-    l_obj = F.binary_cross_entropy_with_logits(boxes[:, :, 4], label, pos_weight=torch.tensor([2.0]))
+    l_obj = F.binary_cross_entropy_with_logits(boxes[:, :, 4], label, pos_weight=dist.new_tensor([2.0]))
     l_obj = torch.sum(l_obj * mask) / (torch.sum(mask) + 1e-6)
     l_box = F.smooth_l1_loss(boxes[:, :, :4], box_label[:, None, :4].expand_as(boxes[:, :, :4]), reduction="none")
     l_box = torch.sum(l_box.mean(2) * label) / (label.sum() + 1e-6)

@@ -1,7 +1,12 @@
-"""GPU parity of the fused grouped-MLP kernels (csrc/mlp.hip) against plain PyTorch fp32
-references of the same operators (this is the floating-point kernel of the path, so a torch
-fp32 reference is the yardstick; tolerance 1e-4 relative to the tensor scale, as north_star
-states, 1e-3 on gradients which accumulate over up to 786k positions)."""
+"""GPU parity of the fused grouped-MLP kernels (csrc/mlp.hip) against plain PyTorch references
+of the same operators (this is the floating-point kernel of the path, so a torch reference is
+the yardstick).  Forward features: 1e-4 relative to the tensor scale, as north_star states
+(measured ~1e-6).  Gradients are judged against an fp64 shadow of the composed operator chain:
+ReLU masks and max-pool winners are discrete, so two correct fp32 evaluations whose forward
+values differ by 1e-6 can route a gradient differently at a near-tie; an fp32-vs-fp32 max-norm
+comparison is therefore noisy (measured on the GPU box: torch's own CPU fp32 backward is 2e-2
+away from its fp64 run on some RPN weights, tools/diag_grad2.py).  Criterion: relative L2 error
+<= 5e-4 and max error <= 1e-2 of the tensor scale, against fp64."""
 import numpy as np
 import pytest
 import torch
@@ -13,6 +18,49 @@ pytestmark = pytest.mark.gpu
 def rel(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-20))
+
+
+def l2rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+def assert_grad_close(a, b, what, l2tol=5e-4, maxtol=1e-2):
+    # (eval-mode BatchNorm has no normalisation to damp a routing flip: callers pass l2tol=3e-3 there)
+    assert l2rel(a, b) < l2tol and rel(a, b) < maxtol, (what, l2rel(a, b), rel(a, b))
+
+
+def shadow64(mlp, xyz, new_xyz, feats, idx, train, inv_radius=1.0):
+    """fp64 restatement of QueryAndGroup -> SharedMLP -> max over nsample on torch ops
+    (pointnet2_utils.py:299-339, pytorch_utils.py:12-37, pointnet2_modules.py:69-73).
+    -> (out, leaves: dict name -> fp64 leaf, buffers: dict name -> fp64 running stat)"""
+    B, npoint, ns = idx.shape
+    flat = idx.long().reshape(B, 1, npoint * ns)
+    leaves, bufs = {}, {}
+
+    def leaf(name, t):
+        if t is None:
+            return None
+        leaves[name] = t.detach().double().clone().requires_grad_(True)
+        return leaves[name]
+    parts = []
+    if xyz is not None:
+        x64, n64 = leaf("xyz", xyz), leaf("new_xyz", new_xyz)
+        g = x64.transpose(1, 2).gather(2, flat.expand(B, 3, -1)).reshape(B, 3, npoint, ns)
+        parts.append((g - n64.transpose(1, 2).unsqueeze(-1)) * inv_radius)
+    if feats is not None:
+        f64 = leaf("feats", feats)
+        parts.append(f64.gather(2, flat.expand(B, f64.shape[1], -1)).reshape(B, -1, npoint, ns))
+    x = torch.cat(parts, dim=1)
+    for name, layer in mlp.named_children():
+        conv, bn = layer.conv, layer.bn.bn
+        x = F.conv2d(x, leaf(name + ".conv.weight", conv.weight))
+        rm, rv = bn.running_mean.detach().double().clone(), bn.running_var.detach().double().clone()
+        x = F.batch_norm(x, rm, rv, leaf(name + ".bn.bn.weight", bn.weight), leaf(name + ".bn.bn.bias", bn.bias),
+                         train, bn.momentum, bn.eps)
+        bufs[name + ".bn.bn.running_mean"], bufs[name + ".bn.bn.running_var"] = rm, rv
+        x = F.relu(x)
+    return x.max(dim=-1)[0], leaves, bufs
 
 
 @pytest.fixture(scope="module")
@@ -124,49 +172,59 @@ def test_fused_sa_matches_composed(kind, train):
     for t in (xyz, new_xyz, feats):
         leaves.append(t.clone().requires_grad_(True) if t is not None and (t is feats or want_xyz) else t)
     leaves_ref = [t.detach().clone().requires_grad_(t.requires_grad) if t is not None else None for t in leaves]
+    idx = grouper.query(xyz, new_xyz)
+    ref64, l64, b64 = shadow64(mlp_ref, xyz, new_xyz, feats, idx, train)
     out = fused.sa_group_mlp_pool(grouper, mlp, *leaves)
-    ref = composed(grouper, mlp_ref, *leaves_ref)
+    ref = composed(grouper, mlp_ref, *leaves_ref)          # torch fp32 (MIOpen) on the same HIP index ops
     assert out.shape == ref.shape
-    assert rel(out, ref) < 1e-4, ("forward", rel(out, ref))
+    assert rel(out, ref) < 1e-4, ("forward vs torch fp32", rel(out, ref))
+    assert rel(out, ref64) < 2e-5, ("forward vs fp64 shadow", rel(out, ref64))
     go = torch.randn(out.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
     if not train and not any(t is not None and t.requires_grad for t in leaves):
         return
     out.backward(go)
-    ref.backward(go)
-    for (n1, p1), (n2, p2) in zip(mlp.named_parameters(), mlp_ref.named_parameters()):
+    ref64.backward(go.double())
+    for n1, p1 in mlp.named_parameters():
         assert p1.grad is not None, n1
-        assert rel(p1.grad, p2.grad) < 5e-3, (n1, rel(p1.grad, p2.grad))
-    for nm, a, b_ in zip(("xyz", "new_xyz", "feats"), leaves, leaves_ref):
+        assert_grad_close(p1.grad, l64[n1].grad, n1, l2tol=5e-4 if train else 3e-3)
+    for nm, a in zip(("xyz", "new_xyz", "feats"), leaves):
         if a is not None and a.requires_grad:
-            assert rel(a.grad, b_.grad) < 1e-3, (nm, rel(a.grad, b_.grad))
+            assert_grad_close(a.grad, l64[nm].grad, nm, l2tol=5e-4 if train else 3e-3)
     if train:
-        for (n1, b1), (n2, b2) in zip(mlp.named_buffers(), mlp_ref.named_buffers()):
+        for n1, b1 in mlp.named_buffers():
             if b1.dtype.is_floating_point:
-                assert rel(b1, b2) < 1e-4, n1
+                assert rel(b1, b64[n1]) < 1e-5, n1
             else:
-                assert torch.equal(b1, b2), n1
+                assert int(b1) == 1, n1
 
 
 @pytest.mark.parametrize("train", [True, False])
 def test_fused_xcorr_group_mlp_pool(train):
-    import copy
     from open3dsot_amd import fused, nn_blocks, ops
     torch.manual_seed(4)
     B, M, N, k, f = 3, 64, 128, 4, 256
     bundle = torch.randn(B, 3 + 9 + f, M, device="cuda", requires_grad=True)
     idx = torch.randint(0, M, (B, N, k), device="cuda", dtype=torch.int32)
     mlp = nn_blocks.SharedMLP([3 + 9 + f, 256, 256, 256], bn=True).cuda().train(train)
-    mlp_ref = copy.deepcopy(mlp)
+    ref64, l64, _ = shadow64(mlp, None, None, bundle, idx, train)
+    with torch.no_grad():
+        ref32 = copy_eval(mlp, ops.grouping_operation(bundle.detach(), idx), train)
     out = fused.group_mlp_pool(mlp, bundle, idx)
-    b2 = bundle.detach().clone().requires_grad_(True)
-    ref = mlp_ref(ops.grouping_operation(b2, idx)).max(dim=-1)[0]
-    assert rel(out, ref) < 1e-4
-    go = torch.randn_like(ref)
+    assert rel(out, ref32) < 1e-4
+    assert rel(out, ref64) < 2e-5
+    go = torch.randn_like(out)
     out.backward(go)
-    ref.backward(go)
-    assert rel(bundle.grad, b2.grad) < 1e-3
-    for (n1, p1), (n2, p2) in zip(mlp.named_parameters(), mlp_ref.named_parameters()):
-        assert rel(p1.grad, p2.grad) < 1e-3, (n1, rel(p1.grad, p2.grad))
+    ref64.backward(go.double())
+    assert_grad_close(bundle.grad, l64["feats"].grad, "bundle")
+    for n1, p1 in mlp.named_parameters():
+        assert_grad_close(p1.grad, l64[n1].grad, n1)
+
+
+def copy_eval(mlp, x, train):
+    """torch fp32 forward of a deep copy (so the running statistics of `mlp` are not advanced twice)"""
+    import copy
+    m = copy.deepcopy(mlp).train(train)
+    return m(x).max(dim=-1)[0]
 
 
 def test_fused_full_size_layer_properties():
