@@ -18,6 +18,7 @@ SOURCES = [
     ("fps.hip", ["-ffp-contract=off"]),
     ("index_ops.hip", ["-ffp-contract=off"]),
     ("mlp.hip", []),
+    ("group.hip", []),
     ("capi_misc.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",

@@ -596,7 +596,7 @@ __global__ __launch_bounds__(BM * 2) void conv_dgrad_kernel(DgradArgs a) {
     __syncthreads();
     for (int t = 0; t < nchunks; ++t) {
         if (t + 1 < nchunks) load_chunk((t + 1) * BK);
-        if (EPI == 0) mma_chunk<BK, false, false>(As(t & 1), BM, Bs(t & 1), BN_POS, wm0, wn0, l31, h, acc);
+        if (EPI != 1) mma_chunk<BK, false, false>(As(t & 1), BM, Bs(t & 1), BN_POS, wm0, wn0, l31, h, acc);
         else          mma_chunk<BK, false, false>(Bs(t & 1), BN_POS, As(t & 1), BM, wn0, wm0, l31, h, acc);
         if (t + 1 < nchunks) store_chunk((t + 1) & 1);
         __syncthreads();
@@ -637,6 +637,19 @@ __global__ __launch_bounds__(BM * 2) void conv_dgrad_kernel(DgradArgs a) {
             dst[0] = red[tid * 2 + 0] + red[(BM + tid) * 2 + 0];
             dst[a.M] = red[tid * 2 + 1] + red[(BM + tid) * 2 + 1];
         }
+    } else if (EPI == 2) {
+        // plain store of G (B,M,P): the gradient w.r.t. an operand that is not a BN+ReLU output
+#pragma unroll
+        for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + 32 * tm + acc_row(r, h);
+                if (m < a.M) {
+                    float* dst = a.dNprev + ((long)b * a.M + m) * a.P + p0 + wn0 + l31;
+                    dst[0] = acc[tm][0][r];
+                    dst[32] = acc[tm][1][r];
+                }
+            }
     } else {
         // operand roles were swapped for this epilogue: acc[tm][tn] holds positions (rows) x input
         // channels (lane = channel), so G^T (B,P,M) is stored with 128-byte channel rows.  The
@@ -1048,6 +1061,18 @@ extern "C" int o3d_mlp_conv_dgrad(const float* dN, const float* dOut, const floa
     a.W = W; a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = P; a.c_lo = 0; a.M = Cin;
     a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p; a.dNprev = dNprev; a.part = part;
     return dN ? launch_dgrad<false, 0>(a, o3d_stream(stream)) : launch_dgrad<true, 0>(a, o3d_stream(stream));
+}
+
+// dX (B,Cin,P) = W^T dY with dY = A1*dN + A2*Y + A3, no mask, no statistics: the gradient w.r.t. an
+// operand that is not the BN+ReLU output of a previous layer (the per-point operand of layer 0).
+extern "C" int o3d_mlp_conv_dgrad_plain(const float* dN, const float* Y, const float* A1, const float* A2,
+                                        const float* A3, const float* W, int B, int Cin, int Cout, int P,
+                                        float* dX, void* stream) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || P <= 0 || P % BN_POS != 0 || !W || !dN || !dX) return O3D_EINVAL;
+    DgradArgs a = {};
+    if (fill_dy(a.dy, dN, nullptr, nullptr, nullptr, Y, A1, A2, A3, 4) != O3D_OK) return O3D_EINVAL;
+    a.W = W; a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = P; a.c_lo = 0; a.M = Cin; a.dNprev = dX;
+    return launch_dgrad<false, 2>(a, o3d_stream(stream));
 }
 
 // data gradient of grouped layer 0: GT (B,P,M) = (W[:, c_lo:]^T dY)^T, M = Cin - c_lo, then gathered

@@ -26,19 +26,22 @@ from .ops import QueryAndGroup
 
 _vp, _i, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double
 capi.register("o3d_mlp_conv_fwd", [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
-capi.register("o3d_mlp_conv_grouped_fwd", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _vp])
+capi.register("o3d_group_meta", [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp])
+capi.register("o3d_group_expand_fwd", [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_group_reduce_bwd", [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp])
+capi.register("o3d_group_bwd_combine", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp])
+capi.register("o3d_mlp_conv_dgrad_plain", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp])
 capi.register("o3d_bn_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_bn_relu_maxpool_fwd", [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_bwd_partials", [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp])
 capi.register("o3d_bn_bwd_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_dgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp])
-capi.register("o3d_mlp_conv_grouped_dgrad", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
-                                             _i, _i, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_wgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp])
 
-TILE = 128  # positions per workgroup tile of the GEMM kernels (csrc/mlp.hip BN_POS)
+TILE = 128   # positions per workgroup tile of the GEMM kernels (csrc/mlp.hip BN_POS)
+ETILE = 256  # positions per workgroup tile of the layer-0 expand kernel (csrc/group.hip EXP_TP)
 
 # ---- optional per-kernel timing (bench.py's roofline leg) ---------------------------------
 _PROF = {"on": False, "events": []}
@@ -84,8 +87,8 @@ def profile_step(step_fn, peak_tflops, repeats=3):
         a[1] += flops
         a[2] += e0.elapsed_time(e1)
     _PROF["events"] = []
-    gemm = {k: v for k, v in agg.items() if k in ("conv_fwd", "conv_grouped_fwd", "conv_dgrad",
-                                                    "conv_grouped_dgrad", "conv_wgrad")}
+    gemm = {k: v for k, v in agg.items() if k in ("conv_fwd", "conv_fwd_points", "conv_dgrad", "conv_dgrad_points",
+                                                    "conv_wgrad", "conv_wgrad_points")}
     if not gemm:
         return None
     launches = sum(v[0] for v in gemm.values())
@@ -124,7 +127,8 @@ def _layers(mlp):
 
 
 def supports_mlp(mlp):
-    return _layers(mlp) is not None
+    layers = _layers(mlp)
+    return layers is not None and len(layers) >= 2     # layer 0 runs on the points, layers >= 1 on positions
 
 
 def supports(grouper, mlp, features):
@@ -132,7 +136,18 @@ def supports(grouper, mlp, features):
 
 
 def _shape_ok(npoint, ns):
-    return ns % 4 == 0 and (npoint * ns) % TILE == 0
+    return 4 <= ns <= 256 and (ns & (ns - 1)) == 0 and (npoint * ns) % ETILE == 0
+
+
+def _const_vec(dev, n, value):
+    key = (str(dev), n, value)
+    v = _CONST.get(key)
+    if v is None:
+        v = _CONST[key] = torch.full((n,), float(value), device=dev, dtype=torch.float32)
+    return v
+
+
+_CONST = {}
 
 
 # ---- the autograd function ---------------------------------------------------------------
@@ -156,12 +171,21 @@ class FusedGroupedMLP(torch.autograd.Function):
         nxyz = cfg.nxyz
         C = feats.shape[1] if feats is not None else 0
         N = feats.shape[2] if feats is not None else xyz.shape[1]
-        xyz_c = xyz.detach().contiguous() if nxyz else None
-        new_c = new_xyz.detach().contiguous() if nxyz else None
-        feats_c = feats.detach().contiguous() if feats is not None else None
+        # per-point operand of layer 0: [xyz * inv_radius ; feats] as (B, nxyz+C, Npad), zero padded to
+        # the GEMM's position tile
+        Npad = -(-N // TILE) * TILE
+        X0n = (torch.zeros if Npad != N else torch.empty)((B, nxyz + C, Npad), device=dev, dtype=torch.float32)
+        if nxyz:
+            X0n[:, :3, :N] = xyz.detach().transpose(1, 2) * cfg.inv_radius
+        if C:
+            X0n[:, nxyz:, :N] = feats.detach()
+        new_c = (new_xyz.detach() * cfg.inv_radius).contiguous() if nxyz else None
+        Z = torch.empty((B, Ws[0].shape[0], Npad), device=dev, dtype=torch.float32)
+        need_bwd = any(ctx.needs_input_grad)
         ntiles = B * (P // TILE)
         st = _stream()
         Ys, means, invstds, scales, shifts = [], [], [], [], []
+        GY = None
         for l in range(L):
             Cout, Cin = Ws[l].shape
             bn = cfg.bns[l]
@@ -170,16 +194,22 @@ class FusedGroupedMLP(torch.autograd.Function):
             stat_c = bn.running_mean if cfg.training else None
             flops = 2.0 * Cin * Cout * B * P
             if l == 0:
-                _call("conv_grouped_fwd", flops, lib.o3d_mlp_conv_grouped_fwd, _ptr(xyz_c), _ptr(new_c), _ptr(feats_c),
-                      idx.data_ptr(), Ws[0].data_ptr(), B, N, C, npoint, ns, nxyz, cfg.inv_radius, Cout,
-                      Y.data_ptr(), _ptr(part), _ptr(stat_c), st)
+                # layer 0 = one small GEMM over the N points + gather-expand (csrc/group.hip)
+                _call("conv_fwd_points", 2.0 * Cin * Cout * B * Npad, lib.o3d_mlp_conv_fwd, X0n.data_ptr(),
+                      Ws[0].data_ptr(), None, None, B, Cin, Cout, Npad, Z.data_ptr(), None, None, st)
+                part = torch.empty((B * (P // ETILE), 2, Cout), device=dev, dtype=torch.float32) if cfg.training else None
+                GY = torch.empty((B, Cout, npoint), device=dev, dtype=torch.float32) if (need_bwd and nxyz) else None
+                _call("group_expand", 0.0, lib.o3d_group_expand_fwd, Z.data_ptr(), Npad, idx.data_ptr(), _ptr(new_c),
+                      Ws[0].data_ptr(), Cin, B, Cout, npoint, ns, Y.data_ptr(), _ptr(part), _ptr(stat_c), _ptr(GY), st)
+                nparts = B * (P // ETILE)
             else:
+                nparts = ntiles
                 _call("conv_fwd", flops, lib.o3d_mlp_conv_fwd, Ys[-1].data_ptr(), Ws[l].data_ptr(),
                       scales[-1].data_ptr(), shifts[-1].data_ptr(), B, Cin, Cout, P, Y.data_ptr(), _ptr(part),
                       _ptr(stat_c), st)
             vec = torch.empty((4, Cout), device=dev, dtype=torch.float32)
             if cfg.training:
-                _call("bn_finalize", 0.0, lib.o3d_bn_finalize, part.data_ptr(), ntiles, Cout, float(B) * P,
+                _call("bn_finalize", 0.0, lib.o3d_bn_finalize, part.data_ptr(), nparts, Cout, float(B) * P,
                       stat_c.data_ptr(), gammas[l].data_ptr(), betas[l].data_ptr(), bn.running_mean.data_ptr(),
                       bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps), vec[0].data_ptr(),
                       vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), st)
@@ -193,7 +223,6 @@ class FusedGroupedMLP(torch.autograd.Function):
             means.append(vec[0]); invstds.append(vec[1]); scales.append(vec[2]); shifts.append(vec[3])
         Cl = Ws[-1].shape[0]
         out = torch.empty((B, Cl, npoint), device=dev, dtype=torch.float32)
-        need_bwd = any(ctx.needs_input_grad)
         arg = torch.empty((B, Cl, npoint), device=dev, dtype=torch.int32) if need_bwd else None
         yarg = torch.empty((B, Cl, npoint), device=dev, dtype=torch.float32) if need_bwd else None
         _call("pool_fwd", 0.0, lib.o3d_bn_relu_maxpool_fwd, Ys[-1].data_ptr(), scales[-1].data_ptr(),
@@ -203,7 +232,7 @@ class FusedGroupedMLP(torch.autograd.Function):
             ctx.dims = (B, N, C, npoint, ns, L)
             # NB: `out` itself must not be stored on ctx (out.grad_fn is this node: a reference cycle
             # that keeps the whole graph -- and last step's AccumulateGrad nodes -- alive until the GC runs)
-            ctx.saved = (xyz_c, new_c, feats_c, idx, Ws, gammas, Ys, means, invstds, scales, shifts,
+            ctx.saved = (X0n, new_c, Z, GY, idx, Ws, gammas, Ys, means, invstds, scales, shifts,
                          out.detach(), arg, yarg)
         return out
 
@@ -212,7 +241,8 @@ class FusedGroupedMLP(torch.autograd.Function):
         lib = capi.load()
         cfg = ctx.cfg
         B, N, C, npoint, ns, L = ctx.dims
-        xyz_c, new_c, feats_c, idx, Ws, gammas, Ys, means, invstds, scales, shifts, out, arg, yarg = ctx.saved
+        X0n, new_c, Z, GY, idx, Ws, gammas, Ys, means, invstds, scales, shifts, out, arg, yarg = ctx.saved
+        Npad = X0n.shape[2]
         P = npoint * ns
         dev = idx.device
         st = _stream()
@@ -222,7 +252,7 @@ class FusedGroupedMLP(torch.autograd.Function):
         ntiles = B * (P // TILE)
         grads = [None] * (3 * L)
         want_xyz = nxyz > 0 and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
-        want_feats = feats_c is not None and ctx.needs_input_grad[2]
+        want_feats = C > 0 and ctx.needs_input_grad[2]
 
         # BN-backward coefficients of the last (pooled) layer
         Cl = Ws[-1].shape[0]
@@ -246,47 +276,61 @@ class FusedGroupedMLP(torch.autograd.Function):
                   (dN.data_ptr(), None, None, None)
             A = (coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr())
             flops = 2.0 * Cin * Cout * B * P
+            if l == 0:
+                # layer 0 on the N points: S = sum of dY0 over each point's list, T = per-ball sums
+                one, zero = _const_vec(dev, Cout, 1.0), _const_vec(dev, Cout, 0.0)
+                cnt = torch.empty((B, Npad), device=dev, dtype=torch.float32)
+                R = torch.empty((B, Npad, 3), device=dev, dtype=torch.float32) if nxyz else None
+                _call("group_meta", 0.0, lib.o3d_group_meta, idx.data_ptr(), _ptr(new_c), B, N, Npad, npoint, ns,
+                      cnt.data_ptr(), _ptr(R), st)
+                S = torch.empty((B, Cout, Npad), device=dev, dtype=torch.float32)
+                T = torch.empty((B, Cout, npoint), device=dev, dtype=torch.float32) if nxyz else None
+                _call("group_reduce", 0.0, lib.o3d_group_reduce_bwd, dN.data_ptr(), idx.data_ptr(), B, Cout, Npad,
+                      npoint, ns, S.data_ptr(), _ptr(T), st)
+                _call("group_combine", 0.0, lib.o3d_group_bwd_combine, S.data_ptr(), _ptr(T), Z.data_ptr(), _ptr(GY),
+                      cnt.data_ptr(), _ptr(R), Ws[0].data_ptr(), Cin, A[0], A[1], A[2], B, Cout, Npad, npoint, ns, st)
+                tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
+                total_chunks = B * (Npad // 32)
+                nsl = max(1, min(total_chunks // 4 if total_chunks >= 4 else 1, 768 // tiles))
+                wpart = torch.empty((nsl + 16, Cout, Cin), device=dev, dtype=torch.float32)
+                dW = torch.empty((Cout, Cin), device=dev, dtype=torch.float32)
+                _call("conv_wgrad_points", 2.0 * Cin * Cout * B * Npad, lib.o3d_mlp_conv_wgrad, S.data_ptr(), None,
+                      None, None, 4, S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(),
+                      None, None, None, None, None, None, 0, 0, 0, 1.0, B, Cin, Cout, Npad, nsl, wpart.data_ptr(),
+                      dW.data_ptr(), st)
+                if nxyz:      # the centre term of grouped_xyz = xyz[idx] - new_xyz
+                    dW[:, :3] -= torch.einsum("bcj,bjk->ck", T, new_c)
+                grads[0] = dW
+                if want_xyz or want_feats:
+                    dX = torch.empty((B, Cin, Npad), device=dev, dtype=torch.float32)
+                    _call("conv_dgrad_points", 2.0 * Cin * Cout * B * Npad, lib.o3d_mlp_conv_dgrad_plain,
+                          S.data_ptr(), S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(),
+                          Ws[0].data_ptr(), B, Cin, Cout, Npad, dX.data_ptr(), st)
+                    if want_feats:
+                        dfeats = dX[:, nxyz:, :N]
+                    if want_xyz:
+                        dxyz = dX[:, :3, :N].transpose(1, 2) * cfg.inv_radius
+                        dnew = torch.einsum("bcj,ck->bjk", T, Ws[0][:, :3]) * (-cfg.inv_radius)
+                continue
             # ---- weight gradient
             tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
             total_chunks = B * (P // 32)
             nsl = max(1, min(total_chunks // 4 if total_chunks >= 4 else 1, 768 // tiles))
             wpart = torch.empty((nsl + 16, Cout, Cin), device=dev, dtype=torch.float32)
             dW = torch.empty((Cout, Cin), device=dev, dtype=torch.float32)
-            if l == 0:
-                xsrc = (None, None, None, _ptr(xyz_c), _ptr(new_c), _ptr(feats_c), idx.data_ptr(), N, C, nxyz,
-                        cfg.inv_radius)
-            else:
-                xsrc = (Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), None, None, None,
-                        None, 0, 0, 0, 1.0)
             _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad, src[0], src[1], src[2], src[3], ns, Ys[l].data_ptr(),
-                  A[0], A[1], A[2], *xsrc, B, Cin, Cout, P, nsl, wpart.data_ptr(), dW.data_ptr(), st)
+                  A[0], A[1], A[2], Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), None,
+                  None, None, None, 0, 0, 0, 1.0, B, Cin, Cout, P, nsl, wpart.data_ptr(), dW.data_ptr(), st)
             grads[3 * l] = dW
-            # ---- data gradient
-            if l > 0:
-                dNp = torch.empty((B, Cin, P), device=dev, dtype=torch.float32)
-                part = torch.empty((ntiles, 2, Cin), device=dev, dtype=torch.float32)
-                _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad, src[0], src[1], src[2], src[3], ns,
-                      Ys[l].data_ptr(), A[0], A[1], A[2], Ws[l].data_ptr(), B, Cin, Cout, P, Ys[l - 1].data_ptr(),
-                      scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),
-                      part.data_ptr(), st)
-                nparts = ntiles
-                dN = dNp
-            elif want_xyz or want_feats:
-                c_lo = 0 if want_xyz else nxyz
-                M = Cin - c_lo
-                GT = torch.empty((B, P, M), device=dev, dtype=torch.float32)
-                offs = torch.empty((B, N + 1), device=dev, dtype=torch.int32)
-                perm = torch.empty((B, P), device=dev, dtype=torch.int32)
-                dgrp = torch.empty((B, M, N), device=dev, dtype=torch.float32)
-                _call("conv_grouped_dgrad", 2.0 * M * Cout * B * P, lib.o3d_mlp_conv_grouped_dgrad,
-                      src[0], src[1], src[2], src[3], Ys[0].data_ptr(), A[0], A[1], A[2], Ws[0].data_ptr(),
-                      idx.data_ptr(), B, N, Cin, npoint, ns, Cout, c_lo, GT.data_ptr(), offs.data_ptr(),
-                      perm.data_ptr(), dgrp.data_ptr(), st)
-                if want_feats:
-                    dfeats = dgrp[:, nxyz - c_lo:, :]
-                if want_xyz:      # grouped_xyz = (xyz[idx] - new_xyz) * inv_radius
-                    dxyz = dgrp[:, :3, :].transpose(1, 2) * cfg.inv_radius
-                    dnew = GT[:, :, :3].reshape(B, npoint, ns, 3).sum(2) * (-cfg.inv_radius)
+            # ---- data gradient: masked by the producer's ReLU, with its BN-backward partials
+            dNp = torch.empty((B, Cin, P), device=dev, dtype=torch.float32)
+            part = torch.empty((ntiles, 2, Cin), device=dev, dtype=torch.float32)
+            _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad, src[0], src[1], src[2], src[3], ns,
+                  Ys[l].data_ptr(), A[0], A[1], A[2], Ws[l].data_ptr(), B, Cin, Cout, P, Ys[l - 1].data_ptr(),
+                  scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),
+                  part.data_ptr(), st)
+            nparts = ntiles
+            dN = dNp
         gw = []
         for l in range(L):
             shape = (Ws[l].shape[0], Ws[l].shape[1], 1, 1)

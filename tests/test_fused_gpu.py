@@ -243,3 +243,60 @@ def test_fused_full_size_layer_properties():
     out.backward(2 * g1)
     for a, p in zip(w, mlp.parameters()):
         assert rel(p.grad, 2 * a) < 1e-5
+
+
+@pytest.mark.parametrize("N,npoint,ns,C0,nxyz", [(256, 128, 32, 64, 3), (100, 64, 16, 40, 3), (64, 128, 4, 32, 0)])
+def test_group_layer0_kernels(lib, N, npoint, ns, C0, nxyz):
+    """csrc/group.hip against torch gathers/scatters: expand (Y0, statistics partials, per-ball sums),
+    list/ball reductions, the point counts / centre sums, and the affine recombination."""
+    g = torch.Generator(device="cuda").manual_seed(N + ns)
+    B, P, ld = 3, npoint * ns, -(-N // 128) * 128
+    idx = torch.randint(0, N, (B, npoint, ns), device="cuda", generator=g).int()
+    idx[:, :, ns // 2:] = idx[:, :, :1]                      # ball padding: repeated first hit
+    Z = torch.randn(B, C0, ld, device="cuda", generator=g)
+    W0 = torch.randn(C0, 5 + nxyz, device="cuda", generator=g)
+    new_xyz = torch.randn(B, npoint, 3, device="cuda", generator=g) if nxyz else None
+    c = torch.randn(C0, device="cuda", generator=g) * 0.1
+    Y0 = torch.empty(B, C0, P, device="cuda")
+    part = torch.empty(B * P // 256, 2, C0, device="cuda")
+    GY = torch.empty(B, C0, npoint, device="cuda")
+    ptr = lambda t: t.data_ptr() if t is not None else None
+    assert lib.o3d_group_expand_fwd(Z.data_ptr(), ld, idx.data_ptr(), ptr(new_xyz), W0.data_ptr(), W0.shape[1], B, C0,
+                                    npoint, ns, Y0.data_ptr(), part.data_ptr(), c.data_ptr(), GY.data_ptr(), st()) == 0
+    flat = idx.long().reshape(B, 1, P).expand(B, C0, P)
+    ref = Z.double().gather(2, flat)
+    if nxyz:
+        cc = torch.einsum("ck,bjk->bcj", W0[:, :3].double(), new_xyz.double())
+        ref = ref - cc.repeat_interleave(ns, dim=2)
+    assert rel(Y0, ref) < 1e-6
+    assert rel(GY, ref.reshape(B, C0, npoint, ns).sum(3)) < 1e-5
+    assert rel(part[:, 0].double().sum(0), ref.sum((0, 2))) < 1e-5
+    assert rel(part[:, 1].double().sum(0), ((ref - c.double()[None, :, None]) ** 2).sum((0, 2))) < 1e-5
+    # counts and centre sums
+    cnt = torch.empty(B, ld, device="cuda")
+    R = torch.empty(B, ld, 3, device="cuda") if nxyz else None
+    assert lib.o3d_group_meta(idx.data_ptr(), ptr(new_xyz), B, N, ld, npoint, ns, cnt.data_ptr(), ptr(R), st()) == 0
+    cnt_ref = torch.zeros(B, ld, device="cuda", dtype=torch.float64).scatter_add_(
+        1, idx.long().reshape(B, P), torch.ones(B, P, device="cuda", dtype=torch.float64))
+    assert torch.equal(cnt.double(), cnt_ref)
+    if nxyz:
+        R_ref = torch.zeros(B, ld, 3, device="cuda", dtype=torch.float64).scatter_add_(
+            1, idx.long().reshape(B, P, 1).expand(B, P, 3), new_xyz.double().repeat_interleave(ns, dim=1))
+        assert rel(R, R_ref) < 1e-5
+    # reductions of a dense gradient
+    dN = torch.randn(B, C0, P, device="cuda", generator=g)
+    S = torch.empty(B, C0, ld, device="cuda")
+    T = torch.empty(B, C0, npoint, device="cuda")
+    assert lib.o3d_group_reduce_bwd(dN.data_ptr(), idx.data_ptr(), B, C0, ld, npoint, ns, S.data_ptr(), T.data_ptr(), st()) == 0
+    S_ref = torch.zeros(B, C0, ld, device="cuda", dtype=torch.float64).scatter_add_(2, flat, dN.double())
+    T_ref = dN.double().reshape(B, C0, npoint, ns).sum(3)
+    assert rel(S, S_ref) < 1e-5 and rel(T, T_ref) < 1e-5
+    # S = sum over lists of dY0, dY0 = A1*dN + A2*Y0 + A3
+    A1, A2, A3 = (torch.randn(C0, device="cuda", generator=g) for _ in range(3))
+    dY = A1.double()[None, :, None] * dN.double() + A2.double()[None, :, None] * ref + A3.double()[None, :, None]
+    assert lib.o3d_group_bwd_combine(S.data_ptr(), T.data_ptr() if nxyz else None, Z.data_ptr(), GY.data_ptr(), cnt.data_ptr(),
+                                     ptr(R), W0.data_ptr(), W0.shape[1], A1.data_ptr(), A2.data_ptr(), A3.data_ptr(), B, C0, ld,
+                                     npoint, ns, st()) == 0
+    assert rel(S, torch.zeros(B, C0, ld, device="cuda", dtype=torch.float64).scatter_add_(2, flat, dY)) < 2e-5
+    if nxyz:
+        assert rel(T, dY.reshape(B, C0, npoint, ns).sum(3)) < 2e-5

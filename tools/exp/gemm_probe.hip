@@ -1,0 +1,102 @@
+// gemm_probe.hip -- standalone micro-benchmarks (GPU box only; NOT part of the product):
+//   1. fp32-MFMA issue-rate ceiling on this box (no memory traffic)
+//   2. the product's conv_fwd / conv_dgrad / conv_wgrad C-ABI entries at the BAT shapes
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/exp/gemm_probe.hip -o tools/exp/gemm_probe \
+//        -Lopen3dsot_amd/_lib -lo3dsot_hip -Wl,-rpath,'$ORIGIN/../../open3dsot_amd/_lib'
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../include/o3dsot.h"
+
+extern "C" int o3d_mlp_conv_fwd(const float*, const float*, const float*, const float*, int, int, int, int, float*,
+                                float*, const float*, void*);
+extern "C" int o3d_mlp_conv_dgrad(const float* dN, const float* dOut, const float* out, const int32_t* arg, int ns,
+                                  const float* Y, const float* A1, const float* A2, const float* A3, const float* W,
+                                  int B, int Cin, int Cout, int P, const float* Yprev, const float* scale_p,
+                                  const float* shift_p, const float* mean_p, float* dNprev, float* part, void* stream);
+extern "C" int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const float* out, const int32_t* arg, int ns,
+                                  const float* Y, const float* A1, const float* A2, const float* A3, const float* X,
+                                  const float* in_scale, const float* in_shift, const float* xyz, const float* new_xyz,
+                                  const float* feats, const int32_t* idx, int N, int C, int nxyz, float inv_radius,
+                                  int B, int Cin, int Cout, int P, int nslices, float* part, float* dW, void* stream);
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
+    f32x16 acc[4];
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+    float a = threadIdx.x * 1e-3f, b = blockIdx.x * 1e-3f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 123.456f) out[0] = s;
+}
+
+static float* dev_rand(size_t n, float scale = 1.f) {
+    std::vector<float> h(n);
+    for (size_t i = 0; i < n; ++i) h[i] = scale * ((rand() & 0xffff) / 32768.f - 1.f);
+    float* d; CK(hipMalloc(&d, n * sizeof(float)));
+    CK(hipMemcpy(d, h.data(), n * sizeof(float), hipMemcpyHostToDevice));
+    return d;
+}
+
+template <typename F>
+static float time_ms(F f, int reps) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    f(); f();
+    CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0, 0));
+    for (int i = 0; i < reps; ++i) f();
+    CK(hipEventRecord(e1, 0));
+    CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps;
+}
+
+int main(int argc, char** argv) {
+    const char* only = argc > 1 ? argv[1] : "all";
+    int reps = argc > 2 ? atoi(argv[2]) : 10;
+    if (!strcmp(only, "all") || !strcmp(only, "peak")) {
+        float* out; CK(hipMalloc(&out, 4));
+        for (int wpc : {4, 8, 16}) {  // waves per CU: blocks of 4 waves, 256 CUs
+            const int blocks = 256 * wpc / 4, iters = 4096;
+            float ms = time_ms([&] { hipLaunchKernelGGL(mfma_peak_kernel, dim3(blocks), dim3(256), 0, 0, out, iters); }, 5);
+            double flops = (double)blocks * 4 * iters * 32.0 * (2.0 * 32 * 32 * 2);
+            printf("mfma_peak waves/CU=%2d: %.3f ms  %.1f TFLOP/s\n", wpc, ms, flops / ms * 1e-9);
+        }
+    }
+    struct Shape { const char* name; int B, Cin, Cout, P; };
+    const Shape shapes[] = {{"S-SA3 256->256", 48, 256, 256, 4096}, {"T-SA3 256->256", 48, 256, 256, 2048},
+                            {"S-SA2 128->128", 48, 128, 128, 8192}, {"S-SA2 128->256", 48, 128, 256, 8192},
+                            {"S-SA1 64->64", 48, 64, 64, 16384},    {"S-SA1 64->128", 48, 64, 128, 16384},
+                            {"RPN 256->256", 48, 256, 256, 1024},   {"xcorr 256->256", 48, 256, 256, 512}};
+    for (const Shape& s : shapes) {
+        if (strcmp(only, "all") && strcmp(only, "gemm") && !strstr(s.name, only)) continue;
+        const size_t nx = (size_t)s.B * s.Cin * s.P, ny = (size_t)s.B * s.Cout * s.P;
+        float *X = dev_rand(nx), *W = dev_rand((size_t)s.Cin * s.Cout, 0.1f), *Y = dev_rand(ny), *dN = dev_rand(ny);
+        float *sc = dev_rand(s.Cin), *sh = dev_rand(s.Cin), *mu = dev_rand(s.Cin), *c = dev_rand(s.Cout);
+        float *A1 = dev_rand(s.Cout), *A2 = dev_rand(s.Cout, 0.01f), *A3 = dev_rand(s.Cout, 0.01f);
+        const int ntiles = s.B * (s.P / 128);
+        float *part; CK(hipMalloc(&part, sizeof(float) * (size_t)ntiles * 2 * 256));
+        float *dNp; CK(hipMalloc(&dNp, nx * sizeof(float)));
+        const int nsl = 768 / (((s.Cin + 127) / 128) * ((s.Cout + 127) / 128));
+        float *wpart; CK(hipMalloc(&wpart, sizeof(float) * (size_t)(nsl + 16) * s.Cin * s.Cout));
+        float *dW; CK(hipMalloc(&dW, sizeof(float) * s.Cin * s.Cout));
+        const double gf = 2.0 * s.Cin * s.Cout * (double)s.B * s.P * 1e-9;
+        float t_f = time_ms([&] { o3d_mlp_conv_fwd(X, W, sc, sh, s.B, s.Cin, s.Cout, s.P, Y, part, c, 0); }, reps);
+        float t_d = time_ms([&] { o3d_mlp_conv_dgrad(dN, 0, 0, 0, 32, Y, A1, A2, A3, W, s.B, s.Cin, s.Cout, s.P, X, sc, sh, mu, dNp, part, 0); }, reps);
+        float t_w = time_ms([&] { o3d_mlp_conv_wgrad(dN, 0, 0, 0, 32, Y, A1, A2, A3, X, sc, sh, 0, 0, 0, 0, 0, 0, 0, 1.f, s.B, s.Cin, s.Cout, s.P, nsl, wpart, dW, 0); }, reps);
+        printf("%-16s %6.2f GF | fwd %.3f ms %6.1f TF | dgrad %.3f ms %6.1f TF | wgrad %.3f ms %6.1f TF\n", s.name, gf,
+               t_f, gf / t_f, t_d, gf / t_d, t_w, gf / t_w);
+        for (float* p : {X, W, Y, dN, sc, sh, mu, c, A1, A2, A3, part, dNp, wpart, dW}) CK(hipFree(p));
+    }
+    return 0;
+}
