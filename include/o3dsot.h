@@ -152,6 +152,47 @@ int o3d_mlp_conv_dgrad(const float* dN, const float* dOut, const float* out, con
                        const float* scale_p, const float* shift_p, const float* mean_p,
                        float* dNprev, float* part, void* stream);
 
+/* o3d_mlp_conv_dgrad with the transposed weights Wt (Cin,Cout) supplied as well: aligned shapes
+ * (Cin % 64 == 0, Cout % 16 == 0) run the LDS-free kernel, which reads its A operand along Cout. */
+int o3d_mlp_conv_dgrad_wt(const float* dN, const float* dOut, const float* out, const int32_t* arg,
+                          int ns, const float* Y, const float* A1, const float* A2, const float* A3,
+                          const float* W, const float* Wt, int B, int Cin, int Cout, int P,
+                          const float* Yprev, const float* scale_p, const float* shift_p,
+                          const float* mean_p, float* dNprev, float* part, void* stream);
+
+/* dX (B,Cin,P) = W^T (A1*dN + A2*Y + A3): gradient w.r.t. an operand that is not a BN+ReLU output
+ * (the per-point operand [xyz;feats] of layer 0).  No mask, no statistics. */
+int o3d_mlp_conv_dgrad_plain(const float* dN, const float* Y, const float* A1, const float* A2,
+                             const float* A3, const float* W, int B, int Cin, int Cout, int P,
+                             float* dX, void* stream);
+
+/* ---- layer 0 of a grouped MLP on the N points instead of the P positions (csrc/group.hip) ----
+ * A 1x1 convolution commutes with the grouping gather: Z = W0.[xyz;feats] over the points, then
+ * Y0[b,co,p] = Z[b,co,idx[b,p]] - W0[co,0:3].new_xyz[b,j(p)]  (QueryAndGroup + layer 0,
+ * pointnet2_utils.py:299-339, pytorch_utils.py:12-37).  ld = row stride of the per-point tensors. */
+
+/* cnt[b,n] = number of positions referencing point n; R[b,n,:] = sum of the centres of those
+ * positions (R / new_xyz may be NULL).  cnt (B,ld), R (B,ld,3).  N <= 8192. */
+int o3d_group_meta(const int32_t* idx, const float* new_xyz, int B, int N, int ld, int npoint, int ns,
+                   float* cnt, float* R, void* stream);
+
+/* Y0 (B,C0,P) from Z (B,C0,ldz); part [B*P/256][2][C0] statistics partials (may be NULL); GY
+ * (B,C0,npoint) = per-ball sums of Y0 (may be NULL).  ns a power of two in 4..256, P % 256 == 0. */
+int o3d_group_expand_fwd(const float* Z, int ldz, const int32_t* idx, const float* new_xyz,
+                         const float* W0, int ldw, int B, int C0, int npoint, int ns, float* Y0,
+                         float* part, const float* stat_c, float* GY, void* stream);
+
+/* SdN[b,co,n] = sum over positions p with idx[b,p]==n of dN[b,co,p] (= group_points_grad,
+ * pointnet2_utils.py:237); TdN[b,co,j] = sum_k dN[b,co,j*ns+k] (may be NULL). */
+int o3d_group_reduce_bwd(const float* dN, const int32_t* idx, int B, int C0, int ld, int npoint, int ns,
+                         float* SdN, float* TdN, void* stream);
+
+/* In place: S = A1*S + A2*(cnt*Z - W0[:,0:3].R) + A3*cnt, T = A1*T + A2*GY + A3*ns: the list / ball
+ * sums of dY0 = A1*dN0 + A2*Y0 + A3 without reading Y0. */
+int o3d_group_bwd_combine(float* S, float* T, const float* Z, const float* GY, const float* cnt,
+                          const float* R, const float* W0, int ldw, const float* A1, const float* A2,
+                          const float* A3, int B, int C0, int ld, int npoint, int ns, void* stream);
+
 /* Data gradient of grouped layer 0.  GT (B,P,M), M = Cin - c_lo, receives (W[:, c_lo:]^T dY)^T
  * (caller scratch, left filled); dgrouped (B,M,N) receives its sum through the grouping map:
  * dgrouped[b,m,n] = sum over positions p with idx[b,p] == n of GT[b,p,m]  (= group_points_grad,

@@ -18,6 +18,7 @@ SOURCES = [
     ("fps.hip", ["-ffp-contract=off"]),
     ("index_ops.hip", ["-ffp-contract=off"]),
     ("mlp.hip", []),
+    ("mlp_direct.hip", []),
     ("group.hip", []),
     ("capi_misc.hip", []),
 ]

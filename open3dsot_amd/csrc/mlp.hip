@@ -24,27 +24,28 @@
 // K index permutation: inside each group of 8 k's, MFMA step s (0..3) consumes k = 8g+s on
 // lanes 0-31 and k = 8g+4+s on lanes 32-63, so an operand stored [row][k] is fetched with one
 // ds_read_b128 per 4 steps; an operand stored [k][row] uses ds_read_b32 with the same mapping.
-#include "o3d_common.hpp"
+#include "mlp_common.hpp"
 
 #include <mutex>
 #include <unordered_set>
 
+// aligned fast path (mlp_direct.hip)
+bool o3d_direct_ok(int M, int K, int P);
+int o3d_direct_fwd(const float* X, const float* W, const float* in_scale, const float* in_shift, int B, int Cin,
+                   int Cout, int P, float* Y, float* part, const float* stat_c, hipStream_t st);
+int o3d_direct_dgrad(const float* dN, const float* dOut, const float* out, const int32_t* arg, int ns,
+                     const float* Y, const float* A1, const float* A2, const float* A3, const float* Wt, int B,
+                     int Cin, int Cout, int P, const float* Yprev, const float* scale_p, const float* shift_p,
+                     const float* mean_p, float* dNprev, float* part, hipStream_t st);
+
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BN_POS = 128;  // positions per workgroup tile (forward / dgrad)
 constexpr int BK = 16;       // channel chunk (forward / dgrad)
 constexpr int LDMK = BK + 4; // [row][k] LDS stride (conflict-free ds_read_b128)
 constexpr int WBK = 32;      // position chunk of the weight-gradient kernel
 constexpr int WLD = WBK + 4;
-
-__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
-    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
-}
-
-// accumulator register r of a 32x32 tile holds row (r&3) + 8*(r>>2) + 4*(lane>>5), col lane&31
-__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
 
 // One K chunk of CH k's for a 64x64 wave tile.  A_MK: A stored [m][k] (stride lda) else [k][m].
 template <int CH, bool A_MK, bool B_MK>
@@ -77,25 +78,6 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ As, int lda,
             for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
                 for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = mfma32(a[tm][s], b[tn][s], acc[tm][tn]);
-    }
-}
-
-// Reduce-scatter of 32 per-lane values over the 32 lanes of each half-wave: afterwards lane
-// (l&31) holds in x[0] the sum over those 32 lanes of the value with index (l&31).
-__device__ __forceinline__ void reduce_scatter32(float (&x)[32], int l31) {
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) {
-        const bool up = (l31 & m) != 0;
-#pragma unroll
-        for (int v = 0; v < m; ++v) {
-            // operands made opaque first: otherwise LLVM rewrites select(up, x[v+m], x[v]) into a
-            // dynamically indexed extract of the 32-wide array (a 32-way v_cndmask chain per access)
-            float lo = x[v], hi = x[v + m];
-            asm volatile("" : "+v"(lo), "+v"(hi));
-            const float keep = up ? hi : lo;
-            const float send = up ? lo : hi;
-            x[v] = keep + __shfl_xor(send, m, 64);
-        }
     }
 }
 
@@ -975,6 +957,8 @@ extern "C" int o3d_mlp_conv_fwd(const float* X, const float* W, const float* in_
                                 const float* in_shift, int B, int Cin, int Cout, int P, float* Y,
                                 float* part, const float* stat_c, void* stream) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || P <= 0 || P % BN_POS != 0 || !X || !W || !Y) return O3D_EINVAL;
+    if (o3d_direct_ok(Cout, Cin, P) && (in_scale == nullptr) == (in_shift == nullptr))
+        return o3d_direct_fwd(X, W, in_scale, in_shift, B, Cin, Cout, P, Y, part, stat_c, o3d_stream(stream));
     FwdArgs a = {};
     a.X = X; a.W = W; a.Y = Y; a.in_scale = in_scale; a.in_shift = in_shift; a.part = part; a.stat_c = stat_c;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = P; a.ns = 4; a.inv_radius = 1.f;
@@ -1061,6 +1045,21 @@ extern "C" int o3d_mlp_conv_dgrad(const float* dN, const float* dOut, const floa
     a.W = W; a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = P; a.c_lo = 0; a.M = Cin;
     a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p; a.dNprev = dNprev; a.part = part;
     return dN ? launch_dgrad<false, 0>(a, o3d_stream(stream)) : launch_dgrad<true, 0>(a, o3d_stream(stream));
+}
+
+// Same contract as o3d_mlp_conv_dgrad plus Wt = W^T (Cin,Cout) contiguous: shapes with Cin % 64 == 0 and
+// Cout % 16 == 0 take the LDS-free kernel of mlp_direct.hip (its A operand is read along Cout).
+extern "C" int o3d_mlp_conv_dgrad_wt(const float* dN, const float* dOut, const float* out, const int32_t* arg,
+                                     int ns, const float* Y, const float* A1, const float* A2, const float* A3,
+                                     const float* W, const float* Wt, int B, int Cin, int Cout, int P,
+                                     const float* Yprev, const float* scale_p, const float* shift_p,
+                                     const float* mean_p, float* dNprev, float* part, void* stream) {
+    if (Wt && o3d_direct_ok(Cin, Cout, P) && B > 0 && Yprev && scale_p && shift_p && mean_p && dNprev && part &&
+        Y && A1 && A2 && A3 && (dN || (dOut && out && arg && ns > 0 && ns % 4 == 0)))
+        return o3d_direct_dgrad(dN, dOut, out, arg, ns, Y, A1, A2, A3, Wt, B, Cin, Cout, P, Yprev, scale_p, shift_p,
+                                mean_p, dNprev, part, o3d_stream(stream));
+    return o3d_mlp_conv_dgrad(dN, dOut, out, arg, ns, Y, A1, A2, A3, W, B, Cin, Cout, P, Yprev, scale_p, shift_p,
+                              mean_p, dNprev, part, stream);
 }
 
 // dX (B,Cin,P) = W^T dY with dY = A1*dN + A2*Y + A3, no mask, no statistics: the gradient w.r.t. an

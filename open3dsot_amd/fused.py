@@ -30,6 +30,8 @@ capi.register("o3d_group_meta", [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp])
 capi.register("o3d_group_expand_fwd", [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_group_reduce_bwd", [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp])
 capi.register("o3d_group_bwd_combine", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp])
+capi.register("o3d_mlp_conv_dgrad_wt", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
+                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_dgrad_plain", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp])
 capi.register("o3d_bn_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_bn_relu_maxpool_fwd", [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
@@ -325,8 +327,9 @@ class FusedGroupedMLP(torch.autograd.Function):
             # ---- data gradient: masked by the producer's ReLU, with its BN-backward partials
             dNp = torch.empty((B, Cin, P), device=dev, dtype=torch.float32)
             part = torch.empty((ntiles, 2, Cin), device=dev, dtype=torch.float32)
-            _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad, src[0], src[1], src[2], src[3], ns,
-                  Ys[l].data_ptr(), A[0], A[1], A[2], Ws[l].data_ptr(), B, Cin, Cout, P, Ys[l - 1].data_ptr(),
+            Wt = Ws[l].t().contiguous()      # (Cin, Cout): the LDS-free kernel reads its A operand along Cout
+            _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_wt, src[0], src[1], src[2], src[3], ns,
+                  Ys[l].data_ptr(), A[0], A[1], A[2], Ws[l].data_ptr(), Wt.data_ptr(), B, Cin, Cout, P, Ys[l - 1].data_ptr(),
                   scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),
                   part.data_ptr(), st)
             nparts = ntiles

@@ -16,6 +16,11 @@ extern "C" int o3d_mlp_conv_dgrad(const float* dN, const float* dOut, const floa
                                   const float* Y, const float* A1, const float* A2, const float* A3, const float* W,
                                   int B, int Cin, int Cout, int P, const float* Yprev, const float* scale_p,
                                   const float* shift_p, const float* mean_p, float* dNprev, float* part, void* stream);
+extern "C" int o3d_mlp_conv_dgrad_wt(const float* dN, const float* dOut, const float* out, const int32_t* arg, int ns,
+                                     const float* Y, const float* A1, const float* A2, const float* A3, const float* W,
+                                     const float* Wt, int B, int Cin, int Cout, int P, const float* Yprev,
+                                     const float* scale_p, const float* shift_p, const float* mean_p, float* dNprev,
+                                     float* part, void* stream);
 extern "C" int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const float* out, const int32_t* arg, int ns,
                                   const float* Y, const float* A1, const float* A2, const float* A3, const float* X,
                                   const float* in_scale, const float* in_shift, const float* xyz, const float* new_xyz,
@@ -37,6 +42,43 @@ __global__ __launch_bounds__(256) void mfma_peak_kernel(float* out, int iters) {
     }
     float s = 0.f;
     for (int i = 0; i < 4; ++i) for (int r = 0; r < 16; ++r) s += acc[i][r];
+    if (s == 123.456f) out[0] = s;
+}
+
+// variants of the issue-rate probe: 8 accumulators (128 acc registers) like the direct kernel,
+// MODE 1: + a dependent v_fma/v_max producing the B operand of every MFMA pair,
+// MODE 2: MODE 1 + four dwordx4 loads per 32 MFMAs (L2-resident buffer)
+template <int MODE>
+__global__ __launch_bounds__(64) void mfma_peak8_kernel(float* out, const float* src, int iters) {
+    f32x16 acc[2][4];
+    for (int i = 0; i < 2; ++i) for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
+    float a0 = threadIdx.x * 1e-3f, a1 = blockIdx.x * 1e-3f, sc = 1.0001f, sh = 1e-3f;
+    float4 b[4];
+    for (int s = 0; s < 4; ++s) b[s] = make_float4(0.1f * s, 0.2f, 0.3f, 0.4f);
+    const float4* p = reinterpret_cast<const float4*>(src) + threadIdx.x;
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 2) {
+#pragma unroll
+            for (int s = 0; s < 4; ++s) b[s] = p[(it * 4 + s) * 64 % 4096];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            float bv[4] = {b[s].x, b[s].y, b[s].z, b[s].w};
+            if (MODE >= 1) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) bv[t] = fmaxf(fmaf(bv[t], sc, sh), 0.f);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, bv[t], acc[0][t], 0, 0, 0);
+                acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, bv[t], acc[1][t], 0, 0, 0);
+            }
+            if (MODE == 1) { b[s].x = bv[1]; b[s].y = bv[2]; b[s].z = bv[3]; b[s].w = bv[0]; }
+        }
+    }
+    float s = 0.f;
+    for (int i = 0; i < 2; ++i) for (int t = 0; t < 4; ++t) for (int r = 0; r < 16; ++r) s += acc[i][t][r];
     if (s == 123.456f) out[0] = s;
 }
 
@@ -72,6 +114,16 @@ int main(int argc, char** argv) {
             double flops = (double)blocks * 4 * iters * 32.0 * (2.0 * 32 * 32 * 2);
             printf("mfma_peak waves/CU=%2d: %.3f ms  %.1f TFLOP/s\n", wpc, ms, flops / ms * 1e-9);
         }
+        float* src = dev_rand(1 << 16);
+        for (int wpc : {4, 8}) {
+            const int blocks = 256 * wpc, iters = 1024;
+            const double flops = (double)blocks * iters * 32.0 * 4096.0;
+            float m0 = time_ms([&] { hipLaunchKernelGGL(mfma_peak8_kernel<0>, dim3(blocks), dim3(64), 0, 0, out, src, iters); }, 5);
+            float m1 = time_ms([&] { hipLaunchKernelGGL(mfma_peak8_kernel<1>, dim3(blocks), dim3(64), 0, 0, out, src, iters); }, 5);
+            float m2 = time_ms([&] { hipLaunchKernelGGL(mfma_peak8_kernel<2>, dim3(blocks), dim3(64), 0, 0, out, src, iters); }, 5);
+            printf("mfma_peak8 waves/CU=%d: plain %.1f TF | +valu %.1f TF | +valu+loads %.1f TF\n", wpc, flops / m0 * 1e-9,
+                   flops / m1 * 1e-9, flops / m2 * 1e-9);
+        }
     }
     struct Shape { const char* name; int B, Cin, Cout, P; };
     const Shape shapes[] = {{"S-SA3 256->256", 48, 256, 256, 4096}, {"T-SA3 256->256", 48, 256, 256, 2048},
@@ -92,10 +144,11 @@ int main(int argc, char** argv) {
         float *dW; CK(hipMalloc(&dW, sizeof(float) * s.Cin * s.Cout));
         const double gf = 2.0 * s.Cin * s.Cout * (double)s.B * s.P * 1e-9;
         float t_f = time_ms([&] { o3d_mlp_conv_fwd(X, W, sc, sh, s.B, s.Cin, s.Cout, s.P, Y, part, c, 0); }, reps);
-        float t_d = time_ms([&] { o3d_mlp_conv_dgrad(dN, 0, 0, 0, 32, Y, A1, A2, A3, W, s.B, s.Cin, s.Cout, s.P, X, sc, sh, mu, dNp, part, 0); }, reps);
+        float t_f0 = time_ms([&] { o3d_mlp_conv_fwd(X, W, sc, sh, s.B, s.Cin, s.Cout, s.P, Y, nullptr, nullptr, 0); }, reps);
+        float t_d = time_ms([&] { o3d_mlp_conv_dgrad_wt(dN, 0, 0, 0, 32, Y, A1, A2, A3, W, W, s.B, s.Cin, s.Cout, s.P, X, sc, sh, mu, dNp, part, 0); }, reps);
         float t_w = time_ms([&] { o3d_mlp_conv_wgrad(dN, 0, 0, 0, 32, Y, A1, A2, A3, X, sc, sh, 0, 0, 0, 0, 0, 0, 0, 1.f, s.B, s.Cin, s.Cout, s.P, nsl, wpart, dW, 0); }, reps);
-        printf("%-16s %6.2f GF | fwd %.3f ms %6.1f TF | dgrad %.3f ms %6.1f TF | wgrad %.3f ms %6.1f TF\n", s.name, gf,
-               t_f, gf / t_f, t_d, gf / t_d, t_w, gf / t_w);
+        printf("%-16s %6.2f GF | fwd-nostat %.3f ms | fwd %.3f ms %6.1f TF | dgrad %.3f ms %6.1f TF | wgrad %.3f ms %6.1f TF\n", s.name, gf,
+               t_f0, t_f, gf / t_f, t_d, gf / t_d, t_w, gf / t_w);
         for (float* p : {X, W, Y, dN, sc, sh, mu, c, A1, A2, A3, part, dNp, wpart, dW}) CK(hipFree(p));
     }
     return 0;
