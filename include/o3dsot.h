@@ -132,9 +132,11 @@ int o3d_bn_relu_maxpool_fwd(const float* Y, const float* scale, const float* shi
                             int npoint, int ns, float* out, int32_t* arg, float* yarg, void* stream);
 
 /* Backward statistics of the pooled layer: part [B][2][C] = {sum g, sum g*(yarg-mean)},
- * g = dOut where out > 0. */
+ * g = dOut where out > 0.  pk != NULL (needs arg): also writes the packed pooled-gradient source
+ * pk (B,C,npoint) float2 = {g, bits(arg)} that o3d_mlp_conv_dgrad_wt reads. */
 int o3d_pool_bwd_partials(const float* dOut, const float* out, const float* yarg, const float* mean,
-                          int B, int C, int npoint, float* part, void* stream);
+                          int B, int C, int npoint, float* part, const int32_t* arg, float* pk,
+                          void* stream);
 
 /* BatchNorm backward from partials {sum dN, sum dN*(Y-mean)}: dgamma, dbeta and the per-channel
  * coefficients of dY = A1*dN + A2*Y + A3. */
@@ -153,10 +155,11 @@ int o3d_mlp_conv_dgrad(const float* dN, const float* dOut, const float* out, con
                        float* dNprev, float* part, void* stream);
 
 /* o3d_mlp_conv_dgrad with the transposed weights Wt (Cin,Cout) supplied as well: aligned shapes
- * (Cin % 64 == 0, Cout % 16 == 0) run the LDS-free kernel, which reads its A operand along Cout. */
+ * (Cin % 64 == 0, Cout % 16 == 0) run the LDS-free kernel, which reads its A operand along Cout
+ * and, for the pooled source, the packed pk of o3d_pool_bwd_partials instead of (dOut,out,arg). */
 int o3d_mlp_conv_dgrad_wt(const float* dN, const float* dOut, const float* out, const int32_t* arg,
                           int ns, const float* Y, const float* A1, const float* A2, const float* A3,
-                          const float* W, const float* Wt, int B, int Cin, int Cout, int P,
+                          const float* W, const float* Wt, const float* pk, int B, int Cin, int Cout, int P,
                           const float* Yprev, const float* scale_p, const float* shift_p,
                           const float* mean_p, float* dNprev, float* part, void* stream);
 

@@ -33,14 +33,46 @@ __global__ __launch_bounds__(256) void group_meta_kernel(const int32_t* __restri
     for (int i = threadIdx.x; i < 4 * N; i += 256) sm[i] = 0.f;
     __syncthreads();
     const int32_t* id = idx + (long)b * P;
-    for (int p = threadIdx.x; p < P; p += 256) {
-        const int n = id[p];
-        atomicAdd(&sm[n], 1.f);
-        if (new_xyz) {
-            const float* c = new_xyz + ((long)b * npoint + p / ns) * 3;
-            atomicAdd(&sm[N + 3 * n + 0], c[0]);
-            atomicAdd(&sm[N + 3 * n + 1], c[1]);
-            atomicAdd(&sm[N + 3 * n + 2], c[2]);
+    // A ball lists distinct points and pads with its first hit (Appendix A.2 of SURVEY.md): all
+    // references to the first hit are counted by the ball's first lane and added once -- without
+    // this the padded slots of one ball serialise on a single LDS address.
+    const int lane = threadIdx.x & 63;
+    if (ns <= 64 && (ns & (ns - 1)) == 0 && (P & 255) == 0) {
+        for (int p = threadIdx.x; p < P; p += 256) {
+            const int n = id[p];
+            const int first = __shfl(n, lane & ~(ns - 1), 64);
+            const bool is_first = n == first;
+            unsigned long long m = __ballot(is_first);
+            const int base = lane & ~(ns - 1);
+            const unsigned long long seg = ns == 64 ? ~0ull : (((1ull << ns) - 1) << base);
+            const int k = __popcll(m & seg);
+            const float* c = new_xyz ? new_xyz + ((long)b * npoint + p / ns) * 3 : nullptr;
+            if (lane == base) {
+                atomicAdd(&sm[n], (float)k);
+                if (c) {
+                    atomicAdd(&sm[N + 3 * n + 0], k * c[0]);
+                    atomicAdd(&sm[N + 3 * n + 1], k * c[1]);
+                    atomicAdd(&sm[N + 3 * n + 2], k * c[2]);
+                }
+            } else if (!is_first) {
+                atomicAdd(&sm[n], 1.f);
+                if (c) {
+                    atomicAdd(&sm[N + 3 * n + 0], c[0]);
+                    atomicAdd(&sm[N + 3 * n + 1], c[1]);
+                    atomicAdd(&sm[N + 3 * n + 2], c[2]);
+                }
+            }
+        }
+    } else {
+        for (int p = threadIdx.x; p < P; p += 256) {
+            const int n = id[p];
+            atomicAdd(&sm[n], 1.f);
+            if (new_xyz) {
+                const float* c = new_xyz + ((long)b * npoint + p / ns) * 3;
+                atomicAdd(&sm[N + 3 * n + 0], c[0]);
+                atomicAdd(&sm[N + 3 * n + 1], c[1]);
+                atomicAdd(&sm[N + 3 * n + 2], c[2]);
+            }
         }
     }
     __syncthreads();
@@ -135,22 +167,27 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(const float* __restri
     for (int q4 = threadIdx.x; q4 < P / 4; q4 += 256) {
         const int4 id = *reinterpret_cast<const int4*>(&id_b[4 * q4]);
         const int j = (4 * q4) / ns;
+        // first hit of this lane's ball (= the value its padded slots repeat): those contributions are
+        // summed over the ball with shuffles and added once, everything else goes through LDS atomics
+        const int first = __shfl(id.x, lane & ~(seg - 1), 64);
+        const bool fx = id.x == first, fy = id.y == first, fz = id.z == first, fw = id.w == first;
+        const bool leader = (lane & (seg - 1)) == 0;
 #pragma unroll
         for (int c = 0; c < RED_CS; ++c) {
             if (c0 + c >= C0) break;
             const float4 v = *reinterpret_cast<const float4*>(&dN[((long)b * C0 + c0 + c) * P + 4 * q4]);
             float* a = acc + c * ld;
-            // consecutive neighbours often repeat one index (ball padding): merge before the atomics
-            float r = v.x;
-            if (id.y == id.x) r += v.y; else { atomicAdd(&a[id.x], r); r = v.y; }
-            if (id.z == id.y) r += v.z; else { atomicAdd(&a[id.y], r); r = v.z; }
-            if (id.w == id.z) r += v.w; else { atomicAdd(&a[id.z], r); r = v.w; }
-            atomicAdd(&a[id.w], r);
-            if (TdN) {
-                float s = (v.x + v.y) + (v.z + v.w);
-                for (int m = 1; m < seg; m <<= 1) s += __shfl_xor(s, m, 64);
-                if ((lane & (seg - 1)) == 0) TdN[((long)b * C0 + c0 + c) * npoint + j] = s;
+            float f = (fx ? v.x : 0.f) + (fy ? v.y : 0.f) + (fz ? v.z : 0.f) + (fw ? v.w : 0.f);
+            float s = (v.x + v.y) + (v.z + v.w);
+            for (int m = 1; m < seg; m <<= 1) { f += __shfl_xor(f, m, 64); s += __shfl_xor(s, m, 64); }
+            if (leader) {
+                atomicAdd(&a[first], f);
+                if (TdN) TdN[((long)b * C0 + c0 + c) * npoint + j] = s;
             }
+            if (!fx) atomicAdd(&a[id.x], v.x);
+            if (!fy) atomicAdd(&a[id.y], v.y);
+            if (!fz) atomicAdd(&a[id.z], v.z);
+            if (!fw) atomicAdd(&a[id.w], v.w);
         }
     }
     __syncthreads();

@@ -33,7 +33,7 @@
 bool o3d_direct_ok(int M, int K, int P);
 int o3d_direct_fwd(const float* X, const float* W, const float* in_scale, const float* in_shift, int B, int Cin,
                    int Cout, int P, float* Y, float* part, const float* stat_c, hipStream_t st);
-int o3d_direct_dgrad(const float* dN, const float* dOut, const float* out, const int32_t* arg, int ns,
+int o3d_direct_dgrad(const float* dN, const float* pk, int ns,
                      const float* Y, const float* A1, const float* A2, const float* A3, const float* Wt, int B,
                      int Cin, int Cout, int P, const float* Yprev, const float* scale_p, const float* shift_p,
                      const float* mean_p, float* dNprev, float* part, hipStream_t st);
@@ -368,7 +368,9 @@ __global__ __launch_bounds__(256) void pool_bwd_partials_kernel(const float* __r
                                                                 const float* __restrict__ yarg,
                                                                 const float* __restrict__ mean, int B,
                                                                 int C, int npoint,
-                                                                float* __restrict__ part) {
+                                                                float* __restrict__ part,
+                                                                const int32_t* __restrict__ arg,
+                                                                float2* __restrict__ pk) {
     const int lane = threadIdx.x & 63;
     const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b,c)
     if (w >= (long)B * C) return;
@@ -378,6 +380,7 @@ __global__ __launch_bounds__(256) void pool_bwd_partials_kernel(const float* __r
     for (int j = lane; j < npoint; j += 64) {
         const long i = w * npoint + j;
         const float g = out[i] > 0.f ? dOut[i] : 0.f;
+        if (pk) pk[i] = make_float2(g, __int_as_float(arg[i]));   // packed source of the pooled dN
         s += g;
         q += g * (yarg[i] - mu);
     }
@@ -759,7 +762,8 @@ struct WgradArgs {
     int N, C, ns, nxyz; float inv_radius;
     int B, Cin, Cout, P;
     int chunks_per_block, total_chunks;
-    float* part;   // [gridDim.z][Cout][Cin]
+    int tiles_ci, tiles_co, nslices;
+    float* part;   // [nslices][Cout][Cin]
 };
 
 template <bool POOLED, bool GATHER, bool XFORM>
@@ -770,8 +774,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 64;
-    const int ci0 = blockIdx.x * 128, co0 = blockIdx.y * 128;
-    const int c_begin = blockIdx.z * a.chunks_per_block;
+    // 1-D grid.  Workgroup w is dispatched to XCD w % 8: the tiles_ci x tiles_co output tiles of one
+    // position slice read the same dN / Y / X rows, so they are made neighbours on ONE XCD (shared L2)
+    // instead of round-robin neighbours on different XCDs (every tile re-reading HBM).
+    const int ntile = a.tiles_ci * a.tiles_co;
+    int tile_id, slice;
+    if ((a.nslices & 7) == 0) {
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        tile_id = local % ntile;
+        slice = (local / ntile) * 8 + xcd;
+    } else {
+        tile_id = blockIdx.x % ntile;
+        slice = blockIdx.x / ntile;
+    }
+    const int ci0 = (tile_id % a.tiles_ci) * 128, co0 = (tile_id / a.tiles_ci) * 128;
+    const int c_begin = slice * a.chunks_per_block;
     int c_end = c_begin + a.chunks_per_block;
     if (c_end > a.total_chunks) c_end = a.total_chunks;
     const int chunks_per_b = a.P / WBK;
@@ -870,7 +887,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             __syncthreads();
         }
     }
-    float* dst = a.part + (long)blockIdx.z * a.Cout * a.Cin;
+    float* dst = a.part + (long)slice * a.Cout * a.Cin;
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
@@ -1006,10 +1023,12 @@ extern "C" int o3d_bn_relu_maxpool_fwd(const float* Y, const float* scale, const
 
 extern "C" int o3d_pool_bwd_partials(const float* dOut, const float* out, const float* yarg,
                                      const float* mean, int B, int C, int npoint, float* part,
-                                     void* stream) {
-    if (B <= 0 || C <= 0 || npoint <= 0 || !dOut || !out || !yarg || !mean || !part) return O3D_EINVAL;
+                                     const int32_t* arg, float* pk, void* stream) {
+    if (B <= 0 || C <= 0 || npoint <= 0 || !dOut || !out || !yarg || !mean || !part || (pk && !arg))
+        return O3D_EINVAL;
     hipLaunchKernelGGL(pool_bwd_partials_kernel, dim3(o3d_cdiv((long)B * C, 4)), dim3(256), 0,
-                       o3d_stream(stream), dOut, out, yarg, mean, B, C, npoint, part);
+                       o3d_stream(stream), dOut, out, yarg, mean, B, C, npoint, part, arg,
+                       reinterpret_cast<float2*>(pk));
     return o3d_launch_status();
 }
 
@@ -1047,16 +1066,17 @@ extern "C" int o3d_mlp_conv_dgrad(const float* dN, const float* dOut, const floa
     return dN ? launch_dgrad<false, 0>(a, o3d_stream(stream)) : launch_dgrad<true, 0>(a, o3d_stream(stream));
 }
 
-// Same contract as o3d_mlp_conv_dgrad plus Wt = W^T (Cin,Cout) contiguous: shapes with Cin % 64 == 0 and
+// Same contract as o3d_mlp_conv_dgrad plus Wt = W^T (Cin,Cout) contiguous and, for the pooled source,
+// pk (B,Cout,npoint) float2 = {dOut where out > 0 else 0, bits(arg)} from o3d_pool_bwd_partials: shapes with Cin % 64 == 0 and
 // Cout % 16 == 0 take the LDS-free kernel of mlp_direct.hip (its A operand is read along Cout).
 extern "C" int o3d_mlp_conv_dgrad_wt(const float* dN, const float* dOut, const float* out, const int32_t* arg,
                                      int ns, const float* Y, const float* A1, const float* A2, const float* A3,
-                                     const float* W, const float* Wt, int B, int Cin, int Cout, int P,
-                                     const float* Yprev, const float* scale_p, const float* shift_p,
+                                     const float* W, const float* Wt, const float* pk, int B, int Cin, int Cout,
+                                     int P, const float* Yprev, const float* scale_p, const float* shift_p,
                                      const float* mean_p, float* dNprev, float* part, void* stream) {
     if (Wt && o3d_direct_ok(Cin, Cout, P) && B > 0 && Yprev && scale_p && shift_p && mean_p && dNprev && part &&
-        Y && A1 && A2 && A3 && (dN || (dOut && out && arg && ns > 0 && ns % 4 == 0)))
-        return o3d_direct_dgrad(dN, dOut, out, arg, ns, Y, A1, A2, A3, Wt, B, Cin, Cout, P, Yprev, scale_p, shift_p,
+        Y && A1 && A2 && A3 && (dN || (pk && ns > 0 && ns % 4 == 0)))
+        return o3d_direct_dgrad(dN, pk, ns, Y, A1, A2, A3, Wt, B, Cin, Cout, P, Yprev, scale_p, shift_p,
                                 mean_p, dNprev, part, o3d_stream(stream));
     return o3d_mlp_conv_dgrad(dN, dOut, out, arg, ns, Y, A1, A2, A3, W, B, Cin, Cout, P, Yprev, scale_p, shift_p,
                               mean_p, dNprev, part, stream);
@@ -1127,7 +1147,8 @@ extern "C" int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const floa
     a.total_chunks = B * (P / WBK);
     a.chunks_per_block = (a.total_chunks + nslices - 1) / nslices;
     a.part = part;
-    const dim3 grid(o3d_cdiv(Cin, 128), o3d_cdiv(Cout, 128), nslices), block(256);
+    a.tiles_ci = o3d_cdiv(Cin, 128); a.tiles_co = o3d_cdiv(Cout, 128); a.nslices = nslices;
+    const dim3 grid(a.tiles_ci * a.tiles_co * nslices), block(256);
     const size_t lds = sizeof(float) * 4 * 128 * WLD;
     hipStream_t s = o3d_stream(stream);
     int rc;

@@ -36,7 +36,7 @@ struct RawB {
     float4 y[4];      // DY: raw conv output Y
     float4 c1, c2, c3;  // per-k constants: (scale, shift, -) or (A1, A2, A3)
 };
-// pooled dY source: v[s] = {dOut, bits(arg), out, -} of this lane's ball for k row s
+// pooled dY source: v[s].xy = {dOut masked by out > 0, bits(arg)} of this lane's ball for k row s
 
 enum BMode { B_PLAIN = 0, B_XFORM = 1, B_DY = 2, B_DYPOOL = 3 };
 
@@ -45,7 +45,7 @@ struct DirectArgs {
     const float* X;        // B main tensor (B, K, P): X / dN (NULL when pooled)
     const float* Y;        // DY modes: raw output of this layer (B, K, P)
     const float* c1; const float* c2; const float* c3;   // per-k constants (K each)
-    const float* dOut; const int32_t* arg; const float* out; int ns;   // pooled source (B, K, P/ns)
+    const float2* pk; int ns;   // pooled source (B, K, P/ns): {dOut masked by out > 0, bits(arg)}
     float* Out;            // (B, M, P)
     int M, K, P, B;
     // epilogue
@@ -63,7 +63,8 @@ __device__ __forceinline__ void load_b(const DirectArgs& a, const float* xb, con
         if (MODE >= B_DY) f.y[s] = *reinterpret_cast<const float4*>(yb + (long)(kb + s) * rowP);
         if (MODE == B_DYPOOL) {
             const long i = pool_base + (long)(kb + s) * np;
-            f.v[s] = make_float4(a.dOut[i], __int_as_float(a.arg[i]), a.out[i], 0.f);
+            const float2 t = a.pk[i];
+            f.v[s].x = t.x; f.v[s].y = t.y;
         }
     }
     if (MODE != B_PLAIN) {
@@ -84,7 +85,7 @@ __device__ __forceinline__ void compute_group(const RawB& f, const float4& a0v, 
     for (int s = 0; s < 4; ++s) {
         float bv[4];
         if (MODE == B_DYPOOL) {
-            const float go = f.v[s].z > 0.f ? f.v[s].x : 0.f;
+            const float go = f.v[s].x;
             const int ak = __float_as_int(f.v[s].y);
 #pragma unroll
             for (int t = 0; t < 4; ++t) bv[t] = (kk + t == ak) ? go : 0.f;
@@ -231,12 +232,12 @@ int o3d_direct_fwd(const float* X, const float* W, const float* in_scale, const 
 }
 
 // data gradient with the weights already transposed: Wt (Cin, Cout); see o3d_mlp_conv_dgrad
-int o3d_direct_dgrad(const float* dN, const float* dOut, const float* out, const int32_t* arg, int ns,
+int o3d_direct_dgrad(const float* dN, const float* pk, int ns,
                      const float* Y, const float* A1, const float* A2, const float* A3, const float* Wt, int B,
                      int Cin, int Cout, int P, const float* Yprev, const float* scale_p, const float* shift_p,
                      const float* mean_p, float* dNprev, float* part, hipStream_t st) {
     DirectArgs a = {};
-    a.A = Wt; a.X = dN; a.Y = Y; a.c1 = A1; a.c2 = A2; a.c3 = A3; a.dOut = dOut; a.arg = arg; a.out = out; a.ns = ns;
+    a.A = Wt; a.X = dN; a.Y = Y; a.c1 = A1; a.c2 = A2; a.c3 = A3; a.pk = reinterpret_cast<const float2*>(pk); a.ns = ns;
     a.Out = dNprev; a.M = Cin; a.K = Cout; a.P = P; a.B = B; a.part = part;
     a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p;
     return dN ? launch_direct<B_DY, 1>(a, st) : launch_direct<B_DYPOOL, 1>(a, st);

@@ -30,12 +30,12 @@ capi.register("o3d_group_meta", [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp])
 capi.register("o3d_group_expand_fwd", [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_group_reduce_bwd", [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp])
 capi.register("o3d_group_bwd_combine", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp])
-capi.register("o3d_mlp_conv_dgrad_wt", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
+capi.register("o3d_mlp_conv_dgrad_wt", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_dgrad_plain", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp])
 capi.register("o3d_bn_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_bn_relu_maxpool_fwd", [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
-capi.register("o3d_pool_bwd_partials", [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp])
+capi.register("o3d_pool_bwd_partials", [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_bn_bwd_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_dgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp])
@@ -259,8 +259,9 @@ class FusedGroupedMLP(torch.autograd.Function):
         # BN-backward coefficients of the last (pooled) layer
         Cl = Ws[-1].shape[0]
         part = torch.empty((B, 2, Cl), device=dev, dtype=torch.float32)
+        pk = torch.empty((B, Cl, npoint, 2), device=dev, dtype=torch.float32)   # {masked dOut, bits(arg)}
         _call("pool_bwd_partials", 0.0, lib.o3d_pool_bwd_partials, dOut.data_ptr(), out.data_ptr(), yarg.data_ptr(),
-              means[-1].data_ptr(), B, Cl, npoint, part.data_ptr(), st)
+              means[-1].data_ptr(), B, Cl, npoint, part.data_ptr(), arg.data_ptr(), pk.data_ptr(), st)
         nparts = B
         dN = None  # dense dN of the current layer (None = pooled source)
         dfeats = dxyz = dnew = None
@@ -329,7 +330,8 @@ class FusedGroupedMLP(torch.autograd.Function):
             part = torch.empty((ntiles, 2, Cin), device=dev, dtype=torch.float32)
             Wt = Ws[l].t().contiguous()      # (Cin, Cout): the LDS-free kernel reads its A operand along Cout
             _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_wt, src[0], src[1], src[2], src[3], ns,
-                  Ys[l].data_ptr(), A[0], A[1], A[2], Ws[l].data_ptr(), Wt.data_ptr(), B, Cin, Cout, P, Ys[l - 1].data_ptr(),
+                  Ys[l].data_ptr(), A[0], A[1], A[2], Ws[l].data_ptr(), Wt.data_ptr(), pk.data_ptr(), B, Cin, Cout, P,
+                  Ys[l - 1].data_ptr(),
                   scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),
                   part.data_ptr(), st)
             nparts = ntiles

@@ -18,7 +18,7 @@ extern "C" int o3d_mlp_conv_dgrad(const float* dN, const float* dOut, const floa
                                   const float* shift_p, const float* mean_p, float* dNprev, float* part, void* stream);
 extern "C" int o3d_mlp_conv_dgrad_wt(const float* dN, const float* dOut, const float* out, const int32_t* arg, int ns,
                                      const float* Y, const float* A1, const float* A2, const float* A3, const float* W,
-                                     const float* Wt, int B, int Cin, int Cout, int P, const float* Yprev,
+                                     const float* Wt, const float* pk, int B, int Cin, int Cout, int P, const float* Yprev,
                                      const float* scale_p, const float* shift_p, const float* mean_p, float* dNprev,
                                      float* part, void* stream);
 extern "C" int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const float* out, const int32_t* arg, int ns,
@@ -145,7 +145,7 @@ int main(int argc, char** argv) {
         const double gf = 2.0 * s.Cin * s.Cout * (double)s.B * s.P * 1e-9;
         float t_f = time_ms([&] { o3d_mlp_conv_fwd(X, W, sc, sh, s.B, s.Cin, s.Cout, s.P, Y, part, c, 0); }, reps);
         float t_f0 = time_ms([&] { o3d_mlp_conv_fwd(X, W, sc, sh, s.B, s.Cin, s.Cout, s.P, Y, nullptr, nullptr, 0); }, reps);
-        float t_d = time_ms([&] { o3d_mlp_conv_dgrad_wt(dN, 0, 0, 0, 32, Y, A1, A2, A3, W, W, s.B, s.Cin, s.Cout, s.P, X, sc, sh, mu, dNp, part, 0); }, reps);
+        float t_d = time_ms([&] { o3d_mlp_conv_dgrad_wt(dN, 0, 0, 0, 32, Y, A1, A2, A3, W, W, 0, s.B, s.Cin, s.Cout, s.P, X, sc, sh, mu, dNp, part, 0); }, reps);
         float t_w = time_ms([&] { o3d_mlp_conv_wgrad(dN, 0, 0, 0, 32, Y, A1, A2, A3, X, sc, sh, 0, 0, 0, 0, 0, 0, 0, 1.f, s.B, s.Cin, s.Cout, s.P, nsl, wpart, dW, 0); }, reps);
         printf("%-16s %6.2f GF | fwd-nostat %.3f ms | fwd %.3f ms %6.1f TF | dgrad %.3f ms %6.1f TF | wgrad %.3f ms %6.1f TF\n", s.name, gf,
                t_f0, t_f, gf / t_f, t_d, gf / t_d, t_w, gf / t_w);
