@@ -217,6 +217,16 @@ int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const float* out, con
                        int nxyz, float inv_radius, int B, int Cin, int Cout, int P, int nslices,
                        float* part, float* dW, void* stream);
 
+/* Weight gradient of an aligned inner layer (Cin, Cout multiples of 64; P multiple of 128), workgroup
+ * tile matched to the layer: dW (Cout,Cin) = sum dY * f(X), dY = A1*dN + A2*Y + A3 from dN (dense) or,
+ * when dN == NULL, from the packed pooled source pk of o3d_pool_bwd_partials; f(x) =
+ * max(x*in_scale+in_shift, 0).  scratch: o3d_mlp_conv_wgrad2_scratch(...) floats. */
+long o3d_mlp_conv_wgrad2_scratch(int B, int Cin, int Cout, int P);
+int o3d_mlp_conv_wgrad2(const float* dN, const float* pk, int ns, const float* Y, const float* A1,
+                        const float* A2, const float* A3, const float* X, const float* in_scale,
+                        const float* in_shift, int B, int Cin, int Cout, int P, float* scratch, float* dW,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,6 +19,7 @@ SOURCES = [
     ("index_ops.hip", ["-ffp-contract=off"]),
     ("mlp.hip", []),
     ("mlp_direct.hip", []),
+    ("mlp_wgrad.hip", []),
     ("group.hip", []),
     ("capi_misc.hip", []),
 ]

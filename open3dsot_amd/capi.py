@@ -53,7 +53,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export it
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_long if name.endswith("_scratch") else ctypes.c_int
     lib.o3d_version.restype = ctypes.c_char_p
     lib.o3d_version.argtypes = []
     _lib = lib
@@ -66,7 +66,7 @@ def register(name, argtypes):
     if _lib is not None:
         fn = getattr(_lib, name)
         fn.argtypes = argtypes
-        fn.restype = ctypes.c_int
+        fn.restype = ctypes.c_long if name.endswith("_scratch") else ctypes.c_int
 
 
 _ERR = {-1: "invalid argument (shape / null pointer / unsupported size)",

@@ -1123,6 +1123,21 @@ extern "C" int o3d_mlp_conv_grouped_dgrad(const float* dN, const float* dOut, co
                   GT, offsets, perm, a.M, (int)P, N, dgrouped);
 }
 
+// dW[i] = sum over slices of part[z][i], in a fixed order (two stages above 32 slices; scratch2 holds
+// 16 * n floats)
+void o3d_wgrad_reduce(const float* part, int nslices, long n, float* scratch2, float* dW, hipStream_t s) {
+    if (nslices > 32) {
+        const int groups = 16, per = (nslices + groups - 1) / groups;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(o3d_cdiv(n, 256), groups), dim3(256), 0, s, part, nslices, per,
+                           n, scratch2);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(o3d_cdiv(n, 256), 1), dim3(256), 0, s, scratch2, groups, groups,
+                           n, dW);
+    } else {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(o3d_cdiv(n, 256), 1), dim3(256), 0, s, part, nslices, nslices,
+                           n, dW);
+    }
+}
+
 // weight gradient.  `part` is scratch of (nslices+16)*Cout*Cin floats; dW (Cout,Cin) is overwritten.
 // X source: (X, in_scale, in_shift) for inner layers (in_scale NULL = identity), or the layer-0
 // gather (xyz,new_xyz,feats,idx,N,C,nxyz) when X == NULL.
@@ -1164,17 +1179,6 @@ extern "C" int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const floa
                     : launch(conv_wgrad_kernel<false, false, false>, grid, block, lds, s, a);
     }
     if (rc != O3D_OK) return rc;
-    const long n = (long)Cout * Cin;
-    if (nslices > 32) {   // stage 1: 16 groups written over the first 16 slices' worth of scratch tail
-        const int groups = 16, per = (nslices + groups - 1) / groups;
-        float* part2 = part + (long)nslices * n;   // caller provides (nslices + 16) * n floats
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(o3d_cdiv(n, 256), groups), dim3(256), 0, s, part, nslices, per,
-                           n, part2);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(o3d_cdiv(n, 256), 1), dim3(256), 0, s, part2, groups, groups,
-                           n, dW);
-    } else {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(o3d_cdiv(n, 256), 1), dim3(256), 0, s, part, nslices, nslices,
-                           n, dW);
-    }
+    o3d_wgrad_reduce(part, nslices, (long)Cout * Cin, part + (long)nslices * Cout * Cin, dW, s);
     return o3d_launch_status();
 }

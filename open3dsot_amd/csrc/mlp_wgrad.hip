@@ -1,0 +1,248 @@
+// mlp_wgrad.hip -- weight gradient of the aligned inner layers (Cin, Cout multiples of 64):
+//     dW[co,ci] = sum_{b,p} dY[b,co,p] * f(X[b,ci,p]),   dY = A1*dN + A2*Y + A3,  f = BN+ReLU of the producer
+// (backward of Conv2d 1x1 + BatchNorm2d, pointnet2/utils/pytorch_utils.py:12-37,68-121).
+//
+// The contraction runs over positions, so both MFMA operands are rows that are contiguous along k:
+// here LDS staging IS the right tool (a lane of an MFMA fragment wants 16 bytes of ONE row; a coalesced
+// global load wants 128 bytes of a row from 8 neighbouring lanes) -- unlike the forward / data-gradient
+// kernels of mlp_direct.hip.  What this version fixes over the generic kernel in mlp.hip:
+//   * the workgroup tile matches the layer (64x64, 128x64, 64x128, 128x128): the 64-channel layers of
+//     SA1 no longer multiply 75 % zeros; waves left over split the chunk's positions (k) instead;
+//   * no bounds checks, per-row constants hoisted out of the position loop;
+//   * exactly one resident round of workgroups (2 per CU x 256 CUs) instead of 1.5;
+//   * the output tiles of one position slice sit on one XCD (they re-read the same rows: L2 hits);
+//   * pooled source read as the packed {gradient, arg} pairs of o3d_pool_bwd_partials.
+// Partial tiles [slice][Cout][Cin] are summed in a fixed order by wgrad_reduce_kernel (mlp.hip).
+#include "mlp_common.hpp"
+
+namespace {
+
+struct Wgrad2Args {
+    const float* dN;       // (B,Cout,P) dense source or NULL
+    const float2* pk;      // pooled source (B,Cout,P/ns)
+    int ns;
+    const float* Y;        // (B,Cout,P)
+    const float* A1; const float* A2; const float* A3;
+    const float* X;        // (B,Cin,P) raw output of the producer
+    const float* in_scale; const float* in_shift;
+    int B, Cin, Cout, P;
+    int chunks_per_block, total_chunks, nslices;
+    float* part;           // [nslices*WK][Cout][Cin]
+};
+
+template <int TM, int TN, bool POOLED>
+__global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
+    constexpr int WM = TM / 64, WN = TN / 64, WK = 4 / (WM * WN);
+    constexpr int CP = (TM + TN == 128) ? 64 : 32;      // positions per staged chunk
+    constexpr int LD = CP + 4;                          // [row][pos] stride: conflict-free ds_read_b128
+    constexpr int F = CP / 4;                           // float4 per row
+    constexpr int RPP = 256 / F;                        // rows staged per pass
+    constexpr int PA = TM / RPP, PB = TN / RPP;         // passes
+    constexpr int NG = CP / WK / 8;                     // k groups of 8 per wave per chunk
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    auto As = [&](int buf) -> float* { return smem + buf * ((TM + TN) * LD); };
+    auto Bs = [&](int buf) -> float* { return smem + buf * ((TM + TN) * LD) + TM * LD; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int wk = wave / (WM * WN), wmn = wave - wk * (WM * WN);
+    const int wm0 = (wmn / WN) * 64, wn0 = (wmn % WN) * 64;
+    const int tiles_ci = a.Cin / TN, ntile = tiles_ci * (a.Cout / TM);
+    int tile_id, slice;
+    if ((a.nslices & 7) == 0) {      // keep the tiles of one position slice on one XCD (shared L2)
+        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        tile_id = local % ntile;
+        slice = (local / ntile) * 8 + xcd;
+    } else {
+        tile_id = blockIdx.x % ntile;
+        slice = blockIdx.x / ntile;
+    }
+    const int ci0 = (tile_id % tiles_ci) * TN, co0 = (tile_id / tiles_ci) * TM;
+    const int c_begin = slice * a.chunks_per_block;
+    int c_end = c_begin + a.chunks_per_block;
+    if (c_end > a.total_chunks) c_end = a.total_chunks;
+    const int chunks_per_b = a.P / CP;
+    const int r0 = tid / F, c4 = tid % F;
+    const int np = POOLED ? a.P / a.ns : 1;
+
+    // per-row constants of this thread's staging rows
+    float ka1[PA], ka2[PA], ka3[PA], ksc[PB], ksh[PB];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) {
+        const int co = co0 + r0 + RPP * i;
+        ka1[i] = a.A1[co]; ka2[i] = a.A2[co]; ka3[i] = a.A3[co];
+    }
+#pragma unroll
+    for (int i = 0; i < PB; ++i) {
+        const int ci = ci0 + r0 + RPP * i;
+        ksc[i] = a.in_scale[ci]; ksh[i] = a.in_shift[ci];
+    }
+
+    float4 rg[PA], ry[PA], rx[PB];
+    int rk = 0;
+    auto load_chunk = [&](int ch) {
+        const long b = ch / chunks_per_b;
+        const int p = (ch - (int)b * chunks_per_b) * CP + 4 * c4;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const long row = b * a.Cout + co0 + r0 + RPP * i;
+            ry[i] = *reinterpret_cast<const float4*>(&a.Y[row * a.P + p]);
+            if (POOLED) {
+                const int j = p / a.ns;
+                const float2 t = a.pk[row * np + j];
+                rg[i].x = t.x; rg[i].y = t.y;
+                rk = p - j * a.ns;
+            } else {
+                rg[i] = *reinterpret_cast<const float4*>(&a.dN[row * a.P + p]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            rx[i] = *reinterpret_cast<const float4*>(&a.X[(b * a.Cin + ci0 + r0 + RPP * i) * a.P + p]);
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            float4 g;
+            if (POOLED) {
+                const int ak = __float_as_int(rg[i].y);
+                const float go = rg[i].x;
+                g.x = (rk + 0 == ak) ? go : 0.f; g.y = (rk + 1 == ak) ? go : 0.f;
+                g.z = (rk + 2 == ak) ? go : 0.f; g.w = (rk + 3 == ak) ? go : 0.f;
+            } else {
+                g = rg[i];
+            }
+            float4 o;
+            o.x = fmaf(ka1[i], g.x, fmaf(ka2[i], ry[i].x, ka3[i])); o.y = fmaf(ka1[i], g.y, fmaf(ka2[i], ry[i].y, ka3[i]));
+            o.z = fmaf(ka1[i], g.z, fmaf(ka2[i], ry[i].z, ka3[i])); o.w = fmaf(ka1[i], g.w, fmaf(ka2[i], ry[i].w, ka3[i]));
+            *reinterpret_cast<float4*>(&As(buf)[(r0 + RPP * i) * LD + 4 * c4]) = o;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            float4 v = rx[i];
+            v.x = fmaxf(fmaf(v.x, ksc[i], ksh[i]), 0.f); v.y = fmaxf(fmaf(v.y, ksc[i], ksh[i]), 0.f);
+            v.z = fmaxf(fmaf(v.z, ksc[i], ksh[i]), 0.f); v.w = fmaxf(fmaf(v.w, ksc[i], ksh[i]), 0.f);
+            *reinterpret_cast<float4*>(&Bs(buf)[(r0 + RPP * i) * LD + 4 * c4]) = v;
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
+        store_chunk(0);
+        __syncthreads();
+        for (int ch = c_begin; ch < c_end; ++ch) {
+            const int t = ch - c_begin;
+            if (ch + 1 < c_end) load_chunk(ch + 1);
+            const float* A_ = As(t & 1) + wk * (CP / WK);
+            const float* B_ = Bs(t & 1) + wk * (CP / WK);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                float av[2][4], bv[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const float4 x = *reinterpret_cast<const float4*>(&A_[(wm0 + 32 * u + l31) * LD + 8 * g + 4 * h]);
+                    av[u][0] = x.x; av[u][1] = x.y; av[u][2] = x.z; av[u][3] = x.w;
+                    const float4 y = *reinterpret_cast<const float4*>(&B_[(wn0 + 32 * u + l31) * LD + 8 * g + 4 * h]);
+                    bv[u][0] = y.x; bv[u][1] = y.y; bv[u][2] = y.z; bv[u][3] = y.w;
+                }
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                        for (int tn = 0; tn < 2; ++tn) acc[tm][tn] = mfma32(av[tm][s], bv[tn][s], acc[tm][tn]);
+            }
+            if (ch + 1 < c_end) store_chunk((t + 1) & 1);
+            __syncthreads();
+        }
+    }
+    // every k-split wave writes its own partial slice (summed later in a fixed order)
+    float* dst = a.part + (long)(slice * WK + wk) * a.Cout * a.Cin;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm0 + 32 * tm + acc_row(r, h);
+#pragma unroll
+            for (int tn = 0; tn < 2; ++tn) dst[(long)co * a.Cin + ci0 + wn0 + 32 * tn + l31] = acc[tm][tn][r];
+        }
+}
+
+template <int TM, int TN>
+int launch_wgrad2(const Wgrad2Args& a, hipStream_t s) {
+    constexpr int CP = (TM + TN == 128) ? 64 : 32;
+    const size_t lds = sizeof(float) * 2 * (TM + TN) * (CP + 4);
+    const void* fn = a.dN ? reinterpret_cast<const void*>(wgrad2_kernel<TM, TN, false>)
+                          : reinterpret_cast<const void*>(wgrad2_kernel<TM, TN, true>);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return O3D_ELAUNCH;
+    const int ntile = (a.Cout / TM) * (a.Cin / TN);
+    if (a.dN) hipLaunchKernelGGL((wgrad2_kernel<TM, TN, false>), dim3(ntile * a.nslices), dim3(256), lds, s, a);
+    else      hipLaunchKernelGGL((wgrad2_kernel<TM, TN, true>), dim3(ntile * a.nslices), dim3(256), lds, s, a);
+    return o3d_launch_status();
+}
+
+}  // namespace
+
+void o3d_wgrad_reduce(const float* part, int nslices, long n, float* scratch2, float* dW, hipStream_t s);
+
+static void wgrad2_plan(int Cin, int Cout, int B, int P, int& TM, int& TN, int& WK, int& CP, int& nsl) {
+    TM = Cout % 128 == 0 ? 128 : 64;
+    TN = Cin % 128 == 0 ? 128 : 64;
+    WK = 4 / ((TM / 64) * (TN / 64));
+    CP = (TM + TN == 128) ? 64 : 32;
+    const int ntile = (Cout / TM) * (Cin / TN);
+    const long total = (long)B * (P / CP);
+    nsl = 512 / ntile;                 // one resident round: 2 workgroups per CU x 256 CUs
+    if (nsl < 8) nsl = 8;
+    while (nsl > 8 && total / nsl < 4) nsl -= 8;
+    if (nsl > total) nsl = (int)total;
+}
+
+// floats of scratch needed by o3d_mlp_conv_wgrad2 (partial tiles + second-stage groups)
+extern "C" long o3d_mlp_conv_wgrad2_scratch(int B, int Cin, int Cout, int P) {
+    if (Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || P <= 0 || P % 128 || B <= 0) return -1;
+    int TM, TN, WK, CP, nsl;
+    wgrad2_plan(Cin, Cout, B, P, TM, TN, WK, CP, nsl);
+    return ((long)nsl * WK + 16) * Cout * Cin;
+}
+
+// dW (Cout,Cin) = sum_{b,p} dY * f(X); dY from dN (dense) or pk (pooled, needs ns); X raw producer output
+// with (in_scale,in_shift).  Cin, Cout multiples of 64, P multiple of 128.
+extern "C" int o3d_mlp_conv_wgrad2(const float* dN, const float* pk, int ns, const float* Y, const float* A1,
+                                   const float* A2, const float* A3, const float* X, const float* in_scale,
+                                   const float* in_shift, int B, int Cin, int Cout, int P, float* scratch,
+                                   float* dW, void* stream) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || P <= 0 || P % 128 || !Y || !A1 || !A2 || !A3 ||
+        !X || !in_scale || !in_shift || !scratch || !dW || (!dN && (!pk || ns < 4 || ns % 4)))
+        return O3D_EINVAL;
+    int TM, TN, WK, CP, nsl;
+    wgrad2_plan(Cin, Cout, B, P, TM, TN, WK, CP, nsl);
+    Wgrad2Args a = {};
+    a.dN = dN; a.pk = reinterpret_cast<const float2*>(pk); a.ns = ns > 0 ? ns : 4; a.Y = Y;
+    a.A1 = A1; a.A2 = A2; a.A3 = A3; a.X = X; a.in_scale = in_scale; a.in_shift = in_shift;
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = P;
+    a.total_chunks = B * (P / CP);
+    a.chunks_per_block = (a.total_chunks + nsl - 1) / nsl;
+    a.nslices = nsl;
+    a.part = scratch;
+    hipStream_t s = o3d_stream(stream);
+    int rc;
+    if (TM == 128 && TN == 128) rc = launch_wgrad2<128, 128>(a, s);
+    else if (TM == 128)         rc = launch_wgrad2<128, 64>(a, s);
+    else if (TN == 128)         rc = launch_wgrad2<64, 128>(a, s);
+    else                        rc = launch_wgrad2<64, 64>(a, s);
+    if (rc != O3D_OK) return rc;
+    const long n = (long)Cout * Cin;
+    o3d_wgrad_reduce(scratch, nsl * WK, n, scratch + (long)nsl * WK * n, dW, s);
+    return o3d_launch_status();
+}

@@ -32,6 +32,8 @@ capi.register("o3d_group_reduce_bwd", [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _
 capi.register("o3d_group_bwd_combine", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp])
 capi.register("o3d_mlp_conv_dgrad_wt", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_wgrad2", [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_wgrad2_scratch", [_i, _i, _i, _i])
 capi.register("o3d_mlp_conv_dgrad_plain", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp])
 capi.register("o3d_bn_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_bn_relu_maxpool_fwd", [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
@@ -316,14 +318,21 @@ class FusedGroupedMLP(torch.autograd.Function):
                         dnew = torch.einsum("bcj,ck->bjk", T, Ws[0][:, :3]) * (-cfg.inv_radius)
                 continue
             # ---- weight gradient
-            tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
-            total_chunks = B * (P // 32)
-            nsl = max(1, min(total_chunks // 4 if total_chunks >= 4 else 1, 768 // tiles))
-            wpart = torch.empty((nsl + 16, Cout, Cin), device=dev, dtype=torch.float32)
             dW = torch.empty((Cout, Cin), device=dev, dtype=torch.float32)
-            _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad, src[0], src[1], src[2], src[3], ns, Ys[l].data_ptr(),
-                  A[0], A[1], A[2], Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), None,
-                  None, None, None, 0, 0, 0, 1.0, B, Cin, Cout, P, nsl, wpart.data_ptr(), dW.data_ptr(), st)
+            if Cin % 64 == 0 and Cout % 64 == 0:
+                lib.o3d_mlp_conv_wgrad2_scratch.restype = ctypes.c_long
+                wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(B, Cin, Cout, P),), device=dev, dtype=torch.float32)
+                _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2, _ptr(dN), pk.data_ptr(), ns, Ys[l].data_ptr(),
+                      A[0], A[1], A[2], Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), B, Cin,
+                      Cout, P, wpart.data_ptr(), dW.data_ptr(), st)
+            else:
+                tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
+                total_chunks = B * (P // 32)
+                nsl = max(1, min(total_chunks // 4 if total_chunks >= 4 else 1, 768 // tiles))
+                wpart = torch.empty((nsl + 16, Cout, Cin), device=dev, dtype=torch.float32)
+                _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad, src[0], src[1], src[2], src[3], ns, Ys[l].data_ptr(),
+                      A[0], A[1], A[2], Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), None,
+                      None, None, None, 0, 0, 0, 1.0, B, Cin, Cout, P, nsl, wpart.data_ptr(), dW.data_ptr(), st)
             grads[3 * l] = dW
             # ---- data gradient: masked by the producer's ReLU, with its BN-backward partials
             dNp = torch.empty((B, Cin, P), device=dev, dtype=torch.float32)

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <cmath>
 #include "../../include/o3dsot.h"
 
 extern "C" int o3d_mlp_conv_fwd(const float*, const float*, const float*, const float*, int, int, int, int, float*,
@@ -27,6 +28,11 @@ extern "C" int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const floa
                                   const float* feats, const int32_t* idx, int N, int C, int nxyz, float inv_radius,
                                   int B, int Cin, int Cout, int P, int nslices, float* part, float* dW, void* stream);
 
+extern "C" long o3d_mlp_conv_wgrad2_scratch(int B, int Cin, int Cout, int P);
+extern "C" int o3d_mlp_conv_wgrad2(const float* dN, const float* pk, int ns, const float* Y, const float* A1,
+                                   const float* A2, const float* A3, const float* X, const float* in_scale,
+                                   const float* in_shift, int B, int Cin, int Cout, int P, float* scratch, float* dW,
+                                   void* stream);
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 
@@ -147,6 +153,17 @@ int main(int argc, char** argv) {
         float t_f0 = time_ms([&] { o3d_mlp_conv_fwd(X, W, sc, sh, s.B, s.Cin, s.Cout, s.P, Y, nullptr, nullptr, 0); }, reps);
         float t_d = time_ms([&] { o3d_mlp_conv_dgrad_wt(dN, 0, 0, 0, 32, Y, A1, A2, A3, W, W, 0, s.B, s.Cin, s.Cout, s.P, X, sc, sh, mu, dNp, part, 0); }, reps);
         float t_w = time_ms([&] { o3d_mlp_conv_wgrad(dN, 0, 0, 0, 32, Y, A1, A2, A3, X, sc, sh, 0, 0, 0, 0, 0, 0, 0, 1.f, s.B, s.Cin, s.Cout, s.P, nsl, wpart, dW, 0); }, reps);
+        float* w2s; CK(hipMalloc(&w2s, sizeof(float) * o3d_mlp_conv_wgrad2_scratch(s.B, s.Cin, s.Cout, s.P)));
+        float* dW2; CK(hipMalloc(&dW2, sizeof(float) * s.Cin * s.Cout));
+        float t_w2 = time_ms([&] { o3d_mlp_conv_wgrad2(dN, 0, 32, Y, A1, A2, A3, X, sc, sh, s.B, s.Cin, s.Cout, s.P, w2s, dW2, 0); }, reps);
+        {
+            std::vector<float> h1((size_t)s.Cin * s.Cout), h2(h1.size());
+            CK(hipMemcpy(h1.data(), dW, h1.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(h2.data(), dW2, h2.size() * 4, hipMemcpyDeviceToHost));
+            double md = 0, mx = 0;
+            for (size_t i = 0; i < h1.size(); ++i) { md = fmax(md, fabs((double)h1[i] - h2[i])); mx = fmax(mx, fabs((double)h1[i])); }
+            printf("[wgrad2 %.3f ms %5.1f TF relerr %.1e] ", t_w2, gf / t_w2, md / mx);
+        }
+        CK(hipFree(w2s)); CK(hipFree(dW2));
         printf("%-16s %6.2f GF | fwd-nostat %.3f ms | fwd %.3f ms %6.1f TF | dgrad %.3f ms %6.1f TF | wgrad %.3f ms %6.1f TF\n", s.name, gf,
                t_f0, t_f, gf / t_f, t_d, gf / t_d, t_w, gf / t_w);
         for (float* p : {X, W, Y, dN, sc, sh, mu, c, A1, A2, A3, part, dNp, wpart, dW}) CK(hipFree(p));
