@@ -171,6 +171,17 @@ def main():
             roofline = fused.profile_step(eager_step, PEAK_FP32_MFMA_TFLOPS)
     except ImportError:
         roofline = None
+    if roofline is not None:
+        # the reference gathers first (layer 0 on npoint*nsample positions): rate in those terms as well
+        ref_gflop = 3.0 * mlp_flops_per_pair(args.model) * args.batch / 1e9
+        roofline["reference_formula_gflop_per_step"] = round(ref_gflop, 2)
+        roofline["reference_formula_tflops"] = round(ref_gflop / roofline["gemm_ms_per_step"], 3)
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # rocprofv3 --pmc passes (tools/gpu_prof.sh)
+        if os.path.exists(tfile):
+            t = json.load(open(tfile))
+            if t.get("workload_batch") == args.batch and t.get("model") == args.model:
+                roofline["traffic"] = t["gemm_family_hbm_bytes_per_launch"]
+                roofline["traffic_source"] = t["source"]
     if roofline is None:  # no instrumented kernels yet: whole-step algorithmic rate (labelled as such)
         flops = 3.0 * mlp_flops_per_pair(args.model) * args.batch
         ach = flops / (elapsed / args.steps) / 1e12

@@ -118,13 +118,15 @@ int o3d_mlp_conv_grouped_fwd(const float* xyz, const float* new_xyz, const float
                              int ns, int nxyz, float inv_radius, int Cout, float* Y, float* part,
                              const float* stat_c, void* stream);
 
-/* Training-mode BatchNorm statistics from the partials: mean, invstd = 1/sqrt(var_biased+eps),
+/* (fold: optional scratch of 64*C floats; long partial lists are first folded into 32 parts by a
+ * wide kernel so the finalize does not walk thousands of rows from a handful of workgroups.)
+ * Training-mode BatchNorm statistics from the partials: mean, invstd = 1/sqrt(var_biased+eps),
  * scale = gamma*invstd, shift = beta - mean*scale (C each); when running_mean != NULL and
  * momentum >= 0 the running statistics are updated like torch.nn.BatchNorm (unbiased var). */
 int o3d_bn_finalize(const float* part, int nparts, int C, double count, const float* stat_c,
                     const float* gamma, const float* beta, float* running_mean, float* running_var,
                     float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
-                    void* stream);
+                    float* fold, void* stream);
 
 /* out[b,c,j] = max_k relu(Y[b,c,j*ns+k]*scale[c] + shift[c]); optional arg (k of the max) and
  * yarg (raw Y at that k) for the backward pass. */
@@ -142,7 +144,7 @@ int o3d_pool_bwd_partials(const float* dOut, const float* out, const float* yarg
  * coefficients of dY = A1*dN + A2*Y + A3. */
 int o3d_bn_bwd_finalize(const float* part, int nparts, int C, double count, const float* gamma,
                         const float* mean, const float* invstd, float* dgamma, float* dbeta,
-                        float* A1, float* A2, float* A3, void* stream);
+                        float* A1, float* A2, float* A3, float* fold, void* stream);
 
 /* Data gradient of an inner layer.  dY comes from dN (dense, (B,Cout,P)) or, when dN == NULL,
  * from the pooled triple (dOut, out, arg) of o3d_bn_relu_maxpool_fwd.  Writes
@@ -186,9 +188,10 @@ int o3d_group_expand_fwd(const float* Z, int ldz, const int32_t* idx, const floa
                          float* part, const float* stat_c, float* GY, void* stream);
 
 /* SdN[b,co,n] = sum over positions p with idx[b,p]==n of dN[b,co,p] (= group_points_grad,
- * pointnet2_utils.py:237); TdN[b,co,j] = sum_k dN[b,co,j*ns+k] (may be NULL). */
+ * pointnet2_utils.py:237); TdN[b,co,j] = sum_k dN[b,co,j*ns+k] (may be NULL).  cnt != NULL: also
+ * produces cnt / R of o3d_group_meta in the same pass (R needs new_xyz). */
 int o3d_group_reduce_bwd(const float* dN, const int32_t* idx, int B, int C0, int ld, int npoint, int ns,
-                         float* SdN, float* TdN, void* stream);
+                         float* SdN, float* TdN, const float* new_xyz, float* cnt, float* R, void* stream);
 
 /* In place: S = A1*S + A2*(cnt*Z - W0[:,0:3].R) + A3*cnt, T = A1*T + A2*GY + A3*ns: the list / ball
  * sums of dY0 = A1*dN0 + A2*Y0 + A3 without reading Y0. */

@@ -21,6 +21,7 @@ SOURCES = [
     ("mlp_direct.hip", []),
     ("mlp_wgrad.hip", []),
     ("group.hip", []),
+    ("compact.hip", []),
     ("capi_misc.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",

@@ -145,55 +145,88 @@ __global__ __launch_bounds__(256) void group_expand_kernel(const float* __restri
 
 // ---------------------------------------------------------------------------------------
 // reduce: SdN[b,co,n] = sum_{p in list(n)} dN[b,co,p]   TdN[b,co,j] = sum_k dN[b,co,j*ns+k]
-//   workgroup = (cloud b, RED_CS channels); per-channel accumulators [RED_CS][ld] in LDS, fp32 LDS
-//   atomics (upstream scatters with global atomics too, pointnet2_utils.py:237; the summation order
-//   inside a point's list is not fixed).
+//   workgroup = (cloud b, CS channels); per-channel accumulators [CS][ld] in LDS, fp32 LDS atomics
+//   (upstream scatters with global atomics too, pointnet2_utils.py:237; the summation order inside a
+//   point's list is not fixed).  A ball lists distinct points and pads with its first hit (SURVEY.md
+//   Appendix A.2): everything that refers to the first hit is summed over the ball with shuffles and
+//   added once -- otherwise the padded slots of one ball serialise on a single LDS address.
+//   The workgroup of channel slab 0 also produces the index-only quantities cnt[b,n] (references to
+//   point n) and R[b,n,:] (sum of the centres of the balls referencing n) as four virtual channels.
 // ---------------------------------------------------------------------------------------
-constexpr int RED_CS = 8;
+#ifdef O3D_EXP_NOATOMIC   // experiment only (tools/exp): how much of the kernel is LDS-atomic time
+#define O3D_LDS_ADD(p, v) (*(p) = (v))
+#else
+#define O3D_LDS_ADD(p, v) atomicAdd((p), (v))
+#endif
+__device__ __forceinline__ float scatter4(float* a, const float4& v, const int4& id, int first, bool fx, bool fy,
+                                          bool fz, bool fw, bool leader, int seg) {
+    float f = (fx ? v.x : 0.f) + (fy ? v.y : 0.f) + (fz ? v.z : 0.f) + (fw ? v.w : 0.f);
+    float s = (v.x + v.y) + (v.z + v.w);
+    for (int m = 1; m < seg; m <<= 1) { f += __shfl_xor(f, m, 64); s += __shfl_xor(s, m, 64); }
+    if (leader) O3D_LDS_ADD(&a[first], f);
+    if (!fx) O3D_LDS_ADD(&a[id.x], v.x);
+    if (!fy) O3D_LDS_ADD(&a[id.y], v.y);
+    if (!fz) O3D_LDS_ADD(&a[id.z], v.z);
+    if (!fw) O3D_LDS_ADD(&a[id.w], v.w);
+    return s;      // ball sum (valid on every lane of the ball)
+}
 
+template <int CS>
 __global__ __launch_bounds__(256) void group_reduce_kernel(const float* __restrict__ dN,
                                                            const int32_t* __restrict__ idx, int C0, int ld,
                                                            int npoint, int ns, float* __restrict__ SdN,
-                                                           float* __restrict__ TdN) {
-    extern __shared__ __attribute__((aligned(16))) float acc[];   // [RED_CS][ld]
+                                                           float* __restrict__ TdN,
+                                                           const float* __restrict__ new_xyz,
+                                                           float* __restrict__ cnt, float* __restrict__ R) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];   // [CS (+4 for slab 0)][ld]
     const int P = npoint * ns;
-    const int slabs = (C0 + RED_CS - 1) / RED_CS;
-    const int b = blockIdx.x / slabs, c0 = (blockIdx.x - b * slabs) * RED_CS;
+    const int slabs = (C0 + CS - 1) / CS;
+    const int b = blockIdx.x / slabs, c0 = (blockIdx.x - b * slabs) * CS;
     const int lane = threadIdx.x & 63;
-    for (int i = threadIdx.x; i < RED_CS * ld; i += 256) acc[i] = 0.f;
+    const bool meta = cnt != nullptr && c0 == 0;
+    const int rows = CS + (meta ? 4 : 0);
+    for (int i = threadIdx.x; i < rows * ld; i += 256) acc[i] = 0.f;
     __syncthreads();
     const int32_t* id_b = idx + (long)b * P;
     const int seg = ns / 4;
     for (int q4 = threadIdx.x; q4 < P / 4; q4 += 256) {
         const int4 id = *reinterpret_cast<const int4*>(&id_b[4 * q4]);
         const int j = (4 * q4) / ns;
-        // first hit of this lane's ball (= the value its padded slots repeat): those contributions are
-        // summed over the ball with shuffles and added once, everything else goes through LDS atomics
-        const int first = __shfl(id.x, lane & ~(seg - 1), 64);
+        const int first = __shfl(id.x, lane & ~(seg - 1), 64);    // first hit of this lane's ball
         const bool fx = id.x == first, fy = id.y == first, fz = id.z == first, fw = id.w == first;
         const bool leader = (lane & (seg - 1)) == 0;
 #pragma unroll
-        for (int c = 0; c < RED_CS; ++c) {
+        for (int c = 0; c < CS; ++c) {
             if (c0 + c >= C0) break;
             const float4 v = *reinterpret_cast<const float4*>(&dN[((long)b * C0 + c0 + c) * P + 4 * q4]);
-            float* a = acc + c * ld;
-            float f = (fx ? v.x : 0.f) + (fy ? v.y : 0.f) + (fz ? v.z : 0.f) + (fw ? v.w : 0.f);
-            float s = (v.x + v.y) + (v.z + v.w);
-            for (int m = 1; m < seg; m <<= 1) { f += __shfl_xor(f, m, 64); s += __shfl_xor(s, m, 64); }
-            if (leader) {
-                atomicAdd(&a[first], f);
-                if (TdN) TdN[((long)b * C0 + c0 + c) * npoint + j] = s;
+            const float s = scatter4(acc + c * ld, v, id, first, fx, fy, fz, fw, leader, seg);
+            if (TdN && leader) TdN[((long)b * C0 + c0 + c) * npoint + j] = s;
+        }
+        if (meta) {
+            scatter4(acc + CS * ld, make_float4(1.f, 1.f, 1.f, 1.f), id, first, fx, fy, fz, fw, leader, seg);
+            if (R) {
+                const float* ctr = new_xyz + ((long)b * npoint + j) * 3;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    const float cv = ctr[k];
+                    scatter4(acc + (CS + 1 + k) * ld, make_float4(cv, cv, cv, cv), id, first, fx, fy, fz, fw, leader, seg);
+                }
             }
-            if (!fx) atomicAdd(&a[id.x], v.x);
-            if (!fy) atomicAdd(&a[id.y], v.y);
-            if (!fz) atomicAdd(&a[id.z], v.z);
-            if (!fw) atomicAdd(&a[id.w], v.w);
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < RED_CS * ld; i += 256) {
+    for (int i = threadIdx.x; i < CS * ld; i += 256) {
         const int c = i / ld, n = i - c * ld;
         if (c0 + c < C0) SdN[((long)b * C0 + c0 + c) * ld + n] = acc[i];
+    }
+    if (meta) {
+        for (int n = threadIdx.x; n < ld; n += 256) {
+            cnt[(long)b * ld + n] = acc[CS * ld + n];
+            if (R) {
+                float* r = R + ((long)b * ld + n) * 3;
+                r[0] = acc[(CS + 1) * ld + n]; r[1] = acc[(CS + 2) * ld + n]; r[2] = acc[(CS + 3) * ld + n];
+            }
+        }
     }
 }
 
@@ -262,22 +295,33 @@ extern "C" int o3d_group_expand_fwd(const float* Z, int ldz, const int32_t* idx,
     return o3d_launch_status();
 }
 
-extern "C" int o3d_group_reduce_bwd(const float* dN, const int32_t* idx, int B, int C0, int ld, int npoint,
-                                    int ns, float* SdN, float* TdN, void* stream) {
-    if (!dN || !idx || !SdN || B <= 0 || C0 <= 0 || ld <= 0 || npoint <= 0 || ns < 4 || ns > 256 || !pow2(ns) ||
-        ((long)npoint * ns) % 256 != 0)
-        return O3D_EINVAL;
-    const size_t lds = sizeof(float) * RED_CS * (size_t)ld;
+template <int CS>
+static int launch_reduce(const float* dN, const int32_t* idx, int B, int C0, int ld, int npoint, int ns, float* SdN,
+                         float* TdN, const float* new_xyz, float* cnt, float* R, hipStream_t s) {
+    const size_t lds = sizeof(float) * (CS + (cnt ? 4 : 0)) * (size_t)ld;
     if (lds > 64 * 1024) return O3D_EINVAL;
-    if (lds > 48 * 1024) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(group_reduce_kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return O3D_ELAUNCH;
-    }
-    const int slabs = (C0 + RED_CS - 1) / RED_CS;
-    hipLaunchKernelGGL(group_reduce_kernel, dim3(B * slabs), dim3(256), lds, o3d_stream(stream), dN, idx, C0, ld,
-                       npoint, ns, SdN, TdN);
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(group_reduce_kernel<CS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return O3D_ELAUNCH;
+    const int slabs = (C0 + CS - 1) / CS;
+    hipLaunchKernelGGL(group_reduce_kernel<CS>, dim3(B * slabs), dim3(256), lds, s, dN, idx, C0, ld, npoint, ns, SdN,
+                       TdN, new_xyz, cnt, R);
     return o3d_launch_status();
+}
+
+extern "C" int o3d_group_reduce_bwd(const float* dN, const int32_t* idx, int B, int C0, int ld, int npoint,
+                                    int ns, float* SdN, float* TdN, const float* new_xyz, float* cnt, float* R,
+                                    void* stream) {
+    if (!dN || !idx || !SdN || B <= 0 || C0 <= 0 || ld <= 0 || npoint <= 0 || ns < 4 || ns > 256 || !pow2(ns) ||
+        ((long)npoint * ns) % 256 != 0 || (R && (!cnt || !new_xyz)))
+        return O3D_EINVAL;
+    hipStream_t s = o3d_stream(stream);
+    // enough workgroups to fill 256 CUs several times over: fewer channels per workgroup on small layers
+    const long rows = (long)B * C0;
+    if (rows >= 8 * 2048) return launch_reduce<8>(dN, idx, B, C0, ld, npoint, ns, SdN, TdN, new_xyz, cnt, R, s);
+    if (rows >= 4 * 2048) return launch_reduce<4>(dN, idx, B, C0, ld, npoint, ns, SdN, TdN, new_xyz, cnt, R, s);
+    return launch_reduce<2>(dN, idx, B, C0, ld, npoint, ns, SdN, TdN, new_xyz, cnt, R, s);
 }
 
 extern "C" int o3d_group_bwd_combine(float* S, float* T, const float* Z, const float* GY, const float* cnt,

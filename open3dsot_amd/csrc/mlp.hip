@@ -32,11 +32,13 @@
 // aligned fast path (mlp_direct.hip)
 bool o3d_direct_ok(int M, int K, int P);
 int o3d_direct_fwd(const float* X, const float* W, const float* in_scale, const float* in_shift, int B, int Cin,
-                   int Cout, int P, float* Y, float* part, const float* stat_c, hipStream_t st);
+                   int Cout, int P, float* Y, float* part, const float* stat_c, const float* w, const int32_t* meta,
+                   hipStream_t st);
 int o3d_direct_dgrad(const float* dN, const float* pk, int ns,
                      const float* Y, const float* A1, const float* A2, const float* A3, const float* Wt, int B,
                      int Cin, int Cout, int P, const float* Yprev, const float* scale_p, const float* shift_p,
-                     const float* mean_p, float* dNprev, float* part, hipStream_t st);
+                     const float* mean_p, float* dNprev, float* part, const float* w, const int32_t* meta,
+                     hipStream_t st);
 
 namespace {
 
@@ -273,6 +275,7 @@ __global__ __launch_bounds__(BM * 2) void conv_fwd_kernel(FwdArgs a) {
 struct BnFinArgs {
     const float* part;  // [nparts][2][C]
     int nparts, C;
+    const int32_t* meta; int tile;   // compact layout: only the first meta[0]/tile parts are live (or NULL)
     double count;       // positions reduced (B*P)
     const float* stat_c; // shift used by the producer for the second moment, or NULL
     const float* gamma; const float* beta;
@@ -288,9 +291,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
     const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
     const int c = blockIdx.x * 4 + cl;
     double s = 0.0, q = 0.0;
+    int nparts = a.nparts;
+    if (a.meta) { const int live = a.meta[0] / a.tile; nparts = live < nparts ? live : nparts; }
     if (c < a.C) {
 #pragma unroll 8
-        for (int t = sl; t < a.nparts; t += 64) {
+        for (int t = sl; t < nparts; t += 64) {
             s += (double)a.part[((long)t * 2 + 0) * a.C + c];
             q += (double)a.part[((long)t * 2 + 1) * a.C + c];
         }
@@ -318,6 +323,36 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
             a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
         }
     }
+}
+
+// Stage 1 of a long partial list: out[g][i] = sum over parts t = g, g+G, g+2G, ... of part[t][i],
+// i over the 2*C (statistic, channel) columns; coalesced rows, G x ceil(2C/256) workgroups.  The
+// finalize kernels then walk G parts instead of thousands from 1-4 workgroups.
+__global__ __launch_bounds__(256) void partials_fold_kernel(const float* __restrict__ part, int nparts, int n2c,
+                                                            int G, float* __restrict__ out) {
+    const int i = blockIdx.y * 256 + threadIdx.x, g = blockIdx.x;
+    if (i >= n2c) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int t = g;
+    for (; t + 3 * G < nparts; t += 4 * G) {
+        s0 += part[(long)t * n2c + i];
+        s1 += part[(long)(t + G) * n2c + i];
+        s2 += part[(long)(t + 2 * G) * n2c + i];
+        s3 += part[(long)(t + 3 * G) * n2c + i];
+    }
+    for (; t < nparts; t += G) s0 += part[(long)t * n2c + i];
+    out[(long)g * n2c + i] = (s0 + s1) + (s2 + s3);
+}
+
+constexpr int FOLD_G = 32;
+
+// folds a long partial list into FOLD_G parts in caller scratch (FOLD_G*2*C floats); no-op when short
+static const float* fold_partials(const float* part, int& nparts, int C, float* fold, hipStream_t s) {
+    if (!fold || nparts <= 4 * FOLD_G) return part;
+    hipLaunchKernelGGL(partials_fold_kernel, dim3(FOLD_G, o3d_cdiv(2 * C, 256)), dim3(256), 0, s, part, nparts, 2 * C,
+                       FOLD_G, fold);
+    nparts = FOLD_G;
+    return fold;
 }
 
 // ======================================================================================
@@ -396,6 +431,7 @@ __global__ __launch_bounds__(256) void pool_bwd_partials_kernel(const float* __r
 // coefficients of dY = A1*dN + A2*Y + A3 (per channel).
 struct BnBwdFinArgs {
     const float* part; int nparts, C; double count;
+    const int32_t* meta; int tile;
     const float* gamma; const float* mean; const float* invstd;
     float* dgamma; float* dbeta; float* A1; float* A2; float* A3;
 };
@@ -405,9 +441,11 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFinArgs a) {
     const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
     const int c = blockIdx.x * 4 + cl;
     double s = 0.0, q = 0.0;
+    int nparts = a.nparts;
+    if (a.meta) { const int live = a.meta[0] / a.tile; nparts = live < nparts ? live : nparts; }
     if (c < a.C) {
 #pragma unroll 8
-        for (int t = sl; t < a.nparts; t += 64) {
+        for (int t = sl; t < nparts; t += 64) {
             s += (double)a.part[((long)t * 2 + 0) * a.C + c];
             q += (double)a.part[((long)t * 2 + 1) * a.C + c];
         }
@@ -975,7 +1013,8 @@ extern "C" int o3d_mlp_conv_fwd(const float* X, const float* W, const float* in_
                                 float* part, const float* stat_c, void* stream) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || P <= 0 || P % BN_POS != 0 || !X || !W || !Y) return O3D_EINVAL;
     if (o3d_direct_ok(Cout, Cin, P) && (in_scale == nullptr) == (in_shift == nullptr))
-        return o3d_direct_fwd(X, W, in_scale, in_shift, B, Cin, Cout, P, Y, part, stat_c, o3d_stream(stream));
+        return o3d_direct_fwd(X, W, in_scale, in_shift, B, Cin, Cout, P, Y, part, stat_c, nullptr, nullptr,
+                              o3d_stream(stream));
     FwdArgs a = {};
     a.X = X; a.W = W; a.Y = Y; a.in_scale = in_scale; a.in_shift = in_shift; a.part = part; a.stat_c = stat_c;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = P; a.ns = 4; a.inv_radius = 1.f;
@@ -1002,9 +1041,10 @@ extern "C" int o3d_mlp_conv_grouped_fwd(const float* xyz, const float* new_xyz, 
 extern "C" int o3d_bn_finalize(const float* part, int nparts, int C, double count, const float* stat_c,
                                const float* gamma, const float* beta, float* running_mean,
                                float* running_var, float momentum, float eps, float* mean,
-                               float* invstd, float* scale, float* shift, void* stream) {
+                               float* invstd, float* scale, float* shift, float* fold, void* stream) {
     if (!part || nparts <= 0 || C <= 0 || !mean || !invstd || !scale || !shift) return O3D_EINVAL;
-    BnFinArgs a = {part, nparts, C, count, stat_c, gamma, beta, running_mean, running_var, momentum, eps,
+    part = fold_partials(part, nparts, C, fold, o3d_stream(stream));
+    BnFinArgs a = {part, nparts, C, nullptr, 1, count, stat_c, gamma, beta, running_mean, running_var, momentum, eps,
                    mean, invstd, scale, shift};
     return launch(bn_finalize_kernel, dim3(o3d_cdiv(C, 4)), dim3(256), 0, o3d_stream(stream), a);
 }
@@ -1034,10 +1074,32 @@ extern "C" int o3d_pool_bwd_partials(const float* dOut, const float* out, const 
 
 extern "C" int o3d_bn_bwd_finalize(const float* part, int nparts, int C, double count, const float* gamma,
                                    const float* mean, const float* invstd, float* dgamma, float* dbeta,
-                                   float* A1, float* A2, float* A3, void* stream) {
+                                   float* A1, float* A2, float* A3, float* fold, void* stream) {
     if (!part || nparts <= 0 || C <= 0 || !mean || !invstd || !dgamma || !dbeta || !A1 || !A2 || !A3)
         return O3D_EINVAL;
-    BnBwdFinArgs a = {part, nparts, C, count, gamma, mean, invstd, dgamma, dbeta, A1, A2, A3};
+    part = fold_partials(part, nparts, C, fold, o3d_stream(stream));
+    BnBwdFinArgs a = {part, nparts, C, count, nullptr, 1, gamma, mean, invstd, dgamma, dbeta, A1, A2, A3};
+    return launch(bn_bwd_finalize_kernel, dim3(o3d_cdiv(C, 4)), dim3(256), 0, o3d_stream(stream), a);
+}
+
+// compact layout: only the first meta[0]/tile partial rows are live (tile = positions per partial row)
+extern "C" int o3d_bn_finalize_c(const float* part, int nparts, int C, double count, const float* stat_c,
+                                 const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                 float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                                 const int32_t* meta, int tile, void* stream) {
+    if (!part || nparts <= 0 || C <= 0 || !mean || !invstd || !scale || !shift || !meta || tile <= 0) return O3D_EINVAL;
+    BnFinArgs a = {part, nparts, C, meta, tile, count, stat_c, gamma, beta, running_mean, running_var, momentum, eps,
+                   mean, invstd, scale, shift};
+    return launch(bn_finalize_kernel, dim3(o3d_cdiv(C, 4)), dim3(256), 0, o3d_stream(stream), a);
+}
+
+extern "C" int o3d_bn_bwd_finalize_c(const float* part, int nparts, int C, double count, const float* gamma,
+                                     const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                                     float* A1, float* A2, float* A3, const int32_t* meta, int tile, void* stream) {
+    if (!part || nparts <= 0 || C <= 0 || !mean || !invstd || !dgamma || !dbeta || !A1 || !A2 || !A3 || !meta ||
+        tile <= 0)
+        return O3D_EINVAL;
+    BnBwdFinArgs a = {part, nparts, C, count, meta, tile, gamma, mean, invstd, dgamma, dbeta, A1, A2, A3};
     return launch(bn_bwd_finalize_kernel, dim3(o3d_cdiv(C, 4)), dim3(256), 0, o3d_stream(stream), a);
 }
 
@@ -1077,9 +1139,33 @@ extern "C" int o3d_mlp_conv_dgrad_wt(const float* dN, const float* dOut, const f
     if (Wt && o3d_direct_ok(Cin, Cout, P) && B > 0 && Yprev && scale_p && shift_p && mean_p && dNprev && part &&
         Y && A1 && A2 && A3 && (dN || (pk && ns > 0 && ns % 4 == 0)))
         return o3d_direct_dgrad(dN, pk, ns, Y, A1, A2, A3, Wt, B, Cin, Cout, P, Yprev, scale_p, shift_p,
-                                mean_p, dNprev, part, o3d_stream(stream));
+                                mean_p, dNprev, part, nullptr, nullptr, o3d_stream(stream));
     return o3d_mlp_conv_dgrad(dN, dOut, out, arg, ns, Y, A1, A2, A3, W, B, Cin, Cout, P, Yprev, scale_p, shift_p,
                               mean_p, dNprev, part, stream);
+}
+
+// ---- compact (distinct-neighbour) layout, csrc/compact.hip: flat (C, ldp) matrices, per-position weights w
+// (ldp) and the live column count meta[0] in device memory.  Aligned shapes only.
+extern "C" int o3d_mlp_conv_fwd_c(const float* X, const float* W, const float* in_scale, const float* in_shift,
+                                  int Cin, int Cout, long ldp, const float* w, const int32_t* meta, float* Y,
+                                  float* part, const float* stat_c, void* stream) {
+    if (!X || !W || !Y || !w || !meta || !in_scale || !in_shift || ldp <= 0 || ldp > 0x7fffffff ||
+        !o3d_direct_ok(Cout, Cin, (int)ldp))
+        return O3D_EINVAL;
+    return o3d_direct_fwd(X, W, in_scale, in_shift, 1, Cin, Cout, (int)ldp, Y, part, stat_c, w, meta,
+                          o3d_stream(stream));
+}
+
+extern "C" int o3d_mlp_conv_dgrad_c(const float* dN, const float* Y, const float* A1, const float* A2,
+                                    const float* A3, const float* Wt, int Cin, int Cout, long ldp, const float* w,
+                                    const int32_t* meta, const float* Yprev, const float* scale_p,
+                                    const float* shift_p, const float* mean_p, float* dNprev, float* part,
+                                    void* stream) {
+    if (!dN || !Y || !A1 || !A2 || !A3 || !Wt || !w || !meta || !Yprev || !scale_p || !shift_p || !mean_p ||
+        !dNprev || !part || ldp <= 0 || ldp > 0x7fffffff || !o3d_direct_ok(Cin, Cout, (int)ldp))
+        return O3D_EINVAL;
+    return o3d_direct_dgrad(dN, nullptr, 4, Y, A1, A2, A3, Wt, 1, Cin, Cout, (int)ldp, Yprev, scale_p, shift_p,
+                            mean_p, dNprev, part, w, meta, o3d_stream(stream));
 }
 
 // dX (B,Cin,P) = W^T dY with dY = A1*dN + A2*Y + A3, no mask, no statistics: the gradient w.r.t. an

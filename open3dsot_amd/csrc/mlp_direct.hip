@@ -48,6 +48,9 @@ struct DirectArgs {
     const float2* pk; int ns;   // pooled source (B, K, P/ns): {dOut masked by out > 0, bits(arg)}
     float* Out;            // (B, M, P)
     int M, K, P, B;
+    // compact (distinct-neighbour) layout, csrc/compact.hip: per-position weights and the live column count
+    const float* w;        // (P) or NULL: weights of the statistics (forward) / of the A2*Y+A3 term (DY modes)
+    const int32_t* meta;   // device int: positions >= meta[0] are dead (tiles beyond it return) or NULL
     // epilogue
     float* part;           // [B*P/128][2][M] or NULL
     const float* stat_c;   // forward: shift of the second moment
@@ -77,7 +80,7 @@ __device__ __forceinline__ void load_b(const DirectArgs& a, const float* xb, con
 // one group: 8 k's (4 per half-wave) x (2 m-tiles x 4 n-tiles) = 32 MFMAs
 template <int MODE>
 __device__ __forceinline__ void compute_group(const RawB& f, const float4& a0v, const float4& a1v,
-                                              int kk, f32x16 (&acc)[2][4]) {
+                                              int kk, const float (&wv)[4], f32x16 (&acc)[2][4]) {
     const float a0[4] = {a0v.x, a0v.y, a0v.z, a0v.w}, a1[4] = {a1v.x, a1v.y, a1v.z, a1v.w};
     const float c1[4] = {f.c1.x, f.c1.y, f.c1.z, f.c1.w}, c2[4] = {f.c2.x, f.c2.y, f.c2.z, f.c2.w};
     const float c3[4] = {f.c3.x, f.c3.y, f.c3.z, f.c3.w};
@@ -98,7 +101,7 @@ __device__ __forceinline__ void compute_group(const RawB& f, const float4& a0v, 
         } else if (MODE >= B_DY) {
             const float y[4] = {f.y[s].x, f.y[s].y, f.y[s].z, f.y[s].w};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bv[t] = fmaf(c1[s], bv[t], fmaf(c2[s], y[t], c3[s]));
+            for (int t = 0; t < 4; ++t) bv[t] = fmaf(c1[s], bv[t], wv[t] * fmaf(c2[s], y[t], c3[s]));
         }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
@@ -117,8 +120,14 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
     const int tiles_per_b = a.P / DT_POS;
     const int tile = blockIdx.x;
     const int b = tile / tiles_per_b, p0 = (tile - b * tiles_per_b) * DT_POS;
+    if (a.meta && (long)tile * DT_POS >= a.meta[0]) return;     // compact layout: dead tile
     const int m0 = (blockIdx.y * WAVES + wave) * DT_M;
     const int p = p0 + 4 * l31;
+    float wv[4] = {1.f, 1.f, 1.f, 1.f};
+    if (a.w) {
+        const float4 t4 = *reinterpret_cast<const float4*>(a.w + (long)b * a.P + p);
+        wv[0] = t4.x; wv[1] = t4.y; wv[2] = t4.z; wv[3] = t4.w;
+    }
     const long rowP = a.P;
     const float* xb = (MODE != B_DYPOOL) ? a.X + (long)b * a.K * rowP + p : nullptr;
     const float* yb = (MODE >= B_DY) ? a.Y + (long)b * a.K * rowP + p : nullptr;
@@ -154,11 +163,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int g = 0; g < G; g += 2) {
         load(1, g + 1);
         __builtin_amdgcn_sched_barrier(0);
-        compute_group<MODE>(f[0], wa0[0], wa1[0], kk, acc);
+        compute_group<MODE>(f[0], wa0[0], wa1[0], kk, wv, acc);
         __builtin_amdgcn_sched_barrier(0);
         load(0, g + 2 < G ? g + 2 : G - 1);       // tail: harmless re-load of the last group
         __builtin_amdgcn_sched_barrier(0);
-        compute_group<MODE>(f[1], wa0[1], wa1[1], kk, acc);
+        compute_group<MODE>(f[1], wa0[1], wa1[1], kk, wv, acc);
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -181,7 +190,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
                 acc[i][0][r] = v.x; acc[i][1][r] = v.y; acc[i][2][r] = v.z; acc[i][3][r] = v.w;
             }
             *reinterpret_cast<float4*>(a.Out + o) = v;
-            red[i * 16 + r] = (v.x + v.y) + (v.z + v.w);
+            red[i * 16 + r] = EPI == 0 ? fmaf(wv[0], v.x, fmaf(wv[1], v.y, fmaf(wv[2], v.z, wv[3] * v.w)))
+                                       : (v.x + v.y) + (v.z + v.w);
         }
     if (!a.part) return;
     // lane l31 of half h ends up owning value index l31 -> (i = l31>>4, r = l31&15)
@@ -196,7 +206,8 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
             const float4 v = make_float4(acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]);
             if (EPI == 0) {
                 const float c = a.stat_c ? a.stat_c[m] : 0.f;
-                red[i * 16 + r] = (v.x - c) * (v.x - c) + (v.y - c) * (v.y - c) + (v.z - c) * (v.z - c) + (v.w - c) * (v.w - c);
+                red[i * 16 + r] = wv[0] * (v.x - c) * (v.x - c) + wv[1] * (v.y - c) * (v.y - c) +
+                                  wv[2] * (v.z - c) * (v.z - c) + wv[3] * (v.w - c) * (v.w - c);
             } else {      // masked entries of v are zero, so the mask needs no second evaluation
                 const float4 yp = *reinterpret_cast<const float4*>(a.Yprev + ((long)b * a.M + m) * rowP + p);
                 const float mu = a.mean_p[m];
@@ -207,13 +218,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
     dst[a.M] = red[0];
 }
 
+// All M/64 row slabs of a position tile run as the waves of ONE workgroup: they read the same B rows,
+// so those come from HBM once and from L1/L2 for the other slabs (rocprofv3 FETCH_SIZE of the
+// two-workgroup variant showed every slab re-reading HBM: 604 MB instead of 350 MB per launch).
 template <int MODE, int EPI>
 int launch_direct(const DirectArgs& a, hipStream_t st) {
     const int tiles = a.B * (a.P / DT_POS);
-    if (a.M % 128 == 0) {
-        hipLaunchKernelGGL((direct_gemm_kernel<2, MODE, EPI>), dim3(tiles, a.M / 128), dim3(128), 0, st, a);
+    const int slabs = a.M / DT_M;
+    if (slabs % 4 == 0) {
+        hipLaunchKernelGGL((direct_gemm_kernel<4, MODE, EPI>), dim3(tiles, slabs / 4), dim3(256), 0, st, a);
+    } else if (slabs % 2 == 0) {
+        hipLaunchKernelGGL((direct_gemm_kernel<2, MODE, EPI>), dim3(tiles, slabs / 2), dim3(128), 0, st, a);
     } else {
-        hipLaunchKernelGGL((direct_gemm_kernel<1, MODE, EPI>), dim3(tiles, a.M / 64), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((direct_gemm_kernel<1, MODE, EPI>), dim3(tiles, slabs), dim3(64), 0, st, a);
     }
     return o3d_launch_status();
 }
@@ -224,8 +241,10 @@ bool o3d_direct_ok(int M, int K, int P) { return M % DT_M == 0 && K % 16 == 0 &&
 
 // forward: Y = W . f(X), see o3d_mlp_conv_fwd
 int o3d_direct_fwd(const float* X, const float* W, const float* in_scale, const float* in_shift, int B, int Cin,
-                   int Cout, int P, float* Y, float* part, const float* stat_c, hipStream_t st) {
+                   int Cout, int P, float* Y, float* part, const float* stat_c, const float* w, const int32_t* meta,
+                   hipStream_t st) {
     DirectArgs a = {};
+    a.w = w; a.meta = meta;
     a.A = W; a.X = X; a.c1 = in_scale; a.c2 = in_shift; a.Out = Y; a.M = Cout; a.K = Cin; a.P = P; a.B = B;
     a.part = part; a.stat_c = stat_c; a.ns = 4;
     return in_scale ? launch_direct<B_XFORM, 0>(a, st) : launch_direct<B_PLAIN, 0>(a, st);
@@ -235,8 +254,10 @@ int o3d_direct_fwd(const float* X, const float* W, const float* in_scale, const 
 int o3d_direct_dgrad(const float* dN, const float* pk, int ns,
                      const float* Y, const float* A1, const float* A2, const float* A3, const float* Wt, int B,
                      int Cin, int Cout, int P, const float* Yprev, const float* scale_p, const float* shift_p,
-                     const float* mean_p, float* dNprev, float* part, hipStream_t st) {
+                     const float* mean_p, float* dNprev, float* part, const float* w, const int32_t* meta,
+                     hipStream_t st) {
     DirectArgs a = {};
+    a.w = w; a.meta = meta;
     a.A = Wt; a.X = dN; a.Y = Y; a.c1 = A1; a.c2 = A2; a.c3 = A3; a.pk = reinterpret_cast<const float2*>(pk); a.ns = ns;
     a.Out = dNprev; a.M = Cin; a.K = Cout; a.P = P; a.B = B; a.part = part;
     a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p;

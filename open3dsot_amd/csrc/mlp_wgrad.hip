@@ -28,6 +28,8 @@ struct Wgrad2Args {
     int B, Cin, Cout, P;
     int chunks_per_block, total_chunks, nslices;
     float* part;           // [nslices*WK][Cout][Cin]
+    const float* w;        // compact layout: per-position weight of the A2*Y+A3 term, or NULL
+    const int32_t* meta;   // compact layout: live positions = meta[0] (device), or NULL
 };
 
 template <int TM, int TN, bool POOLED>
@@ -58,9 +60,14 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
         slice = blockIdx.x / ntile;
     }
     const int ci0 = (tile_id % tiles_ci) * TN, co0 = (tile_id / tiles_ci) * TM;
-    const int c_begin = slice * a.chunks_per_block;
-    int c_end = c_begin + a.chunks_per_block;
-    if (c_end > a.total_chunks) c_end = a.total_chunks;
+    int total_chunks = a.total_chunks, chunks_per_block = a.chunks_per_block;
+    if (a.meta) {      // data-dependent column count: partition the live chunks evenly over the slices
+        total_chunks = a.meta[0] / CP;
+        chunks_per_block = (total_chunks + a.nslices - 1) / a.nslices;
+    }
+    const int c_begin = slice * chunks_per_block;
+    int c_end = c_begin + chunks_per_block;
+    if (c_end > total_chunks) c_end = total_chunks;
     const int chunks_per_b = a.P / CP;
     const int r0 = tid / F, c4 = tid % F;
     const int np = POOLED ? a.P / a.ns : 1;
@@ -79,10 +86,12 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
     }
 
     float4 rg[PA], ry[PA], rx[PB];
+    float4 rw = make_float4(1.f, 1.f, 1.f, 1.f);
     int rk = 0;
     auto load_chunk = [&](int ch) {
         const long b = ch / chunks_per_b;
         const int p = (ch - (int)b * chunks_per_b) * CP + 4 * c4;
+        if (a.w) rw = *reinterpret_cast<const float4*>(&a.w[b * a.P + p]);
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const long row = b * a.Cout + co0 + r0 + RPP * i;
@@ -113,8 +122,8 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
                 g = rg[i];
             }
             float4 o;
-            o.x = fmaf(ka1[i], g.x, fmaf(ka2[i], ry[i].x, ka3[i])); o.y = fmaf(ka1[i], g.y, fmaf(ka2[i], ry[i].y, ka3[i]));
-            o.z = fmaf(ka1[i], g.z, fmaf(ka2[i], ry[i].z, ka3[i])); o.w = fmaf(ka1[i], g.w, fmaf(ka2[i], ry[i].w, ka3[i]));
+            o.x = fmaf(ka1[i], g.x, rw.x * fmaf(ka2[i], ry[i].x, ka3[i])); o.y = fmaf(ka1[i], g.y, rw.y * fmaf(ka2[i], ry[i].y, ka3[i]));
+            o.z = fmaf(ka1[i], g.z, rw.z * fmaf(ka2[i], ry[i].z, ka3[i])); o.w = fmaf(ka1[i], g.w, rw.w * fmaf(ka2[i], ry[i].w, ka3[i]));
             *reinterpret_cast<float4*>(&As(buf)[(r0 + RPP * i) * LD + 4 * c4]) = o;
         }
 #pragma unroll
@@ -218,10 +227,31 @@ extern "C" long o3d_mlp_conv_wgrad2_scratch(int B, int Cin, int Cout, int P) {
 
 // dW (Cout,Cin) = sum_{b,p} dY * f(X); dY from dN (dense) or pk (pooled, needs ns); X raw producer output
 // with (in_scale,in_shift).  Cin, Cout multiples of 64, P multiple of 128.
+static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y, const float* A1, const float* A2,
+                       const float* A3, const float* X, const float* in_scale, const float* in_shift, int B, int Cin,
+                       int Cout, int P, const float* w, const int32_t* meta, float* scratch, float* dW, void* stream);
+
 extern "C" int o3d_mlp_conv_wgrad2(const float* dN, const float* pk, int ns, const float* Y, const float* A1,
                                    const float* A2, const float* A3, const float* X, const float* in_scale,
                                    const float* in_shift, int B, int Cin, int Cout, int P, float* scratch,
                                    float* dW, void* stream) {
+    return wgrad2_impl(dN, pk, ns, Y, A1, A2, A3, X, in_scale, in_shift, B, Cin, Cout, P, nullptr, nullptr, scratch,
+                       dW, stream);
+}
+
+// compact layout (csrc/compact.hip): flat (C, ldp) operands, weights w (ldp), live columns meta[0]
+extern "C" int o3d_mlp_conv_wgrad2_c(const float* dN, const float* Y, const float* A1, const float* A2,
+                                     const float* A3, const float* X, const float* in_scale, const float* in_shift,
+                                     int Cin, int Cout, long ldp, const float* w, const int32_t* meta,
+                                     float* scratch, float* dW, void* stream) {
+    if (!dN || !w || !meta || ldp <= 0 || ldp > 0x7fffffff) return O3D_EINVAL;
+    return wgrad2_impl(dN, nullptr, 4, Y, A1, A2, A3, X, in_scale, in_shift, 1, Cin, Cout, (int)ldp, w, meta, scratch,
+                       dW, stream);
+}
+
+static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y, const float* A1, const float* A2,
+                       const float* A3, const float* X, const float* in_scale, const float* in_shift, int B, int Cin,
+                       int Cout, int P, const float* w, const int32_t* meta, float* scratch, float* dW, void* stream) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || P <= 0 || P % 128 || !Y || !A1 || !A2 || !A3 ||
         !X || !in_scale || !in_shift || !scratch || !dW || (!dN && (!pk || ns < 4 || ns % 4)))
         return O3D_EINVAL;
@@ -235,6 +265,7 @@ extern "C" int o3d_mlp_conv_wgrad2(const float* dN, const float* pk, int ns, con
     a.chunks_per_block = (a.total_chunks + nsl - 1) / nsl;
     a.nslices = nsl;
     a.part = scratch;
+    a.w = w; a.meta = meta;
     hipStream_t s = o3d_stream(stream);
     int rc;
     if (TM == 128 && TN == 128) rc = launch_wgrad2<128, 128>(a, s);

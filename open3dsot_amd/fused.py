@@ -28,21 +28,32 @@ _vp, _i, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double
 capi.register("o3d_mlp_conv_fwd", [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_group_meta", [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp])
 capi.register("o3d_group_expand_fwd", [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
-capi.register("o3d_group_reduce_bwd", [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp])
+capi.register("o3d_group_reduce_bwd", [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_group_bwd_combine", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp])
 capi.register("o3d_mlp_conv_dgrad_wt", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_wgrad2", [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_wgrad2_scratch", [_i, _i, _i, _i])
 capi.register("o3d_mlp_conv_dgrad_plain", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp])
-capi.register("o3d_bn_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_bn_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_bn_relu_maxpool_fwd", [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_bwd_partials", [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp])
-capi.register("o3d_bn_bwd_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_bn_bwd_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_dgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                                      _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_wgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp])
+
+capi.register("o3d_compact_build", [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_group_expand_c", [_vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, ctypes.c_long, _vp, _vp, _vp, _vp])
+capi.register("o3d_pool_fwd_c", [_vp, ctypes.c_long, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp])
+capi.register("o3d_pool_bwd_dense_c", [_vp, _vp, _vp, _i, _i, _i, _vp, ctypes.c_long, _vp, _vp])
+capi.register("o3d_group_reduce_c", [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_fwd_c", [_vp, _vp, _vp, _vp, _i, _i, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_dgrad_c", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_wgrad2_c", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, ctypes.c_long, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_bn_finalize_c", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp])
+capi.register("o3d_bn_bwd_finalize_c", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp])
 
 TILE = 128   # positions per workgroup tile of the GEMM kernels (csrc/mlp.hip BN_POS)
 ETILE = 256  # positions per workgroup tile of the layer-0 expand kernel (csrc/group.hip EXP_TP)
@@ -72,9 +83,14 @@ def _call(name, flops, fn, *args):
     capi.check(rc, name)
 
 
+GEMM_KERNELS = ("conv_fwd", "conv_fwd_points", "conv_dgrad", "conv_dgrad_points", "conv_wgrad", "conv_wgrad_points")
+
+
 def profile_step(step_fn, peak_tflops, repeats=3):
-    """Run `step_fn` with every fused launch bracketed by HIP events; returns the roofline dict
-    of the dominant kernel family (the three MFMA GEMM kernels: forward / dgrad / wgrad)."""
+    """Run `step_fn` with every fused launch bracketed by HIP events (on the launch stream); returns
+    the roofline dict of the dominant kernel family: the fp32-MFMA GEMM kernels (forward / data
+    gradient / weight gradient, on positions and on points).  `achieved` counts the FLOPs those
+    launches EXECUTE (layer 0 runs on the N points, not on the npoint*nsample positions)."""
     torch.cuda.synchronize()
     _PROF["events"] = []
     _PROF["on"] = True
@@ -91,8 +107,7 @@ def profile_step(step_fn, peak_tflops, repeats=3):
         a[1] += flops
         a[2] += e0.elapsed_time(e1)
     _PROF["events"] = []
-    gemm = {k: v for k, v in agg.items() if k in ("conv_fwd", "conv_fwd_points", "conv_dgrad", "conv_dgrad_points",
-                                                    "conv_wgrad", "conv_wgrad_points")}
+    gemm = {k: v for k, v in agg.items() if k in GEMM_KERNELS}
     if not gemm:
         return None
     launches = sum(v[0] for v in gemm.values())
@@ -100,14 +115,17 @@ def profile_step(step_fn, peak_tflops, repeats=3):
     ms = sum(v[2] for v in gemm.values())
     ach = flops / (ms * 1e-3) / 1e12
     per_kernel = {k: {"launches": v[0] // repeats, "ms_per_step": round(v[2] / repeats, 4),
-                      "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2) if v[2] > 0 else None}
+                      "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2) if v[2] > 0 and v[1] > 0 else None}
                   for k, v in sorted(agg.items())}
     return {"bound": "mfma", "achieved": round(ach, 3), "peak": peak_tflops, "unit": "TFLOP/s",
             "frac": round(ach / peak_tflops, 4), "traffic": None,
-            "kernel": "fp32-MFMA grouped-MLP GEMMs (conv_fwd/dgrad/wgrad kernels of csrc/mlp.hip), "
-                      "algorithmic 2*Cin*Cout*positions FLOPs per launch / HIP-event time",
+            "kernel": "fp32-MFMA grouped-MLP GEMM kernels (direct_gemm_kernel fwd/dgrad of csrc/mlp_direct.hip, "
+                      "wgrad2_kernel of csrc/mlp_wgrad.hip, conv_*_kernel of csrc/mlp.hip for the unaligned "
+                      "per-point layer 0); executed FLOPs per launch / HIP-event time of the launch",
             "launches_per_step": launches // repeats, "avg_launch_ms": round(ms / launches, 5),
-            "gemm_ms_per_step": round(ms / repeats, 4), "per_kernel": per_kernel}
+            "gemm_ms_per_step": round(ms / repeats, 4), "gemm_gflop_per_step": round(flops / repeats / 1e9, 2),
+            "fused_kernels_ms_per_step": round(sum(v[2] for v in agg.values()) / repeats, 4),
+            "per_kernel": per_kernel}
 
 
 # ---- module introspection --------------------------------------------------------------
@@ -212,11 +230,12 @@ class FusedGroupedMLP(torch.autograd.Function):
                       scales[-1].data_ptr(), shifts[-1].data_ptr(), B, Cin, Cout, P, Y.data_ptr(), _ptr(part),
                       _ptr(stat_c), st)
             vec = torch.empty((4, Cout), device=dev, dtype=torch.float32)
+            fold = torch.empty((64, Cout), device=dev, dtype=torch.float32)     # scratch: folded partials
             if cfg.training:
                 _call("bn_finalize", 0.0, lib.o3d_bn_finalize, part.data_ptr(), nparts, Cout, float(B) * P,
                       stat_c.data_ptr(), gammas[l].data_ptr(), betas[l].data_ptr(), bn.running_mean.data_ptr(),
                       bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps), vec[0].data_ptr(),
-                      vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), st)
+                      vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), fold.data_ptr(), st)
                 bn.num_batches_tracked.add_(1)
             else:
                 vec[0].copy_(bn.running_mean)
@@ -270,9 +289,10 @@ class FusedGroupedMLP(torch.autograd.Function):
         for l in range(L - 1, -1, -1):
             Cout, Cin = Ws[l].shape
             coef = torch.empty((5, Cout), device=dev, dtype=torch.float32)  # dgamma dbeta A1 A2 A3
+            fold = torch.empty((64, Cout), device=dev, dtype=torch.float32)
             _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize, part.data_ptr(), nparts, Cout, count,
                   gammas[l].data_ptr(), means[l].data_ptr(), invstds[l].data_ptr(), coef[0].data_ptr(),
-                  coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr(), st)
+                  coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr(), fold.data_ptr(), st)
             if not cfg.training:      # eval-mode BN is a fixed affine map: dY = scale * dN
                 coef[3].zero_()
                 coef[4].zero_()
@@ -286,12 +306,10 @@ class FusedGroupedMLP(torch.autograd.Function):
                 one, zero = _const_vec(dev, Cout, 1.0), _const_vec(dev, Cout, 0.0)
                 cnt = torch.empty((B, Npad), device=dev, dtype=torch.float32)
                 R = torch.empty((B, Npad, 3), device=dev, dtype=torch.float32) if nxyz else None
-                _call("group_meta", 0.0, lib.o3d_group_meta, idx.data_ptr(), _ptr(new_c), B, N, Npad, npoint, ns,
-                      cnt.data_ptr(), _ptr(R), st)
                 S = torch.empty((B, Cout, Npad), device=dev, dtype=torch.float32)
                 T = torch.empty((B, Cout, npoint), device=dev, dtype=torch.float32) if nxyz else None
                 _call("group_reduce", 0.0, lib.o3d_group_reduce_bwd, dN.data_ptr(), idx.data_ptr(), B, Cout, Npad,
-                      npoint, ns, S.data_ptr(), _ptr(T), st)
+                      npoint, ns, S.data_ptr(), _ptr(T), _ptr(new_c), cnt.data_ptr(), _ptr(R), st)
                 _call("group_combine", 0.0, lib.o3d_group_bwd_combine, S.data_ptr(), _ptr(T), Z.data_ptr(), _ptr(GY),
                       cnt.data_ptr(), _ptr(R), Ws[0].data_ptr(), Cin, A[0], A[1], A[2], B, Cout, Npad, npoint, ns, st)
                 tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
@@ -353,6 +371,212 @@ class FusedGroupedMLP(torch.autograd.Function):
                 dfeats if ctx.needs_input_grad[2] else None, None, None, *gw)
 
 
+_COMPACT = {"on": True}
+
+
+def set_compact(enabled):
+    """distinct-neighbour (compact) layout on/off (off = one column per ball slot, for A/B tests)"""
+    _COMPACT["on"] = bool(enabled)
+
+
+class FusedGroupedMLPCompact(torch.autograd.Function):
+    """Same contract as FusedGroupedMLP on the compact layout of csrc/compact.hip: one column per
+    DISTINCT neighbour of a ball (ball_query pads with copies of the first hit; copies are folded into
+    a weight), flat (C, Pmax) activations with the live column count in device memory."""
+
+    @staticmethod
+    def forward(ctx, xyz, new_xyz, feats, idx, cfg, *params):
+        lib = capi.load()
+        L = len(params) // 3
+        Ws = [params[3 * l].detach().reshape(params[3 * l].shape[0], -1).contiguous() for l in range(L)]
+        gammas = [params[3 * l + 1].detach().contiguous() for l in range(L)]
+        betas = [params[3 * l + 2].detach().contiguous() for l in range(L)]
+        B, npoint, ns = idx.shape
+        P = npoint * ns
+        Pmax = B * P
+        dev = idx.device
+        nxyz = cfg.nxyz
+        C = feats.shape[1] if feats is not None else 0
+        N = feats.shape[2] if feats is not None else xyz.shape[1]
+        Npad = -(-N // TILE) * TILE
+        Cin0, C0 = nxyz + C, Ws[0].shape[0]
+        nballs = B * npoint
+        st = _stream()
+        f32, i32 = torch.float32, torch.int32
+        need_bwd = any(ctx.needs_input_grad)
+        # ---- compaction of the grouping indices
+        ball_cnt = torch.empty((nballs,), device=dev, dtype=i32)
+        ball_off = torch.empty((nballs + 1,), device=dev, dtype=i32)
+        gp = torch.empty((Pmax,), device=dev, dtype=i32)
+        cball = torch.empty((Pmax,), device=dev, dtype=i32)
+        cw = torch.empty((Pmax,), device=dev, dtype=f32)
+        meta = torch.empty((4,), device=dev, dtype=i32)
+        _call("compact_build", 0.0, lib.o3d_compact_build, idx.data_ptr(), B, npoint, ns, Npad, ball_cnt.data_ptr(),
+              ball_off.data_ptr(), gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), meta.data_ptr(), st)
+        # ---- layer 0 on the points: Z = W0 . [xyz * inv_radius ; feats], flat (C0, B*Npad)
+        X0n = (torch.zeros if Npad != N else torch.empty)((Cin0, B, Npad), device=dev, dtype=f32)
+        if nxyz:
+            X0n[:3, :, :N] = xyz.detach().permute(2, 0, 1) * cfg.inv_radius
+        if C:
+            X0n[nxyz:, :, :N] = feats.detach().permute(1, 0, 2)
+        Z = torch.empty((C0, B * Npad), device=dev, dtype=f32)
+        _call("conv_fwd_points", 2.0 * Cin0 * C0 * B * Npad, lib.o3d_mlp_conv_fwd, X0n.data_ptr(), Ws[0].data_ptr(),
+              None, None, 1, Cin0, C0, B * Npad, Z.data_ptr(), None, None, st)
+        centers = None
+        if nxyz:
+            centers = torch.zeros((nballs + 1, 3), device=dev, dtype=f32)
+            centers[:nballs] = new_xyz.detach().reshape(nballs, 3) * cfg.inv_radius
+        count = float(B) * P
+        Ys, means, invstds, scales, shifts = [], [], [], [], []
+        for l in range(L):
+            Cout, Cin = Ws[l].shape
+            bn = cfg.bns[l]
+            tile = ETILE if l == 0 else TILE
+            Y = torch.empty((Cout, Pmax), device=dev, dtype=f32)
+            part = torch.empty((Pmax // tile, 2, Cout), device=dev, dtype=f32) if cfg.training else None
+            stat_c = bn.running_mean if cfg.training else None
+            if l == 0:
+                _call("group_expand", 0.0, lib.o3d_group_expand_c, Z.data_ptr(), B * Npad, gp.data_ptr(), cball.data_ptr(),
+                      cw.data_ptr(), _ptr(centers), Ws[0].data_ptr(), Cin0, C0, meta.data_ptr(), Pmax, Y.data_ptr(),
+                      _ptr(part), _ptr(stat_c), st)
+            else:
+                _call("conv_fwd", 0.0, lib.o3d_mlp_conv_fwd_c, Ys[-1].data_ptr(), Ws[l].data_ptr(), scales[-1].data_ptr(),
+                      shifts[-1].data_ptr(), Cin, Cout, Pmax, cw.data_ptr(), meta.data_ptr(), Y.data_ptr(), _ptr(part),
+                      _ptr(stat_c), st)
+            vec = torch.empty((4, Cout), device=dev, dtype=f32)
+            if cfg.training:
+                _call("bn_finalize", 0.0, lib.o3d_bn_finalize_c, part.data_ptr(), Pmax // tile, Cout, count,
+                      stat_c.data_ptr(), gammas[l].data_ptr(), betas[l].data_ptr(), bn.running_mean.data_ptr(),
+                      bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps), vec[0].data_ptr(), vec[1].data_ptr(),
+                      vec[2].data_ptr(), vec[3].data_ptr(), meta.data_ptr(), tile, st)
+                bn.num_batches_tracked.add_(1)
+            else:
+                vec[0].copy_(bn.running_mean)
+                vec[1].copy_(torch.rsqrt(bn.running_var + bn.eps))
+                vec[2].copy_(gammas[l] * vec[1])
+                vec[3].copy_(betas[l] - vec[0] * vec[2])
+            Ys.append(Y)
+            means.append(vec[0]); invstds.append(vec[1]); scales.append(vec[2]); shifts.append(vec[3])
+        Cl = Ws[-1].shape[0]
+        out = torch.empty((B, Cl, npoint), device=dev, dtype=f32)
+        argq = torch.empty((B, Cl, npoint), device=dev, dtype=i32) if need_bwd else None
+        yarg = torch.empty((B, Cl, npoint), device=dev, dtype=f32) if need_bwd else None
+        _call("pool_fwd", 0.0, lib.o3d_pool_fwd_c, Ys[-1].data_ptr(), Pmax, scales[-1].data_ptr(), shifts[-1].data_ptr(),
+              ball_off.data_ptr(), B, Cl, npoint, out.data_ptr(), _ptr(argq), _ptr(yarg), st)
+        if need_bwd:
+            ctx.cfg = cfg
+            ctx.dims = (B, N, C, npoint, ns, L)
+            ctx.saved = (X0n, centers, ball_off, gp, cball, cw, meta, Ws, gammas, Ys, means, invstds, scales, shifts,
+                         out.detach(), argq, yarg)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        lib = capi.load()
+        cfg = ctx.cfg
+        B, N, C, npoint, ns, L = ctx.dims
+        (X0n, centers, ball_off, gp, cball, cw, meta, Ws, gammas, Ys, means, invstds, scales, shifts, out, argq,
+         yarg) = ctx.saved
+        Npad = X0n.shape[2]
+        P = npoint * ns
+        Pmax = B * P
+        nballs = B * npoint
+        dev = dOut.device
+        st = _stream()
+        f32 = torch.float32
+        dOut = dOut.contiguous()
+        nxyz = cfg.nxyz
+        count = float(B) * P
+        grads = [None] * (3 * L)
+        want_xyz = nxyz > 0 and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        want_feats = C > 0 and ctx.needs_input_grad[2]
+        Cl = Ws[-1].shape[0]
+        part = torch.empty((B, 2, Cl), device=dev, dtype=f32)
+        _call("pool_bwd_partials", 0.0, lib.o3d_pool_bwd_partials, dOut.data_ptr(), out.data_ptr(), yarg.data_ptr(),
+              means[-1].data_ptr(), B, Cl, npoint, part.data_ptr(), None, None, st)
+        dN = torch.empty((Cl, Pmax), device=dev, dtype=f32)          # dense class-sum gradient of the pooled layer
+        _call("pool_bwd_dense", 0.0, lib.o3d_pool_bwd_dense_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), B, Cl,
+              npoint, meta.data_ptr(), Pmax, dN.data_ptr(), st)
+        dfeats = dxyz = dnew = None
+        for l in range(L - 1, -1, -1):
+            Cout, Cin = Ws[l].shape
+            coef = torch.empty((5, Cout), device=dev, dtype=f32)  # dgamma dbeta A1 A2 A3
+            if l == L - 1:
+                _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize, part.data_ptr(), B, Cout, count, gammas[l].data_ptr(),
+                      means[l].data_ptr(), invstds[l].data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                      coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr(), None, st)
+            else:
+                _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize_c, part.data_ptr(), Pmax // TILE, Cout, count,
+                      gammas[l].data_ptr(), means[l].data_ptr(), invstds[l].data_ptr(), coef[0].data_ptr(),
+                      coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr(), meta.data_ptr(),
+                      TILE, st)
+            if not cfg.training:
+                coef[3].zero_()
+                coef[4].zero_()
+            grads[3 * l + 1], grads[3 * l + 2] = coef[0], coef[1]
+            A = (coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr())
+            if l == 0:
+                S = torch.empty((Cout, B * Npad), device=dev, dtype=f32)
+                T = torch.empty((Cout, nballs), device=dev, dtype=f32) if nxyz else None
+                _call("group_reduce", 0.0, lib.o3d_group_reduce_c, dN.data_ptr(), Ys[0].data_ptr(), Pmax, A[0], A[1], A[2],
+                      gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), ball_off.data_ptr(), B, npoint, Npad, Cout,
+                      S.data_ptr(), _ptr(T), st)
+                one, zero = _const_vec(dev, Cout, 1.0), _const_vec(dev, Cout, 0.0)
+                PN = B * Npad
+                tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
+                total_chunks = PN // 32
+                nsl = max(1, min(total_chunks // 4 if total_chunks >= 4 else 1, 768 // tiles))
+                wpart = torch.empty((nsl + 16, Cout, Cin), device=dev, dtype=f32)
+                dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
+                _call("conv_wgrad_points", 2.0 * Cin * Cout * PN, lib.o3d_mlp_conv_wgrad, S.data_ptr(), None, None, None,
+                      4, S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(), None, None, None,
+                      None, None, None, 0, 0, 0, 1.0, 1, Cin, Cout, PN, nsl, wpart.data_ptr(), dW.data_ptr(), st)
+                if nxyz:      # the centre term of grouped_xyz = xyz[idx] - new_xyz
+                    dW[:, :3] -= T @ centers[:nballs]
+                grads[0] = dW
+                if want_xyz or want_feats:
+                    dX = torch.empty((Cin, B, Npad), device=dev, dtype=f32)
+                    _call("conv_dgrad_points", 2.0 * Cin * Cout * PN, lib.o3d_mlp_conv_dgrad_plain, S.data_ptr(),
+                          S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), Ws[0].data_ptr(), 1, Cin, Cout,
+                          PN, dX.data_ptr(), st)
+                    if want_feats:
+                        dfeats = dX[nxyz:, :, :N].permute(1, 0, 2)
+                    if want_xyz:
+                        dxyz = dX[:3, :, :N].permute(1, 2, 0) * cfg.inv_radius
+                        dnew = (Ws[0][:, :3].t() @ T).view(3, B, npoint).permute(1, 2, 0) * (-cfg.inv_radius)
+                continue
+            flops = 0.0      # data dependent (live columns); bench.py reports time only for these launches
+            dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
+            wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, Pmax),), device=dev, dtype=f32)
+            _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
+                  Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Cin, Cout, Pmax, cw.data_ptr(),
+                  meta.data_ptr(), wpart.data_ptr(), dW.data_ptr(), st)
+            grads[3 * l] = dW
+            Wt = Ws[l].t().contiguous()
+            dNp = torch.empty((Cin, Pmax), device=dev, dtype=f32)
+            part = torch.empty((Pmax // TILE, 2, Cin), device=dev, dtype=f32)
+            _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
+                  Wt.data_ptr(), Cin, Cout, Pmax, cw.data_ptr(), meta.data_ptr(), Ys[l - 1].data_ptr(),
+                  scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),
+                  part.data_ptr(), st)
+            dN = dNp
+        gw = []
+        for l in range(L):
+            shape = (Ws[l].shape[0], Ws[l].shape[1], 1, 1)
+            gw += [grads[3 * l].view(shape), grads[3 * l + 1], grads[3 * l + 2]]
+        return (dxyz if ctx.needs_input_grad[0] else None, dnew if ctx.needs_input_grad[1] else None,
+                dfeats if ctx.needs_input_grad[2] else None, None, None, *gw)
+
+
+def _compact_ok(layers, npoint, ns, B):
+    if ns > 64 or B * npoint > 65536:
+        return False
+    for i, (conv, _) in enumerate(layers):
+        if i >= 1 and (conv.in_channels % 64 or conv.out_channels % 64):
+            return False
+    return layers[0][0].out_channels % 64 == 0
+
+
 def _run(mlp, xyz, new_xyz, feats, idx, nxyz, inv_radius):
     layers = _layers(mlp)
     cfg = _Cfg()
@@ -361,6 +585,9 @@ def _run(mlp, xyz, new_xyz, feats, idx, nxyz, inv_radius):
     params = []
     for conv, bn in layers:
         params += [conv.weight, bn.weight, bn.bias]
+    B, npoint, ns = idx.shape
+    if _COMPACT["on"] and _compact_ok(layers, npoint, ns, B):
+        return FusedGroupedMLPCompact.apply(xyz, new_xyz, feats, idx, cfg, *params)
     return FusedGroupedMLP.apply(xyz, new_xyz, feats, idx, cfg, *params)
 
 

@@ -98,9 +98,9 @@ def test_conv_fwd_and_stats(lib, B, Cin, Cout, P, xform):
     assert rel(q, ((ref - c.double()[None, :, None]) ** 2).sum((0, 2))) < 1e-5
 
 
-def test_bn_finalize_matches_torch(lib):
+@pytest.mark.parametrize("B,C,P", [(4, 96, 256), (40, 96, 512)])     # 8 parts / 160 parts (folded first)
+def test_bn_finalize_matches_torch(lib, B, C, P):
     torch.manual_seed(0)
-    B, C, P = 4, 96, 256
     Y = torch.randn(B, C, P, device="cuda") * 2 + 3
     bn = torch.nn.BatchNorm2d(C).cuda().train()
     with torch.no_grad():
@@ -112,9 +112,10 @@ def test_bn_finalize_matches_torch(lib):
     part = torch.stack([Yt.sum(3), ((Yt - rm[None, :, None, None]) ** 2).sum(3)], 0)  # (2,B,C,T)
     part = part.permute(1, 3, 0, 2).reshape(ntiles, 2, C).contiguous()
     vec = torch.empty(4, C, device="cuda")
+    fold = torch.empty(64, C, device="cuda")
     rc = lib.o3d_bn_finalize(part.data_ptr(), ntiles, C, float(B * P), rm.data_ptr(), bn.weight.data_ptr(),
                              bn.bias.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5, vec[0].data_ptr(),
-                             vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), st())
+                             vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), fold.data_ptr(), st())
     assert rc == 0
     ref = bn(Y.view(B, C, P, 1))
     got = Y * vec[2][None, :, None] + vec[3][None, :, None]
@@ -287,7 +288,13 @@ def test_group_layer0_kernels(lib, N, npoint, ns, C0, nxyz):
     dN = torch.randn(B, C0, P, device="cuda", generator=g)
     S = torch.empty(B, C0, ld, device="cuda")
     T = torch.empty(B, C0, npoint, device="cuda")
-    assert lib.o3d_group_reduce_bwd(dN.data_ptr(), idx.data_ptr(), B, C0, ld, npoint, ns, S.data_ptr(), T.data_ptr(), st()) == 0
+    cnt2 = torch.empty(B, ld, device="cuda")
+    R2 = torch.empty(B, ld, 3, device="cuda") if nxyz else None
+    assert lib.o3d_group_reduce_bwd(dN.data_ptr(), idx.data_ptr(), B, C0, ld, npoint, ns, S.data_ptr(), T.data_ptr(),
+                                    ptr(new_xyz), cnt2.data_ptr(), ptr(R2), st()) == 0
+    assert torch.equal(cnt2, cnt)           # the same pass also yields the index-only quantities
+    if nxyz:
+        assert rel(R2, R_ref) < 1e-5
     S_ref = torch.zeros(B, C0, ld, device="cuda", dtype=torch.float64).scatter_add_(2, flat, dN.double())
     T_ref = dN.double().reshape(B, C0, npoint, ns).sum(3)
     assert rel(S, S_ref) < 1e-5 and rel(T, T_ref) < 1e-5
@@ -300,3 +307,42 @@ def test_group_layer0_kernels(lib, N, npoint, ns, C0, nxyz):
     assert rel(S, torch.zeros(B, C0, ld, device="cuda", dtype=torch.float64).scatter_add_(2, flat, dY)) < 2e-5
     if nxyz:
         assert rel(T, dY.reshape(B, C0, npoint, ns).sum(3)) < 2e-5
+
+
+@pytest.mark.parametrize("ns", [4, 16, 32])
+def test_compact_build(lib, ns):
+    """csrc/compact.hip: one column per distinct neighbour, first hit weighted by its copies"""
+    g = torch.Generator().manual_seed(ns)
+    B, npoint, N, ld = 4, 64, 100, 128
+    idx = torch.zeros(B, npoint, ns, dtype=torch.int32)
+    ref_cnt = []
+    for b in range(B):
+        for j in range(npoint):
+            cnt = int(torch.randint(1, ns + 1, (1,), generator=g))
+            hits = torch.randperm(N, generator=g)[:cnt].sort()[0].int()
+            idx[b, j, :cnt] = hits
+            idx[b, j, cnt:] = hits[0]
+            ref_cnt.append(cnt)
+    dev_idx = idx.cuda()
+    nballs, Pmax = B * npoint, B * npoint * ns
+    i32 = dict(device="cuda", dtype=torch.int32)
+    ball_cnt, ball_off = torch.empty(nballs, **i32), torch.empty(nballs + 1, **i32)
+    gp, cball, meta = torch.empty(Pmax, **i32), torch.empty(Pmax, **i32), torch.empty(4, **i32)
+    cw = torch.empty(Pmax, device="cuda")
+    assert lib.o3d_compact_build(dev_idx.data_ptr(), B, npoint, ns, ld, ball_cnt.data_ptr(), ball_off.data_ptr(),
+                                 gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), meta.data_ptr(), st()) == 0
+    ref_cnt = torch.tensor(ref_cnt, dtype=torch.int32)
+    assert torch.equal(ball_cnt.cpu(), ref_cnt)
+    off = torch.cat([torch.zeros(1, dtype=torch.int64), ref_cnt.long().cumsum(0)])
+    assert torch.equal(ball_off.cpu().long(), off)
+    tot = int(off[-1])
+    assert meta.cpu().tolist()[:3] == [(tot + 255) // 256 * 256, tot, nballs]
+    gp_c, cball_c, cw_c = gp.cpu(), cball.cpu(), cw.cpu()
+    for ball in (0, 7, nballs - 1):
+        b, j, q0, cnt = ball // npoint, ball % npoint, int(off[ball]), int(ref_cnt[ball])
+        assert gp_c[q0:q0 + cnt].tolist() == (idx[b, j, :cnt].long() + b * ld).tolist()
+        assert cball_c[q0:q0 + cnt].tolist() == [ball] * cnt
+        assert cw_c[q0:q0 + cnt].tolist() == [float(1 + ns - cnt)] + [1.0] * (cnt - 1)
+    pad = slice(tot, int(meta[0]))
+    assert bool((cw_c[pad] == 0).all()) and bool((cball_c[pad] == nballs).all())
+    assert abs(float(cw_c[:tot].sum()) - Pmax) < 0.5      # the weights account for every slot
