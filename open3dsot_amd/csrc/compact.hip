@@ -150,30 +150,47 @@ __global__ __launch_bounds__(256) void expand_c_kernel(const float* __restrict__
 
 // ---------------------------------------------------------------------------------------
 // pool: out[b,c,j] = max over the ball's columns of relu(Y*scale+shift); argq = column of the max
+//   8 lanes per ball (its columns are contiguous, 8 on average): a wave reads the columns of 8
+//   consecutive balls, i.e. one nearly contiguous row segment; first-maximum arg-max via 3 shuffles.
+//   workgroup = 32 balls x POOL_CH channels.
 // ---------------------------------------------------------------------------------------
+constexpr int POOL_CH = 8;
+
 __global__ __launch_bounds__(256) void pool_c_kernel(const float* __restrict__ Y, long ldp,
                                                      const float* __restrict__ scale,
                                                      const float* __restrict__ shift,
                                                      const int32_t* __restrict__ ball_off, int C, int npoint,
-                                                     long total, float* __restrict__ out,
+                                                     int nballs, float* __restrict__ out,
                                                      int32_t* __restrict__ argq, float* __restrict__ yarg) {
-    const long i = (long)blockIdx.x * 256 + threadIdx.x;     // (c, ball), ball fastest
-    if (i >= total) return;
-    const int nballs = (int)(total / C);
-    const int c = (int)(i / nballs), ball = (int)(i - (long)c * nballs);
+    const int e = threadIdx.x & 7;
+    int ball = blockIdx.x * 32 + (threadIdx.x >> 3);
+    const bool live = ball < nballs;
+    if (!live) ball = nballs - 1;
     const int q0 = ball_off[ball], q1 = ball_off[ball + 1];
-    const float sc = scale[c], sf = shift[c];
-    const float* y = Y + (long)c * ldp;
-    float best = -INFINITY, yb = 0.f;
-    int bq = q0;
-    for (int q = q0; q < q1; ++q) {
-        const float v = y[q], n = fmaf(v, sc, sf);
-        if (n > best) { best = n; bq = q; yb = v; }
-    }
     const int b = ball / npoint, j = ball - b * npoint;
-    const long o = ((long)b * C + c) * npoint + j;
-    out[o] = fmaxf(best, 0.f);
-    if (argq) { argq[o] = bq; yarg[o] = yb; }
+    const int c0 = blockIdx.y * POOL_CH;
+    for (int cc = 0; cc < POOL_CH && c0 + cc < C; ++cc) {
+        const int c = c0 + cc;
+        const float sc = scale[c], sf = shift[c];
+        const float* y = Y + (long)c * ldp;
+        float best = -INFINITY, yb = 0.f;
+        int bq = 0x7fffffff;
+        for (int q = q0 + e; q < q1; q += 8) {
+            const float v = y[q], n = fmaf(v, sc, sf);
+            if (n > best) { best = n; bq = q; yb = v; }
+        }
+#pragma unroll
+        for (int off = 4; off >= 1; off >>= 1) {
+            const float ob = __shfl_xor(best, off, 64), oy = __shfl_xor(yb, off, 64);
+            const int oq = __shfl_xor(bq, off, 64);
+            if (ob > best || (ob == best && oq < bq)) { best = ob; bq = oq; yb = oy; }
+        }
+        if (live && e == 0) {
+            const long o = ((long)b * C + c) * npoint + j;
+            out[o] = fmaxf(best, 0.f);
+            if (argq) { argq[o] = bq; yarg[o] = yb; }
+        }
+    }
 }
 
 // dense gradient of the pooled layer: zero the live columns, then one value per (c, ball)
@@ -224,16 +241,45 @@ __global__ __launch_bounds__(256) void reduce_c_kernel(const float* __restrict__
         const int cc = c0 + c < C0 ? c0 + c : C0 - 1;
         a1[c] = A1[cc]; a2[c] = A2[cc]; a3[c] = A3[cc];
     }
-    for (int q = q0 + threadIdx.x; q < q1; q += 256) {
-        const int n = gp[q] - b * ld, j = cball[q] - b * npoint;
-        const float w = cw[q];
+    // A ball's columns are consecutive, so its sum T is a segmented reduction over lanes (inclusive
+    // segmented scan by ball id, the last lane of each run adds the run total once): per-element LDS
+    // atomics on T would pile the ~8 columns of a ball onto one address (ds_add_f32 retires roughly
+    // one lane per 8 cycles per CU, measured with tools/exp/group_probe.py).
+    const int lane = threadIdx.x & 63;
+    const int span = q1 - q0;
+    for (int i0 = 0; i0 < span; i0 += 256) {
+        const int q = q0 + i0 + threadIdx.x;
+        const bool live = q < q1;
+        const int n = live ? gp[q] - b * ld : 0, j = live ? cball[q] - b * npoint : -1;
+        const float w = live ? cw[q] : 0.f;
+        unsigned same = 0;           // bit s: lane - 2^s belongs to the same ball
+        if (T) {
+#pragma unroll
+            for (int sft = 0; sft < 6; ++sft) {
+                const int ju = __shfl_up(j, 1 << sft, 64);
+                if (lane >= (1 << sft) && ju == j) same |= 1u << sft;
+            }
+        }
+        const int jn = __shfl_down(j, 1, 64);
+        const bool tail = live && (lane == 63 || jn != j);
 #pragma unroll
         for (int c = 0; c < CS; ++c) {
             if (c0 + c >= C0) break;
-            const long o = (long)(c0 + c) * ldp + q;
-            const float dy = fmaf(a1[c], dN[o], w * fmaf(a2[c], Y0[o], a3[c]));
-            atomicAdd(&acc[c * ld + n], dy);
-            if (T) atomicAdd(&tacc[c * npoint + j], dy);
+            float dy = 0.f;
+            if (live) {
+                const long o = (long)(c0 + c) * ldp + q;
+                dy = fmaf(a1[c], dN[o], w * fmaf(a2[c], Y0[o], a3[c]));
+                atomicAdd(&acc[c * ld + n], dy);
+            }
+            if (T) {
+                float run = dy;
+#pragma unroll
+                for (int sft = 0; sft < 6; ++sft) {
+                    const float up = __shfl_up(run, 1 << sft, 64);
+                    if (same & (1u << sft)) run += up;
+                }
+                if (tail) atomicAdd(&tacc[c * npoint + j], run);
+            }
         }
     }
     __syncthreads();
@@ -287,9 +333,9 @@ extern "C" int o3d_pool_fwd_c(const float* Y, long ldp, const float* scale, cons
                               float* yarg, void* stream) {
     if (!Y || !scale || !shift || !ball_off || !out || B <= 0 || C <= 0 || npoint <= 0 || (argq && !yarg))
         return O3D_EINVAL;
-    const long total = (long)B * npoint * C;
-    hipLaunchKernelGGL(pool_c_kernel, dim3(o3d_cdiv(total, 256)), dim3(256), 0, o3d_stream(stream), Y, ldp, scale,
-                       shift, ball_off, C, npoint, total, out, argq, yarg);
+    const int nballs = B * npoint;
+    hipLaunchKernelGGL(pool_c_kernel, dim3(o3d_cdiv(nballs, 32), o3d_cdiv(C, POOL_CH)), dim3(256), 0,
+                       o3d_stream(stream), Y, ldp, scale, shift, ball_off, C, npoint, nballs, out, argq, yarg);
     return o3d_launch_status();
 }
 

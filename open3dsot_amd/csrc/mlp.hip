@@ -956,6 +956,34 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
     out[(long)blockIdx.y * n + i] = s;
 }
 
+// one launch: 32 outputs x 8 slice groups per workgroup, groups summed through LDS in a fixed order
+__global__ __launch_bounds__(256) void wgrad_reduce1_kernel(const float* __restrict__ part, int nslices, long n,
+                                                            float* __restrict__ out) {
+    __shared__ float sh[8][32];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const long i = (long)blockIdx.x * 32 + col;
+    const int per = (nslices + 7) / 8, z0 = grp * per;
+    int z1 = z0 + per;
+    if (z1 > nslices) z1 = nslices;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int z = z0;
+        for (; z + 3 < z1; z += 4) {
+            s0 += part[(long)z * n + i]; s1 += part[(long)(z + 1) * n + i];
+            s2 += part[(long)(z + 2) * n + i]; s3 += part[(long)(z + 3) * n + i];
+        }
+        for (; z < z1; ++z) s0 += part[(long)z * n + i];
+    }
+    sh[grp][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += sh[g][col];
+        out[i] = t;
+    }
+}
+
 template <typename K, typename... A>
 int launch(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t s, A... args) {
     if (lds > 48 * 1024) {  // dynamic LDS beyond the default window must be opted into, once per kernel
@@ -1212,16 +1240,8 @@ extern "C" int o3d_mlp_conv_grouped_dgrad(const float* dN, const float* dOut, co
 // dW[i] = sum over slices of part[z][i], in a fixed order (two stages above 32 slices; scratch2 holds
 // 16 * n floats)
 void o3d_wgrad_reduce(const float* part, int nslices, long n, float* scratch2, float* dW, hipStream_t s) {
-    if (nslices > 32) {
-        const int groups = 16, per = (nslices + groups - 1) / groups;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(o3d_cdiv(n, 256), groups), dim3(256), 0, s, part, nslices, per,
-                           n, scratch2);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(o3d_cdiv(n, 256), 1), dim3(256), 0, s, scratch2, groups, groups,
-                           n, dW);
-    } else {
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(o3d_cdiv(n, 256), 1), dim3(256), 0, s, part, nslices, nslices,
-                           n, dW);
-    }
+    (void)scratch2;
+    hipLaunchKernelGGL(wgrad_reduce1_kernel, dim3(o3d_cdiv(n, 32)), dim3(256), 0, s, part, nslices, n, dW);
 }
 
 // weight gradient.  `part` is scratch of (nslices+16)*Cout*Cin floats; dW (Cout,Cin) is overwritten.

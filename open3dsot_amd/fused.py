@@ -236,7 +236,6 @@ class FusedGroupedMLP(torch.autograd.Function):
                       stat_c.data_ptr(), gammas[l].data_ptr(), betas[l].data_ptr(), bn.running_mean.data_ptr(),
                       bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps), vec[0].data_ptr(),
                       vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), fold.data_ptr(), st)
-                bn.num_batches_tracked.add_(1)
             else:
                 vec[0].copy_(bn.running_mean)
                 vec[1].copy_(torch.rsqrt(bn.running_var + bn.eps))
@@ -244,6 +243,8 @@ class FusedGroupedMLP(torch.autograd.Function):
                 vec[3].copy_(betas[l] - vec[0] * vec[2])
             Ys.append(Y)
             means.append(vec[0]); invstds.append(vec[1]); scales.append(vec[2]); shifts.append(vec[3])
+        if cfg.training:
+            torch._foreach_add_([bn.num_batches_tracked for bn in cfg.bns], 1)
         Cl = Ws[-1].shape[0]
         out = torch.empty((B, Cl, npoint), device=dev, dtype=torch.float32)
         arg = torch.empty((B, Cl, npoint), device=dev, dtype=torch.int32) if need_bwd else None
@@ -449,7 +450,6 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                       stat_c.data_ptr(), gammas[l].data_ptr(), betas[l].data_ptr(), bn.running_mean.data_ptr(),
                       bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps), vec[0].data_ptr(), vec[1].data_ptr(),
                       vec[2].data_ptr(), vec[3].data_ptr(), meta.data_ptr(), tile, st)
-                bn.num_batches_tracked.add_(1)
             else:
                 vec[0].copy_(bn.running_mean)
                 vec[1].copy_(torch.rsqrt(bn.running_var + bn.eps))
@@ -457,6 +457,8 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                 vec[3].copy_(betas[l] - vec[0] * vec[2])
             Ys.append(Y)
             means.append(vec[0]); invstds.append(vec[1]); scales.append(vec[2]); shifts.append(vec[3])
+        if cfg.training:
+            torch._foreach_add_([bn.num_batches_tracked for bn in cfg.bns], 1)     # one launch for all layers
         Cl = Ws[-1].shape[0]
         out = torch.empty((B, Cl, npoint), device=dev, dtype=f32)
         argq = torch.empty((B, Cl, npoint), device=dev, dtype=i32) if need_bwd else None

@@ -11,7 +11,27 @@ Checkpoint keys are therefore identical to the reference's, e.g.
 The fused MI355X path (open3dsot_amd.fused) reads parameters out of these modules; it
 never changes the tree.
 """
+import torch
 import torch.nn as nn
+
+_FLAT = {"on": True}
+
+
+def set_flat_pointwise(enabled):
+    """1x1 Conv1d stacks as plain GEMMs on the flat (C, B*N) layout (default) or as F.conv1d calls."""
+    _FLAT["on"] = bool(enabled)
+
+
+def pointwise_conv1d(conv, x):
+    """nn.Conv1d with kernel 1 on (B,C,N) as ONE (Cout,Cin) x (Cin,B*N) GEMM.  Same arithmetic as
+    F.conv1d; on the MI355X the library convolution picks 60-90 us kernels for these 6144-column
+    problems (rocprofv3, profiles/) where the plain GEMM takes ~10."""
+    B, C, N = x.shape
+    h = torch.mm(conv.weight[:, :, 0], x.permute(1, 0, 2).reshape(C, B * N))
+    if conv.bias is not None:
+        h = h + conv.bias[:, None]
+    return h.reshape(-1, B, N).permute(1, 0, 2).contiguous()
+
 
 _CONV = {1: nn.Conv1d, 2: nn.Conv2d, 3: nn.Conv3d}
 _BN = {1: nn.BatchNorm1d, 2: nn.BatchNorm2d, 3: nn.BatchNorm3d}
@@ -181,6 +201,39 @@ class Seq(nn.Sequential):
 
     def dropout(self, p=0.5):
         return self._push(nn.Dropout(p=0.5))  # the reference ignores p as well (:431)
+
+    def _flat_units(self):
+        """[(conv, bn | None, activation | None)] when every child is a kernel-1 Conv1d unit, else None"""
+        units = []
+        for unit in self.children():
+            if not isinstance(unit, Conv1d):
+                return None
+            kids = dict(unit.named_children())
+            conv = kids.get("conv")
+            if conv is None or list(kids)[0] != "conv" or conv.kernel_size != (1,) or conv.stride != (1,) or \
+                    conv.padding != (0,) or conv.groups != 1:
+                return None
+            bn = kids.get("bn")
+            units.append((conv, bn.bn if bn is not None else None, kids.get("activation")))
+        return units or None
+
+    def forward(self, x):
+        units = self._flat_units() if (_FLAT["on"] and x.dim() == 3) else None
+        if units is None:
+            return super().forward(x)
+        # flat layout (C, B*N): each layer is one GEMM; BatchNorm1d sees (1, C, B*N), i.e. the same
+        # per-channel statistics over all B*N positions
+        B, C, N = x.shape
+        h = x.permute(1, 0, 2).reshape(C, B * N)
+        for conv, bn, act in units:
+            h = torch.mm(conv.weight[:, :, 0], h)
+            if conv.bias is not None:
+                h = h + conv.bias[:, None]
+            if bn is not None:
+                h = bn(h.unsqueeze(0)).squeeze(0)
+            if act is not None:
+                h = act(h)
+        return h.reshape(-1, B, N).permute(1, 0, 2).contiguous()
 
     def maxpool2d(self, kernel_size, stride=None, padding=0, dilation=1, return_indices=False,
                   ceil_mode=False):

@@ -101,8 +101,8 @@ class P2B(MatchingBaseModel):
         M, N = template.shape[1], search.shape[1]
         template_xyz, template_feature, _ = self.backbone(template, [M // 2, M // 4, M // 8])
         search_xyz, search_feature, sample_idxs = self.backbone(search, [N // 2, N // 4, N // 8])
-        template_feature = self.conv_final(template_feature)
-        search_feature = self.conv_final(search_feature)
+        template_feature = pt_utils.pointwise_conv1d(self.conv_final, template_feature)
+        search_feature = pt_utils.pointwise_conv1d(self.conv_final, search_feature)
         fusion = self.xcorr(template_feature, search_feature, template_xyz)
         boxes, cla, vote_xyz, centers = self.rpn(search_xyz, fusion)
         return {"estimation_boxes": boxes, "vote_center": vote_xyz, "pred_seg_score": cla,
@@ -151,8 +151,8 @@ class BAT(MatchingBaseModel):
         M, N = template.shape[1], search.shape[1]
         template_xyz, template_feature, sample_idxs_t = self.backbone(template, [M // 2, M // 4, M // 8])
         search_xyz, search_feature, sample_idxs = self.backbone(search, [N // 2, N // 4, N // 8])
-        template_feature = self.conv_final(template_feature)
-        search_feature = self.conv_final(search_feature)
+        template_feature = pt_utils.pointwise_conv1d(self.conv_final, template_feature)
+        search_feature = pt_utils.pointwise_conv1d(self.conv_final, search_feature)
         pred_search_bc = self.mlp_bc(torch.cat([search_xyz.transpose(1, 2), search_feature], dim=1))
         pred_search_bc = pred_search_bc.transpose(1, 2)                                    # (B,N/8,9)
         t_idx = sample_idxs_t[:, :M // 8, None].long().expand(-1, -1, self.config.bc_channel)

