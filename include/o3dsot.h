@@ -220,6 +220,63 @@ int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const float* out, con
                        int nxyz, float inv_radius, int B, int Cin, int Cout, int P, int nslices,
                        float* part, float* dW, void* stream);
 
+/* ---- compact (distinct-neighbour) layout, csrc/compact.hip ------------------------------------------
+ * ball_query pads a ball with copies of its first hit (pointnet2_utils.py:268); copies have identical
+ * values at every layer, so each ball keeps its cnt distinct entries as columns of flat (C, ldp)
+ * matrices (ldp = B*npoint*nsample = worst case) and the first hit carries the weight 1+nsample-cnt.
+ * meta (4 device ints) = {live columns rounded up to 256, live columns, B*npoint, 0}; kernels skip
+ * tiles beyond meta[0] -- no host synchronisation. */
+
+/* idx (B,npoint,ns) -> ball_cnt (B*npoint), ball_off (B*npoint+1), per column gp = b*ld + point,
+ * cball = ball id (B*npoint for padding columns), cw = weight; ns a power of two <= 64. */
+int o3d_compact_build(const int32_t* idx, int B, int npoint, int ns, int ld, int32_t* ball_cnt,
+                      int32_t* ball_off, int32_t* gp, int32_t* cball, float* cw, int32_t* meta, void* stream);
+
+/* Y0[c,q] = Z[c,gp[q]] - W0[c,0:3].centers[cball[q]] (QueryAndGroup + layer 0 after the per-point GEMM
+ * Z = W0.[xyz;feats], pointnet2_utils.py:299-339); centers ((B*npoint+1),3) or NULL; weighted
+ * statistics partials part [ldp/256][2][C0] or NULL. */
+int o3d_group_expand_c(const float* Z, long ldz, const int32_t* gp, const int32_t* cball, const float* cw,
+                       const float* centers, const float* W0, int ldw, int C0, const int32_t* meta, long ldp,
+                       float* Y0, float* part, const float* stat_c, void* stream);
+
+/* Inner layers on the compact layout: forward (BN+ReLU of the producer on load, weighted statistics),
+ * data gradient (dY = A1*dN + w*(A2*Y + A3), ReLU mask, statistics; Wt = W^T), weight gradient. */
+int o3d_mlp_conv_fwd_c(const float* X, const float* W, const float* in_scale, const float* in_shift, int Cin,
+                       int Cout, long ldp, const float* w, const int32_t* meta, float* Y, float* part,
+                       const float* stat_c, void* stream);
+int o3d_mlp_conv_dgrad_c(const float* dN, const float* Y, const float* A1, const float* A2, const float* A3,
+                         const float* Wt, int Cin, int Cout, long ldp, const float* w, const int32_t* meta,
+                         const float* Yprev, const float* scale_p, const float* shift_p, const float* mean_p,
+                         float* dNprev, float* part, void* stream);
+int o3d_mlp_conv_wgrad2_c(const float* dN, const float* Y, const float* A1, const float* A2, const float* A3,
+                          const float* X, const float* in_scale, const float* in_shift, int Cin, int Cout,
+                          long ldp, const float* w, const int32_t* meta, float* scratch, float* dW, void* stream);
+
+/* BatchNorm finalize kernels reading only the live partial rows (meta[0] / tile). */
+int o3d_bn_finalize_c(const float* part, int nparts, int C, double count, const float* stat_c,
+                      const float* gamma, const float* beta, float* running_mean, float* running_var,
+                      float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
+                      const int32_t* meta, int tile, void* stream);
+int o3d_bn_bwd_finalize_c(const float* part, int nparts, int C, double count, const float* gamma,
+                          const float* mean, const float* invstd, float* dgamma, float* dbeta, float* A1,
+                          float* A2, float* A3, const int32_t* meta, int tile, void* stream);
+
+/* out[b,c,j] = max over the ball's columns of relu(Y*scale+shift) (max_pool2d over nsample,
+ * pointnet2_modules.py:69-73); argq = column of the maximum, yarg = raw Y there. */
+int o3d_pool_fwd_c(const float* Y, long ldp, const float* scale, const float* shift, const int32_t* ball_off,
+                   int B, int C, int npoint, float* out, int32_t* argq, float* yarg, void* stream);
+
+/* Dense class-sum gradient of the pooled layer: D (C,ldp) zero on the live columns, D[c,argq] = dOut. */
+int o3d_pool_bwd_dense_c(const float* dOut, const float* out, const int32_t* argq, int B, int C, int npoint,
+                         const int32_t* meta, long ldp, float* D, void* stream);
+
+/* Layer-0 backward sums of dY = A1*dN + w*(A2*Y0 + A3): S (C0, B*ld) per source point
+ * (= group_points_grad, pointnet2_utils.py:237), T (C0, B*npoint) per ball (may be NULL). */
+int o3d_group_reduce_c(const float* dN, const float* Y0, long ldp, const float* A1, const float* A2,
+                       const float* A3, const int32_t* gp, const int32_t* cball, const float* cw,
+                       const int32_t* ball_off, int B, int npoint, int ld, int C0, float* S, float* T,
+                       void* stream);
+
 /* Weight gradient of an aligned inner layer (Cin, Cout multiples of 64; P multiple of 128), workgroup
  * tile matched to the layer: dW (Cout,Cin) = sum dY * f(X), dY = A1*dN + A2*Y + A3 from dN (dense) or,
  * when dN == NULL, from the packed pooled source pk of o3d_pool_bwd_partials; f(x) =

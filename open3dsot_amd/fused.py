@@ -102,6 +102,8 @@ def profile_step(step_fn, peak_tflops, repeats=3):
         _PROF["on"] = False
     agg = {}
     for name, flops, e0, e1 in _PROF["events"]:
+        if isinstance(flops, tuple):       # (per-column FLOPs, meta): the live column count is data dependent
+            flops = flops[0] * float(flops[1][0].item())
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += flops
@@ -441,7 +443,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                       cw.data_ptr(), _ptr(centers), Ws[0].data_ptr(), Cin0, C0, meta.data_ptr(), Pmax, Y.data_ptr(),
                       _ptr(part), _ptr(stat_c), st)
             else:
-                _call("conv_fwd", 0.0, lib.o3d_mlp_conv_fwd_c, Ys[-1].data_ptr(), Ws[l].data_ptr(), scales[-1].data_ptr(),
+                _call("conv_fwd", (2.0 * Cin * Cout, meta), lib.o3d_mlp_conv_fwd_c, Ys[-1].data_ptr(), Ws[l].data_ptr(), scales[-1].data_ptr(),
                       shifts[-1].data_ptr(), Cin, Cout, Pmax, cw.data_ptr(), meta.data_ptr(), Y.data_ptr(), _ptr(part),
                       _ptr(stat_c), st)
             vec = torch.empty((4, Cout), device=dev, dtype=f32)
@@ -547,7 +549,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                         dxyz = dX[:3, :, :N].permute(1, 2, 0) * cfg.inv_radius
                         dnew = (Ws[0][:, :3].t() @ T).view(3, B, npoint).permute(1, 2, 0) * (-cfg.inv_radius)
                 continue
-            flops = 0.0      # data dependent (live columns); bench.py reports time only for these launches
+            flops = (2.0 * Cin * Cout, meta)      # executed FLOPs = per live column (count read back when profiling)
             dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
             wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, Pmax),), device=dev, dtype=f32)
             _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],

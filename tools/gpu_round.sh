@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round artefacts on the GPU box: full gpu test suite, smoke, bench (graph, with cpu baseline), rocprofv3
+# kernel stats of the eager step + steady-state graph trace + FETCH/WRITE PMC passes.  usage: gpu_round.sh <tag>
+TAG=${1:-round}
+REPO=$(pwd)
+OUT=$REPO/gpurun_out/$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+{ nproc; lscpu | grep -E "Model name|^CPU\(s\)|Socket|Thread"; rocminfo 2>/dev/null | grep -E "Marketing Name|gfx|Compute Unit|Max Clock" | head -8; } > $OUT/env.txt 2>&1
+timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" | tee -a $OUT/smoke.log
+timeout 1200 python -m pytest tests -m gpu -q --timeout=600 -p no:cacheprovider > $OUT/pytest.log 2>&1
+echo "pytest exit $?" >> $OUT/pytest.log
+grep -E "passed|failed|^E  |exit" $OUT/pytest.log | cut -c1-250 | head -20
+timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
+grep -E "bench\]|Error" $OUT/bench.err | tail -4
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_eager -o bench -- python $REPO/bench.py --steps 5 --warmup 3 --no-graph --no-cpu-baseline > $OUT/rocprof_eager.log 2>&1; echo "trace eager exit $?"
+timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_graph -o bench -- python $REPO/bench.py --steps 40 --warmup 5 --no-cpu-baseline > $OUT/rocprof_graph.log 2>&1; echo "trace graph exit $?"
+timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python $REPO/bench.py --steps 2 --warmup 3 --no-graph --no-cpu-baseline > $OUT/rocprof_fetch.log 2>&1; echo "pmc fetch exit $?"
+timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- python $REPO/bench.py --steps 2 --warmup 3 --no-graph --no-cpu-baseline > $OUT/rocprof_write.log 2>&1; echo "pmc write exit $?"
+cd $REPO
+F=$(find $OUT/trace_eager -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" $OUT/kernel_stats_eager.csv
+G=$(find $OUT/trace_graph -name "*kernel_trace.csv" | head -1); [ -n "$G" ] && python tools/trace_steps.py "$G" 20 80 > $OUT/steady_state_per_step.txt
+mkdir -p $OUT/pmc; find $OUT/pmc_fetch $OUT/pmc_write -name "*counter_collection.csv" | while read f; do cp "$f" $OUT/pmc/$(echo $f | grep -o "pmc_[a-z]*")_$(basename $f); done
+python tools/pmc_summary.py $OUT/pmc $OUT/pmc_summary.csv
+rm -rf $OUT/trace_eager $OUT/trace_graph $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc
+head -3 $OUT/steady_state_per_step.txt; cat $OUT/bench.json | cut -c1-600
