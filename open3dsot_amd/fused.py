@@ -374,7 +374,24 @@ class FusedGroupedMLP(torch.autograd.Function):
                 dfeats if ctx.needs_input_grad[2] else None, None, None, *gw)
 
 
+import os as _os
 _COMPACT = {"on": True}
+_SIDE = {}
+_USE_SIDE = {"on": _os.environ.get("O3D_SIDE_STREAM", "0") == "1"}
+
+
+def _side_stream(dev):
+    """second HIP stream per device: the weight-gradient kernels of a layer run beside its data-gradient
+    kernel (both only read dN / Y).  OFF by default (O3D_SIDE_STREAM=1 enables it): measured on the
+    MI355X it LOSES 8 % (11.9 vs 11.0 ms/step) -- the two kernels contend for the same CUs and L2 and
+    the fork/join adds graph nodes; kept as a switch for larger batches."""
+    if not _USE_SIDE["on"]:
+        return torch.cuda.current_stream()
+    key = (dev.type, dev.index)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
 
 
 def set_compact(enabled):
@@ -502,6 +519,8 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         _call("pool_bwd_dense", 0.0, lib.o3d_pool_bwd_dense_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), B, Cl,
               npoint, meta.data_ptr(), Pmax, dN.data_ptr(), st)
         dfeats = dxyz = dnew = None
+        main, side = torch.cuda.current_stream(), _side_stream(dev)
+        keep = []        # buffers the side stream still reads: must outlive the join at the end
         for l in range(L - 1, -1, -1):
             Cout, Cin = Ws[l].shape
             coef = torch.empty((5, Cout), device=dev, dtype=f32)  # dgamma dbeta A1 A2 A3
@@ -532,11 +551,15 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                 nsl = max(1, min(total_chunks // 4 if total_chunks >= 4 else 1, 768 // tiles))
                 wpart = torch.empty((nsl + 16, Cout, Cin), device=dev, dtype=f32)
                 dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
-                _call("conv_wgrad_points", 2.0 * Cin * Cout * PN, lib.o3d_mlp_conv_wgrad, S.data_ptr(), None, None, None,
-                      4, S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(), None, None, None,
-                      None, None, None, 0, 0, 0, 1.0, 1, Cin, Cout, PN, nsl, wpart.data_ptr(), dW.data_ptr(), st)
-                if nxyz:      # the centre term of grouped_xyz = xyz[idx] - new_xyz
-                    dW[:, :3] -= T @ centers[:nballs]
+                keep += [S, T, wpart, one, zero]
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    _call("conv_wgrad_points", 2.0 * Cin * Cout * PN, lib.o3d_mlp_conv_wgrad, S.data_ptr(), None, None,
+                          None, 4, S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(), None,
+                          None, None, None, None, None, 0, 0, 0, 1.0, 1, Cin, Cout, PN, nsl, wpart.data_ptr(),
+                          dW.data_ptr(), side.cuda_stream)
+                    if nxyz:      # the centre term of grouped_xyz = xyz[idx] - new_xyz
+                        dW[:, :3] -= T @ centers[:nballs]
                 grads[0] = dW
                 if want_xyz or want_feats:
                     dX = torch.empty((Cin, B, Npad), device=dev, dtype=f32)
@@ -552,9 +575,12 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             flops = (2.0 * Cin * Cout, meta)      # executed FLOPs = per live column (count read back when profiling)
             dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
             wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, Pmax),), device=dev, dtype=f32)
-            _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
-                  Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Cin, Cout, Pmax, cw.data_ptr(),
-                  meta.data_ptr(), wpart.data_ptr(), dW.data_ptr(), st)
+            keep += [dN, wpart, coef]
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
+                      Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Cin, Cout, Pmax,
+                      cw.data_ptr(), meta.data_ptr(), wpart.data_ptr(), dW.data_ptr(), side.cuda_stream)
             grads[3 * l] = dW
             Wt = Ws[l].t().contiguous()
             dNp = torch.empty((Cin, Pmax), device=dev, dtype=f32)
@@ -564,6 +590,8 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                   scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),
                   part.data_ptr(), st)
             dN = dNp
+        main.wait_stream(side)       # join: every weight gradient is complete before autograd sees it
+        del keep
         gw = []
         for l in range(L):
             shape = (Ws[l].shape[0], Ws[l].shape[1], 1, 1)
