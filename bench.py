@@ -167,7 +167,7 @@ def main():
         if sa_modules.fused_enabled() and hasattr(fused, "profile_step"):
             def eager_step():      # event-bracketed launches cannot be replayed from a graph
                 trainer._forward_backward(pool[0])
-                trainer.grads.rebind(); trainer.reduce_gradients(); trainer.optimizer.step()
+                trainer.reduce_gradients(); trainer.optimizer.step()
             roofline = fused.profile_step(eager_step, PEAK_FP32_MFMA_TFLOPS)
     except ImportError:
         roofline = None

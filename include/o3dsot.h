@@ -241,12 +241,14 @@ int o3d_group_expand_c(const float* Z, long ldz, const int32_t* gp, const int32_
 
 /* Inner layers on the compact layout: forward (BN+ReLU of the producer on load, weighted statistics),
  * data gradient (dY = A1*dN + w*(A2*Y + A3), ReLU mask, statistics; Wt = W^T), weight gradient. */
+/* tile = columns per wave tile = columns per statistics partial row: o3d_direct_tile(ldp, M, 1) (64 or 128) */
+int o3d_direct_tile(long P, int M, int compact);
 int o3d_mlp_conv_fwd_c(const float* X, const float* W, const float* in_scale, const float* in_shift, int Cin,
-                       int Cout, long ldp, const float* w, const int32_t* meta, float* Y, float* part,
+                       int Cout, long ldp, const float* w, const int32_t* meta, int tile, float* Y, float* part,
                        const float* stat_c, void* stream);
 int o3d_mlp_conv_dgrad_c(const float* dN, const float* Y, const float* A1, const float* A2, const float* A3,
                          const float* Wt, int Cin, int Cout, long ldp, const float* w, const int32_t* meta,
-                         const float* Yprev, const float* scale_p, const float* shift_p, const float* mean_p,
+                         int tile, const float* Yprev, const float* scale_p, const float* shift_p, const float* mean_p,
                          float* dNprev, float* part, void* stream);
 int o3d_mlp_conv_wgrad2_c(const float* dN, const float* Y, const float* A1, const float* A2, const float* A3,
                           const float* X, const float* in_scale, const float* in_shift, int Cin, int Cout,

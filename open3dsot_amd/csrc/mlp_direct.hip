@@ -27,16 +27,31 @@
 
 namespace {
 
-constexpr int DT_POS = 128;   // positions per wave tile
-constexpr int DT_M = 64;      // output rows per wave tile
+constexpr int DT_M = 64;      // output rows per wave tile; columns per wave tile = 32 * NT (NT = 4 or 2)
 
-// raw B operand of one group of 8 k's (this lane: 4 of them) x 4 consecutive positions
+template <int NT>
+__device__ __forceinline__ void ldv(float (&d)[NT], const float* p) {
+    if constexpr (NT == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
+    } else {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        d[0] = t.x; d[1] = t.y;
+    }
+}
+template <int NT>
+__device__ __forceinline__ void stv(float* p, const float (&d)[NT]) {
+    if constexpr (NT == 4) *reinterpret_cast<float4*>(p) = make_float4(d[0], d[1], d[2], d[3]);
+    else                   *reinterpret_cast<float2*>(p) = make_float2(d[0], d[1]);
+}
+
+// raw B operand of one group of 8 k's (this lane: 4 of them) x NT consecutive positions
+template <int NT>
 struct RawB {
-    float4 v[4];      // the main tensor (X, or dN)
-    float4 y[4];      // DY: raw conv output Y
+    float v[4][NT];   // the main tensor (X, or dN); pooled: v[s][0..1] = {dOut masked by out > 0, bits(arg)}
+    float y[4][NT];   // DY: raw conv output Y
     float4 c1, c2, c3;  // per-k constants: (scale, shift, -) or (A1, A2, A3)
 };
-// pooled dY source: v[s].xy = {dOut masked by out > 0, bits(arg)} of this lane's ball for k row s
 
 enum BMode { B_PLAIN = 0, B_XFORM = 1, B_DY = 2, B_DYPOOL = 3 };
 
@@ -52,22 +67,21 @@ struct DirectArgs {
     const float* w;        // (P) or NULL: weights of the statistics (forward) / of the A2*Y+A3 term (DY modes)
     const int32_t* meta;   // device int: positions >= meta[0] are dead (tiles beyond it return) or NULL
     // epilogue
-    float* part;           // [B*P/128][2][M] or NULL
+    float* part;           // [B*P/(32*NT)][2][M] or NULL
     const float* stat_c;   // forward: shift of the second moment
     const float* Yprev; const float* scale_p; const float* shift_p; const float* mean_p;  // dgrad mask
 };
 
-template <int MODE>
+template <int MODE, int NT>
 __device__ __forceinline__ void load_b(const DirectArgs& a, const float* xb, const float* yb, long rowP, int kb,
-                                       long pool_base, int np, RawB& f) {
+                                       long pool_base, int np, RawB<NT>& f) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        if (MODE != B_DYPOOL) f.v[s] = *reinterpret_cast<const float4*>(xb + (long)(kb + s) * rowP);
-        if (MODE >= B_DY) f.y[s] = *reinterpret_cast<const float4*>(yb + (long)(kb + s) * rowP);
+        if (MODE != B_DYPOOL) ldv<NT>(f.v[s], xb + (long)(kb + s) * rowP);
+        if (MODE >= B_DY) ldv<NT>(f.y[s], yb + (long)(kb + s) * rowP);
         if (MODE == B_DYPOOL) {
-            const long i = pool_base + (long)(kb + s) * np;
-            const float2 t = a.pk[i];
-            f.v[s].x = t.x; f.v[s].y = t.y;
+            const float2 t = a.pk[pool_base + (long)(kb + s) * np];
+            f.v[s][0] = t.x; f.v[s][1] = t.y;
         }
     }
     if (MODE != B_PLAIN) {
@@ -77,34 +91,34 @@ __device__ __forceinline__ void load_b(const DirectArgs& a, const float* xb, con
     }
 }
 
-// one group: 8 k's (4 per half-wave) x (2 m-tiles x 4 n-tiles) = 32 MFMAs
-template <int MODE>
-__device__ __forceinline__ void compute_group(const RawB& f, const float4& a0v, const float4& a1v,
-                                              int kk, const float (&wv)[4], f32x16 (&acc)[2][4]) {
+// one group: 8 k's (4 per half-wave) x (2 m-tiles x NT n-tiles) = 8*NT MFMAs
+template <int MODE, int NT>
+__device__ __forceinline__ void compute_group(const RawB<NT>& f, const float4& a0v, const float4& a1v, int kk,
+                                              const float (&wv)[NT], f32x16 (&acc)[2][NT]) {
     const float a0[4] = {a0v.x, a0v.y, a0v.z, a0v.w}, a1[4] = {a1v.x, a1v.y, a1v.z, a1v.w};
     const float c1[4] = {f.c1.x, f.c1.y, f.c1.z, f.c1.w}, c2[4] = {f.c2.x, f.c2.y, f.c2.z, f.c2.w};
     const float c3[4] = {f.c3.x, f.c3.y, f.c3.z, f.c3.w};
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        float bv[4];
+        float bv[NT];
         if (MODE == B_DYPOOL) {
-            const float go = f.v[s].x;
-            const int ak = __float_as_int(f.v[s].y);
+            const float go = f.v[s][0];
+            const int ak = __float_as_int(f.v[s][1]);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bv[t] = (kk + t == ak) ? go : 0.f;
+            for (int t = 0; t < NT; ++t) bv[t] = (kk + t == ak) ? go : 0.f;
         } else {
-            bv[0] = f.v[s].x; bv[1] = f.v[s].y; bv[2] = f.v[s].z; bv[3] = f.v[s].w;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bv[t] = f.v[s][t];
         }
         if (MODE == B_XFORM) {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bv[t] = fmaxf(fmaf(bv[t], c1[s], c2[s]), 0.f);
+            for (int t = 0; t < NT; ++t) bv[t] = fmaxf(fmaf(bv[t], c1[s], c2[s]), 0.f);
         } else if (MODE >= B_DY) {
-            const float y[4] = {f.y[s].x, f.y[s].y, f.y[s].z, f.y[s].w};
 #pragma unroll
-            for (int t = 0; t < 4; ++t) bv[t] = fmaf(c1[s], bv[t], wv[t] * fmaf(c2[s], y[t], c3[s]));
+            for (int t = 0; t < NT; ++t) bv[t] = fmaf(c1[s], bv[t], wv[t] * fmaf(c2[s], f.y[s][t], c3[s]));
         }
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < NT; ++t) {
             acc[0][t] = mfma32(a0[s], bv[t], acc[0][t]);
             acc[1][t] = mfma32(a1[s], bv[t], acc[1][t]);
         }
@@ -113,21 +127,24 @@ __device__ __forceinline__ void compute_group(const RawB& f, const float4& a0v, 
 
 // EPI 0: forward (store raw output, statistics {sum y, sum (y-c)^2})
 // EPI 1: data gradient (mask by the producer's ReLU, store, statistics {sum g, sum g*(yprev-mean)})
-template <int WAVES, int MODE, int EPI>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2))) void direct_gemm_kernel(DirectArgs a) {
+// NT = 4: 128 columns per wave (one dwordx4 B load per k row); NT = 2: 64 columns (dwordx2) -- twice the waves
+// of half the length for launches that do not fill the chip (everything after compaction at batch 48).
+template <int WAVES, int MODE, int EPI, int NT>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ? 2 : 4)))
+void direct_gemm_kernel(DirectArgs a) {
+    constexpr int POS = 32 * NT;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int tiles_per_b = a.P / DT_POS;
+    const int tiles_per_b = a.P / POS;
     const int tile = blockIdx.x;
-    const int b = tile / tiles_per_b, p0 = (tile - b * tiles_per_b) * DT_POS;
-    if (a.meta && (long)tile * DT_POS >= a.meta[0]) return;     // compact layout: dead tile
+    const int b = tile / tiles_per_b, p0 = (tile - b * tiles_per_b) * POS;
+    if (a.meta && (long)tile * POS >= a.meta[0]) return;     // compact layout: dead tile
     const int m0 = (blockIdx.y * WAVES + wave) * DT_M;
-    const int p = p0 + 4 * l31;
-    float wv[4] = {1.f, 1.f, 1.f, 1.f};
-    if (a.w) {
-        const float4 t4 = *reinterpret_cast<const float4*>(a.w + (long)b * a.P + p);
-        wv[0] = t4.x; wv[1] = t4.y; wv[2] = t4.z; wv[3] = t4.w;
-    }
+    const int p = p0 + NT * l31;
+    float wv[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) wv[t] = 1.f;
+    if (a.w) ldv<NT>(wv, a.w + (long)b * a.P + p);
     const long rowP = a.P;
     const float* xb = (MODE != B_DYPOOL) ? a.X + (long)b * a.K * rowP + p : nullptr;
     const float* yb = (MODE >= B_DY) ? a.Y + (long)b * a.K * rowP + p : nullptr;
@@ -142,20 +159,20 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
         pool_base = (long)b * a.K * np + j;
     }
 
-    f32x16 acc[2][4];
+    f32x16 acc[2][NT];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
 
     const int G = a.K / 8;       // even (K % 16 == 0)
-    RawB f[2];
+    RawB<NT> f[2];
     float4 wa0[2], wa1[2];
     auto load = [&](int st, int g) {
         const int kb = 8 * g + 4 * h;
-        load_b<MODE>(a, xb, yb, rowP, kb, pool_base, np, f[st]);
+        load_b<MODE, NT>(a, xb, yb, rowP, kb, pool_base, np, f[st]);
         wa0[st] = *reinterpret_cast<const float4*>(wa + 8 * g);
         wa1[st] = *reinterpret_cast<const float4*>(wa + 8 * g + wstep);
     };
@@ -163,11 +180,11 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int g = 0; g < G; g += 2) {
         load(1, g + 1);
         __builtin_amdgcn_sched_barrier(0);
-        compute_group<MODE>(f[0], wa0[0], wa1[0], kk, wv, acc);
+        compute_group<MODE, NT>(f[0], wa0[0], wa1[0], kk, wv, acc);
         __builtin_amdgcn_sched_barrier(0);
         load(0, g + 2 < G ? g + 2 : G - 1);       // tail: harmless re-load of the last group
         __builtin_amdgcn_sched_barrier(0);
-        compute_group<MODE>(f[1], wa0[1], wa1[1], kk, wv, acc);
+        compute_group<MODE, NT>(f[1], wa0[1], wa1[1], kk, wv, acc);
         __builtin_amdgcn_sched_barrier(0);
     }
 
@@ -179,19 +196,26 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + 32 * i + acc_row(r, h);
             const long o = ((long)b * a.M + m) * rowP + p;
-            float4 v = make_float4(acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]);
+            float v[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[t] = acc[i][t][r];
+            float sum = 0.f;
             if (EPI == 1) {
-                const float4 yp = *reinterpret_cast<const float4*>(a.Yprev + o);
+                float yp[NT];
+                ldv<NT>(yp, a.Yprev + o);
                 const float sc = a.scale_p[m], sf = a.shift_p[m];
-                v.x = fmaf(yp.x, sc, sf) > 0.f ? v.x : 0.f;
-                v.y = fmaf(yp.y, sc, sf) > 0.f ? v.y : 0.f;
-                v.z = fmaf(yp.z, sc, sf) > 0.f ? v.z : 0.f;
-                v.w = fmaf(yp.w, sc, sf) > 0.f ? v.w : 0.f;
-                acc[i][0][r] = v.x; acc[i][1][r] = v.y; acc[i][2][r] = v.z; acc[i][3][r] = v.w;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    v[t] = fmaf(yp[t], sc, sf) > 0.f ? v[t] : 0.f;
+                    acc[i][t][r] = v[t];
+                    sum += v[t];
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) sum = fmaf(wv[t], v[t], sum);
             }
-            *reinterpret_cast<float4*>(a.Out + o) = v;
-            red[i * 16 + r] = EPI == 0 ? fmaf(wv[0], v.x, fmaf(wv[1], v.y, fmaf(wv[2], v.z, wv[3] * v.w)))
-                                       : (v.x + v.y) + (v.z + v.w);
+            stv<NT>(a.Out + o, v);
+            red[i * 16 + r] = sum;
         }
     if (!a.part) return;
     // lane l31 of half h ends up owning value index l31 -> (i = l31>>4, r = l31&15)
@@ -203,16 +227,19 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + 32 * i + acc_row(r, h);
-            const float4 v = make_float4(acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]);
+            float q = 0.f;
             if (EPI == 0) {
                 const float c = a.stat_c ? a.stat_c[m] : 0.f;
-                red[i * 16 + r] = wv[0] * (v.x - c) * (v.x - c) + wv[1] * (v.y - c) * (v.y - c) +
-                                  wv[2] * (v.z - c) * (v.z - c) + wv[3] * (v.w - c) * (v.w - c);
-            } else {      // masked entries of v are zero, so the mask needs no second evaluation
-                const float4 yp = *reinterpret_cast<const float4*>(a.Yprev + ((long)b * a.M + m) * rowP + p);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) q += wv[t] * (acc[i][t][r] - c) * (acc[i][t][r] - c);
+            } else {      // masked entries are zero, so the mask needs no second evaluation
+                float yp[NT];
+                ldv<NT>(yp, a.Yprev + ((long)b * a.M + m) * rowP + p);
                 const float mu = a.mean_p[m];
-                red[i * 16 + r] = v.x * (yp.x - mu) + v.y * (yp.y - mu) + v.z * (yp.z - mu) + v.w * (yp.w - mu);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) q = fmaf(acc[i][t][r], yp[t] - mu, q);
             }
+            red[i * 16 + r] = q;
         }
     reduce_scatter32(red, l31);
     dst[a.M] = red[0];
@@ -221,33 +248,47 @@ __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2
 // All M/64 row slabs of a position tile run as the waves of ONE workgroup: they read the same B rows,
 // so those come from HBM once and from L1/L2 for the other slabs (rocprofv3 FETCH_SIZE of the
 // two-workgroup variant showed every slab re-reading HBM: 604 MB instead of 350 MB per launch).
-template <int MODE, int EPI>
-int launch_direct(const DirectArgs& a, hipStream_t st) {
-    const int tiles = a.B * (a.P / DT_POS);
+template <int MODE, int EPI, int NT>
+int launch_direct_nt(const DirectArgs& a, hipStream_t st) {
+    const int tiles = a.B * (a.P / (32 * NT));
     const int slabs = a.M / DT_M;
     if (slabs % 4 == 0) {
-        hipLaunchKernelGGL((direct_gemm_kernel<4, MODE, EPI>), dim3(tiles, slabs / 4), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((direct_gemm_kernel<4, MODE, EPI, NT>), dim3(tiles, slabs / 4), dim3(256), 0, st, a);
     } else if (slabs % 2 == 0) {
-        hipLaunchKernelGGL((direct_gemm_kernel<2, MODE, EPI>), dim3(tiles, slabs / 2), dim3(128), 0, st, a);
+        hipLaunchKernelGGL((direct_gemm_kernel<2, MODE, EPI, NT>), dim3(tiles, slabs / 2), dim3(128), 0, st, a);
     } else {
-        hipLaunchKernelGGL((direct_gemm_kernel<1, MODE, EPI>), dim3(tiles, slabs), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((direct_gemm_kernel<1, MODE, EPI, NT>), dim3(tiles, slabs), dim3(64), 0, st, a);
     }
     return o3d_launch_status();
 }
 
+template <int MODE, int EPI>
+int launch_direct(const DirectArgs& a, int tile, hipStream_t st) {
+    return tile == 64 ? launch_direct_nt<MODE, EPI, 2>(a, st) : launch_direct_nt<MODE, EPI, 4>(a, st);
+}
+
 }  // namespace
 
-bool o3d_direct_ok(int M, int K, int P) { return M % DT_M == 0 && K % 16 == 0 && P % DT_POS == 0; }
+bool o3d_direct_ok(int M, int K, int P) { return M % DT_M == 0 && K % 16 == 0 && P % 128 == 0; }
+
+// Columns per wave tile (= columns per statistics partial row) for a problem of P worst-case columns and
+// M output rows: 64 while the expected number of waves (a quarter of the worst case is live after
+// compaction) does not fill the 256 CUs a few times over, else 128.
+extern "C" int o3d_direct_tile(long P, int M, int compact) {
+    const long live = compact ? P / 4 : P;
+    (void)live; (void)M;
+    return 128;   // measured (O3D_DIRECT_TILE=64 vs 128, batch 48): 64-column tiles lose 1.3 % -- more loads per MFMA
+}
 
 // forward: Y = W . f(X), see o3d_mlp_conv_fwd
 int o3d_direct_fwd(const float* X, const float* W, const float* in_scale, const float* in_shift, int B, int Cin,
                    int Cout, int P, float* Y, float* part, const float* stat_c, const float* w, const int32_t* meta,
-                   hipStream_t st) {
+                   int tile, hipStream_t st) {
     DirectArgs a = {};
     a.w = w; a.meta = meta;
     a.A = W; a.X = X; a.c1 = in_scale; a.c2 = in_shift; a.Out = Y; a.M = Cout; a.K = Cin; a.P = P; a.B = B;
     a.part = part; a.stat_c = stat_c; a.ns = 4;
-    return in_scale ? launch_direct<B_XFORM, 0>(a, st) : launch_direct<B_PLAIN, 0>(a, st);
+    return in_scale ? launch_direct<B_XFORM, 0>(a, tile, st) : launch_direct<B_PLAIN, 0>(a, tile, st);
 }
 
 // data gradient with the weights already transposed: Wt (Cin, Cout); see o3d_mlp_conv_dgrad
@@ -255,11 +296,11 @@ int o3d_direct_dgrad(const float* dN, const float* pk, int ns,
                      const float* Y, const float* A1, const float* A2, const float* A3, const float* Wt, int B,
                      int Cin, int Cout, int P, const float* Yprev, const float* scale_p, const float* shift_p,
                      const float* mean_p, float* dNprev, float* part, const float* w, const int32_t* meta,
-                     hipStream_t st) {
+                     int tile, hipStream_t st) {
     DirectArgs a = {};
     a.w = w; a.meta = meta;
     a.A = Wt; a.X = dN; a.Y = Y; a.c1 = A1; a.c2 = A2; a.c3 = A3; a.pk = reinterpret_cast<const float2*>(pk); a.ns = ns;
     a.Out = dNprev; a.M = Cin; a.K = Cout; a.P = P; a.B = B; a.part = part;
     a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p;
-    return dN ? launch_direct<B_DY, 1>(a, st) : launch_direct<B_DYPOOL, 1>(a, st);
+    return dN ? launch_direct<B_DY, 1>(a, tile, st) : launch_direct<B_DYPOOL, 1>(a, tile, st);
 }

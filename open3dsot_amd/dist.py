@@ -44,33 +44,35 @@ def shard_indices(step, rank, world, per_rank_batch):
 
 
 class FlatGrads:
-    """All parameter gradients as views of one contiguous fp32 buffer."""
+    """One contiguous fp32 buffer for the gradient exchange.  Autograd is left to ASSIGN each p.grad
+    (p.grad is None before backward: AccumulateGrad then keeps the produced tensor, no `grad += new`
+    kernel per parameter -- 76 launches per step here); `gather()` packs them into the flat buffer with
+    one foreach copy for the all-reduce, `views` are the per-parameter slices of that buffer."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.requires_grad]
         total = sum(p.numel() for p in self.params)
         ref = self.params[0]
         self.flat = torch.zeros(total, dtype=ref.dtype, device=ref.device)
+        self.views = []
         off = 0
         for p in self.params:
             n = p.numel()
-            p.grad = self.flat[off:off + n].view_as(p)
+            self.views.append(self.flat[off:off + n].view_as(p))
             off += n
 
-    def zero(self):
-        self.flat.zero_()
-
-    def rebind(self):
-        """re-attach views if something replaced p.grad (e.g. zero_grad(set_to_none=True))"""
-        off = 0
+    def clear(self):
         for p in self.params:
-            n = p.numel()
-            view = self.flat[off:off + n].view_as(p)
-            if p.grad is None or p.grad.data_ptr() != view.data_ptr():
-                if p.grad is not None:
-                    view.copy_(p.grad)
-                p.grad = view
-            off += n
+            p.grad = None
+
+    def gather(self, grads):
+        """flat buffer <- the gradients autograd produced (None -> zeros)"""
+        src = [g if g is not None else torch.zeros_like(v) for g, v in zip(grads, self.views)]
+        torch._foreach_copy_(self.views, src)
+
+    def bind_views(self):
+        for p, v in zip(self.params, self.views):
+            p.grad = v
 
 
 class DataParallelStep:
@@ -97,15 +99,19 @@ class DataParallelStep:
         self.graph_error = None
         self._static = None
         self._static_loss = None
+        self._static_grads = None      # the gradient tensors the captured backward writes (graph pool)
         self._eager_steps = 0
 
     def reduce_gradients(self):
+        """p.grad as produced by backward -> mean over ranks, left in p.grad"""
         if self.world > 1:
+            self.grads.gather([p.grad for p in self.grads.params])
             dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM)
             self.grads.flat.div_(self.world)
+            self.grads.bind_views()
 
     def _forward_backward(self, batch):
-        self.grads.zero()
+        self.grads.clear()
         loss, _ = self.model.training_loss(batch)
         loss.backward()
         return loss.detach()
@@ -121,6 +127,7 @@ class DataParallelStep:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             self._static_loss = self._forward_backward(self._static)
+        self._static_grads = [p.grad for p in self.grads.params]
         self.graph = g
 
     def step(self, batch):
@@ -128,6 +135,8 @@ class DataParallelStep:
             for k, v in batch.items():
                 self._static[k].copy_(v, non_blocking=True)
             self.graph.replay()
+            for p, g in zip(self.grads.params, self._static_grads):   # replay rewrote these buffers in place
+                p.grad = g
             loss = self._static_loss
         else:
             if self.graph_requested and self._eager_steps >= self.graph_warmup:
@@ -142,7 +151,6 @@ class DataParallelStep:
                 return self.step(batch)
             loss = self._forward_backward(batch)
             self._eager_steps += 1
-        self.grads.rebind()
         self.reduce_gradients()
         self.optimizer.step()
         return loss

@@ -49,8 +49,10 @@ capi.register("o3d_group_expand_c", [_vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp
 capi.register("o3d_pool_fwd_c", [_vp, ctypes.c_long, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_bwd_dense_c", [_vp, _vp, _vp, _i, _i, _i, _vp, ctypes.c_long, _vp, _vp])
 capi.register("o3d_group_reduce_c", [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp])
-capi.register("o3d_mlp_conv_fwd_c", [_vp, _vp, _vp, _vp, _i, _i, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp])
-capi.register("o3d_mlp_conv_dgrad_c", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_direct_tile", [ctypes.c_long, _i, _i])
+capi.register("o3d_mlp_conv_fwd_c", [_vp, _vp, _vp, _vp, _i, _i, ctypes.c_long, _vp, _vp, _i, _vp, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_dgrad_c", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, ctypes.c_long, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp,
+                                       _vp, _vp])
 capi.register("o3d_mlp_conv_wgrad2_c", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, ctypes.c_long, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_bn_finalize_c", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp])
 capi.register("o3d_bn_bwd_finalize_c", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp])
@@ -380,6 +382,11 @@ _SIDE = {}
 _USE_SIDE = {"on": _os.environ.get("O3D_SIDE_STREAM", "0") == "1"}
 
 
+def _direct_tile(lib, pmax, m):
+    t = _os.environ.get("O3D_DIRECT_TILE")          # experiment switch: force 64 / 128 columns per wave tile
+    return int(t) if t else lib.o3d_direct_tile(pmax, m, 1)
+
+
 def _side_stream(dev):
     """second HIP stream per device: the weight-gradient kernels of a layer run beside its data-gradient
     kernel (both only read dN / Y).  OFF by default (O3D_SIDE_STREAM=1 enables it): measured on the
@@ -435,8 +442,9 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
               ball_off.data_ptr(), gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), meta.data_ptr(), st)
         # ---- layer 0 on the points: Z = W0 . [xyz * inv_radius ; feats], flat (C0, B*Npad)
         X0n = (torch.zeros if Npad != N else torch.empty)((Cin0, B, Npad), device=dev, dtype=f32)
+        unit = cfg.inv_radius == 1.0          # normalize_xyz False in every tracker config: no scaling launches
         if nxyz:
-            X0n[:3, :, :N] = xyz.detach().permute(2, 0, 1) * cfg.inv_radius
+            X0n[:3, :, :N] = xyz.detach().permute(2, 0, 1) if unit else xyz.detach().permute(2, 0, 1) * cfg.inv_radius
         if C:
             X0n[nxyz:, :, :N] = feats.detach().permute(1, 0, 2)
         Z = torch.empty((C0, B * Npad), device=dev, dtype=f32)
@@ -444,14 +452,16 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
               None, None, 1, Cin0, C0, B * Npad, Z.data_ptr(), None, None, st)
         centers = None
         if nxyz:
-            centers = torch.zeros((nballs + 1, 3), device=dev, dtype=f32)
-            centers[:nballs] = new_xyz.detach().reshape(nballs, 3) * cfg.inv_radius
+            centers = torch.empty((nballs + 1, 3), device=dev, dtype=f32)
+            centers[:nballs] = new_xyz.detach().reshape(nballs, 3) if unit else \
+                new_xyz.detach().reshape(nballs, 3) * cfg.inv_radius
+            centers[nballs:].zero_()           # dummy ball of the padding columns
         count = float(B) * P
         Ys, means, invstds, scales, shifts = [], [], [], [], []
         for l in range(L):
             Cout, Cin = Ws[l].shape
             bn = cfg.bns[l]
-            tile = ETILE if l == 0 else TILE
+            tile = ETILE if l == 0 else _direct_tile(lib, Pmax, Cout)
             Y = torch.empty((Cout, Pmax), device=dev, dtype=f32)
             part = torch.empty((Pmax // tile, 2, Cout), device=dev, dtype=f32) if cfg.training else None
             stat_c = bn.running_mean if cfg.training else None
@@ -461,8 +471,8 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                       _ptr(part), _ptr(stat_c), st)
             else:
                 _call("conv_fwd", (2.0 * Cin * Cout, meta), lib.o3d_mlp_conv_fwd_c, Ys[-1].data_ptr(), Ws[l].data_ptr(), scales[-1].data_ptr(),
-                      shifts[-1].data_ptr(), Cin, Cout, Pmax, cw.data_ptr(), meta.data_ptr(), Y.data_ptr(), _ptr(part),
-                      _ptr(stat_c), st)
+                      shifts[-1].data_ptr(), Cin, Cout, Pmax, cw.data_ptr(), meta.data_ptr(), tile, Y.data_ptr(),
+                      _ptr(part), _ptr(stat_c), st)
             vec = torch.empty((4, Cout), device=dev, dtype=f32)
             if cfg.training:
                 _call("bn_finalize", 0.0, lib.o3d_bn_finalize_c, part.data_ptr(), Pmax // tile, Cout, count,
@@ -529,10 +539,10 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                       means[l].data_ptr(), invstds[l].data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
                       coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr(), None, st)
             else:
-                _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize_c, part.data_ptr(), Pmax // TILE, Cout, count,
+                _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize_c, part.data_ptr(), Pmax // dtile, Cout, count,
                       gammas[l].data_ptr(), means[l].data_ptr(), invstds[l].data_ptr(), coef[0].data_ptr(),
                       coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr(), meta.data_ptr(),
-                      TILE, st)
+                      dtile, st)
             if not cfg.training:
                 coef[3].zero_()
                 coef[4].zero_()
@@ -569,8 +579,11 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                     if want_feats:
                         dfeats = dX[nxyz:, :, :N].permute(1, 0, 2)
                     if want_xyz:
-                        dxyz = dX[:3, :, :N].permute(1, 2, 0) * cfg.inv_radius
-                        dnew = (Ws[0][:, :3].t() @ T).view(3, B, npoint).permute(1, 2, 0) * (-cfg.inv_radius)
+                        dxyz = dX[:3, :, :N].permute(1, 2, 0)
+                        dnew = ((-cfg.inv_radius) * Ws[0][:, :3]).t() @ T      # (3, nballs); scaling on the 3xC0 side
+                        dnew = dnew.view(3, B, npoint).permute(1, 2, 0)
+                        if cfg.inv_radius != 1.0:
+                            dxyz = dxyz * cfg.inv_radius
                 continue
             flops = (2.0 * Cin * Cout, meta)      # executed FLOPs = per live column (count read back when profiling)
             dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
@@ -584,9 +597,10 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             grads[3 * l] = dW
             Wt = Ws[l].t().contiguous()
             dNp = torch.empty((Cin, Pmax), device=dev, dtype=f32)
-            part = torch.empty((Pmax // TILE, 2, Cin), device=dev, dtype=f32)
+            dtile = _direct_tile(lib, Pmax, Cin)
+            part = torch.empty((Pmax // dtile, 2, Cin), device=dev, dtype=f32)
             _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
-                  Wt.data_ptr(), Cin, Cout, Pmax, cw.data_ptr(), meta.data_ptr(), Ys[l - 1].data_ptr(),
+                  Wt.data_ptr(), Cin, Cout, Pmax, cw.data_ptr(), meta.data_ptr(), dtile, Ys[l - 1].data_ptr(),
                   scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),
                   part.data_ptr(), st)
             dN = dNp

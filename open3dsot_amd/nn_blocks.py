@@ -226,7 +226,10 @@ class Seq(nn.Sequential):
         B, C, N = x.shape
         h = x.permute(1, 0, 2).reshape(C, B * N)
         for conv, bn, act in units:
-            h = torch.mm(conv.weight[:, :, 0], h)
+            w = conv.weight[:, :, 0]
+            if w.shape[0] < 32:     # hipBLASLt picks a 16-row macro tile (87 us per call, rocprofv3) for the
+                w = torch.nn.functional.pad(w, (0, 0, 0, 32 - w.shape[0]))   # 1/5/9-channel outputs: pad to 32
+            h = torch.mm(w, h)[:conv.out_channels]
             if conv.bias is not None:
                 h = h + conv.bias[:, None]
             if bn is not None:

@@ -33,10 +33,12 @@ class P2BVoteNetRPN(nn.Module):
         score = estimation_cla.sigmoid()
         seeds = torch.cat((xyz.transpose(1, 2).contiguous(), feature), dim=1)   # (B,3+f,N)
         vote = seeds + self.vote_layer(seeds)
-        vote_xyz = vote[:, 0:3, :].transpose(1, 2).contiguous()
-        vote_feature = torch.cat((score.unsqueeze(1), vote[:, 3:, :]), dim=1).contiguous()
+        # split instead of two slices: one backward node (a cat) instead of 2 x (zeros + copy) + add
+        v_xyz, v_feat = vote.split([3, vote.shape[1] - 3], dim=1)
+        vote_xyz = v_xyz.transpose(1, 2).contiguous()
+        vote_feature = torch.cat((score.unsqueeze(1), v_feat), dim=1)
         center_xyzs, proposal_features = self.vote_aggregation(vote_xyz, vote_feature, self.num_proposal)
         offsets = self.FC_proposal(proposal_features)
-        boxes = torch.cat((offsets[:, 0:3, :] + center_xyzs.transpose(1, 2).contiguous(),
-                           offsets[:, 3:5, :]), dim=1)
+        o_xyz, o_rest = offsets.split([3, 2], dim=1)
+        boxes = torch.cat((o_xyz + center_xyzs.transpose(1, 2), o_rest), dim=1)
         return boxes.transpose(1, 2).contiguous(), estimation_cla, vote_xyz, center_xyzs
