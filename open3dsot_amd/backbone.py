@@ -6,8 +6,10 @@ levels (radius 0.3/0.5/0.7, nsample 32, MLPs [C,64,64,128] / [128,128,128,256] /
 prefix of the previous level's points.  `forward(pointcloud (B,N,3+C), numpoints)` returns
 `(xyz_last, feat_last, sample_idxs_level0)` or all levels with `return_intermediate`.
 """
+import torch
 import torch.nn as nn
 
+from . import nn_blocks
 from .sa_modules import PointnetSAModule
 
 _LEVELS = ((0.3, (64, 64, 128)), (0.5, (128, 128, 256)), (0.7, (256, 256, 256)))
@@ -43,3 +45,104 @@ class Pointnet_Backbone(nn.Module):
         if self.return_intermediate:
             return l_xyz[1:], l_features[1:], idx0
         return l_xyz[-1], l_features[-1], idx0
+
+
+def _pointwise_chain(x, layers):
+    """(Conv1d k=1 -> BatchNorm1d -> ReLU)* on (B,C,N) as GEMMs on the flat (C, B*N) layout -- the
+    M2-Track pointwise stack is the grouped MLP with one ball per cloud.
+    `layers` = [(conv, bn, relu)]; returns (B,C',N).  Same statistics as BatchNorm1d on (B,C,N)."""
+    B, C, N = x.shape
+    h = x.permute(1, 0, 2).reshape(C, B * N)
+    for conv, bn, act in layers:
+        h = torch.mm(conv.weight[:, :, 0], h)
+        if conv.bias is not None:
+            h = h + conv.bias[:, None]
+        h = act(bn(h.unsqueeze(0)).squeeze(0))
+    return h.reshape(-1, B, N).permute(1, 0, 2)
+
+
+def _triples(mods):
+    mods = list(mods)
+    return [(mods[i], mods[i + 1], mods[i + 2]) for i in range(0, len(mods), 3)]
+
+
+class MiniPointNet(nn.Module):
+    """Per-point MLP -> global max -> hidden MLP (-> fc).  Mirror of models/backbone/pointnet.py:91-141;
+    the module tree (`features.<i>`, `fc`) and therefore the state_dict keys equal the reference's."""
+
+    def __init__(self, input_channel, per_point_mlp, hidden_mlp, output_size=0):
+        super().__init__()
+        seq, c = [], input_channel
+        for width in per_point_mlp:
+            seq += [nn.Conv1d(c, width, 1), nn.BatchNorm1d(width), nn.ReLU()]
+            c = width
+        self._n_point = len(seq)
+        seq += [nn.AdaptiveMaxPool1d(output_size=1), nn.Flatten()]
+        for width in hidden_mlp:
+            seq += [nn.Linear(c, width), nn.BatchNorm1d(width), nn.ReLU()]
+            c = width
+        self.features = nn.Sequential(*seq)
+        self.output_size = output_size
+        if output_size >= 0:
+            self.fc = nn.Linear(c, output_size)
+
+    def forward(self, x):
+        """x (B,C,N) -> (B, hidden_mlp[-1]) or (B, output_size)"""
+        if nn_blocks._FLAT["on"]:
+            mods = list(self.features)
+            x = _pointwise_chain(x, _triples(mods[:self._n_point])).amax(dim=2)
+            for m in mods[self._n_point + 2:]:
+                x = m(x)
+        else:
+            x = self.features(x)
+        return self.fc(x) if self.output_size > 0 else x
+
+
+class SegPointNet(nn.Module):
+    """Per-point MLP, global max appended to the second layer's features, second per-point MLP, 1x1
+    conv head.  Mirror of models/backbone/pointnet.py:144-204 (same `seq_per_point.<i>.<j>` keys)."""
+
+    def __init__(self, input_channel, per_point_mlp1, per_point_mlp2, output_size=0, return_intermediate=False):
+        super().__init__()
+        self.return_intermediate = return_intermediate
+        self.seq_per_point = nn.ModuleList()
+        c = input_channel
+        for width in per_point_mlp1:
+            self.seq_per_point.append(nn.Sequential(nn.Conv1d(c, width, 1), nn.BatchNorm1d(width), nn.ReLU()))
+            c = width
+        self.pool = nn.AdaptiveMaxPool1d(output_size=1)
+        self.seq_per_point2 = nn.ModuleList()
+        c = c + per_point_mlp1[1]
+        for width in per_point_mlp2:
+            self.seq_per_point2.append(nn.Sequential(nn.Conv1d(c, width, 1), nn.BatchNorm1d(width), nn.ReLU()))
+            c = width
+        self.output_size = output_size
+        if output_size >= 0:
+            self.fc = nn.Conv1d(c, output_size, 1)
+
+    def forward(self, x):
+        """x (B,C,N) -> (B,output_size,N) [, pooled (B,C1)]"""
+        if nn_blocks._FLAT["on"]:
+            first = [tuple(m) for m in self.seq_per_point]
+            second = _pointwise_chain(x, first[:2])
+            x = _pointwise_chain(second, first[2:])
+            pooled = x.amax(dim=2, keepdim=True)
+            x = torch.cat([second, pooled.expand_as(x)], dim=1)
+            x = _pointwise_chain(x, [tuple(m) for m in self.seq_per_point2])
+            if self.output_size > 0:
+                x = nn_blocks.pointwise_conv1d(self.fc, x.contiguous())
+        else:
+            second = None
+            for i, m in enumerate(self.seq_per_point):
+                x = m(x)
+                if i == 1:
+                    second = x
+            pooled = self.pool(x)
+            x = torch.cat([second, pooled.expand_as(x)], dim=1)
+            for m in self.seq_per_point2:
+                x = m(x)
+            if self.output_size > 0:
+                x = self.fc(x)
+        if self.return_intermediate:
+            return x, pooled.squeeze(-1)
+        return x

@@ -1,0 +1,158 @@
+"""M2-Track: the motion-centric two-stage tracker (BASELINE config 4).
+
+Host-side mirror (plain nn.Module, no Lightning) of models/m2track.py: `__init__` :18-71 (module
+names = state_dict keys of the reference), `forward` :73-151, `compute_loss` :153-231 and the
+training-step arithmetic :233-264.  It uses no pointnet2 operator: the per-point stacks
+(`SegPointNet`, `MiniPointNet`, models/backbone/pointnet.py:91-204) are 1x1 Conv1d + BatchNorm1d +
+ReLU + global max, run here as GEMMs on the flat (C, B*N) layout (open3dsot_amd/backbone.py).
+Differences from the reference, by design: the class weights of the segmentation loss are created
+on the logits' device (the reference calls `.cuda()`, :171); no torchmetrics / `.item()` logging.
+"""
+from types import SimpleNamespace
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import box_utils
+from .backbone import MiniPointNet, SegPointNet
+
+# cfgs/M2_track_kitti.yaml (model / loss keys)
+M2_KITTI = dict(net_model="m2track", box_aware=True, use_motion_cls=True, use_second_stage=True,
+                use_prev_refinement=True, center_weight=2, angle_weight=10.0, seg_weight=0.1, bc_weight=1,
+                motion_cls_seg_weight=0.1, point_sample_size=1024, optimizer="Adam", lr=0.001, wd=0,
+                lr_decay_step=20, lr_decay_rate=0.1, batch_size=100)
+
+
+def _head(out):
+    return nn.Sequential(nn.Linear(256, 128), nn.BatchNorm1d(128), nn.ReLU(),
+                         nn.Linear(128, 128), nn.BatchNorm1d(128), nn.ReLU(), nn.Linear(128, out))
+
+
+class M2TRACK(nn.Module):
+    def __init__(self, config=None, **kwargs):
+        super().__init__()
+        cfg = dict(M2_KITTI)
+        cfg.update(kwargs)
+        self.config = config if config is not None else SimpleNamespace(**cfg)
+        c = self.config
+        self.box_aware = getattr(c, "box_aware", False)
+        self.use_motion_cls = getattr(c, "use_motion_cls", True)
+        self.use_second_stage = getattr(c, "use_second_stage", True)
+        self.use_prev_refinement = getattr(c, "use_prev_refinement", True)
+        bc = 9 if self.box_aware else 0
+        self.seg_pointnet = SegPointNet(input_channel=3 + 1 + 1 + bc, per_point_mlp1=[64, 64, 64, 128, 1024],
+                                        per_point_mlp2=[512, 256, 128, 128], output_size=2 + bc)
+        self.mini_pointnet = MiniPointNet(input_channel=3 + 1 + bc, per_point_mlp=[64, 128, 256, 512],
+                                          hidden_mlp=[512, 256], output_size=-1)
+        if self.use_second_stage:
+            self.mini_pointnet2 = MiniPointNet(input_channel=3 + bc, per_point_mlp=[64, 128, 256, 512],
+                                               hidden_mlp=[512, 256], output_size=-1)
+            self.box_mlp = _head(4)
+        if self.use_prev_refinement:
+            self.final_mlp = _head(4)
+        if self.use_motion_cls:
+            self.motion_state_mlp = _head(2)
+        self.motion_mlp = _head(4)
+
+    def forward(self, input_dict):
+        """points (B,N,5) [+ candidate_bc (B,N,9)] -> dict with estimation_boxes (B,4), seg_logits (B,2,N), ..."""
+        out = {}
+        x = input_dict["points"].transpose(1, 2)
+        if self.box_aware:
+            x = torch.cat([x, input_dict["candidate_bc"].transpose(1, 2)], dim=1)
+        N = x.shape[2]
+        seg_out = self.seg_pointnet(x)
+        seg_logits = seg_out[:, :2, :]
+        pred_cls = torch.argmax(seg_logits, dim=1, keepdim=True)                  # (B,1,N) hard mask, no gradient
+        mask_points = x[:, :4, :] * pred_cls
+        mask_xyz_t0, mask_xyz_t1 = mask_points[:, :3, :N // 2], mask_points[:, :3, N // 2:]
+        if self.box_aware:
+            pred_bc = seg_out[:, 2:, :]
+            mask_pred_bc = pred_bc * pred_cls
+            mask_points = torch.cat([mask_points, mask_pred_bc], dim=1)
+            out["pred_bc"] = pred_bc.transpose(1, 2)
+        point_feature = self.mini_pointnet(mask_points)
+        motion_pred = self.motion_mlp(point_feature)                               # (B,4)
+        if self.use_motion_cls:
+            logits = self.motion_state_mlp(point_feature)
+            motion_pred_masked = motion_pred * torch.argmax(logits, dim=1, keepdim=True)
+            out["motion_cls"] = logits
+        else:
+            motion_pred_masked = motion_pred
+        if self.use_prev_refinement:
+            prev_boxes = self.final_mlp(point_feature)
+            out["estimation_boxes_prev"] = prev_boxes[:, :4]
+        else:
+            prev_boxes = torch.zeros_like(motion_pred)
+        aux_box = box_utils.get_offset_box_tensor(prev_boxes, motion_pred_masked)  # first-stage box
+        if self.use_second_stage:
+            moved = box_utils.get_offset_points_tensor(mask_xyz_t0.transpose(1, 2), prev_boxes[:, :4],
+                                                       motion_pred_masked).transpose(1, 2)
+            merged = torch.cat([moved, mask_xyz_t1], dim=-1)                       # (B,3,N)
+            merged = box_utils.remove_transform_points_tensor(merged.transpose(1, 2), aux_box).transpose(1, 2)
+            if self.box_aware:
+                merged = torch.cat([merged, mask_pred_bc], dim=1)
+            offset = self.box_mlp(self.mini_pointnet2(merged))
+            out["estimation_boxes"] = box_utils.get_offset_box_tensor(aux_box, offset)
+        else:
+            out["estimation_boxes"] = aux_box
+        out.update({"seg_logits": seg_logits, "motion_pred": motion_pred, "aux_estimation_boxes": aux_box})
+        return out
+
+    def compute_loss(self, data, output):
+        c = self.config
+        total = 0.0
+        ld = {}
+        aux, motion_pred, seg_logits = output["aux_estimation_boxes"], output["motion_pred"], output["seg_logits"]
+        box_label, box_prev, motion_label = data["box_label"], data["box_label_prev"], data["motion_label"]
+        state = data["motion_state_label"]
+        center, angle = box_label[:, :3], torch.sin(box_label[:, 3])
+        center_prev, angle_prev = box_prev[:, :3], torch.sin(box_prev[:, 3])
+        center_motion, angle_motion = motion_label[:, :3], torch.sin(motion_label[:, 3])
+        cls_w = torch.tensor([0.5, 2.0], device=seg_logits.device, dtype=seg_logits.dtype)
+        loss_seg = F.cross_entropy(seg_logits, data["seg_label"], weight=cls_w)
+        if self.use_motion_cls:
+            loss_cls = F.cross_entropy(output["motion_cls"], state)
+            total = total + loss_cls * c.motion_cls_seg_weight
+            ld["loss_motion_cls"] = loss_cls
+            lc = F.smooth_l1_loss(motion_pred[:, :3], center_motion, reduction="none")
+            loss_center_motion = (state * lc.mean(dim=1)).sum() / (state.sum() + 1e-6)
+            la = F.smooth_l1_loss(torch.sin(motion_pred[:, 3]), angle_motion, reduction="none")
+            loss_angle_motion = (state * la).sum() / (state.sum() + 1e-6)
+        else:
+            loss_center_motion = F.smooth_l1_loss(motion_pred[:, :3], center_motion)
+            loss_angle_motion = F.smooth_l1_loss(torch.sin(motion_pred[:, 3]), angle_motion)
+        if self.use_second_stage:
+            est = output["estimation_boxes"]
+            ld["loss_center"] = F.smooth_l1_loss(est[:, :3], center)
+            ld["loss_angle"] = F.smooth_l1_loss(torch.sin(est[:, 3]), angle)
+            total = total + ld["loss_center"] * c.center_weight + ld["loss_angle"] * c.angle_weight
+        if self.use_prev_refinement:
+            est = output["estimation_boxes_prev"]
+            ld["loss_center_prev"] = F.smooth_l1_loss(est[:, :3], center_prev)
+            ld["loss_angle_prev"] = F.smooth_l1_loss(torch.sin(est[:, 3]), angle_prev)
+            total = total + ld["loss_center_prev"] * c.center_weight + ld["loss_angle_prev"] * c.angle_weight
+        loss_center_aux = F.smooth_l1_loss(aux[:, :3], center)
+        loss_angle_aux = F.smooth_l1_loss(torch.sin(aux[:, 3]), angle)
+        total = (total + loss_seg * c.seg_weight + loss_center_aux * c.center_weight + loss_angle_aux * c.angle_weight
+                 + loss_center_motion * c.center_weight + loss_angle_motion * c.angle_weight)
+        ld.update({"loss_seg": loss_seg, "loss_center_aux": loss_center_aux, "loss_center_motion": loss_center_motion,
+                   "loss_angle_aux": loss_angle_aux, "loss_angle_motion": loss_angle_motion})
+        if self.box_aware:
+            bc_label = torch.cat([data["prev_bc"], data["this_bc"]], dim=1)
+            ld["loss_bc"] = F.smooth_l1_loss(output["pred_bc"], bc_label)
+            total = total + ld["loss_bc"] * c.bc_weight
+        ld["loss_total"] = total
+        return ld
+
+    def training_loss(self, batch):
+        """forward + losses (m2track.py:233-264 minus logging); returns (loss, loss_dict)"""
+        ld = self.compute_loss(batch, self(batch))
+        return ld["loss_total"], ld
+
+    def configure_optimizers(self):
+        c = self.config
+        opt = torch.optim.Adam(self.parameters(), lr=c.lr, weight_decay=c.wd, betas=(0.5, 0.999), eps=1e-06)
+        sched = torch.optim.lr_scheduler.StepLR(opt, step_size=c.lr_decay_step, gamma=c.lr_decay_rate)
+        return {"optimizer": opt, "lr_scheduler": sched}

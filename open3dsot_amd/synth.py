@@ -100,6 +100,44 @@ def make_batch(first_index, batch_size, template_size=512, search_size=1024, see
     return {k: np.stack([it[k] for it in items], 0) for k in items[0]}
 
 
+def make_motion_batch(first_index, batch_size, point_sample_size=1024, seed0=4321):
+    """Synthetic M2-Track input (datasets/sampler.py::motion_processing :143-179): two consecutive
+    frames of one target, each resampled to `point_sample_size` points, stacked as
+    points (B,2N,5) = [xyz, time stamp (0 | 0.1), prior-box mask (previous frame only)], candidate_bc
+    (B,2N,9), seg_label (B,2N) int64, box_label / box_label_prev / motion_label (B,4),
+    motion_state_label (B,) int64, prev_bc / this_bc (B,N,9)."""
+    out = []
+    N = point_sample_size
+    for i in range(batch_size):
+        rng = np.random.default_rng(seed0 + int(first_index) + i)
+        wlh = np.array([1.6, 3.9, 1.5]) * rng.uniform(0.9, 1.1, 3)
+        moving = rng.uniform() < 0.6
+        motion = np.array([rng.uniform(0.2, 1.0) if moving else rng.uniform(0, 0.1), rng.uniform(-0.1, 0.1), 0.0,
+                           np.deg2rad(rng.uniform(-5, 5))])
+        prev_off = np.array([rng.uniform(-0.3, 0.3), rng.uniform(-0.3, 0.3), 0.0, np.deg2rad(rng.uniform(-3, 3))])
+        frames, labels, bcs = [], [], []
+        for t, pose in enumerate((prev_off, prev_off + motion)):
+            rot, ctr = _rotz(pose[3]), pose[:3]
+            n_obj, n_bg = int(rng.integers(20, 400)), int(rng.integers(100, 1500))
+            ext = wlh[[1, 0, 2]] * 1.25 + 4.0
+            pts = np.concatenate([_surface(rng, wlh, n_obj) @ rot.T + ctr, rng.uniform(-ext / 2, ext / 2, (n_bg, 3))], 0)
+            lab = np.concatenate([np.ones(n_obj), np.zeros(n_bg)])
+            p, sel = regularize(rng, pts, N)
+            frames.append(p)
+            labels.append(lab[sel])
+            bcs.append(boxcloud(p, ctr, rot, wlh))
+        stamp = np.concatenate([np.zeros(N), np.full(N, 0.1)])[:, None]
+        prior = np.concatenate([labels[0] * 0.8 + 0.1, np.full(N, 0.15)])[:, None]
+        out.append({
+            "points": np.concatenate([np.concatenate(frames, 0), stamp, prior], 1).astype(np.float32),
+            "candidate_bc": np.concatenate([bcs[0], np.zeros((N, 9))], 0).astype(np.float32),
+            "seg_label": np.concatenate(labels).astype(np.int64),
+            "box_label": (prev_off + motion).astype(np.float32), "box_label_prev": prev_off.astype(np.float32),
+            "motion_label": motion.astype(np.float32), "motion_state_label": np.int64(moving),
+            "prev_bc": bcs[0].astype(np.float32), "this_bc": bcs[1].astype(np.float32)})
+    return {k: np.stack([o[k] for o in out], 0) for k in out[0]}
+
+
 def to_torch(batch, device=None):
     import torch
     return {k: torch.from_numpy(v).to(device) if device is not None else torch.from_numpy(v)

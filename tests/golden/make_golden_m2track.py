@@ -1,0 +1,116 @@
+"""Generate tests/golden/ref_m2track.npz by running the REFERENCE'S OWN M2-Track code in this container.
+
+Run from the repo root, only where /root/reference exists:  python tests/golden/make_golden_m2track.py
+Reference code executed (read-only, from /root/reference): models/m2track.py (M2TRACK.__init__ / forward /
+compute_loss), models/backbone/pointnet.py (MiniPointNet, SegPointNet), datasets/points_utils.py (the
+tensor box helpers).  What is stubbed because the packages are absent from the sandbox: pytorch_lightning
+(`models.base_model.MotionBaseModel` -> a bare nn.Module holding `config`), torchmetrics, nuscenes,
+pyquaternion, shapely (imported at module level by files we load, never called on this path);
+`Tensor.cuda()` is the identity (m2track.py:171 hard-codes it).  Inputs: open3dsot_amd/synth.py.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+torch.Tensor.cuda = lambda self, *a, **k: self
+from oracle import ext_shim  # noqa: E402  (pointnet.py imports the SA modules, which import pointnet2_ops._ext)
+
+ext_shim.install()
+sys.path.insert(0, REF)     # for `pointnet2.utils...`
+
+
+def stub(name, **attrs):
+    m = types.ModuleType(name)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    return m
+
+
+def load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class _Dummy:
+    def __init__(self, *a, **k):
+        pass
+
+
+stub("nuscenes"); stub("nuscenes.utils"); stub("nuscenes.utils.geometry_utils")
+stub("pyquaternion", Quaternion=_Dummy)
+stub("datasets"); stub("datasets.data_classes", PointCloud=_Dummy, Box=_Dummy)
+stub("torchmetrics", Accuracy=_Dummy)
+stub("utils"); stub("utils.metrics", estimateOverlap=None, estimateAccuracy=None)
+stub("models"); stub("models.backbone")
+
+
+class MotionBaseModel(torch.nn.Module):
+    def __init__(self, config=None, **kwargs):
+        super().__init__()
+        self.config = config
+
+
+stub("models.base_model", MotionBaseModel=MotionBaseModel)
+points_utils = load("datasets.points_utils", "datasets/points_utils.py")
+sys.modules["datasets"].points_utils = points_utils
+ref_pointnet = load("models.backbone.pointnet", "models/backbone/pointnet.py")
+ref_m2 = load("models.m2track", "models/m2track.py")
+
+from open3dsot_amd import m2track as ours, synth  # noqa: E402
+
+
+def main():
+    from types import SimpleNamespace
+    import copy
+    g = torch.Generator().manual_seed(77)
+    torch.manual_seed(77)
+    cfg = SimpleNamespace(**ours.M2_KITTI)
+    net = ref_m2.M2TRACK(cfg)
+    for m in net.modules():      # non-trivial BatchNorm state
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.weight.data = torch.empty_like(m.weight).uniform_(0.5, 1.5, generator=g)
+            m.bias.data = torch.empty_like(m.bias).normal_(0, 0.1, generator=g)
+            m.running_mean.data = torch.empty_like(m.running_mean).normal_(0, 0.1, generator=g)
+            m.running_var.data = torch.empty_like(m.running_var).uniform_(0.5, 1.5, generator=g)
+    fix = {"sd." + k: v.detach().numpy().copy() for k, v in net.state_dict().items()}
+    batch = synth.make_motion_batch(11, 8, point_sample_size=128)
+    for k, v in batch.items():
+        fix["in." + k] = v
+    tb = synth.to_torch(batch)
+    for mode in ("train", "eval"):
+        n2 = copy.deepcopy(net).train(mode == "train")
+        out = n2({k: v.clone() for k, v in tb.items()})
+        for k, v in out.items():
+            fix["%s.out.%s" % (mode, k)] = v.detach().numpy()
+        ld = n2.compute_loss(tb, out)
+        for k, v in ld.items():
+            fix["%s.loss.%s" % (mode, k)] = np.float32(float(v))
+        if mode == "train":
+            for k, v in n2.state_dict().items():
+                if "running" in k:
+                    fix["train.sd_after." + k] = v.detach().numpy().copy()
+    # the tensor box helpers on their own
+    pts = torch.randn(2, 16, 3, generator=g)
+    ref_box = torch.randn(2, 4, generator=g)
+    off_box = torch.randn(2, 4, generator=g) * 0.3
+    fix["box.in.pts"], fix["box.in.ref"], fix["box.in.off"] = pts.numpy(), ref_box.numpy(), off_box.numpy()
+    fix["box.offset_points"] = points_utils.get_offset_points_tensor(pts.clone(), ref_box, off_box).numpy()
+    fix["box.offset_box"] = points_utils.get_offset_box_tensor(ref_box, off_box).numpy()
+    fix["box.remove_transform"] = points_utils.remove_transform_points_tensor(pts.clone(), ref_box).numpy()
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_m2track.npz")
+    np.savez_compressed(path, **fix)
+    print("wrote", path, "%.1f MB" % (os.path.getsize(path) / 1e6), len(fix), "arrays")
+
+
+if __name__ == "__main__":
+    main()
