@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=48, help="pairs per GPU (BASELINE config 2: 48)")
-    ap.add_argument("--model", default="BAT", choices=["BAT", "P2B"])
+    ap.add_argument("--model", default="BAT", choices=["BAT", "P2B", "M2TRACK"])
     ap.add_argument("--pool", type=int, default=4, help="distinct resident synthetic batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
@@ -122,7 +122,14 @@ def main():
         sa_modules.set_fused(False)
 
     torch.manual_seed(1234)
-    model = trackers.get_model(args.model)().to(dev).train()
+    if args.model == "M2TRACK":      # BASELINE config 4 (parity case; no pointnet2 operator on this path)
+        from open3dsot_amd import m2track
+        model = m2track.M2TRACK().to(dev).train()
+        make = lambda first, n: synth.make_motion_batch(first, n, 1024)
+        args.no_cpu_baseline = True
+    else:
+        model = trackers.get_model(args.model)().to(dev).train()
+        make = synth.make_batch
     sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     trainer = D.DataParallelStep(model, world=world, graph=not args.no_graph, graph_warmup=2)
 
@@ -130,7 +137,7 @@ def main():
     pool = []
     for s in range(args.pool):
         first, n = D.shard_indices(s, rank, world, args.batch)
-        pool.append(synth.to_torch(synth.make_batch(first, n), dev))
+        pool.append(synth.to_torch(make(first, n), dev))
     torch.cuda.synchronize()
 
     def barrier():
@@ -164,7 +171,7 @@ def main():
     roofline = None
     try:
         from open3dsot_amd import fused
-        if sa_modules.fused_enabled() and hasattr(fused, "profile_step"):
+        if sa_modules.fused_enabled() and hasattr(fused, "profile_step") and args.model != "M2TRACK":
             def eager_step():      # event-bracketed launches cannot be replayed from a graph
                 trainer._forward_backward(pool[0])
                 trainer.reduce_gradients(); trainer.optimizer.step()
@@ -182,6 +189,9 @@ def main():
             if t.get("workload_batch") == args.batch and t.get("model") == args.model:
                 roofline["traffic"] = t["gemm_family_hbm_bytes_per_launch"]
                 roofline["traffic_source"] = t["source"]
+    if roofline is None and args.model == "M2TRACK":
+        roofline = {"bound": "mfma", "achieved": None, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
+                    "traffic": None, "kernel": "rocBLAS GEMMs of the flat per-point stacks (not instrumented)"}
     if roofline is None:  # no instrumented kernels yet: whole-step algorithmic rate (labelled as such)
         flops = 3.0 * mlp_flops_per_pair(args.model) * args.batch
         ach = flops / (elapsed / args.steps) / 1e12
@@ -192,14 +202,17 @@ def main():
     if rank == 0:
         pairs = world * args.batch * args.steps
         line = {
-            "metric": "template/search pairs/sec (fwd+bwd), BAT KITTI-Car 512/1024 pts" if args.model == "BAT"
-                      else "template/search pairs/sec (fwd+bwd), P2B KITTI-Car 512/1024 pts",
+            "metric": {"BAT": "template/search pairs/sec (fwd+bwd), BAT KITTI-Car 512/1024 pts",
+                       "P2B": "template/search pairs/sec (fwd+bwd), P2B KITTI-Car 512/1024 pts",
+                       "M2TRACK": "frame pairs/sec (fwd+bwd), M2-Track KITTI 2x1024 pts"}[args.model],
             "value": round(pairs / elapsed, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic KITTI-Car-like pairs (open3dsot_amd/synth.py, seed 1234+index), random-init weights",
-            "config": {"workload": "%s_Car.yaml KITTI-Car, template 512 / search 1024 pts, batch %d per GPU, "
-                                   "fwd+bwd+Adam, fp32" % (args.model, args.batch),
+            "config": {"workload": ("M2_track_kitti.yaml, 2x1024 pts, batch %d per GPU, fwd+bwd+Adam, fp32" % args.batch)
+                       if args.model == "M2TRACK" else
+                       "%s_Car.yaml KITTI-Car, template 512 / search 1024 pts, batch %d per GPU, "
+                       "fwd+bwd+Adam, fp32" % (args.model, args.batch),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "fused_kernels": bool(sa_modules.fused_enabled()),
                        "hip_graph": trainer.graph is not None},
