@@ -171,14 +171,14 @@ def main():
     roofline = None
     try:
         from open3dsot_amd import fused
-        if sa_modules.fused_enabled() and hasattr(fused, "profile_step") and args.model != "M2TRACK":
+        if sa_modules.fused_enabled() and hasattr(fused, "profile_step"):
             def eager_step():      # event-bracketed launches cannot be replayed from a graph
                 trainer._forward_backward(pool[0])
                 trainer.reduce_gradients(); trainer.optimizer.step()
             roofline = fused.profile_step(eager_step, PEAK_FP32_MFMA_TFLOPS)
     except ImportError:
         roofline = None
-    if roofline is not None:
+    if roofline is not None and args.model != "M2TRACK":
         # the reference gathers first (layer 0 on npoint*nsample positions): rate in those terms as well
         ref_gflop = 3.0 * mlp_flops_per_pair(args.model) * args.batch / 1e9
         roofline["reference_formula_gflop_per_step"] = round(ref_gflop, 2)
@@ -189,9 +189,6 @@ def main():
             if t.get("workload_batch") == args.batch and t.get("model") == args.model:
                 roofline["traffic"] = t["gemm_family_hbm_bytes_per_launch"]
                 roofline["traffic_source"] = t["source"]
-    if roofline is None and args.model == "M2TRACK":
-        roofline = {"bound": "mfma", "achieved": None, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": None,
-                    "traffic": None, "kernel": "rocBLAS GEMMs of the flat per-point stacks (not instrumented)"}
     if roofline is None:  # no instrumented kernels yet: whole-step algorithmic rate (labelled as such)
         flops = 3.0 * mlp_flops_per_pair(args.model) * args.batch
         ach = flops / (elapsed / args.steps) / 1e12

@@ -279,6 +279,19 @@ int o3d_group_reduce_c(const float* dN, const float* Y0, long ldp, const float* 
                        const int32_t* ball_off, int B, int npoint, int ld, int C0, float* S, float* T,
                        void* stream);
 
+/* ---- ends of a per-point MLP chain on the flat (C, P = B*N) layout (csrc/pointwise.hip): the M2-Track
+ * stacks (models/backbone/pointnet.py:91-204) run on the GEMM kernels above; these finish a chain. */
+/* out = relu(Y*scale+shift) */
+int o3d_bn_relu_apply(const float* Y, const float* scale, const float* shift, int C, long P, float* out,
+                      void* stream);
+/* dN = g masked by the activation, part [P/128][2][C] = {sum dN, sum dN*(Y-mean)} */
+int o3d_act_bwd_partials(const float* g, const float* Y, const float* scale, const float* shift,
+                         const float* mean, int C, long P, float* dN, float* part, void* stream);
+/* AdaptiveMaxPool1d(1) of relu(bn(Y)) per cloud: out (B,C), argq (B,C) column of the first maximum,
+ * yarg raw Y there */
+int o3d_gmax_fwd(const float* Y, const float* scale, const float* shift, int B, int C, int N, float* out,
+                 int32_t* argq, float* yarg, void* stream);
+
 /* Weight gradient of an aligned inner layer (Cin, Cout multiples of 64; P multiple of 128), workgroup
  * tile matched to the layer: dW (Cout,Cin) = sum dY * f(X), dY = A1*dN + A2*Y + A3 from dN (dense) or,
  * when dN == NULL, from the packed pooled source pk of o3d_pool_bwd_partials; f(x) =

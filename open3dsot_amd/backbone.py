@@ -47,10 +47,29 @@ class Pointnet_Backbone(nn.Module):
         return l_xyz[-1], l_features[-1], idx0
 
 
-def _pointwise_chain(x, layers):
-    """(Conv1d k=1 -> BatchNorm1d -> ReLU)* on (B,C,N) as GEMMs on the flat (C, B*N) layout -- the
-    M2-Track pointwise stack is the grouped MLP with one ball per cloud.
-    `layers` = [(conv, bn, relu)]; returns (B,C',N).  Same statistics as BatchNorm1d on (B,C,N)."""
+def _pointwise_chain(x, layers, pool=False):
+    """(Conv1d k=1 -> BatchNorm1d -> ReLU)* on (B,C,N) -- the M2-Track pointwise stack is the grouped MLP
+    with one ball per cloud.  `layers` = [(conv, bn, relu)]; returns (B,C',N), or
+    the global max over N (B,C') with `pool`.  On the GPU it runs on the library's fp32-MFMA GEMM kernels
+    (open3dsot_amd/fused_pointwise.py); otherwise as GEMMs on the flat (C, B*N) layout with torch ops
+    (same statistics as BatchNorm1d on (B,C,N))."""
+    if x.is_cuda and _FUSED_PW["on"]:
+        from . import fused_pointwise
+        pairs = [(conv, bn) for conv, bn, _ in layers]
+        if fused_pointwise.supported(x, pairs):
+            return fused_pointwise.chain(x.contiguous(), pairs, "gmax" if pool else "act")
+    h = _pointwise_chain_torch(x, layers)
+    return h.amax(dim=2) if pool else h
+
+
+_FUSED_PW = {"on": True}
+
+
+def set_fused_pointwise(enabled):
+    _FUSED_PW["on"] = bool(enabled)
+
+
+def _pointwise_chain_torch(x, layers):
     B, C, N = x.shape
     h = x.permute(1, 0, 2).reshape(C, B * N)
     for conv, bn, act in layers:
@@ -90,7 +109,7 @@ class MiniPointNet(nn.Module):
         """x (B,C,N) -> (B, hidden_mlp[-1]) or (B, output_size)"""
         if nn_blocks._FLAT["on"]:
             mods = list(self.features)
-            x = _pointwise_chain(x, _triples(mods[:self._n_point])).amax(dim=2)
+            x = _pointwise_chain(x, _triples(mods[:self._n_point]), pool=True)
             for m in mods[self._n_point + 2:]:
                 x = m(x)
         else:
@@ -125,9 +144,8 @@ class SegPointNet(nn.Module):
         if nn_blocks._FLAT["on"]:
             first = [tuple(m) for m in self.seq_per_point]
             second = _pointwise_chain(x, first[:2])
-            x = _pointwise_chain(second, first[2:])
-            pooled = x.amax(dim=2, keepdim=True)
-            x = torch.cat([second, pooled.expand_as(x)], dim=1)
+            pooled = _pointwise_chain(second, first[2:], pool=True).unsqueeze(-1)      # (B,C1,1)
+            x = torch.cat([second, pooled.expand(-1, -1, second.shape[2])], dim=1)
             x = _pointwise_chain(x, [tuple(m) for m in self.seq_per_point2])
             if self.output_size > 0:
                 x = nn_blocks.pointwise_conv1d(self.fc, x.contiguous())

@@ -22,6 +22,7 @@ SOURCES = [
     ("mlp_wgrad.hip", []),
     ("group.hip", []),
     ("compact.hip", []),
+    ("pointwise.hip", []),
     ("capi_misc.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",

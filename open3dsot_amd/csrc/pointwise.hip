@@ -1,0 +1,119 @@
+// pointwise.hip -- ends of a per-point MLP chain on the flat (C, P) layout, P = B*N columns.
+//
+// The M2-Track stacks (models/backbone/pointnet.py:91-204: Conv1d 1x1 -> BatchNorm1d -> ReLU, global
+// max-pool) are the grouped MLP with ONE ball per cloud, so they run on the GEMM kernels of
+// mlp_direct.hip / mlp_wgrad.hip unchanged (BN+ReLU applied by the consumer on load).  What is left is
+// the two ways a chain ends:
+//   * materialised activation  out = relu(Y*scale+shift)            (bn_relu_apply / act_bwd_partials)
+//   * global max over the N points of a cloud (AdaptiveMaxPool1d(1)) (gmax_fwd; backward = the pooled
+//     kernels of mlp.hip / compact.hip with one ball per cloud)
+#include "o3d_common.hpp"
+
+namespace {
+
+__global__ __launch_bounds__(256) void bn_relu_apply_kernel(const float* __restrict__ Y,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ shift, long P,
+                                                            float* __restrict__ out) {
+    const int c = blockIdx.y;
+    const long p = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (p >= P) return;
+    const float sc = scale[c], sf = shift[c];
+    const float4 y = *reinterpret_cast<const float4*>(&Y[(long)c * P + p]);
+    float4 o;
+    o.x = fmaxf(fmaf(y.x, sc, sf), 0.f); o.y = fmaxf(fmaf(y.y, sc, sf), 0.f);
+    o.z = fmaxf(fmaf(y.z, sc, sf), 0.f); o.w = fmaxf(fmaf(y.w, sc, sf), 0.f);
+    *reinterpret_cast<float4*>(&out[(long)c * P + p]) = o;
+}
+
+// dN = g where the activation is positive, plus the BatchNorm-backward partials of that layer per
+// 128-column tile: part[tile][0][c] = sum dN, part[tile][1][c] = sum dN*(Y-mean).
+// block = 8 channels x 32 lanes (float4 each).
+__global__ __launch_bounds__(256) void act_bwd_partials_kernel(const float* __restrict__ g,
+                                                               const float* __restrict__ Y,
+                                                               const float* __restrict__ scale,
+                                                               const float* __restrict__ shift,
+                                                               const float* __restrict__ mean, int C, long P,
+                                                               float* __restrict__ dN, float* __restrict__ part) {
+    const int lane = threadIdx.x & 31, c = blockIdx.y * 8 + (threadIdx.x >> 5);
+    const long tile = blockIdx.x, p = tile * 128 + 4 * lane;
+    const bool live = c < C;
+    const int cc = live ? c : C - 1;
+    const float sc = scale[cc], sf = shift[cc], mu = mean[cc];
+    const float4 y = *reinterpret_cast<const float4*>(&Y[(long)cc * P + p]);
+    float4 v = *reinterpret_cast<const float4*>(&g[(long)cc * P + p]);
+    v.x = fmaf(y.x, sc, sf) > 0.f ? v.x : 0.f; v.y = fmaf(y.y, sc, sf) > 0.f ? v.y : 0.f;
+    v.z = fmaf(y.z, sc, sf) > 0.f ? v.z : 0.f; v.w = fmaf(y.w, sc, sf) > 0.f ? v.w : 0.f;
+    if (live) *reinterpret_cast<float4*>(&dN[(long)c * P + p]) = v;
+    float s = (v.x + v.y) + (v.z + v.w);
+    float q = v.x * (y.x - mu) + v.y * (y.y - mu) + v.z * (y.z - mu) + v.w * (y.w - mu);
+#pragma unroll
+    for (int m = 1; m < 32; m <<= 1) { s += __shfl_xor(s, m, 64); q += __shfl_xor(q, m, 64); }
+    if (live && lane == 0) {
+        part[(tile * 2 + 0) * C + c] = s;
+        part[(tile * 2 + 1) * C + c] = q;
+    }
+}
+
+// out[b,c] = max over the cloud's N columns of relu(Y*scale+shift); argq = column of the (first) maximum,
+// yarg = raw Y there.  block = 4 channels x 64 lanes.
+__global__ __launch_bounds__(256) void gmax_fwd_kernel(const float* __restrict__ Y,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int C, int N, long P,
+                                                       float* __restrict__ out, int32_t* __restrict__ argq,
+                                                       float* __restrict__ yarg) {
+    const int lane = threadIdx.x & 63, b = blockIdx.x;
+    int c = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const bool live = c < C;
+    if (!live) c = C - 1;
+    const float sc = scale[c], sf = shift[c];
+    const float* y = Y + (long)c * P + (long)b * N;
+    float best = -INFINITY, yb = 0.f;
+    int bq = 0x7fffffff;
+    for (int i = 4 * lane; i < N; i += 256) {
+        const float4 v4 = *reinterpret_cast<const float4*>(&y[i]);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float n = fmaf(v[t], sc, sf);
+            if (n > best) { best = n; bq = i + t; yb = v[t]; }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64), oy = __shfl_xor(yb, off, 64);
+        const int oq = __shfl_xor(bq, off, 64);
+        if (ob > best || (ob == best && oq < bq)) { best = ob; bq = oq; yb = oy; }
+    }
+    if (live && lane == 0) {
+        const long o = (long)b * C + c;
+        out[o] = fmaxf(best, 0.f);
+        if (argq) { argq[o] = b * N + bq; yarg[o] = yb; }
+    }
+}
+
+}  // namespace
+
+extern "C" int o3d_bn_relu_apply(const float* Y, const float* scale, const float* shift, int C, long P, float* out,
+                                 void* stream) {
+    if (!Y || !scale || !shift || !out || C <= 0 || P <= 0 || P % 4 != 0) return O3D_EINVAL;
+    hipLaunchKernelGGL(bn_relu_apply_kernel, dim3(o3d_cdiv(P / 4, 256), C), dim3(256), 0, o3d_stream(stream), Y, scale,
+                       shift, P, out);
+    return o3d_launch_status();
+}
+
+extern "C" int o3d_act_bwd_partials(const float* g, const float* Y, const float* scale, const float* shift,
+                                    const float* mean, int C, long P, float* dN, float* part, void* stream) {
+    if (!g || !Y || !scale || !shift || !mean || !dN || !part || C <= 0 || P <= 0 || P % 128 != 0) return O3D_EINVAL;
+    hipLaunchKernelGGL(act_bwd_partials_kernel, dim3((unsigned)(P / 128), o3d_cdiv(C, 8)), dim3(256), 0,
+                       o3d_stream(stream), g, Y, scale, shift, mean, C, P, dN, part);
+    return o3d_launch_status();
+}
+
+extern "C" int o3d_gmax_fwd(const float* Y, const float* scale, const float* shift, int B, int C, int N, float* out,
+                            int32_t* argq, float* yarg, void* stream) {
+    if (!Y || !scale || !shift || !out || B <= 0 || C <= 0 || N <= 0 || N % 4 != 0 || (argq && !yarg)) return O3D_EINVAL;
+    hipLaunchKernelGGL(gmax_fwd_kernel, dim3(B, o3d_cdiv(C, 4)), dim3(256), 0, o3d_stream(stream), Y, scale, shift, C, N,
+                       (long)B * N, out, argq, yarg);
+    return o3d_launch_status();
+}

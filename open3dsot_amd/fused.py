@@ -85,7 +85,8 @@ def _call(name, flops, fn, *args):
     capi.check(rc, name)
 
 
-GEMM_KERNELS = ("conv_fwd", "conv_fwd_points", "conv_dgrad", "conv_dgrad_points", "conv_wgrad", "conv_wgrad_points")
+GEMM_KERNELS = ("conv_fwd", "conv_fwd_points", "conv_dgrad", "conv_dgrad_points", "conv_wgrad", "conv_wgrad_points",
+                "pw_conv_fwd", "pw_conv_dgrad", "pw_conv_wgrad")
 
 
 def profile_step(step_fn, peak_tflops, repeats=3):

@@ -1,0 +1,198 @@
+"""Per-point MLP chains (Conv1d 1x1 -> BatchNorm1d -> ReLU)* on the library's GEMM kernels.
+
+The M2-Track stacks (models/backbone/pointnet.py:91-204) are the grouped MLP with ONE ball per cloud
+(SURVEY.md section 8f-1): no gather, flat (C, P = B*N) activations, BatchNorm+ReLU applied by the
+consumer kernel on load, backward folded into per-channel constants exactly as in open3dsot_amd/fused.py.
+A chain ends either in its materialised activation ("act") or in the global max over the N points of
+each cloud ("gmax", AdaptiveMaxPool1d(1)).  Parameters stay in the caller's nn.Conv1d / nn.BatchNorm1d
+modules.  A Conv1d bias in front of a training-mode BatchNorm cancels in the output and has zero
+gradient; it only shifts the running mean, which is updated accordingly.
+"""
+import ctypes
+
+import torch
+
+from . import capi
+from .fused import _call, _const_vec, _ptr, _stream, TILE
+
+_vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
+capi.register("o3d_bn_relu_apply", [_vp, _vp, _vp, _i, _l, _vp, _vp])
+capi.register("o3d_act_bwd_partials", [_vp, _vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _vp])
+capi.register("o3d_gmax_fwd", [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp])
+
+
+class _Cfg:
+    __slots__ = ("mode", "training", "bns")
+
+
+def supported(x, layers):
+    B, C, N = x.shape
+    return x.is_cuda and N % TILE == 0 and all(c.kernel_size == (1,) and c.stride == (1,) and c.padding == (0,) and
+                                               c.groups == 1 for c, _ in layers)
+
+
+class FusedPointwiseChain(torch.autograd.Function):
+    """(x (B,Cin,N), cfg, W0,b0,g0,beta0, W1,...) -> act (B,C_L,N) | pooled (B,C_L)"""
+
+    @staticmethod
+    def forward(ctx, x, cfg, *params):
+        lib = capi.load()
+        L = len(params) // 4
+        Ws = [params[4 * l].detach()[:, :, 0].contiguous() for l in range(L)]
+        biases = [params[4 * l + 1] for l in range(L)]
+        gammas = [params[4 * l + 2].detach().contiguous() for l in range(L)]
+        betas = [params[4 * l + 3].detach().contiguous() for l in range(L)]
+        B, Cin0, N = x.shape
+        P = B * N
+        dev, f32 = x.device, torch.float32
+        st = _stream()
+        X0 = x.detach().permute(1, 0, 2).reshape(Cin0, P).contiguous()
+        ntiles = P // TILE
+        Ys, means, invstds, scales, shifts = [], [], [], [], []
+        for l in range(L):
+            Cout, Cin = Ws[l].shape
+            bn = cfg.bns[l]
+            Y = torch.empty((Cout, P), device=dev, dtype=f32)
+            part = torch.empty((ntiles, 2, Cout), device=dev, dtype=f32) if cfg.training else None
+            stat_c = bn.running_mean if cfg.training else None
+            src = X0 if l == 0 else Ys[-1]
+            _call("pw_conv_fwd", 2.0 * Cin * Cout * P, lib.o3d_mlp_conv_fwd, src.data_ptr(), Ws[l].data_ptr(),
+                  None if l == 0 else scales[-1].data_ptr(), None if l == 0 else shifts[-1].data_ptr(), 1, Cin, Cout, P,
+                  Y.data_ptr(), _ptr(part), _ptr(stat_c), st)
+            vec = torch.empty((4, Cout), device=dev, dtype=f32)
+            b = biases[l].detach() if biases[l] is not None else None
+            if cfg.training:
+                fold = torch.empty((64, Cout), device=dev, dtype=f32)
+                _call("bn_finalize", 0.0, lib.o3d_bn_finalize, part.data_ptr(), ntiles, Cout, float(P), stat_c.data_ptr(),
+                      gammas[l].data_ptr(), betas[l].data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+                      float(bn.momentum), float(bn.eps), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
+                      vec[3].data_ptr(), fold.data_ptr(), st)
+                if b is not None:       # statistics were taken without the bias: mean(Y + b) = mean(Y) + b
+                    bn.running_mean.add_(b, alpha=float(bn.momentum))
+            else:
+                mu = bn.running_mean - b if b is not None else bn.running_mean
+                vec[0].copy_(mu)
+                vec[1].copy_(torch.rsqrt(bn.running_var + bn.eps))
+                vec[2].copy_(gammas[l] * vec[1])
+                vec[3].copy_(betas[l] - vec[0] * vec[2])
+            Ys.append(Y)
+            means.append(vec[0]); invstds.append(vec[1]); scales.append(vec[2]); shifts.append(vec[3])
+        if cfg.training:
+            torch._foreach_add_([bn.num_batches_tracked for bn in cfg.bns], 1)
+        Cl = Ws[-1].shape[0]
+        need_bwd = any(ctx.needs_input_grad)
+        argq = yarg = None
+        if cfg.mode == "act":
+            act = torch.empty((Cl, P), device=dev, dtype=f32)
+            _call("pw_apply", 0.0, lib.o3d_bn_relu_apply, Ys[-1].data_ptr(), scales[-1].data_ptr(), shifts[-1].data_ptr(),
+                  Cl, P, act.data_ptr(), st)
+            out = act.view(Cl, B, N).permute(1, 0, 2)
+        else:
+            out = torch.empty((B, Cl), device=dev, dtype=f32)
+            argq = torch.empty((B, Cl), device=dev, dtype=torch.int32) if need_bwd else None
+            yarg = torch.empty((B, Cl), device=dev, dtype=f32) if need_bwd else None
+            _call("pw_gmax", 0.0, lib.o3d_gmax_fwd, Ys[-1].data_ptr(), scales[-1].data_ptr(), shifts[-1].data_ptr(), B, Cl,
+                  N, out.data_ptr(), _ptr(argq), _ptr(yarg), st)
+        if need_bwd:
+            ctx.cfg = cfg
+            ctx.dims = (B, N, L)
+            ctx.has_bias = [b is not None for b in biases]
+            ctx.saved = (X0, Ws, gammas, Ys, means, invstds, scales, shifts, out.detach() if cfg.mode != "act" else None,
+                         argq, yarg)
+        return out
+
+    @staticmethod
+    def backward(ctx, dOut):
+        lib = capi.load()
+        cfg = ctx.cfg
+        B, N, L = ctx.dims
+        X0, Ws, gammas, Ys, means, invstds, scales, shifts, out, argq, yarg = ctx.saved
+        P = B * N
+        dev, f32 = dOut.device, torch.float32
+        st = _stream()
+        ntiles = P // TILE
+        Cl = Ws[-1].shape[0]
+        dN = torch.empty((Cl, P), device=dev, dtype=f32)
+        if cfg.mode == "act":
+            g = dOut.permute(1, 0, 2).reshape(Cl, P).contiguous()
+            part = torch.empty((ntiles, 2, Cl), device=dev, dtype=f32)
+            _call("pw_act_bwd", 0.0, lib.o3d_act_bwd_partials, g.data_ptr(), Ys[-1].data_ptr(), scales[-1].data_ptr(),
+                  shifts[-1].data_ptr(), means[-1].data_ptr(), Cl, P, dN.data_ptr(), part.data_ptr(), st)
+            nparts = ntiles
+        else:
+            dOut = dOut.contiguous()
+            part = torch.empty((B, 2, Cl), device=dev, dtype=f32)
+            _call("pool_bwd_partials", 0.0, lib.o3d_pool_bwd_partials, dOut.data_ptr(), out.data_ptr(), yarg.data_ptr(),
+                  means[-1].data_ptr(), B, Cl, 1, part.data_ptr(), None, None, st)
+            meta = _meta_full(dev, P, B)       # every column is live: one "ball" of N columns per cloud
+            _call("pool_bwd_dense", 0.0, lib.o3d_pool_bwd_dense_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), B, Cl,
+                  1, meta.data_ptr(), P, dN.data_ptr(), st)
+            nparts = B
+        grads = [None] * (4 * L)
+        dx = None
+        for l in range(L - 1, -1, -1):
+            Cout, Cin = Ws[l].shape
+            coef = torch.empty((5, Cout), device=dev, dtype=f32)
+            fold = torch.empty((64, Cout), device=dev, dtype=f32)
+            _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize, part.data_ptr(), nparts, Cout, float(P),
+                  gammas[l].data_ptr(), means[l].data_ptr(), invstds[l].data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                  coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr(), fold.data_ptr(), st)
+            if not cfg.training:
+                coef[3].zero_()
+                coef[4].zero_()
+            grads[4 * l + 2], grads[4 * l + 3] = coef[0], coef[1]
+            if ctx.has_bias[l]:      # dL/db = sum dY: zero behind a training-mode BatchNorm, A1 * sum dN in eval mode
+                grads[4 * l + 1] = torch.zeros_like(coef[0]) if cfg.training else coef[2] * coef[1]
+            A = (coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr())
+            dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
+            flops = 2.0 * Cin * Cout * P
+            if l >= 1 and Cin % 64 == 0 and Cout % 64 == 0:
+                wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, P),), device=dev, dtype=f32)
+                _call("pw_conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2, dN.data_ptr(), None, 4, Ys[l].data_ptr(), A[0], A[1],
+                      A[2], Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), 1, Cin, Cout, P,
+                      wpart.data_ptr(), dW.data_ptr(), st)
+            else:
+                tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
+                nsl = max(1, min(P // 32 // 4, 768 // tiles))
+                wpart = torch.empty((nsl + 16, Cout, Cin), device=dev, dtype=f32)
+                xs = (X0.data_ptr(), None, None) if l == 0 else \
+                     (Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr())
+                _call("pw_conv_wgrad", flops, lib.o3d_mlp_conv_wgrad, dN.data_ptr(), None, None, None, 4, Ys[l].data_ptr(),
+                      A[0], A[1], A[2], xs[0], xs[1], xs[2], None, None, None, None, 0, 0, 0, 1.0, 1, Cin, Cout, P, nsl,
+                      wpart.data_ptr(), dW.data_ptr(), st)
+            grads[4 * l] = dW.unsqueeze(-1)
+            if l >= 1:
+                Wt = Ws[l].t().contiguous()
+                dNp = torch.empty((Cin, P), device=dev, dtype=f32)
+                part = torch.empty((ntiles, 2, Cin), device=dev, dtype=f32)
+                _call("pw_conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_wt, dN.data_ptr(), None, None, None, 4,
+                      Ys[l].data_ptr(), A[0], A[1], A[2], Ws[l].data_ptr(), Wt.data_ptr(), None, 1, Cin, Cout, P,
+                      Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(),
+                      dNp.data_ptr(), part.data_ptr(), st)
+                dN, nparts = dNp, ntiles
+            elif ctx.needs_input_grad[0]:
+                dX = torch.empty((Cin, B, N), device=dev, dtype=f32)
+                _call("pw_conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_plain, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1],
+                      A[2], Ws[0].data_ptr(), 1, Cin, Cout, P, dX.data_ptr(), st)
+                dx = dX.permute(1, 0, 2)
+        return (dx, None, *grads)
+
+
+_META = {}
+
+
+def _meta_full(dev, P, B):
+    key = (str(dev), P, B)
+    if key not in _META:
+        _META[key] = torch.tensor([P, P, B, 0], dtype=torch.int32, device=dev)
+    return _META[key]
+
+
+def chain(x, layers, mode):
+    """layers = [(conv1d, batchnorm1d)]; mode "act" -> (B,C_L,N), "gmax" -> (B,C_L)"""
+    cfg = _Cfg()
+    cfg.mode, cfg.training, cfg.bns = mode, bool(layers[0][1].training), [bn for _, bn in layers]
+    params = []
+    for conv, bn in layers:
+        params += [conv.weight, conv.bias, bn.weight, bn.bias]
+    return FusedPointwiseChain.apply(x, cfg, *params)

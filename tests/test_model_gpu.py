@@ -220,6 +220,56 @@ def test_m2track_gpu_matches_cpu_mirror():
     lc, ldc = cpu.training_loss(synth.to_torch(host))
     lg, ldg = gpu.training_loss(synth.to_torch(host, torch.device("cuda", 0)))
     lg.backward()
+    lc.backward()
     for k in ldc:
         assert abs(float(ldg[k]) - float(ldc[k])) <= 2e-3 * (1 + abs(float(ldc[k]))), (k, float(ldg[k]), float(ldc[k]))
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in gpu.parameters())
+    # gradients of the fused per-point chains vs the torch CPU mirror: direction and norm of the whole vector
+    a = torch.cat([p.grad.detach().cpu().flatten() for p in gpu.parameters()]).double()
+    b = torch.cat([p.grad.detach().flatten() for p in cpu.parameters()]).double()
+    cos = float(a @ b / (a.norm() * b.norm()))
+    assert cos > 0.995 and abs(float(a.norm() / b.norm()) - 1) < 0.03, (cos, float(a.norm() / b.norm()))
+    for (k, v), (_, w) in zip(gpu.state_dict().items(), cpu.state_dict().items()):
+        if "running" in k:
+            assert rel(v, w) < 1e-3, k
+
+
+@pytest.mark.parametrize("mode", ["act", "gmax"])
+@pytest.mark.parametrize("train", [True, False])
+def test_fused_pointwise_chain_vs_fp64(mode, train):
+    """open3dsot_amd/fused_pointwise.py against an fp64 torch evaluation of Conv1d -> BatchNorm1d -> ReLU (x3)
+    [-> global max]: outputs, parameter / input gradients, running statistics"""
+    from open3dsot_amd import fused_pointwise
+    torch.manual_seed(9)
+    B, N, widths = 4, 256, [14, 64, 128, 64]
+    convs = [torch.nn.Conv1d(a, b, 1).cuda() for a, b in zip(widths[:-1], widths[1:])]
+    bns = [torch.nn.BatchNorm1d(b).cuda().train(train) for b in widths[1:]]
+    with torch.no_grad():
+        for bn in bns:
+            bn.weight.uniform_(0.5, 1.5); bn.bias.normal_(0, 0.2); bn.running_mean.normal_(0, 0.2); bn.running_var.uniform_(0.5, 1.5)
+    x = torch.randn(B, widths[0], N, device="cuda", requires_grad=True)
+    x64 = x.detach().double().requires_grad_(True)
+    h = x64
+    p64 = []
+    rms = []
+    for conv, bn in zip(convs, bns):
+        w, b_, g_, be = (t.detach().double().requires_grad_(True) for t in (conv.weight, conv.bias, bn.weight, bn.bias))
+        p64 += [w, b_, g_, be]
+        rm, rv = bn.running_mean.double().clone(), bn.running_var.double().clone()
+        rms += [rm, rv]
+        h = torch.relu(torch.nn.functional.batch_norm(torch.nn.functional.conv1d(h, w, b_), rm, rv, g_, be, train, 0.1, 1e-5))
+    ref = h.amax(dim=2) if mode == "gmax" else h
+    out = fused_pointwise.chain(x, list(zip(convs, bns)), mode)
+    assert rel(out, ref) < 2e-5
+    go = torch.randn_like(out)
+    out.backward(go)
+    ref.backward(go.double())
+    got = [t for conv, bn in zip(convs, bns) for t in (conv.weight, conv.bias, bn.weight, bn.bias)]
+    gmax = max(float(t.grad.abs().max()) for t in p64)
+    for a, b in zip(got, p64):
+        err = float((a.grad.detach().cpu().double() - b.grad.cpu()).norm() / (b.grad.norm().cpu() + 1e-3 * gmax * b.numel() ** 0.5))
+        assert err < 2e-3, err
+    assert float((x.grad.double() - x64.grad).norm() / x64.grad.norm()) < 2e-3
+    if train:
+        for bn, rm, rv in zip(bns, rms[0::2], rms[1::2]):
+            assert rel(bn.running_mean, rm) < 1e-5 and rel(bn.running_var, rv) < 1e-5
