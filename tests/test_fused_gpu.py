@@ -199,6 +199,31 @@ def test_fused_sa_matches_composed(kind, train):
                 assert int(b1) == 1, n1
 
 
+def test_slotwise_fallback_path_matches_fp64():
+    """the slot-per-neighbour layout (used when the compact layout does not apply: nsample > 64 or more than
+    65536 balls) stays correct: same SA block, compact layout switched off"""
+    import copy
+    from open3dsot_amd import fused
+    grouper, mlp, xyz, new_xyz, feats = make_case("sa2", train=True)
+    mlp_ref = copy.deepcopy(mlp)
+    f = feats.clone().requires_grad_(True)
+    idx = grouper.query(xyz, new_xyz)
+    ref64, l64, b64 = shadow64(mlp_ref, xyz, new_xyz, feats, idx, True)
+    fused.set_compact(False)
+    try:
+        out = fused.sa_group_mlp_pool(grouper, mlp, xyz, new_xyz, f)
+    finally:
+        fused.set_compact(True)
+    assert out.grad_fn.name().startswith("FusedGroupedMLPBackward")
+    assert rel(out, ref64) < 2e-5
+    go = torch.randn(out.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    out.backward(go)
+    ref64.backward(go.double())
+    for n1, p1 in mlp.named_parameters():
+        assert_grad_close(p1.grad, l64[n1].grad, n1)
+    assert_grad_close(f.grad, l64["feats"].grad, "feats")
+
+
 @pytest.mark.parametrize("train", [True, False])
 def test_fused_xcorr_group_mlp_pool(train):
     from open3dsot_amd import fused, nn_blocks, ops
