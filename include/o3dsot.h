@@ -223,38 +223,47 @@ int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const float* out, con
 /* ---- compact (distinct-neighbour) layout, csrc/compact.hip ------------------------------------------
  * ball_query pads a ball with copies of its first hit (pointnet2_utils.py:268); copies have identical
  * values at every layer, so each ball keeps its cnt distinct entries as columns of flat (C, ldp)
- * matrices (ldp = B*npoint*nsample = worst case) and the first hit carries the weight 1+nsample-cnt.
- * meta (4 device ints) = {live columns rounded up to 256, live columns, B*npoint, 0}; kernels skip
- * tiles beyond meta[0] -- no host synchronisation. */
+ * matrices (ldp = worst-case column count) and the first hit carries the weight 1+nsample-cnt.
+ * meta: 4 device ints per SEGMENT = {live columns rounded up to 256, live columns, balls, 0}; kernels
+ * skip tiles beyond the live range -- no host synchronisation.
+ * Segments: one fused call can carry two independent sets of clouds through the SAME weights with
+ * SEPARATE BatchNorm statistics (template and search branch of the backbone, models/bat.py:89-90).
+ * Segment 1's columns start at `start1` (a multiple of 256, = worst-case size of segment 0; 0 means one
+ * segment), its point columns after segment 0's, its balls after segment 0's, and every per-channel
+ * constant array holds segment 1's values right after segment 0's. */
 
-/* idx (B,npoint,ns) -> ball_cnt (B*npoint), ball_off (B*npoint+1), per column gp = b*ld + point,
- * cball = ball id (B*npoint for padding columns), cw = weight; ns a power of two <= 64. */
-int o3d_compact_build(const int32_t* idx, int B, int npoint, int ns, int ld, int32_t* ball_cnt,
-                      int32_t* ball_off, int32_t* gp, int32_t* cball, float* cw, int32_t* meta, void* stream);
+/* One segment: idx (B,npoint,ns) -> ball_cnt (B*npoint), ball_off (B*npoint+1, absolute columns), per
+ * column gp = pt_base + b*ld + point, cball = ball_base + ball (dummy_ball for padding columns), cw;
+ * written at [col_base, col_base+live).  ns a power of two <= 64, B*npoint <= 65536. */
+int o3d_compact_build(const int32_t* idx, int B, int npoint, int ns, int ld, int col_base, int pt_base,
+                      int ball_base, int dummy_ball, int32_t* ball_cnt, int32_t* ball_off, int32_t* gp,
+                      int32_t* cball, float* cw, int32_t* meta, void* stream);
 
 /* Y0[c,q] = Z[c,gp[q]] - W0[c,0:3].centers[cball[q]] (QueryAndGroup + layer 0 after the per-point GEMM
- * Z = W0.[xyz;feats], pointnet2_utils.py:299-339); centers ((B*npoint+1),3) or NULL; weighted
- * statistics partials part [ldp/256][2][C0] or NULL. */
+ * Z = W0.[xyz;feats], pointnet2_utils.py:299-339); centers (balls+1, 3) or NULL; weighted statistics
+ * partials part [ldp/256][2][C0] or NULL (stat_c: C0 floats per segment). */
 int o3d_group_expand_c(const float* Z, long ldz, const int32_t* gp, const int32_t* cball, const float* cw,
-                       const float* centers, const float* W0, int ldw, int C0, const int32_t* meta, long ldp,
-                       float* Y0, float* part, const float* stat_c, void* stream);
+                       const float* centers, const float* W0, int ldw, int C0, const int32_t* meta, long start1,
+                       long ldp, float* Y0, float* part, const float* stat_c, void* stream);
 
 /* Inner layers on the compact layout: forward (BN+ReLU of the producer on load, weighted statistics),
- * data gradient (dY = A1*dN + w*(A2*Y + A3), ReLU mask, statistics; Wt = W^T), weight gradient. */
-/* tile = columns per wave tile = columns per statistics partial row: o3d_direct_tile(ldp, M, 1) (64 or 128) */
+ * data gradient (dY = A1*dN + w*(A2*Y + A3), ReLU mask, statistics; Wt = W^T), weight gradient.
+ * tile = columns per wave tile = columns per statistics partial row: o3d_direct_tile(ldp, M, 1). */
 int o3d_direct_tile(long P, int M, int compact);
 int o3d_mlp_conv_fwd_c(const float* X, const float* W, const float* in_scale, const float* in_shift, int Cin,
-                       int Cout, long ldp, const float* w, const int32_t* meta, int tile, float* Y, float* part,
-                       const float* stat_c, void* stream);
+                       int Cout, long ldp, const float* w, const int32_t* meta, long start1, int tile, float* Y,
+                       float* part, const float* stat_c, void* stream);
 int o3d_mlp_conv_dgrad_c(const float* dN, const float* Y, const float* A1, const float* A2, const float* A3,
                          const float* Wt, int Cin, int Cout, long ldp, const float* w, const int32_t* meta,
-                         int tile, const float* Yprev, const float* scale_p, const float* shift_p, const float* mean_p,
-                         float* dNprev, float* part, void* stream);
+                         long start1, int tile, const float* Yprev, const float* scale_p, const float* shift_p,
+                         const float* mean_p, float* dNprev, float* part, void* stream);
 int o3d_mlp_conv_wgrad2_c(const float* dN, const float* Y, const float* A1, const float* A2, const float* A3,
                           const float* X, const float* in_scale, const float* in_shift, int Cin, int Cout,
-                          long ldp, const float* w, const int32_t* meta, float* scratch, float* dW, void* stream);
+                          long ldp, const float* w, const int32_t* meta, long start1, float* scratch, float* dW,
+                          void* stream);
 
-/* BatchNorm finalize kernels reading only the live partial rows (meta[0] / tile). */
+/* BatchNorm finalize kernels reading only the live partial rows (meta[0] / tile); per segment: pass the
+ * segment's first partial row and its meta block. */
 int o3d_bn_finalize_c(const float* part, int nparts, int C, double count, const float* stat_c,
                       const float* gamma, const float* beta, float* running_mean, float* running_var,
                       float momentum, float eps, float* mean, float* invstd, float* scale, float* shift,
@@ -264,20 +273,24 @@ int o3d_bn_bwd_finalize_c(const float* part, int nparts, int C, double count, co
                           float* A2, float* A3, const int32_t* meta, int tile, void* stream);
 
 /* out[b,c,j] = max over the ball's columns of relu(Y*scale+shift) (max_pool2d over nsample,
- * pointnet2_modules.py:69-73); argq = column of the maximum, yarg = raw Y there. */
+ * pointnet2_modules.py:69-73); argq = column of the maximum, yarg = raw Y there.  Pooled tensors hold
+ * one (B,C,npoint_s) block per segment, segment 1's after segment 0's (npoint1 = 0: one segment). */
 int o3d_pool_fwd_c(const float* Y, long ldp, const float* scale, const float* shift, const int32_t* ball_off,
-                   int B, int C, int npoint, float* out, int32_t* argq, float* yarg, void* stream);
+                   const int32_t* ball_cnt, int B, int C, int npoint0, int npoint1, float* out, int32_t* argq,
+                   float* yarg, void* stream);
 
-/* Dense class-sum gradient of the pooled layer: D (C,ldp) zero on the live columns, D[c,argq] = dOut. */
-int o3d_pool_bwd_dense_c(const float* dOut, const float* out, const int32_t* argq, int B, int C, int npoint,
-                         const int32_t* meta, long ldp, float* D, void* stream);
+/* Backward of the pool: D (C,ldp) = dense class-sum gradient (zero on live columns, D[c,argq] = dOut where
+ * out > 0) and the BatchNorm-backward partials part [nseg][2][C] of the pooled layer. */
+int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t* argq, const float* yarg,
+                   const float* mean, int B, int C, int npoint0, int npoint1, const int32_t* meta, long start1,
+                   long ldp, float* D, float* part, void* stream);
 
-/* Layer-0 backward sums of dY = A1*dN + w*(A2*Y0 + A3): S (C0, B*ld) per source point
- * (= group_points_grad, pointnet2_utils.py:237), T (C0, B*npoint) per ball (may be NULL). */
+/* Layer-0 backward sums of dY = A1*dN + w*(A2*Y0 + A3): S (C0, point columns) per source point
+ * (= group_points_grad, pointnet2_utils.py:237), T (C0, balls) per ball (may be NULL). */
 int o3d_group_reduce_c(const float* dN, const float* Y0, long ldp, const float* A1, const float* A2,
                        const float* A3, const int32_t* gp, const int32_t* cball, const float* cw,
-                       const int32_t* ball_off, int B, int npoint, int ld, int C0, float* S, float* T,
-                       void* stream);
+                       const int32_t* ball_off, const int32_t* ball_cnt, int B, int nseg, int npoint0, int ld0,
+                       int npoint1, int ld1, int C0, float* S, float* T, void* stream);
 
 /* ---- ends of a per-point MLP chain on the flat (C, P = B*N) layout (csrc/pointwise.hip): the M2-Track
  * stacks (models/backbone/pointnet.py:91-204) run on the GEMM kernels above; these finish a chain. */
@@ -288,7 +301,7 @@ int o3d_bn_relu_apply(const float* Y, const float* scale, const float* shift, in
 int o3d_act_bwd_partials(const float* g, const float* Y, const float* scale, const float* shift,
                          const float* mean, int C, long P, float* dN, float* part, void* stream);
 /* AdaptiveMaxPool1d(1) of relu(bn(Y)) per cloud: out (B,C), argq (B,C) column of the first maximum,
- * yarg raw Y there */
+ * yarg raw Y there (backward: o3d_pool_bwd_c with one ball per cloud) */
 int o3d_gmax_fwd(const float* Y, const float* scale, const float* shift, int B, int C, int N, float* out,
                  int32_t* argq, float* yarg, void* stream);
 

@@ -47,6 +47,28 @@ class Pointnet_Backbone(nn.Module):
         return l_xyz[-1], l_features[-1], idx0
 
 
+def _backbone_forward_pair(self, pc_a, numpoints_a, pc_b, numpoints_b):
+    """self(pc_a, numpoints_a), self(pc_b, numpoints_b) with every level's two module calls issued as one
+    (sa_modules.forward_pair): same numbers as the two calls in that order."""
+    xyz_a, feat_a = self._break_up_pc(pc_a)
+    xyz_b, feat_b = self._break_up_pc(pc_b)
+    la, lb = ([xyz_a], [feat_a]), ([xyz_b], [feat_b])
+    idx0 = [None, None]
+    for i, sa in enumerate(self.SA_modules):
+        ra, rb = sa.forward_pair(la[0][i], la[1][i], numpoints_a[i], lb[0][i], lb[1][i], numpoints_b[i])
+        for k, (lst, r) in enumerate(((la, ra), (lb, rb))):
+            lst[0].append(r[0])
+            lst[1].append(r[1])
+            if i == 0:
+                idx0[k] = r[2]
+    if self.return_intermediate:
+        return (la[0][1:], la[1][1:], idx0[0]), (lb[0][1:], lb[1][1:], idx0[1])
+    return (la[0][-1], la[1][-1], idx0[0]), (lb[0][-1], lb[1][-1], idx0[1])
+
+
+Pointnet_Backbone.forward_pair = _backbone_forward_pair
+
+
 def _pointwise_chain(x, layers, pool=False):
     """(Conv1d k=1 -> BatchNorm1d -> ReLU)* on (B,C,N) -- the M2-Track pointwise stack is the grouped MLP
     with one ball per cloud.  `layers` = [(conv, bn, relu)]; returns (B,C',N), or

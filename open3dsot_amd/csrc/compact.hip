@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void compact_count_kernel(const int32_t* __res
 
 // exclusive scan of ball_cnt (n <= 65536) by one workgroup; meta = {Ptot rounded up to 256, Ptot, n, 0}
 __global__ __launch_bounds__(1024) void compact_scan_kernel(const int32_t* __restrict__ ball_cnt, int n,
-                                                            int32_t* __restrict__ ball_off,
+                                                            int col_base, int32_t* __restrict__ ball_off,
                                                             int32_t* __restrict__ meta) {
     __shared__ int sh[1024];
     const int per = (n + 1023) / 1024;
@@ -56,14 +56,13 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(const int32_t* __res
         sh[threadIdx.x] += v;
         __syncthreads();
     }
-    int run = sh[threadIdx.x] - local;
+    int run = col_base + sh[threadIdx.x] - local;
     for (int i = i0; i < i0 + per && i < n; ++i) {
         ball_off[i] = run;
         run += ball_cnt[i];
     }
     if (threadIdx.x == 1023) {
         const int tot = sh[1023];
-        ball_off[n] = tot;
         meta[0] = (tot + 255) & ~255;
         meta[1] = tot;
         meta[2] = n;
@@ -72,7 +71,8 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(const int32_t* __res
 }
 
 __global__ __launch_bounds__(256) void compact_fill_kernel(const int32_t* __restrict__ idx, long nslots, int ns,
-                                                           int npoint, int ld,
+                                                           int npoint, int ld, int col_base, int pt_base,
+                                                           int ball_base, int dummy_ball,
                                                            const int32_t* __restrict__ ball_cnt,
                                                            const int32_t* __restrict__ ball_off,
                                                            const int32_t* __restrict__ meta,
@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(const int32_t* __rest
                                                            float* __restrict__ cw) {
     if (blockIdx.x == gridDim.x - 1) {       // padding columns [Ptot, Ptot_pad)
         const int q = meta[1] + threadIdx.x;
-        if (q < meta[0]) { gp[q] = 0; cball[q] = meta[2]; cw[q] = 0.f; }
+        if (q < meta[0]) { gp[col_base + q] = 0; cball[col_base + q] = dummy_ball; cw[col_base + q] = 0.f; }
         return;
     }
     const long s = (long)blockIdx.x * 256 + threadIdx.x;
@@ -88,9 +88,9 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(const int32_t* __rest
     const int ball = (int)(s / ns), k = (int)(s - (long)ball * ns);
     const int cnt = ball_cnt[ball];
     if (k >= cnt) return;
-    const int q = ball_off[ball] + k;
-    gp[q] = (ball / npoint) * ld + idx[s];
-    cball[q] = ball;
+    const int q = ball_off[ball] + k;                     // ball_off already includes col_base
+    gp[q] = pt_base + (ball / npoint) * ld + idx[s];
+    cball[q] = ball_base + ball;
     cw[q] = k == 0 ? (float)(1 + ns - cnt) : 1.f;
 }
 
@@ -104,11 +104,13 @@ __global__ __launch_bounds__(256) void expand_c_kernel(const float* __restrict__
                                                        const float* __restrict__ cw,
                                                        const float* __restrict__ centers,
                                                        const float* __restrict__ W0, int ldw, int C0,
-                                                       const int32_t* __restrict__ meta, long ldp,
+                                                       const int32_t* __restrict__ meta, long start1, long ldp,
                                                        float* __restrict__ Y0, float* __restrict__ part,
                                                        const float* __restrict__ stat_c) {
     const int q0 = blockIdx.x * 256;
-    if (q0 >= meta[0]) return;
+    const int seg = (start1 > 0 && q0 >= start1) ? 1 : 0;
+    if (q0 - (seg ? start1 : 0) >= meta[4 * seg]) return;
+    if (stat_c && seg) stat_c += C0;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int q = q0 + 4 * lane;
     const int4 id = *reinterpret_cast<const int4*>(&gp[q]);
@@ -149,26 +151,36 @@ __global__ __launch_bounds__(256) void expand_c_kernel(const float* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------
-// pool: out[b,c,j] = max over the ball's columns of relu(Y*scale+shift); argq = column of the max
+// pool: out[c,ball] = max over the ball's columns of relu(Y*scale+shift); argq = column of the max
 //   8 lanes per ball (its columns are contiguous, 8 on average): a wave reads the columns of 8
 //   consecutive balls, i.e. one nearly contiguous row segment; first-maximum arg-max via 3 shuffles.
 //   workgroup = 32 balls x POOL_CH channels.
 // ---------------------------------------------------------------------------------------
 constexpr int POOL_CH = 8;
 
+// pooled tensors are stored per segment in the reference's (B, C, npoint) layout, segment 1's block after
+// segment 0's: element (c, ball)
+__device__ __forceinline__ long pool_index(int c, int ball, int C, int seg1_ball, int np0, int np1) {
+    const bool s1 = ball >= seg1_ball;
+    const int local = s1 ? ball - seg1_ball : ball, np = s1 ? np1 : np0;
+    const int b = local / np, j = local - b * np;
+    return (s1 ? (long)seg1_ball * C : 0) + ((long)b * C + c) * np + j;
+}
+
 __global__ __launch_bounds__(256) void pool_c_kernel(const float* __restrict__ Y, long ldp,
                                                      const float* __restrict__ scale,
                                                      const float* __restrict__ shift,
-                                                     const int32_t* __restrict__ ball_off, int C, int npoint,
-                                                     int nballs, float* __restrict__ out,
+                                                     const int32_t* __restrict__ ball_off,
+                                                     const int32_t* __restrict__ ball_cnt, int C, int seg1_ball,
+                                                     int np0, int np1, int nballs, float* __restrict__ out,
                                                      int32_t* __restrict__ argq, float* __restrict__ yarg) {
     const int e = threadIdx.x & 7;
     int ball = blockIdx.x * 32 + (threadIdx.x >> 3);
     const bool live = ball < nballs;
     if (!live) ball = nballs - 1;
-    const int q0 = ball_off[ball], q1 = ball_off[ball + 1];
-    const int b = ball / npoint, j = ball - b * npoint;
+    const int q0 = ball_off[ball], q1 = q0 + ball_cnt[ball];
     const int c0 = blockIdx.y * POOL_CH;
+    if (ball >= seg1_ball) { scale += C; shift += C; }       // second segment: its own BatchNorm constants
     for (int cc = 0; cc < POOL_CH && c0 + cc < C; ++cc) {
         const int c = c0 + cc;
         const float sc = scale[c], sf = shift[c];
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(256) void pool_c_kernel(const float* __restrict__ Y
             if (ob > best || (ob == best && oq < bq)) { best = ob; bq = oq; yb = oy; }
         }
         if (live && e == 0) {
-            const long o = ((long)b * C + c) * npoint + j;
+            const long o = pool_index(c, ball, C, seg1_ball, np0, np1);
             out[o] = fmaxf(best, 0.f);
             if (argq) { argq[o] = bq; yarg[o] = yb; }
         }
@@ -195,21 +207,54 @@ __global__ __launch_bounds__(256) void pool_c_kernel(const float* __restrict__ Y
 
 // dense gradient of the pooled layer: zero the live columns, then one value per (c, ball)
 __global__ __launch_bounds__(256) void zero_cols_kernel(float* __restrict__ D, long ldp,
-                                                        const int32_t* __restrict__ meta) {
-    const int q = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (q >= meta[0]) return;
+                                                        const int32_t* __restrict__ meta, long start1) {
+    const long q = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (q >= ldp) return;
+    const int seg = (start1 > 0 && q >= start1) ? 1 : 0;
+    if (q - (seg ? start1 : 0) >= meta[4 * seg]) return;
     *reinterpret_cast<float4*>(&D[(long)blockIdx.y * ldp + q]) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
+// D[c, argq[c,ball]] = dOut where out > 0
 __global__ __launch_bounds__(256) void pool_scatter_c_kernel(const float* __restrict__ dOut,
                                                              const float* __restrict__ out,
-                                                             const int32_t* __restrict__ argq, int C,
-                                                             int npoint, long total, long ldp,
+                                                             const int32_t* __restrict__ argq, int C, int nballs,
+                                                             int seg1_ball, int np0, int np1, long total, long ldp,
                                                              float* __restrict__ D) {
-    const long o = (long)blockIdx.x * 256 + threadIdx.x;     // (b, c, j)
-    if (o >= total) return;
-    const int c = (int)((o / npoint) % C);
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;     // (c, ball), ball fastest
+    if (t >= total) return;
+    const int c = (int)(t / nballs), ball = (int)(t - (long)c * nballs);
+    const long o = pool_index(c, ball, C, seg1_ball, np0, np1);
     if (out[o] > 0.f) D[(long)c * ldp + argq[o]] = dOut[o];
+}
+
+// BatchNorm-backward partials of the pooled layer, one row per segment: part[seg][0][c] = sum g,
+// part[seg][1][c] = sum g*(yarg - mean), g = dOut where out > 0.  grid (C, nseg).
+__global__ __launch_bounds__(256) void pool_bwd_partials_c_kernel(const float* __restrict__ dOut,
+                                                                  const float* __restrict__ out,
+                                                                  const float* __restrict__ yarg,
+                                                                  const float* __restrict__ mean, int C,
+                                                                  int nballs, int seg1_ball, int np0, int np1,
+                                                                  float* __restrict__ part) {
+    __shared__ float sh[2][4];
+    const int c = blockIdx.x, seg = blockIdx.y;
+    const int b0 = seg ? seg1_ball : 0, b1 = seg ? nballs : seg1_ball;
+    const float mu = mean[seg * C + c];
+    float s = 0.f, q = 0.f;
+    for (int ball = b0 + threadIdx.x; ball < b1; ball += 256) {
+        const long o = pool_index(c, ball, C, seg1_ball, np0, np1);
+        const float g = out[o] > 0.f ? dOut[o] : 0.f;
+        s += g;
+        q += g * (yarg[o] - mu);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) { s += __shfl_xor(s, m, 64); q += __shfl_xor(q, m, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((long)seg * 2 + 0) * C + c] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        part[((long)seg * 2 + 1) * C + c] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -217,6 +262,9 @@ __global__ __launch_bounds__(256) void pool_scatter_c_kernel(const float* __rest
 // reference point n, T[c, ball] = sum of dY over the ball.  Workgroup = (cloud, CS channels), LDS fp32
 // atomics (no duplicates inside a ball any more, so no same-address pile-ups).
 // ---------------------------------------------------------------------------------------
+struct SegParams { int npoint, ld, pt_base, ball_base; };   // per segment: balls / points per cloud, first point
+                                                             // column and first ball of the segment
+
 template <int CS>
 __global__ __launch_bounds__(256) void reduce_c_kernel(const float* __restrict__ dN, const float* __restrict__ Y0,
                                                        long ldp, const float* __restrict__ A1,
@@ -225,20 +273,25 @@ __global__ __launch_bounds__(256) void reduce_c_kernel(const float* __restrict__
                                                        const int32_t* __restrict__ gp,
                                                        const int32_t* __restrict__ cball,
                                                        const float* __restrict__ cw,
-                                                       const int32_t* __restrict__ ball_off, int npoint, int ld,
-                                                       int C0, long lds_row, float* __restrict__ S,
-                                                       float* __restrict__ T, int nballs) {
+                                                       const int32_t* __restrict__ ball_off,
+                                                       const int32_t* __restrict__ ball_cnt, int B, SegParams sp0,
+                                                       SegParams sp1, int C0, long lds_row,
+                                                       float* __restrict__ S, float* __restrict__ T, int nballs) {
     extern __shared__ __attribute__((aligned(16))) float acc[];   // [CS][ld] then [CS][npoint]
     const int slabs = (C0 + CS - 1) / CS;
-    const int b = blockIdx.x / slabs, c0 = (blockIdx.x - b * slabs) * CS;
+    const int cloud = blockIdx.x / slabs, c0 = (blockIdx.x - cloud * slabs) * CS;
+    const int seg = cloud >= B ? 1 : 0, b = cloud - seg * B;
+    const SegParams sp = seg ? sp1 : sp0;
+    const int npoint = sp.npoint, ld = sp.ld;
+    const int pbase = sp.pt_base + b * ld, bbase = sp.ball_base + b * npoint;
     float* tacc = acc + CS * ld;
     for (int i = threadIdx.x; i < CS * (ld + npoint); i += 256) acc[i] = 0.f;
     __syncthreads();
-    const int q0 = ball_off[b * npoint], q1 = ball_off[(b + 1) * npoint];
+    const int q0 = ball_off[bbase], q1 = ball_off[bbase + npoint - 1] + ball_cnt[bbase + npoint - 1];
     float a1[CS], a2[CS], a3[CS];
 #pragma unroll
     for (int c = 0; c < CS; ++c) {
-        const int cc = c0 + c < C0 ? c0 + c : C0 - 1;
+        const int cc = seg * C0 + (c0 + c < C0 ? c0 + c : C0 - 1);     // segment 1: its own BN-backward constants
         a1[c] = A1[cc]; a2[c] = A2[cc]; a3[c] = A3[cc];
     }
     // A ball's columns are consecutive, so its sum T is a segmented reduction over lanes (inclusive
@@ -250,7 +303,7 @@ __global__ __launch_bounds__(256) void reduce_c_kernel(const float* __restrict__
     for (int i0 = 0; i0 < span; i0 += 256) {
         const int q = q0 + i0 + threadIdx.x;
         const bool live = q < q1;
-        const int n = live ? gp[q] - b * ld : 0, j = live ? cball[q] - b * npoint : -1;
+        const int n = live ? gp[q] - pbase : 0, j = live ? cball[q] - bbase : -1;
         const float w = live ? cw[q] : 0.f;
         unsigned same = 0;           // bit s: lane - 2^s belongs to the same ball
         if (T) {
@@ -285,12 +338,12 @@ __global__ __launch_bounds__(256) void reduce_c_kernel(const float* __restrict__
     __syncthreads();
     for (int i = threadIdx.x; i < CS * ld; i += 256) {
         const int c = i / ld, n = i - c * ld;
-        if (c0 + c < C0) S[(long)(c0 + c) * lds_row + (long)b * ld + n] = acc[i];
+        if (c0 + c < C0) S[(long)(c0 + c) * lds_row + pbase + n] = acc[i];
     }
     if (T)
         for (int i = threadIdx.x; i < CS * npoint; i += 256) {
             const int c = i / npoint, j = i - c * npoint;
-            if (c0 + c < C0) T[(long)(c0 + c) * nballs + b * npoint + j] = tacc[i];
+            if (c0 + c < C0) T[(long)(c0 + c) * nballs + bbase + j] = tacc[i];
         }
 }
 
@@ -298,87 +351,112 @@ __global__ __launch_bounds__(256) void reduce_c_kernel(const float* __restrict__
 
 static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
-// idx (B,npoint,ns) -> ball_cnt (B*npoint), ball_off (B*npoint+1), gp/cball/cw (B*npoint*ns worst case),
-// meta (4 ints).  ld = row length of the per-point matrices per cloud (N rounded up).
-extern "C" int o3d_compact_build(const int32_t* idx, int B, int npoint, int ns, int ld, int32_t* ball_cnt,
-                                 int32_t* ball_off, int32_t* gp, int32_t* cball, float* cw, int32_t* meta,
-                                 void* stream) {
+// One segment of the compact layout: idx (B,npoint,ns) -> ball_cnt (B*npoint), ball_off (B*npoint+1, absolute
+// columns), and per column gp / cball / cw written at [col_base, col_base + live); meta (4 ints) = {live rounded
+// up to 256, live, B*npoint, 0}.  pt_base / ball_base = first point column / first ball id of the segment,
+// dummy_ball = ball id of the padding columns (a zero row of the centre table).  ld = point columns per cloud.
+extern "C" int o3d_compact_build(const int32_t* idx, int B, int npoint, int ns, int ld, int col_base, int pt_base,
+                                 int ball_base, int dummy_ball, int32_t* ball_cnt, int32_t* ball_off, int32_t* gp,
+                                 int32_t* cball, float* cw, int32_t* meta, void* stream) {
     const long nballs = (long)B * npoint, nslots = nballs * ns;
     if (!idx || !ball_cnt || !ball_off || !gp || !cball || !cw || !meta || B <= 0 || npoint <= 0 || ns < 1 ||
-        ns > 64 || !pow2(ns) || nballs > 65536 || nslots % 256 != 0 || ld <= 0)
+        ns > 64 || !pow2(ns) || nballs > 65536 || nslots % 256 != 0 || ld <= 0 || col_base < 0 || col_base % 256 != 0)
         return O3D_EINVAL;
     hipStream_t s = o3d_stream(stream);
     const int blocks = (int)(nslots / 256);
     hipLaunchKernelGGL(compact_count_kernel, dim3(blocks), dim3(256), 0, s, idx, nslots, ns, ball_cnt);
-    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, s, ball_cnt, (int)nballs, ball_off, meta);
-    hipLaunchKernelGGL(compact_fill_kernel, dim3(blocks + 1), dim3(256), 0, s, idx, nslots, ns, npoint, ld, ball_cnt,
-                       ball_off, meta, gp, cball, cw);
+    hipLaunchKernelGGL(compact_scan_kernel, dim3(1), dim3(1024), 0, s, ball_cnt, (int)nballs, col_base, ball_off, meta);
+    hipLaunchKernelGGL(compact_fill_kernel, dim3(blocks + 1), dim3(256), 0, s, idx, nslots, ns, npoint, ld, col_base,
+                       pt_base, ball_base, dummy_ball, ball_cnt, ball_off, meta, gp, cball, cw);
     return o3d_launch_status();
 }
 
 // Y0 (C0, ldp) from Z (C0, ldz); centers ((nballs+1), 3) or NULL; part [ldp/256][2][C0] or NULL
 extern "C" int o3d_group_expand_c(const float* Z, long ldz, const int32_t* gp, const int32_t* cball,
                                   const float* cw, const float* centers, const float* W0, int ldw, int C0,
-                                  const int32_t* meta, long ldp, float* Y0, float* part, const float* stat_c,
-                                  void* stream) {
-    if (!Z || !gp || !cball || !cw || !meta || !Y0 || C0 <= 0 || ldp <= 0 || ldp % 256 != 0 || (centers && (!W0 || ldw < 3)))
+                                  const int32_t* meta, long start1, long ldp, float* Y0, float* part,
+                                  const float* stat_c, void* stream) {
+    if (!Z || !gp || !cball || !cw || !meta || !Y0 || C0 <= 0 || ldp <= 0 || ldp % 256 != 0 || start1 < 0 ||
+        start1 % 256 != 0 || (centers && (!W0 || ldw < 3)))
         return O3D_EINVAL;
     hipLaunchKernelGGL(expand_c_kernel, dim3((unsigned)(ldp / 256)), dim3(256), 0, o3d_stream(stream), Z, ldz, gp,
-                       cball, cw, centers, W0, ldw, C0, meta, ldp, Y0, part, stat_c);
+                       cball, cw, centers, W0, ldw, C0, meta, start1, ldp, Y0, part, stat_c);
     return o3d_launch_status();
 }
 
+// out / argq / yarg: per segment a (B, C, npoint_s) block (segment 1's block after segment 0's); balls
+// >= seg1_ball = B*npoint0 belong to segment 1 (scale/shift at +C); npoint1 = 0 for one segment
 extern "C" int o3d_pool_fwd_c(const float* Y, long ldp, const float* scale, const float* shift,
-                              const int32_t* ball_off, int B, int C, int npoint, float* out, int32_t* argq,
-                              float* yarg, void* stream) {
-    if (!Y || !scale || !shift || !ball_off || !out || B <= 0 || C <= 0 || npoint <= 0 || (argq && !yarg))
+                              const int32_t* ball_off, const int32_t* ball_cnt, int B, int C, int npoint0,
+                              int npoint1, float* out, int32_t* argq, float* yarg, void* stream) {
+    if (!Y || !scale || !shift || !ball_off || !ball_cnt || !out || B <= 0 || C <= 0 || npoint0 <= 0 || npoint1 < 0 ||
+        (argq && !yarg))
         return O3D_EINVAL;
-    const int nballs = B * npoint;
+    const int seg1_ball = B * npoint0, nballs = B * (npoint0 + npoint1);
     hipLaunchKernelGGL(pool_c_kernel, dim3(o3d_cdiv(nballs, 32), o3d_cdiv(C, POOL_CH)), dim3(256), 0,
-                       o3d_stream(stream), Y, ldp, scale, shift, ball_off, C, npoint, nballs, out, argq, yarg);
+                       o3d_stream(stream), Y, ldp, scale, shift, ball_off, ball_cnt, C, seg1_ball, npoint0,
+                       npoint1 > 0 ? npoint1 : npoint0, nballs, out, argq, yarg);
     return o3d_launch_status();
 }
 
-// D (C, ldp): zero on the live columns, then D[c, argq[b,c,j]] = dOut[b,c,j] where out > 0
-extern "C" int o3d_pool_bwd_dense_c(const float* dOut, const float* out, const int32_t* argq, int B, int C,
-                                    int npoint, const int32_t* meta, long ldp, float* D, void* stream) {
-    if (!dOut || !out || !argq || !meta || !D || B <= 0 || C <= 0 || npoint <= 0 || ldp <= 0 || ldp % 4 != 0)
+// Backward of the pool (pooled tensors in the per-segment (B,C,npoint) blocks of o3d_pool_fwd_c): D (C, ldp) zero on the live columns then D[c, argq] = dOut
+// where out > 0; part [nseg][2][C] = BatchNorm-backward partials of the pooled layer per segment.
+extern "C" int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t* argq, const float* yarg,
+                              const float* mean, int B, int C, int npoint0, int npoint1, const int32_t* meta,
+                              long start1, long ldp, float* D, float* part, void* stream) {
+    if (!dOut || !out || !argq || !yarg || !mean || !meta || !D || !part || B <= 0 || C <= 0 || npoint0 <= 0 ||
+        npoint1 < 0 || ldp <= 0 || ldp % 4 != 0)
         return O3D_EINVAL;
     hipStream_t s = o3d_stream(stream);
-    hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)o3d_cdiv(ldp, 1024), C), dim3(256), 0, s, D, ldp, meta);
-    const long total = (long)B * C * npoint;
-    hipLaunchKernelGGL(pool_scatter_c_kernel, dim3(o3d_cdiv(total, 256)), dim3(256), 0, s, dOut, out, argq, C, npoint,
-                       total, ldp, D);
+    const int nseg = npoint1 > 0 ? 2 : 1;
+    const int seg1_ball = B * npoint0, nballs = B * (npoint0 + npoint1), np1 = npoint1 > 0 ? npoint1 : npoint0;
+    hipLaunchKernelGGL(pool_bwd_partials_c_kernel, dim3(C, nseg), dim3(256), 0, s, dOut, out, yarg, mean, C, nballs,
+                       seg1_ball, npoint0, np1, part);
+    hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)o3d_cdiv(ldp, 1024), C), dim3(256), 0, s, D, ldp, meta, start1);
+    const long total = (long)C * nballs;
+    hipLaunchKernelGGL(pool_scatter_c_kernel, dim3(o3d_cdiv(total, 256)), dim3(256), 0, s, dOut, out, argq, C, nballs,
+                       seg1_ball, npoint0, np1, total, ldp, D);
     return o3d_launch_status();
 }
 
 template <int CS>
 static int launch_reduce_c(const float* dN, const float* Y0, long ldp, const float* A1, const float* A2,
                            const float* A3, const int32_t* gp, const int32_t* cball, const float* cw,
-                           const int32_t* ball_off, int B, int npoint, int ld, int C0, float* S, float* T,
-                           hipStream_t s) {
-    const size_t lds = sizeof(float) * CS * (size_t)(ld + npoint);
+                           const int32_t* ball_off, const int32_t* ball_cnt, int B, int nseg, SegParams sp0,
+                           SegParams sp1, int C0,
+                           long lds_row, int nballs, float* S, float* T, hipStream_t s) {
+    const int span = (sp0.ld + sp0.npoint) > (sp1.ld + sp1.npoint) ? (sp0.ld + sp0.npoint) : (sp1.ld + sp1.npoint);
+    const size_t lds = sizeof(float) * CS * (size_t)span;
     if (lds > 64 * 1024) return O3D_EINVAL;
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(reduce_c_kernel<CS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return O3D_ELAUNCH;
     const int slabs = (C0 + CS - 1) / CS;
-    hipLaunchKernelGGL(reduce_c_kernel<CS>, dim3(B * slabs), dim3(256), lds, s, dN, Y0, ldp, A1, A2, A3, gp, cball, cw,
-                       ball_off, npoint, ld, C0, (long)B * ld, S, T, B * npoint);
+    hipLaunchKernelGGL(reduce_c_kernel<CS>, dim3(B * nseg * slabs), dim3(256), lds, s, dN, Y0, ldp, A1, A2, A3, gp, cball,
+                       cw, ball_off, ball_cnt, B, sp0, sp1, C0, lds_row, S, T, nballs);
     return o3d_launch_status();
 }
 
-// S (C0, B*ld), T (C0, B*npoint) or NULL
+// S (C0, lds_row) per source point, T (C0, nballs) per ball or NULL.  One or two segments of B clouds each
+// (segment s: npoint[s] balls and ld[s] point columns per cloud; segment 1's points start at column B*ld[0],
+// its balls at B*npoint[0], its constants A1..A3 at +C0).
 extern "C" int o3d_group_reduce_c(const float* dN, const float* Y0, long ldp, const float* A1, const float* A2,
                                   const float* A3, const int32_t* gp, const int32_t* cball, const float* cw,
-                                  const int32_t* ball_off, int B, int npoint, int ld, int C0, float* S, float* T,
-                                  void* stream) {
-    if (!dN || !Y0 || !A1 || !A2 || !A3 || !gp || !cball || !cw || !ball_off || !S || B <= 0 || npoint <= 0 ||
-        ld <= 0 || C0 <= 0)
+                                  const int32_t* ball_off, const int32_t* ball_cnt, int B, int nseg, int npoint0,
+                                  int ld0, int npoint1, int ld1, int C0, float* S, float* T, void* stream) {
+    if (!dN || !Y0 || !A1 || !A2 || !A3 || !gp || !cball || !cw || !ball_off || !ball_cnt || !S || B <= 0 || npoint0 <= 0 ||
+        ld0 <= 0 || C0 <= 0 || (nseg != 1 && nseg != 2) || (nseg == 2 && (npoint1 <= 0 || ld1 <= 0)))
         return O3D_EINVAL;
     hipStream_t s = o3d_stream(stream);
-    if ((long)B * C0 >= 8192 && sizeof(float) * 4 * (size_t)(ld + npoint) <= 64 * 1024)
-        return launch_reduce_c<4>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, B, npoint, ld, C0, S, T, s);
-    return launch_reduce_c<2>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, B, npoint, ld, C0, S, T, s);
+    const SegParams sp0 = {npoint0, ld0, 0, 0};
+    const SegParams sp1 = nseg == 2 ? SegParams{npoint1, ld1, B * ld0, B * npoint0} : sp0;
+    const long lds_row = (long)B * ld0 + (nseg == 2 ? (long)B * ld1 : 0);
+    const int nballs = B * npoint0 + (nseg == 2 ? B * npoint1 : 0);
+    const int span = (sp0.ld + sp0.npoint) > (sp1.ld + sp1.npoint) ? (sp0.ld + sp0.npoint) : (sp1.ld + sp1.npoint);
+    if ((long)B * nseg * C0 >= 8192 && sizeof(float) * 4 * (size_t)span <= 64 * 1024)
+        return launch_reduce_c<4>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, ball_cnt, B, nseg, sp0, sp1, C0,
+                                  lds_row, nballs, S, T, s);
+    return launch_reduce_c<2>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, ball_cnt, B, nseg, sp0, sp1, C0, lds_row,
+                              nballs, S, T, s);
 }

@@ -33,12 +33,12 @@
 bool o3d_direct_ok(int M, int K, int P);
 int o3d_direct_fwd(const float* X, const float* W, const float* in_scale, const float* in_shift, int B, int Cin,
                    int Cout, int P, float* Y, float* part, const float* stat_c, const float* w, const int32_t* meta,
-                   int tile, hipStream_t st);
+                   long start1, int tile, hipStream_t st);
 int o3d_direct_dgrad(const float* dN, const float* pk, int ns,
                      const float* Y, const float* A1, const float* A2, const float* A3, const float* Wt, int B,
                      int Cin, int Cout, int P, const float* Yprev, const float* scale_p, const float* shift_p,
                      const float* mean_p, float* dNprev, float* part, const float* w, const int32_t* meta,
-                     int tile, hipStream_t st);
+                     long start1, int tile, hipStream_t st);
 
 namespace {
 
@@ -1041,7 +1041,7 @@ extern "C" int o3d_mlp_conv_fwd(const float* X, const float* W, const float* in_
                                 float* part, const float* stat_c, void* stream) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || P <= 0 || P % BN_POS != 0 || !X || !W || !Y) return O3D_EINVAL;
     if (o3d_direct_ok(Cout, Cin, P) && (in_scale == nullptr) == (in_shift == nullptr))
-        return o3d_direct_fwd(X, W, in_scale, in_shift, B, Cin, Cout, P, Y, part, stat_c, nullptr, nullptr, 128,
+        return o3d_direct_fwd(X, W, in_scale, in_shift, B, Cin, Cout, P, Y, part, stat_c, nullptr, nullptr, 0, 128,
                               o3d_stream(stream));
     FwdArgs a = {};
     a.X = X; a.W = W; a.Y = Y; a.in_scale = in_scale; a.in_shift = in_shift; a.part = part; a.stat_c = stat_c;
@@ -1167,7 +1167,7 @@ extern "C" int o3d_mlp_conv_dgrad_wt(const float* dN, const float* dOut, const f
     if (Wt && o3d_direct_ok(Cin, Cout, P) && B > 0 && Yprev && scale_p && shift_p && mean_p && dNprev && part &&
         Y && A1 && A2 && A3 && (dN || (pk && ns > 0 && ns % 4 == 0)))
         return o3d_direct_dgrad(dN, pk, ns, Y, A1, A2, A3, Wt, B, Cin, Cout, P, Yprev, scale_p, shift_p,
-                                mean_p, dNprev, part, nullptr, nullptr, 128, o3d_stream(stream));
+                                mean_p, dNprev, part, nullptr, nullptr, 0, 128, o3d_stream(stream));
     return o3d_mlp_conv_dgrad(dN, dOut, out, arg, ns, Y, A1, A2, A3, W, B, Cin, Cout, P, Yprev, scale_p, shift_p,
                               mean_p, dNprev, part, stream);
 }
@@ -1175,18 +1175,19 @@ extern "C" int o3d_mlp_conv_dgrad_wt(const float* dN, const float* dOut, const f
 // ---- compact (distinct-neighbour) layout, csrc/compact.hip: flat (C, ldp) matrices, per-position weights w
 // (ldp) and the live column count meta[0] in device memory.  Aligned shapes only.
 extern "C" int o3d_mlp_conv_fwd_c(const float* X, const float* W, const float* in_scale, const float* in_shift,
-                                  int Cin, int Cout, long ldp, const float* w, const int32_t* meta, int tile,
-                                  float* Y, float* part, const float* stat_c, void* stream) {
+                                  int Cin, int Cout, long ldp, const float* w, const int32_t* meta, long start1,
+                                  int tile, float* Y, float* part, const float* stat_c, void* stream) {
     if (!X || !W || !Y || !w || !meta || !in_scale || !in_shift || ldp <= 0 || ldp > 0x7fffffff ||
         !o3d_direct_ok(Cout, Cin, (int)ldp) || (tile != 64 && tile != 128))
         return O3D_EINVAL;
-    return o3d_direct_fwd(X, W, in_scale, in_shift, 1, Cin, Cout, (int)ldp, Y, part, stat_c, w, meta, tile,
+    return o3d_direct_fwd(X, W, in_scale, in_shift, 1, Cin, Cout, (int)ldp, Y, part, stat_c, w, meta, start1, tile,
                           o3d_stream(stream));
 }
 
 extern "C" int o3d_mlp_conv_dgrad_c(const float* dN, const float* Y, const float* A1, const float* A2,
                                     const float* A3, const float* Wt, int Cin, int Cout, long ldp, const float* w,
-                                    const int32_t* meta, int tile, const float* Yprev, const float* scale_p,
+                                    const int32_t* meta, long start1, int tile, const float* Yprev,
+                                    const float* scale_p,
                                     const float* shift_p, const float* mean_p, float* dNprev, float* part,
                                     void* stream) {
     if (!dN || !Y || !A1 || !A2 || !A3 || !Wt || !w || !meta || !Yprev || !scale_p || !shift_p || !mean_p ||
@@ -1194,7 +1195,7 @@ extern "C" int o3d_mlp_conv_dgrad_c(const float* dN, const float* Y, const float
         (tile != 64 && tile != 128))
         return O3D_EINVAL;
     return o3d_direct_dgrad(dN, nullptr, 4, Y, A1, A2, A3, Wt, 1, Cin, Cout, (int)ldp, Yprev, scale_p, shift_p,
-                            mean_p, dNprev, part, w, meta, tile, o3d_stream(stream));
+                            mean_p, dNprev, part, w, meta, start1, tile, o3d_stream(stream));
 }
 
 // dX (B,Cin,P) = W^T dY with dY = A1*dN + A2*Y + A3, no mask, no statistics: the gradient w.r.t. an

@@ -65,7 +65,11 @@ struct DirectArgs {
     int M, K, P, B;
     // compact (distinct-neighbour) layout, csrc/compact.hip: per-position weights and the live column count
     const float* w;        // (P) or NULL: weights of the statistics (forward) / of the A2*Y+A3 term (DY modes)
-    const int32_t* meta;   // device int: positions >= meta[0] are dead (tiles beyond it return) or NULL
+    const int32_t* meta;   // device ints, 4 per segment: meta[4*s] = live columns of segment s (or NULL)
+    long start1;           // first column of segment 1 (0 = one segment).  A second segment is a second set
+                           // of clouds pushed through the SAME weights with its OWN BatchNorm statistics
+                           // (template and search branch of the backbone): its per-channel constants sit
+                           // K (c1..c3) resp. M (stat_c, scale_p, shift_p, mean_p) floats after segment 0's
     // epilogue
     float* part;           // [B*P/(32*NT)][2][M] or NULL
     const float* stat_c;   // forward: shift of the second moment
@@ -138,7 +142,18 @@ void direct_gemm_kernel(DirectArgs a) {
     const int tiles_per_b = a.P / POS;
     const int tile = blockIdx.x;
     const int b = tile / tiles_per_b, p0 = (tile - b * tiles_per_b) * POS;
-    if (a.meta && (long)tile * POS >= a.meta[0]) return;     // compact layout: dead tile
+    if (a.meta) {                                             // compact layout: dead tile?  which segment?
+        const long c0 = (long)tile * POS;
+        const int seg = (a.start1 > 0 && c0 >= a.start1) ? 1 : 0;
+        if (c0 - (seg ? a.start1 : 0) >= a.meta[4 * seg]) return;
+        if (seg) {
+            if (a.c1) a.c1 += a.K;
+            if (a.c2) a.c2 += a.K;
+            if (a.c3) a.c3 += a.K;
+            if (a.stat_c) a.stat_c += a.M;
+            if (a.scale_p) { a.scale_p += a.M; a.shift_p += a.M; a.mean_p += a.M; }
+        }
+    }
     const int m0 = (blockIdx.y * WAVES + wave) * DT_M;
     const int p = p0 + NT * l31;
     float wv[NT];
@@ -283,9 +298,9 @@ extern "C" int o3d_direct_tile(long P, int M, int compact) {
 // forward: Y = W . f(X), see o3d_mlp_conv_fwd
 int o3d_direct_fwd(const float* X, const float* W, const float* in_scale, const float* in_shift, int B, int Cin,
                    int Cout, int P, float* Y, float* part, const float* stat_c, const float* w, const int32_t* meta,
-                   int tile, hipStream_t st) {
+                   long start1, int tile, hipStream_t st) {
     DirectArgs a = {};
-    a.w = w; a.meta = meta;
+    a.w = w; a.meta = meta; a.start1 = start1;
     a.A = W; a.X = X; a.c1 = in_scale; a.c2 = in_shift; a.Out = Y; a.M = Cout; a.K = Cin; a.P = P; a.B = B;
     a.part = part; a.stat_c = stat_c; a.ns = 4;
     return in_scale ? launch_direct<B_XFORM, 0>(a, tile, st) : launch_direct<B_PLAIN, 0>(a, tile, st);
@@ -296,9 +311,9 @@ int o3d_direct_dgrad(const float* dN, const float* pk, int ns,
                      const float* Y, const float* A1, const float* A2, const float* A3, const float* Wt, int B,
                      int Cin, int Cout, int P, const float* Yprev, const float* scale_p, const float* shift_p,
                      const float* mean_p, float* dNprev, float* part, const float* w, const int32_t* meta,
-                     int tile, hipStream_t st) {
+                     long start1, int tile, hipStream_t st) {
     DirectArgs a = {};
-    a.w = w; a.meta = meta;
+    a.w = w; a.meta = meta; a.start1 = start1;
     a.A = Wt; a.X = dN; a.Y = Y; a.c1 = A1; a.c2 = A2; a.c3 = A3; a.pk = reinterpret_cast<const float2*>(pk); a.ns = ns;
     a.Out = dNprev; a.M = Cin; a.K = Cout; a.P = P; a.B = B; a.part = part;
     a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p;

@@ -29,7 +29,9 @@ struct Wgrad2Args {
     int chunks_per_block, total_chunks, nslices;
     float* part;           // [nslices*WK][Cout][Cin]
     const float* w;        // compact layout: per-position weight of the A2*Y+A3 term, or NULL
-    const int32_t* meta;   // compact layout: live positions = meta[0] (device), or NULL
+    const int32_t* meta;   // compact layout: 4 device ints per segment, meta[4*s] = live columns of segment s
+    long start1;           // first column of segment 1 (0 = one segment); its per-channel constants follow
+                           // segment 0's (A1..A3 after Cout floats, in_scale/in_shift after Cin floats)
 };
 
 template <int TM, int TN, bool POOLED>
@@ -60,14 +62,33 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
         slice = blockIdx.x / ntile;
     }
     const int ci0 = (tile_id % tiles_ci) * TN, co0 = (tile_id / tiles_ci) * TM;
-    int total_chunks = a.total_chunks, chunks_per_block = a.chunks_per_block;
-    if (a.meta) {      // data-dependent column count: partition the live chunks evenly over the slices
-        total_chunks = a.meta[0] / CP;
-        chunks_per_block = (total_chunks + a.nslices - 1) / a.nslices;
+    int c_begin, c_end;
+    int seg = 0;
+    long col0 = 0;                 // first column of the range this workgroup's chunks are counted from
+    if (a.meta) {
+        // data-dependent column counts: the live chunks of each segment are split evenly over the slices,
+        // and a slice never straddles segments (its per-channel constants belong to one of them)
+        const int n0 = a.meta[0] / CP, n1 = a.start1 > 0 ? a.meta[4] / CP : 0;
+        int nsl0 = a.nslices;
+        if (n1 > 0) {
+            nsl0 = (int)(((long)a.nslices * n0 + (n0 + n1) / 2) / (n0 + n1));
+            nsl0 = nsl0 < 1 ? 1 : (nsl0 > a.nslices - 1 ? a.nslices - 1 : nsl0);
+        }
+        seg = slice >= nsl0 ? 1 : 0;
+        const int nsl = seg ? a.nslices - nsl0 : nsl0, ls = seg ? slice - nsl0 : slice, n = seg ? n1 : n0;
+        const int per = (n + nsl - 1) / nsl;
+        c_begin = ls * per;
+        c_end = c_begin + per < n ? c_begin + per : n;
+        col0 = seg ? a.start1 : 0;
+    } else {
+        c_begin = slice * a.chunks_per_block;
+        c_end = c_begin + a.chunks_per_block < a.total_chunks ? c_begin + a.chunks_per_block : a.total_chunks;
     }
-    const int c_begin = slice * chunks_per_block;
-    int c_end = c_begin + chunks_per_block;
-    if (c_end > total_chunks) c_end = total_chunks;
+    const float* A1 = a.A1 + (seg ? a.Cout : 0);
+    const float* A2 = a.A2 + (seg ? a.Cout : 0);
+    const float* A3 = a.A3 + (seg ? a.Cout : 0);
+    const float* in_scale = a.in_scale + (seg ? a.Cin : 0);
+    const float* in_shift = a.in_shift + (seg ? a.Cin : 0);
     const int chunks_per_b = a.P / CP;
     const int r0 = tid / F, c4 = tid % F;
     const int np = POOLED ? a.P / a.ns : 1;
@@ -77,20 +98,21 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
 #pragma unroll
     for (int i = 0; i < PA; ++i) {
         const int co = co0 + r0 + RPP * i;
-        ka1[i] = a.A1[co]; ka2[i] = a.A2[co]; ka3[i] = a.A3[co];
+        ka1[i] = A1[co]; ka2[i] = A2[co]; ka3[i] = A3[co];
     }
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
         const int ci = ci0 + r0 + RPP * i;
-        ksc[i] = a.in_scale[ci]; ksh[i] = a.in_shift[ci];
+        ksc[i] = in_scale[ci]; ksh[i] = in_shift[ci];
     }
 
     float4 rg[PA], ry[PA], rx[PB];
     float4 rw = make_float4(1.f, 1.f, 1.f, 1.f);
     int rk = 0;
-    auto load_chunk = [&](int ch) {
-        const long b = ch / chunks_per_b;
-        const int p = (ch - (int)b * chunks_per_b) * CP + 4 * c4;
+    auto load_chunk = [&](int chl) {
+        const long chg = col0 / CP + chl;            // chunk index in the whole column space
+        const long b = chg / chunks_per_b;
+        const int p = (int)(chg - b * chunks_per_b) * CP + 4 * c4;
         if (a.w) rw = *reinterpret_cast<const float4*>(&a.w[b * a.P + p]);
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
@@ -229,29 +251,31 @@ extern "C" long o3d_mlp_conv_wgrad2_scratch(int B, int Cin, int Cout, int P) {
 // with (in_scale,in_shift).  Cin, Cout multiples of 64, P multiple of 128.
 static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y, const float* A1, const float* A2,
                        const float* A3, const float* X, const float* in_scale, const float* in_shift, int B, int Cin,
-                       int Cout, int P, const float* w, const int32_t* meta, float* scratch, float* dW, void* stream);
+                       int Cout, int P, const float* w, const int32_t* meta, long start1, float* scratch, float* dW,
+                       void* stream);
 
 extern "C" int o3d_mlp_conv_wgrad2(const float* dN, const float* pk, int ns, const float* Y, const float* A1,
                                    const float* A2, const float* A3, const float* X, const float* in_scale,
                                    const float* in_shift, int B, int Cin, int Cout, int P, float* scratch,
                                    float* dW, void* stream) {
-    return wgrad2_impl(dN, pk, ns, Y, A1, A2, A3, X, in_scale, in_shift, B, Cin, Cout, P, nullptr, nullptr, scratch,
+    return wgrad2_impl(dN, pk, ns, Y, A1, A2, A3, X, in_scale, in_shift, B, Cin, Cout, P, nullptr, nullptr, 0, scratch,
                        dW, stream);
 }
 
 // compact layout (csrc/compact.hip): flat (C, ldp) operands, weights w (ldp), live columns meta[0]
 extern "C" int o3d_mlp_conv_wgrad2_c(const float* dN, const float* Y, const float* A1, const float* A2,
                                      const float* A3, const float* X, const float* in_scale, const float* in_shift,
-                                     int Cin, int Cout, long ldp, const float* w, const int32_t* meta,
+                                     int Cin, int Cout, long ldp, const float* w, const int32_t* meta, long start1,
                                      float* scratch, float* dW, void* stream) {
-    if (!dN || !w || !meta || ldp <= 0 || ldp > 0x7fffffff) return O3D_EINVAL;
-    return wgrad2_impl(dN, nullptr, 4, Y, A1, A2, A3, X, in_scale, in_shift, 1, Cin, Cout, (int)ldp, w, meta, scratch,
-                       dW, stream);
+    if (!dN || !w || !meta || ldp <= 0 || ldp > 0x7fffffff || start1 < 0 || start1 % 256 != 0) return O3D_EINVAL;
+    return wgrad2_impl(dN, nullptr, 4, Y, A1, A2, A3, X, in_scale, in_shift, 1, Cin, Cout, (int)ldp, w, meta, start1,
+                       scratch, dW, stream);
 }
 
 static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y, const float* A1, const float* A2,
                        const float* A3, const float* X, const float* in_scale, const float* in_shift, int B, int Cin,
-                       int Cout, int P, const float* w, const int32_t* meta, float* scratch, float* dW, void* stream) {
+                       int Cout, int P, const float* w, const int32_t* meta, long start1, float* scratch, float* dW,
+                       void* stream) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || P <= 0 || P % 128 || !Y || !A1 || !A2 || !A3 ||
         !X || !in_scale || !in_shift || !scratch || !dW || (!dN && (!pk || ns < 4 || ns % 4)))
         return O3D_EINVAL;
@@ -265,7 +289,7 @@ static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y,
     a.chunks_per_block = (a.total_chunks + nsl - 1) / nsl;
     a.nslices = nsl;
     a.part = scratch;
-    a.w = w; a.meta = meta;
+    a.w = w; a.meta = meta; a.start1 = start1;
     hipStream_t s = o3d_stream(stream);
     int rc;
     if (TM == 128 && TN == 128) rc = launch_wgrad2<128, 128>(a, s);

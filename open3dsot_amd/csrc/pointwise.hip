@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void gmax_fwd_kernel(const float* __restrict__
         if (ob > best || (ob == best && oq < bq)) { best = ob; bq = oq; yb = oy; }
     }
     if (live && lane == 0) {
-        const long o = (long)b * C + c;
+        const long o = (long)b * C + c;                 // (B, C): the pooled layout of compact.hip with npoint = 1
         out[o] = fmaxf(best, 0.f);
         if (argq) { argq[o] = b * N + bq; yarg[o] = yb; }
     }

@@ -44,16 +44,18 @@ capi.register("o3d_mlp_conv_dgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
 capi.register("o3d_mlp_conv_wgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp])
 
-capi.register("o3d_compact_build", [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
-capi.register("o3d_group_expand_c", [_vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, ctypes.c_long, _vp, _vp, _vp, _vp])
-capi.register("o3d_pool_fwd_c", [_vp, ctypes.c_long, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp])
-capi.register("o3d_pool_bwd_dense_c", [_vp, _vp, _vp, _i, _i, _i, _vp, ctypes.c_long, _vp, _vp])
-capi.register("o3d_group_reduce_c", [_vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp])
+_l = ctypes.c_long
+capi.register("o3d_compact_build", [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_group_expand_c", [_vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _l, _vp, _vp, _vp, _vp])
+capi.register("o3d_pool_fwd_c", [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
+capi.register("o3d_pool_bwd_c", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _l, _vp, _vp, _vp])
+capi.register("o3d_group_reduce_c", [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp,
+                                     _vp, _vp])
 capi.register("o3d_direct_tile", [ctypes.c_long, _i, _i])
-capi.register("o3d_mlp_conv_fwd_c", [_vp, _vp, _vp, _vp, _i, _i, ctypes.c_long, _vp, _vp, _i, _vp, _vp, _vp, _vp])
-capi.register("o3d_mlp_conv_dgrad_c", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, ctypes.c_long, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp,
+capi.register("o3d_mlp_conv_fwd_c", [_vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_dgrad_c", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp])
-capi.register("o3d_mlp_conv_wgrad2_c", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, ctypes.c_long, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_wgrad2_c", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _l, _vp, _vp, _vp])
 capi.register("o3d_bn_finalize_c", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp])
 capi.register("o3d_bn_bwd_finalize_c", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp])
 
@@ -106,7 +108,7 @@ def profile_step(step_fn, peak_tflops, repeats=3):
     agg = {}
     for name, flops, e0, e1 in _PROF["events"]:
         if isinstance(flops, tuple):       # (per-column FLOPs, meta): the live column count is data dependent
-            flops = flops[0] * float(flops[1][0].item())
+            flops = flops[0] * float(flops[1].view(-1, 4)[:, 0].sum().item())      # live columns of every segment
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += flops
@@ -410,198 +412,243 @@ def set_compact(enabled):
 class FusedGroupedMLPCompact(torch.autograd.Function):
     """Same contract as FusedGroupedMLP on the compact layout of csrc/compact.hip: one column per
     DISTINCT neighbour of a ball (ball_query pads with copies of the first hit; copies are folded into
-    a weight), flat (C, Pmax) activations with the live column count in device memory."""
+    a weight), flat (C, ldp) activations with the live column counts in device memory.
+
+    `nseg` independent sets of clouds ("segments": the template and the search branch of the backbone,
+    models/bat.py:89-90) go through the SAME weights in one set of launches with SEPARATE BatchNorm
+    statistics, applied in order like two consecutive module calls.
+    apply(cfg, nseg, xyz_0, new_xyz_0, feats_0, idx_0, [xyz_1, ...], W0,g0,b0, W1,...) -> pooled_0 [, pooled_1]"""
 
     @staticmethod
-    def forward(ctx, xyz, new_xyz, feats, idx, cfg, *params):
+    def forward(ctx, cfg, nseg, *args):
         lib = capi.load()
+        segs = [args[4 * s:4 * s + 4] for s in range(nseg)]
+        params = args[4 * nseg:]
         L = len(params) // 3
         Ws = [params[3 * l].detach().reshape(params[3 * l].shape[0], -1).contiguous() for l in range(L)]
         gammas = [params[3 * l + 1].detach().contiguous() for l in range(L)]
         betas = [params[3 * l + 2].detach().contiguous() for l in range(L)]
-        B, npoint, ns = idx.shape
-        P = npoint * ns
-        Pmax = B * P
-        dev = idx.device
         nxyz = cfg.nxyz
-        C = feats.shape[1] if feats is not None else 0
-        N = feats.shape[2] if feats is not None else xyz.shape[1]
-        Npad = -(-N // TILE) * TILE
-        Cin0, C0 = nxyz + C, Ws[0].shape[0]
-        nballs = B * npoint
-        st = _stream()
+        dev = segs[0][3].device
         f32, i32 = torch.float32, torch.int32
+        st = _stream()
+        B, _, ns = segs[0][3].shape
+        C = segs[0][2].shape[1] if segs[0][2] is not None else 0
+        Cin0, C0 = nxyz + C, Ws[0].shape[0]
+        npoints = [sg[3].shape[1] for sg in segs]
+        Ns = [sg[2].shape[2] if sg[2] is not None else sg[0].shape[1] for sg in segs]
+        Npads = [-(-n // TILE) * TILE for n in Ns]
+        Pmaxs = [B * npt * ns for npt in npoints]
+        starts = [0, Pmaxs[0]][:nseg]
+        start1 = starts[1] if nseg == 2 else 0
+        ldp = sum(Pmaxs)
+        pt_bases = [0, B * Npads[0]][:nseg]
+        ldz = sum(B * n for n in Npads)
+        nballs_s = [B * npt for npt in npoints]
+        ball_bases = [0, nballs_s[0]][:nseg]
+        nballs = sum(nballs_s)
         need_bwd = any(ctx.needs_input_grad)
-        # ---- compaction of the grouping indices
+        unit = cfg.inv_radius == 1.0          # normalize_xyz False in every tracker config: no scaling launches
+        # ---- compaction of the grouping indices (per segment, into joint arrays)
         ball_cnt = torch.empty((nballs,), device=dev, dtype=i32)
         ball_off = torch.empty((nballs + 1,), device=dev, dtype=i32)
-        gp = torch.empty((Pmax,), device=dev, dtype=i32)
-        cball = torch.empty((Pmax,), device=dev, dtype=i32)
-        cw = torch.empty((Pmax,), device=dev, dtype=f32)
-        meta = torch.empty((4,), device=dev, dtype=i32)
-        _call("compact_build", 0.0, lib.o3d_compact_build, idx.data_ptr(), B, npoint, ns, Npad, ball_cnt.data_ptr(),
-              ball_off.data_ptr(), gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), meta.data_ptr(), st)
-        # ---- layer 0 on the points: Z = W0 . [xyz * inv_radius ; feats], flat (C0, B*Npad)
-        X0n = (torch.zeros if Npad != N else torch.empty)((Cin0, B, Npad), device=dev, dtype=f32)
-        unit = cfg.inv_radius == 1.0          # normalize_xyz False in every tracker config: no scaling launches
+        gp = torch.empty((ldp,), device=dev, dtype=i32)
+        cball = torch.empty((ldp,), device=dev, dtype=i32)
+        cw = torch.empty((ldp,), device=dev, dtype=f32)
+        meta = torch.empty((nseg, 4), device=dev, dtype=i32)
+        for s_, sg in enumerate(segs):
+            _call("compact_build", 0.0, lib.o3d_compact_build, sg[3].data_ptr(), B, npoints[s_], ns, Npads[s_], starts[s_],
+                  pt_bases[s_], ball_bases[s_], nballs, ball_cnt[ball_bases[s_]:].data_ptr(),
+                  ball_off[ball_bases[s_]:].data_ptr(), gp.data_ptr(), cball.data_ptr(), cw.data_ptr(),
+                  meta[s_].data_ptr(), st)
+        # ---- layer 0 on the points: Z = W0 . [xyz * inv_radius ; feats], flat (C0, ldz)
+        padded = any(n != npd for n, npd in zip(Ns, Npads))
+        X0n = (torch.zeros if padded else torch.empty)((Cin0, ldz), device=dev, dtype=f32)
+        centers = torch.empty((nballs + 1, 3), device=dev, dtype=f32) if nxyz else None
+        for s_, (xyz, new_xyz, feats, _) in enumerate(segs):
+            view = X0n[:, pt_bases[s_]:pt_bases[s_] + B * Npads[s_]].view(Cin0, B, Npads[s_])
+            if nxyz:
+                view[:3, :, :Ns[s_]] = xyz.detach().permute(2, 0, 1) if unit else xyz.detach().permute(2, 0, 1) * cfg.inv_radius
+                cen = new_xyz.detach().reshape(nballs_s[s_], 3)
+                centers[ball_bases[s_]:ball_bases[s_] + nballs_s[s_]] = cen if unit else cen * cfg.inv_radius
+            if C:
+                view[nxyz:, :, :Ns[s_]] = feats.detach().permute(1, 0, 2)
         if nxyz:
-            X0n[:3, :, :N] = xyz.detach().permute(2, 0, 1) if unit else xyz.detach().permute(2, 0, 1) * cfg.inv_radius
-        if C:
-            X0n[nxyz:, :, :N] = feats.detach().permute(1, 0, 2)
-        Z = torch.empty((C0, B * Npad), device=dev, dtype=f32)
-        _call("conv_fwd_points", 2.0 * Cin0 * C0 * B * Npad, lib.o3d_mlp_conv_fwd, X0n.data_ptr(), Ws[0].data_ptr(),
-              None, None, 1, Cin0, C0, B * Npad, Z.data_ptr(), None, None, st)
-        centers = None
-        if nxyz:
-            centers = torch.empty((nballs + 1, 3), device=dev, dtype=f32)
-            centers[:nballs] = new_xyz.detach().reshape(nballs, 3) if unit else \
-                new_xyz.detach().reshape(nballs, 3) * cfg.inv_radius
             centers[nballs:].zero_()           # dummy ball of the padding columns
-        count = float(B) * P
+        Z = torch.empty((C0, ldz), device=dev, dtype=f32)
+        _call("conv_fwd_points", 2.0 * Cin0 * C0 * ldz, lib.o3d_mlp_conv_fwd, X0n.data_ptr(), Ws[0].data_ptr(),
+              None, None, 1, Cin0, C0, ldz, Z.data_ptr(), None, None, st)
+        counts = [float(pm) for pm in Pmaxs]          # BatchNorm counts every slot (copies included)
         Ys, means, invstds, scales, shifts = [], [], [], [], []
         for l in range(L):
             Cout, Cin = Ws[l].shape
             bn = cfg.bns[l]
-            tile = ETILE if l == 0 else _direct_tile(lib, Pmax, Cout)
-            Y = torch.empty((Cout, Pmax), device=dev, dtype=f32)
-            part = torch.empty((Pmax // tile, 2, Cout), device=dev, dtype=f32) if cfg.training else None
-            stat_c = bn.running_mean if cfg.training else None
-            if l == 0:
-                _call("group_expand", 0.0, lib.o3d_group_expand_c, Z.data_ptr(), B * Npad, gp.data_ptr(), cball.data_ptr(),
-                      cw.data_ptr(), _ptr(centers), Ws[0].data_ptr(), Cin0, C0, meta.data_ptr(), Pmax, Y.data_ptr(),
-                      _ptr(part), _ptr(stat_c), st)
-            else:
-                _call("conv_fwd", (2.0 * Cin * Cout, meta), lib.o3d_mlp_conv_fwd_c, Ys[-1].data_ptr(), Ws[l].data_ptr(), scales[-1].data_ptr(),
-                      shifts[-1].data_ptr(), Cin, Cout, Pmax, cw.data_ptr(), meta.data_ptr(), tile, Y.data_ptr(),
-                      _ptr(part), _ptr(stat_c), st)
-            vec = torch.empty((4, Cout), device=dev, dtype=f32)
+            tile = ETILE if l == 0 else _direct_tile(lib, ldp, Cout)
+            Y = torch.empty((Cout, ldp), device=dev, dtype=f32)
+            part = torch.empty((ldp // tile, 2, Cout), device=dev, dtype=f32) if cfg.training else None
+            # shift of the second moment: the running mean before this call, for every segment
+            statc = None
             if cfg.training:
-                _call("bn_finalize", 0.0, lib.o3d_bn_finalize_c, part.data_ptr(), Pmax // tile, Cout, count,
-                      stat_c.data_ptr(), gammas[l].data_ptr(), betas[l].data_ptr(), bn.running_mean.data_ptr(),
-                      bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps), vec[0].data_ptr(), vec[1].data_ptr(),
-                      vec[2].data_ptr(), vec[3].data_ptr(), meta.data_ptr(), tile, st)
+                statc = bn.running_mean.detach().unsqueeze(0) if nseg == 1 else bn.running_mean.detach().repeat(nseg, 1)
+            if l == 0:
+                _call("group_expand", 0.0, lib.o3d_group_expand_c, Z.data_ptr(), ldz, gp.data_ptr(), cball.data_ptr(),
+                      cw.data_ptr(), _ptr(centers), Ws[0].data_ptr(), Cin0, C0, meta.data_ptr(), start1, ldp, Y.data_ptr(),
+                      _ptr(part), _ptr(statc), st)
+            else:
+                _call("conv_fwd", (2.0 * Cin * Cout, meta), lib.o3d_mlp_conv_fwd_c, Ys[-1].data_ptr(), Ws[l].data_ptr(),
+                      scales[-1].data_ptr(), shifts[-1].data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1,
+                      tile, Y.data_ptr(), _ptr(part), _ptr(statc), st)
+            vec = torch.empty((4, nseg, Cout), device=dev, dtype=f32)      # mean, invstd, scale, shift per segment
+            if cfg.training:
+                for s_ in range(nseg):       # in order: the running statistics see segment 0's update first
+                    _call("bn_finalize", 0.0, lib.o3d_bn_finalize_c, part[starts[s_] // tile:].data_ptr(), Pmaxs[s_] // tile,
+                          Cout, counts[s_], statc[s_].data_ptr(), gammas[l].data_ptr(), betas[l].data_ptr(),
+                          bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
+                          vec[0, s_].data_ptr(), vec[1, s_].data_ptr(), vec[2, s_].data_ptr(), vec[3, s_].data_ptr(),
+                          meta[s_].data_ptr(), tile, st)
             else:
                 vec[0].copy_(bn.running_mean)
                 vec[1].copy_(torch.rsqrt(bn.running_var + bn.eps))
-                vec[2].copy_(gammas[l] * vec[1])
-                vec[3].copy_(betas[l] - vec[0] * vec[2])
+                vec[2].copy_(gammas[l] * vec[1, 0])
+                vec[3].copy_(betas[l] - vec[0, 0] * vec[2, 0])
             Ys.append(Y)
             means.append(vec[0]); invstds.append(vec[1]); scales.append(vec[2]); shifts.append(vec[3])
         if cfg.training:
-            torch._foreach_add_([bn.num_batches_tracked for bn in cfg.bns], 1)     # one launch for all layers
+            torch._foreach_add_([bn.num_batches_tracked for bn in cfg.bns], nseg)     # one launch for all layers
         Cl = Ws[-1].shape[0]
-        out = torch.empty((B, Cl, npoint), device=dev, dtype=f32)
-        argq = torch.empty((B, Cl, npoint), device=dev, dtype=i32) if need_bwd else None
-        yarg = torch.empty((B, Cl, npoint), device=dev, dtype=f32) if need_bwd else None
-        _call("pool_fwd", 0.0, lib.o3d_pool_fwd_c, Ys[-1].data_ptr(), Pmax, scales[-1].data_ptr(), shifts[-1].data_ptr(),
-              ball_off.data_ptr(), B, Cl, npoint, out.data_ptr(), _ptr(argq), _ptr(yarg), st)
+        # pooled tensors: one (B, Cl, npoint_s) block per segment in one buffer
+        out = torch.empty((nballs * Cl,), device=dev, dtype=f32)
+        argq = torch.empty((nballs * Cl,), device=dev, dtype=i32) if need_bwd else None
+        yarg = torch.empty((nballs * Cl,), device=dev, dtype=f32) if need_bwd else None
+        np1 = npoints[1] if nseg == 2 else 0
+        _call("pool_fwd", 0.0, lib.o3d_pool_fwd_c, Ys[-1].data_ptr(), ldp, scales[-1].data_ptr(), shifts[-1].data_ptr(),
+              ball_off.data_ptr(), ball_cnt.data_ptr(), B, Cl, npoints[0], np1, out.data_ptr(), _ptr(argq), _ptr(yarg), st)
         if need_bwd:
             ctx.cfg = cfg
-            ctx.dims = (B, N, C, npoint, ns, L)
-            ctx.saved = (X0n, centers, ball_off, gp, cball, cw, meta, Ws, gammas, Ys, means, invstds, scales, shifts,
-                         out.detach(), argq, yarg)
-        return out
+            ctx.geom = (B, ns, C, nseg, Ns, Npads, npoints, Pmaxs, starts, pt_bases, ball_bases, nballs_s)
+            ctx.saved = (X0n, centers, ball_off, ball_cnt, gp, cball, cw, meta, Ws, gammas, Ys, means, invstds, scales,
+                         shifts, out.detach(), argq, yarg)
+        outs = tuple(out[ball_bases[s_] * Cl:(ball_bases[s_] + nballs_s[s_]) * Cl].view(B, Cl, npoints[s_])
+                     for s_ in range(nseg))
+        return outs if nseg > 1 else outs[0]
 
     @staticmethod
-    def backward(ctx, dOut):
+    def backward(ctx, *dOuts):
         lib = capi.load()
         cfg = ctx.cfg
-        B, N, C, npoint, ns, L = ctx.dims
-        (X0n, centers, ball_off, gp, cball, cw, meta, Ws, gammas, Ys, means, invstds, scales, shifts, out, argq,
-         yarg) = ctx.saved
-        Npad = X0n.shape[2]
-        P = npoint * ns
-        Pmax = B * P
-        nballs = B * npoint
-        dev = dOut.device
+        B, ns, C, nseg, Ns, Npads, npoints, Pmaxs, starts, pt_bases, ball_bases, nballs_s = ctx.geom
+        (X0n, centers, ball_off, ball_cnt, gp, cball, cw, meta, Ws, gammas, Ys, means, invstds, scales, shifts, out,
+         argq, yarg) = ctx.saved
+        L = len(Ws)
+        dev = out.device
         st = _stream()
         f32 = torch.float32
-        dOut = dOut.contiguous()
         nxyz = cfg.nxyz
-        count = float(B) * P
+        ldp, ldz, nballs = sum(Pmaxs), X0n.shape[1], sum(nballs_s)
+        start1 = starts[1] if nseg == 2 else 0
+        counts = [float(pm) for pm in Pmaxs]
         grads = [None] * (3 * L)
-        want_xyz = nxyz > 0 and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
-        want_feats = C > 0 and ctx.needs_input_grad[2]
+        needs = ctx.needs_input_grad[2:2 + 4 * nseg]
+        want_xyz = nxyz > 0 and any(needs[4 * s_] or needs[4 * s_ + 1] for s_ in range(nseg))
+        want_feats = C > 0 and any(needs[4 * s_ + 2] for s_ in range(nseg))
         Cl = Ws[-1].shape[0]
-        part = torch.empty((B, 2, Cl), device=dev, dtype=f32)
-        _call("pool_bwd_partials", 0.0, lib.o3d_pool_bwd_partials, dOut.data_ptr(), out.data_ptr(), yarg.data_ptr(),
-              means[-1].data_ptr(), B, Cl, npoint, part.data_ptr(), None, None, st)
-        dN = torch.empty((Cl, Pmax), device=dev, dtype=f32)          # dense class-sum gradient of the pooled layer
-        _call("pool_bwd_dense", 0.0, lib.o3d_pool_bwd_dense_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), B, Cl,
-              npoint, meta.data_ptr(), Pmax, dN.data_ptr(), st)
-        dfeats = dxyz = dnew = None
+        # pooled-layer gradient: the segments' (B, Cl, npoint) blocks back to back, like `out`
+        if nseg == 1:
+            dOut = dOuts[0].contiguous()
+        else:
+            dOut = torch.empty((nballs * Cl,), device=dev, dtype=f32)
+            for s_ in range(nseg):
+                dst = dOut[ball_bases[s_] * Cl:(ball_bases[s_] + nballs_s[s_]) * Cl].view(B, Cl, npoints[s_])
+                if dOuts[s_] is None:
+                    dst.zero_()
+                else:
+                    dst.copy_(dOuts[s_])
+        part = torch.empty((nseg, 2, Cl), device=dev, dtype=f32)
+        dN = torch.empty((Cl, ldp), device=dev, dtype=f32)          # dense class-sum gradient of the pooled layer
+        np1 = npoints[1] if nseg == 2 else 0
+        _call("pool_bwd", 0.0, lib.o3d_pool_bwd_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
+              means[-1].data_ptr(), B, Cl, npoints[0], np1, meta.data_ptr(), start1, ldp, dN.data_ptr(), part.data_ptr(),
+              st)
+        dtile = 0
         main, side = torch.cuda.current_stream(), _side_stream(dev)
         keep = []        # buffers the side stream still reads: must outlive the join at the end
+        seg_grads = [[None, None, None] for _ in range(nseg)]
         for l in range(L - 1, -1, -1):
             Cout, Cin = Ws[l].shape
-            coef = torch.empty((5, Cout), device=dev, dtype=f32)  # dgamma dbeta A1 A2 A3
-            if l == L - 1:
-                _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize, part.data_ptr(), B, Cout, count, gammas[l].data_ptr(),
-                      means[l].data_ptr(), invstds[l].data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
-                      coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr(), None, st)
-            else:
-                _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize_c, part.data_ptr(), Pmax // dtile, Cout, count,
-                      gammas[l].data_ptr(), means[l].data_ptr(), invstds[l].data_ptr(), coef[0].data_ptr(),
-                      coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr(), meta.data_ptr(),
-                      dtile, st)
+            coef = torch.empty((5, nseg, Cout), device=dev, dtype=f32)  # dgamma dbeta A1 A2 A3, per segment
+            for s_ in range(nseg):
+                if l == L - 1:
+                    _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize, part[s_].data_ptr(), 1, Cout, counts[s_],
+                          gammas[l].data_ptr(), means[l][s_].data_ptr(), invstds[l][s_].data_ptr(), coef[0, s_].data_ptr(),
+                          coef[1, s_].data_ptr(), coef[2, s_].data_ptr(), coef[3, s_].data_ptr(), coef[4, s_].data_ptr(),
+                          None, st)
+                else:
+                    _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize_c, part[starts[s_] // dtile:].data_ptr(),
+                          Pmaxs[s_] // dtile, Cout, counts[s_], gammas[l].data_ptr(), means[l][s_].data_ptr(),
+                          invstds[l][s_].data_ptr(), coef[0, s_].data_ptr(), coef[1, s_].data_ptr(), coef[2, s_].data_ptr(),
+                          coef[3, s_].data_ptr(), coef[4, s_].data_ptr(), meta[s_].data_ptr(), dtile, st)
             if not cfg.training:
                 coef[3].zero_()
                 coef[4].zero_()
-            grads[3 * l + 1], grads[3 * l + 2] = coef[0], coef[1]
+            if nseg == 1:
+                grads[3 * l + 1], grads[3 * l + 2] = coef[0, 0], coef[1, 0]
+            else:        # the same affine parameters served both segments
+                grads[3 * l + 1], grads[3 * l + 2] = coef[0].sum(0), coef[1].sum(0)
             A = (coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr())
             if l == 0:
-                S = torch.empty((Cout, B * Npad), device=dev, dtype=f32)
+                S = torch.empty((Cout, ldz), device=dev, dtype=f32)
                 T = torch.empty((Cout, nballs), device=dev, dtype=f32) if nxyz else None
-                _call("group_reduce", 0.0, lib.o3d_group_reduce_c, dN.data_ptr(), Ys[0].data_ptr(), Pmax, A[0], A[1], A[2],
-                      gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), ball_off.data_ptr(), B, npoint, Npad, Cout,
-                      S.data_ptr(), _ptr(T), st)
+                _call("group_reduce", 0.0, lib.o3d_group_reduce_c, dN.data_ptr(), Ys[0].data_ptr(), ldp, A[0], A[1], A[2],
+                      gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), ball_off.data_ptr(), ball_cnt.data_ptr(), B, nseg,
+                      npoints[0], Npads[0], npoints[-1], Npads[-1], Cout, S.data_ptr(), _ptr(T), st)
                 one, zero = _const_vec(dev, Cout, 1.0), _const_vec(dev, Cout, 0.0)
-                PN = B * Npad
                 tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
-                total_chunks = PN // 32
+                total_chunks = ldz // 32
                 nsl = max(1, min(total_chunks // 4 if total_chunks >= 4 else 1, 768 // tiles))
                 wpart = torch.empty((nsl + 16, Cout, Cin), device=dev, dtype=f32)
                 dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
                 keep += [S, T, wpart, one, zero]
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    _call("conv_wgrad_points", 2.0 * Cin * Cout * PN, lib.o3d_mlp_conv_wgrad, S.data_ptr(), None, None,
+                    _call("conv_wgrad_points", 2.0 * Cin * Cout * ldz, lib.o3d_mlp_conv_wgrad, S.data_ptr(), None, None,
                           None, 4, S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(), None,
-                          None, None, None, None, None, 0, 0, 0, 1.0, 1, Cin, Cout, PN, nsl, wpart.data_ptr(),
+                          None, None, None, None, None, 0, 0, 0, 1.0, 1, Cin, Cout, ldz, nsl, wpart.data_ptr(),
                           dW.data_ptr(), side.cuda_stream)
                     if nxyz:      # the centre term of grouped_xyz = xyz[idx] - new_xyz
                         dW[:, :3] -= T @ centers[:nballs]
                 grads[0] = dW
                 if want_xyz or want_feats:
-                    dX = torch.empty((Cin, B, Npad), device=dev, dtype=f32)
-                    _call("conv_dgrad_points", 2.0 * Cin * Cout * PN, lib.o3d_mlp_conv_dgrad_plain, S.data_ptr(),
+                    dX = torch.empty((Cin, ldz), device=dev, dtype=f32)
+                    _call("conv_dgrad_points", 2.0 * Cin * Cout * ldz, lib.o3d_mlp_conv_dgrad_plain, S.data_ptr(),
                           S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), Ws[0].data_ptr(), 1, Cin, Cout,
-                          PN, dX.data_ptr(), st)
-                    if want_feats:
-                        dfeats = dX[nxyz:, :, :N].permute(1, 0, 2)
-                    if want_xyz:
-                        dxyz = dX[:3, :, :N].permute(1, 2, 0)
-                        dnew = ((-cfg.inv_radius) * Ws[0][:, :3]).t() @ T      # (3, nballs); scaling on the 3xC0 side
-                        dnew = dnew.view(3, B, npoint).permute(1, 2, 0)
-                        if cfg.inv_radius != 1.0:
-                            dxyz = dxyz * cfg.inv_radius
+                          ldz, dX.data_ptr(), st)
+                    dnew_all = ((-cfg.inv_radius) * Ws[0][:, :3]).t() @ T if want_xyz else None       # (3, balls)
+                    for s_ in range(nseg):
+                        view = dX[:, pt_bases[s_]:pt_bases[s_] + B * Npads[s_]].view(Cin, B, Npads[s_])
+                        if want_feats:
+                            seg_grads[s_][2] = view[nxyz:, :, :Ns[s_]].permute(1, 0, 2)
+                        if want_xyz:
+                            dxyz = view[:3, :, :Ns[s_]].permute(1, 2, 0)
+                            seg_grads[s_][0] = dxyz if cfg.inv_radius == 1.0 else dxyz * cfg.inv_radius
+                            seg_grads[s_][1] = dnew_all[:, ball_bases[s_]:ball_bases[s_] + nballs_s[s_]].reshape(
+                                3, B, npoints[s_]).permute(1, 2, 0)
                 continue
             flops = (2.0 * Cin * Cout, meta)      # executed FLOPs = per live column (count read back when profiling)
             dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
-            wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, Pmax),), device=dev, dtype=f32)
+            wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, ldp),), device=dev, dtype=f32)
             keep += [dN, wpart, coef]
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
-                      Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Cin, Cout, Pmax,
-                      cw.data_ptr(), meta.data_ptr(), wpart.data_ptr(), dW.data_ptr(), side.cuda_stream)
+                      Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Cin, Cout, ldp,
+                      cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(), dW.data_ptr(), side.cuda_stream)
             grads[3 * l] = dW
             Wt = Ws[l].t().contiguous()
-            dNp = torch.empty((Cin, Pmax), device=dev, dtype=f32)
-            dtile = _direct_tile(lib, Pmax, Cin)
-            part = torch.empty((Pmax // dtile, 2, Cin), device=dev, dtype=f32)
+            dNp = torch.empty((Cin, ldp), device=dev, dtype=f32)
+            dtile = _direct_tile(lib, ldp, Cin)
+            part = torch.empty((ldp // dtile, 2, Cin), device=dev, dtype=f32)
             _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
-                  Wt.data_ptr(), Cin, Cout, Pmax, cw.data_ptr(), meta.data_ptr(), dtile, Ys[l - 1].data_ptr(),
+                  Wt.data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1, dtile, Ys[l - 1].data_ptr(),
                   scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),
                   part.data_ptr(), st)
             dN = dNp
@@ -611,8 +658,11 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         for l in range(L):
             shape = (Ws[l].shape[0], Ws[l].shape[1], 1, 1)
             gw += [grads[3 * l].view(shape), grads[3 * l + 1], grads[3 * l + 2]]
-        return (dxyz if ctx.needs_input_grad[0] else None, dnew if ctx.needs_input_grad[1] else None,
-                dfeats if ctx.needs_input_grad[2] else None, None, None, *gw)
+        gin = []
+        for s_ in range(nseg):
+            gin += [seg_grads[s_][0] if needs[4 * s_] else None, seg_grads[s_][1] if needs[4 * s_ + 1] else None,
+                    seg_grads[s_][2] if needs[4 * s_ + 2] else None, None]
+        return (None, None, *gin, *gw)
 
 
 def _compact_ok(layers, npoint, ns, B):
@@ -634,7 +684,7 @@ def _run(mlp, xyz, new_xyz, feats, idx, nxyz, inv_radius):
         params += [conv.weight, bn.weight, bn.bias]
     B, npoint, ns = idx.shape
     if _COMPACT["on"] and _compact_ok(layers, npoint, ns, B):
-        return FusedGroupedMLPCompact.apply(xyz, new_xyz, feats, idx, cfg, *params)
+        return FusedGroupedMLPCompact.apply(cfg, 1, xyz, new_xyz, feats, idx, *params)
     return FusedGroupedMLP.apply(xyz, new_xyz, feats, idx, cfg, *params)
 
 
@@ -646,6 +696,32 @@ def sa_group_mlp_pool(grouper, mlp, xyz, new_xyz, features):
         return _composed(grouper, mlp, xyz, new_xyz, features, idx)
     inv_r = 1.0 / grouper.radius if grouper.normalize_xyz else 1.0
     return _run(mlp, xyz, new_xyz, features, idx, 3, inv_r)
+
+
+def sa_group_mlp_pool_pair(grouper, mlp, a, b):
+    """Two independent sets of clouds (a, b = (xyz, new_xyz, features)) through the same grouper and
+    SharedMLP in ONE set of launches, numerically two consecutive calls (a first): separate BatchNorm
+    batch statistics, running statistics updated twice.  Returns (pooled_a, pooled_b), or None when the
+    joint layout does not apply (the caller then makes the two calls)."""
+    if not _COMPACT["on"] or a[0].shape[0] != b[0].shape[0] or (a[2] is None) != (b[2] is None):
+        return None
+    if a[2] is not None and a[2].shape[1] != b[2].shape[1]:
+        return None
+    idx_a, idx_b = grouper.query(a[0], a[1]), grouper.query(b[0], b[1])
+    B, np_a, ns = idx_a.shape
+    np_b = idx_b.shape[1]
+    layers = _layers(mlp)
+    if not (_shape_ok(np_a, ns) and _shape_ok(np_b, ns) and _compact_ok(layers, np_a, ns, B) and
+            _compact_ok(layers, np_b, ns, B) and (B * np_a * ns) % 256 == 0):
+        return None
+    cfg = _Cfg()
+    cfg.nxyz, cfg.training = 3, bool(mlp.training)
+    cfg.inv_radius = float(1.0 / grouper.radius if grouper.normalize_xyz else 1.0)
+    cfg.bns = [bn for _, bn in layers]
+    params = []
+    for conv, bn in layers:
+        params += [conv.weight, bn.weight, bn.bias]
+    return FusedGroupedMLPCompact.apply(cfg, 2, a[0], a[1], a[2], idx_a, b[0], b[1], b[2], idx_b, *params)
 
 
 def group_mlp_pool(mlp, bundle, idx):

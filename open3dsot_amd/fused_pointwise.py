@@ -121,13 +121,11 @@ class FusedPointwiseChain(torch.autograd.Function):
             nparts = ntiles
         else:
             dOut = dOut.contiguous()
-            part = torch.empty((B, 2, Cl), device=dev, dtype=f32)
-            _call("pool_bwd_partials", 0.0, lib.o3d_pool_bwd_partials, dOut.data_ptr(), out.data_ptr(), yarg.data_ptr(),
-                  means[-1].data_ptr(), B, Cl, 1, part.data_ptr(), None, None, st)
+            part = torch.empty((1, 2, Cl), device=dev, dtype=f32)
             meta = _meta_full(dev, P, B)       # every column is live: one "ball" of N columns per cloud
-            _call("pool_bwd_dense", 0.0, lib.o3d_pool_bwd_dense_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), B, Cl,
-                  1, meta.data_ptr(), P, dN.data_ptr(), st)
-            nparts = B
+            _call("pool_bwd", 0.0, lib.o3d_pool_bwd_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
+                  means[-1].data_ptr(), B, Cl, 1, 0, meta.data_ptr(), 0, P, dN.data_ptr(), part.data_ptr(), st)
+            nparts = 1
         grads = [None] * (4 * L)
         dx = None
         for l in range(L - 1, -1, -1):

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from . import nn_blocks as pt_utils
 from . import ops as pointnet2_utils
 
-_FUSED = {"enabled": True}
+_FUSED = {"enabled": True, "paired": True}
 
 
 def set_fused(enabled):
@@ -32,6 +32,11 @@ def set_fused(enabled):
 
 def fused_enabled():
     return _FUSED["enabled"]
+
+
+def set_paired(enabled):
+    """Run the template and the search branch of a shared backbone as one set of launches (default on)."""
+    _FUSED["paired"] = bool(enabled)
 
 
 class _PointnetSAModuleBase(nn.Module):
@@ -68,6 +73,34 @@ class _PointnetSAModuleBase(nn.Module):
         if return_idx:
             return new_xyz, feats, sample_idxs
         return new_xyz, feats
+
+
+    def _sample(self, xyz, npoint):
+        if self.use_fps:
+            sample_idxs = pointnet2_utils.furthest_point_sample(xyz, npoint)
+            new_xyz = pointnet2_utils.gather_operation(
+                xyz.transpose(1, 2).contiguous(), sample_idxs).transpose(1, 2).contiguous()
+        else:
+            sample_idxs = torch.arange(npoint, dtype=torch.int32, device=xyz.device).repeat(xyz.size(0), 1)
+            new_xyz = xyz[:, :npoint, :].contiguous()
+        return sample_idxs, new_xyz
+
+    def forward_pair(self, xyz_a, features_a, npoint_a, xyz_b, features_b, npoint_b):
+        """forward(xyz_a, ...) followed by forward(xyz_b, ...) -- the template and the search cloud through the
+        shared module (models/bat.py:89-90) -- as one set of launches on the fused path: the weights are
+        read once, the BatchNorm batch statistics stay separate and the running statistics see a's update
+        before b's.  Returns ((new_xyz, feats, sample_idxs)_a, (...)_b)."""
+        if (_FUSED["enabled"] and _FUSED["paired"] and xyz_a.is_cuda and len(self.groupers) == 1):
+            from . import fused
+            if fused.supports(self.groupers[0], self.mlps[0], features_a):
+                idx_a, new_a = self._sample(xyz_a, npoint_a)
+                idx_b, new_b = self._sample(xyz_b, npoint_b)
+                outs = fused.sa_group_mlp_pool_pair(self.groupers[0], self.mlps[0], (xyz_a, new_a, features_a),
+                                                    (xyz_b, new_b, features_b))
+                if outs is not None:
+                    self.npoint = npoint_b
+                    return (new_a, outs[0], idx_a), (new_b, outs[1], idx_b)
+        return self.forward(xyz_a, features_a, npoint_a, True), self.forward(xyz_b, features_b, npoint_b, True)
 
 
 class PointnetSAModuleMSG(_PointnetSAModuleBase):

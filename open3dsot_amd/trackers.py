@@ -99,8 +99,8 @@ class P2B(MatchingBaseModel):
     def forward(self, input_dict):
         template, search = input_dict["template_points"], input_dict["search_points"]
         M, N = template.shape[1], search.shape[1]
-        template_xyz, template_feature, _ = self.backbone(template, [M // 2, M // 4, M // 8])
-        search_xyz, search_feature, sample_idxs = self.backbone(search, [N // 2, N // 4, N // 8])
+        (template_xyz, template_feature, _), (search_xyz, search_feature, sample_idxs) = self.backbone.forward_pair(
+            template, [M // 2, M // 4, M // 8], search, [N // 2, N // 4, N // 8])
         template_feature = pt_utils.pointwise_conv1d(self.conv_final, template_feature)
         search_feature = pt_utils.pointwise_conv1d(self.conv_final, search_feature)
         fusion = self.xcorr(template_feature, search_feature, template_xyz)
@@ -149,8 +149,8 @@ class BAT(MatchingBaseModel):
         template, search = input_dict["template_points"], input_dict["search_points"]
         template_bc = input_dict["points2cc_dist_t"]
         M, N = template.shape[1], search.shape[1]
-        template_xyz, template_feature, sample_idxs_t = self.backbone(template, [M // 2, M // 4, M // 8])
-        search_xyz, search_feature, sample_idxs = self.backbone(search, [N // 2, N // 4, N // 8])
+        (template_xyz, template_feature, sample_idxs_t), (search_xyz, search_feature, sample_idxs) = \
+            self.backbone.forward_pair(template, [M // 2, M // 4, M // 8], search, [N // 2, N // 4, N // 8])
         template_feature = pt_utils.pointwise_conv1d(self.conv_final, template_feature)
         search_feature = pt_utils.pointwise_conv1d(self.conv_final, search_feature)
         pred_search_bc = self.mlp_bc(torch.cat([search_xyz.transpose(1, 2), search_feature], dim=1))

@@ -199,6 +199,85 @@ def test_fused_sa_matches_composed(kind, train):
                 assert int(b1) == 1, n1
 
 
+@pytest.mark.parametrize("kind", ["sa1", "sa2", "sa3"])
+@pytest.mark.parametrize("train", [True, False])
+def test_paired_segments_match_two_calls(kind, train):
+    """The template and the search cloud through one shared SA module in ONE set of launches
+    (fused.sa_group_mlp_pool_pair) = two consecutive calls, template first: separate batch statistics,
+    running statistics updated in order, parameter gradients summed (models/bat.py:89-90)."""
+    import copy
+    from open3dsot_amd import fused
+    grouper, mlp, xyz_s, new_s, feats_s = make_case(kind, train=train)
+    N, npoint = xyz_s.shape[1], new_s.shape[1]
+    xyz_t = (xyz_s[:, :N // 2, :] * 0.9 + 0.05).contiguous()          # the template: half the points
+    new_t = xyz_t[:, :npoint // 2, :].contiguous()
+    feats_t = torch.randn(feats_s.shape[0], feats_s.shape[1], N // 2, device="cuda") if feats_s is not None else None
+    mlp_ref = copy.deepcopy(mlp)
+    want_xyz = kind == "sa2"
+    segs, refs, outs64 = [], [], []
+    for xyz, new_xyz, feats in ((xyz_t, new_t, feats_t), (xyz_s, new_s, feats_s)):
+        segs.append([t.clone().requires_grad_(True) if t is not None and (t is feats or want_xyz) else t
+                     for t in (xyz, new_xyz, feats)])
+        idx = grouper.query(xyz, new_xyz)
+        o64, l64, b64 = shadow64(mlp_ref, xyz, new_xyz, feats, idx, train)
+        outs64.append(o64)
+        refs.append(l64)
+        if train:      # the second call starts from the running statistics the first one left
+            with torch.no_grad():
+                for n1, b1 in mlp_ref.named_buffers():
+                    if n1 in b64:
+                        b1.copy_(b64[n1])
+    outs = fused.sa_group_mlp_pool_pair(grouper, mlp, tuple(segs[0]), tuple(segs[1]))
+    assert outs is not None and len(outs) == 2
+    for o, o64 in zip(outs, outs64):
+        assert o.shape == o64.shape and o.is_contiguous()
+        assert rel(o, o64) < 2e-5, ("forward vs fp64 shadow", rel(o, o64))
+    if train:
+        for n1, b1 in mlp.named_buffers():
+            if b1.dtype.is_floating_point:
+                assert rel(b1, b64[n1]) < 1e-5, n1
+            else:
+                assert int(b1) == 2, n1
+    if not train and not any(t is not None and t.requires_grad for sg in segs for t in sg):
+        return
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    gos = [torch.randn(o.shape, device="cuda", generator=gen) for o in outs]
+    torch.autograd.backward(list(outs), gos)
+    for o64, go in zip(outs64, gos):
+        o64.backward(go.double())
+    tol = 5e-4 if train else 6e-3      # eval: nothing damps an argmax flip, and two clouds contribute flips
+    for n1, p1 in mlp.named_parameters():
+        assert_grad_close(p1.grad, refs[0][n1].grad + refs[1][n1].grad, n1, l2tol=tol, maxtol=1e-2 if train else 2e-2)
+    for sg, l64 in zip(segs, refs):
+        for nm, a in zip(("xyz", "new_xyz", "feats"), sg):
+            if a is not None and a.requires_grad:
+                assert_grad_close(a.grad, l64[nm].grad, nm, l2tol=tol, maxtol=1e-2 if train else 4e-2)
+
+
+def test_paired_backbone_matches_sequential():
+    """Pointnet_Backbone.forward_pair = the two backbone calls of the trackers, outputs and sampling indices"""
+    import copy
+    from open3dsot_amd import backbone, sa_modules, synth
+    torch.manual_seed(0)
+    net = backbone.Pointnet_Backbone(use_fps=True, normalize_xyz=False).cuda().train()
+    ref = copy.deepcopy(net)
+    b = synth.to_torch(synth.make_batch(77, 4, 512, 1024), torch.device("cuda"))
+    t, s = b["template_points"], b["search_points"]
+    ra, rb = net.forward_pair(t, [256, 128, 64], s, [512, 256, 128])
+    sa_modules.set_paired(False)
+    try:
+        qa, qb = ref.forward_pair(t, [256, 128, 64], s, [512, 256, 128])
+    finally:
+        sa_modules.set_paired(True)
+    for x, y in zip(ra + rb, qa + qb):
+        if x.dtype.is_floating_point:
+            assert rel(x, y) < 1e-4, rel(x, y)
+        else:
+            assert torch.equal(x, y)
+    for (n1, b1), (_, b2) in zip(net.named_buffers(), ref.named_buffers()):
+        assert rel(b1.float(), b2.float()) < 1e-5, n1
+
+
 def test_slotwise_fallback_path_matches_fp64():
     """the slot-per-neighbour layout (used when the compact layout does not apply: nsample > 64 or more than
     65536 balls) stays correct: same SA block, compact layout switched off"""
@@ -354,12 +433,14 @@ def test_compact_build(lib, ns):
     ball_cnt, ball_off = torch.empty(nballs, **i32), torch.empty(nballs + 1, **i32)
     gp, cball, meta = torch.empty(Pmax, **i32), torch.empty(Pmax, **i32), torch.empty(4, **i32)
     cw = torch.empty(Pmax, device="cuda")
-    assert lib.o3d_compact_build(dev_idx.data_ptr(), B, npoint, ns, ld, ball_cnt.data_ptr(), ball_off.data_ptr(),
-                                 gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), meta.data_ptr(), st()) == 0
+    # one segment: columns, points and balls all based at 0; padding columns point at ball `nballs`
+    assert lib.o3d_compact_build(dev_idx.data_ptr(), B, npoint, ns, ld, 0, 0, 0, nballs, ball_cnt.data_ptr(),
+                                 ball_off.data_ptr(), gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), meta.data_ptr(),
+                                 st()) == 0
     ref_cnt = torch.tensor(ref_cnt, dtype=torch.int32)
     assert torch.equal(ball_cnt.cpu(), ref_cnt)
     off = torch.cat([torch.zeros(1, dtype=torch.int64), ref_cnt.long().cumsum(0)])
-    assert torch.equal(ball_off.cpu().long(), off)
+    assert torch.equal(ball_off.cpu().long()[:nballs], off[:nballs])      # one offset per ball (ends = off + cnt)
     tot = int(off[-1])
     assert meta.cpu().tolist()[:3] == [(tot + 255) // 256 * 256, tot, nballs]
     gp_c, cball_c, cw_c = gp.cpu(), cball.cpu(), cw.cpu()
