@@ -285,6 +285,10 @@ int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t* argq, con
                    const float* mean, int B, int C, int npoint0, int npoint1, const int32_t* meta, long start1,
                    long ldp, float* D, float* part, void* stream);
 
+/* Centre term of the layer-0 weight gradient (grouped_xyz = xyz[idx] - new_xyz, pointnet2_utils.py:322-324):
+ * dW (C0,ldw) columns 0..2 -= T (C0,nballs) . centers (nballs,3) */
+int o3d_center_term(const float* T, const float* centers, int C0, int nballs, int ldw, float* dW, void* stream);
+
 /* Layer-0 backward sums of dY = A1*dN + w*(A2*Y0 + A3): S (C0, point columns) per source point
  * (= group_points_grad, pointnet2_utils.py:237), T (C0, balls) per ball (may be NULL). */
 int o3d_group_reduce_c(const float* dN, const float* Y0, long ldp, const float* A1, const float* A2,
@@ -314,6 +318,16 @@ int o3d_mlp_conv_wgrad2(const float* dN, const float* pk, int ns, const float* Y
                         const float* A2, const float* A3, const float* X, const float* in_scale,
                         const float* in_shift, int B, int Cin, int Cout, int P, float* scratch, float* dW,
                         void* stream);
+
+/* ---- tracker losses (next row of SURVEY.md section 8f: the loss as one launch) ----------------------
+ * MatchingBaseModel.compute_loss (models/base_model.py:122-164) + the BoxCloud term (models/bat.py:57-65)
+ * + the weighted total (models/bat.py:131-137, models/p2b.py:69-74) and the gradients of the total.
+ * losses[6] = {total, objective, box, seg, vote, bc}.  bc_pred == NULL: no BoxCloud term (P2B).
+ * g_* == NULL: losses only. */
+int o3d_track_loss(const float* cla, const float* seg, const float* vote, const float* box_label,
+                   const float* centers, const float* boxes, const float* bc_pred, const float* bc_label, int B,
+                   int N, int P, int K, float w_obj, float w_box, float w_seg, float w_vote, float w_bc,
+                   float* losses, float* g_cla, float* g_vote, float* g_boxes, float* g_bc, void* stream);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,7 @@ SOURCES = [
     ("group.hip", []),
     ("compact.hip", []),
     ("pointwise.hip", []),
+    ("loss.hip", []),
     ("capi_misc.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",

@@ -347,6 +347,38 @@ __global__ __launch_bounds__(256) void reduce_c_kernel(const float* __restrict__
         }
 }
 
+// dW[c, 0..2] -= sum over balls of T[c, ball] * centers[ball, :]: the centre term of
+// grouped_xyz = xyz[idx] - new_xyz (pointnet2_utils.py:322-324) in the layer-0 weight gradient.
+// One 1024-thread workgroup per channel, fixed summation order.
+__global__ __launch_bounds__(1024) void center_term_kernel(const float* __restrict__ T,
+                                                           const float* __restrict__ centers, int nballs, int ldw,
+                                                           float* __restrict__ dW) {
+    __shared__ float red[16][3];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const float* t = T + (long)c * nballs;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    for (int ball = tid; ball < nballs; ball += 1024) {
+        const float v = t[ball];
+        s0 = fmaf(v, centers[3 * ball], s0);
+        s1 = fmaf(v, centers[3 * ball + 1], s1);
+        s2 = fmaf(v, centers[3 * ball + 2], s2);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        s0 += __shfl_xor(s0, off, 64);
+        s1 += __shfl_xor(s1, off, 64);
+        s2 += __shfl_xor(s2, off, 64);
+    }
+    if ((tid & 63) == 0) { red[tid >> 6][0] = s0; red[tid >> 6][1] = s1; red[tid >> 6][2] = s2; }
+    __syncthreads();
+    if (tid < 3) {
+        float a = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) a += red[w][tid];
+        dW[(long)c * ldw + tid] -= a;
+    }
+}
+
 }  // namespace
 
 static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -459,4 +491,12 @@ extern "C" int o3d_group_reduce_c(const float* dN, const float* Y0, long ldp, co
                                   lds_row, nballs, S, T, s);
     return launch_reduce_c<2>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, ball_cnt, B, nseg, sp0, sp1, C0, lds_row,
                               nballs, S, T, s);
+}
+
+// dW (C0, ldw): columns 0..2 -= T (C0, nballs) . centers (nballs, 3)
+extern "C" int o3d_center_term(const float* T, const float* centers, int C0, int nballs, int ldw, float* dW,
+                               void* stream) {
+    if (!T || !centers || !dW || C0 <= 0 || nballs <= 0 || ldw < 3) return O3D_EINVAL;
+    hipLaunchKernelGGL(center_term_kernel, dim3(C0), dim3(1024), 0, o3d_stream(stream), T, centers, nballs, ldw, dW);
+    return o3d_launch_status();
 }

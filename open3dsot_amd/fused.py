@@ -47,6 +47,7 @@ capi.register("o3d_mlp_conv_wgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
 _l = ctypes.c_long
 capi.register("o3d_compact_build", [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_group_expand_c", [_vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _l, _vp, _vp, _vp, _vp])
+capi.register("o3d_center_term", [_vp, _vp, _i, _i, _i, _vp, _vp])
 capi.register("o3d_pool_fwd_c", [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_bwd_c", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _l, _vp, _vp, _vp])
 capi.register("o3d_group_reduce_c", [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp,
@@ -464,32 +465,39 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         # ---- layer 0 on the points: Z = W0 . [xyz * inv_radius ; feats], flat (C0, ldz)
         padded = any(n != npd for n, npd in zip(Ns, Npads))
         X0n = (torch.zeros if padded else torch.empty)((Cin0, ldz), device=dev, dtype=f32)
-        centers = torch.empty((nballs + 1, 3), device=dev, dtype=f32) if nxyz else None
+        centers = None
         for s_, (xyz, new_xyz, feats, _) in enumerate(segs):
             view = X0n[:, pt_bases[s_]:pt_bases[s_] + B * Npads[s_]].view(Cin0, B, Npads[s_])
             if nxyz:
                 view[:3, :, :Ns[s_]] = xyz.detach().permute(2, 0, 1) if unit else xyz.detach().permute(2, 0, 1) * cfg.inv_radius
-                cen = new_xyz.detach().reshape(nballs_s[s_], 3)
-                centers[ball_bases[s_]:ball_bases[s_] + nballs_s[s_]] = cen if unit else cen * cfg.inv_radius
             if C:
                 view[nxyz:, :, :Ns[s_]] = feats.detach().permute(1, 0, 2)
-        if nxyz:
-            centers[nballs:].zero_()           # dummy ball of the padding columns
+        if nxyz:       # ball centres of every segment + the dummy ball (origin) of the padding columns: one launch
+            centers = torch.cat([sg[1].detach().reshape(-1, 3) for sg in segs] + [_const_vec(dev, 3, 0.0).view(1, 3)])
+            if not unit:
+                centers = centers * cfg.inv_radius
         Z = torch.empty((C0, ldz), device=dev, dtype=f32)
         _call("conv_fwd_points", 2.0 * Cin0 * C0 * ldz, lib.o3d_mlp_conv_fwd, X0n.data_ptr(), Ws[0].data_ptr(),
               None, None, 1, Cin0, C0, ldz, Z.data_ptr(), None, None, st)
         counts = [float(pm) for pm in Pmaxs]          # BatchNorm counts every slot (copies included)
         Ys, means, invstds, scales, shifts = [], [], [], [], []
+        if cfg.training:       # shift of the second moment: the running means before this call, one row per segment
+            if nseg == 1:
+                statcs = [bn.running_mean.detach().unsqueeze(0) for bn in cfg.bns]
+            else:
+                allc = torch.cat([bn.running_mean.detach() for bn in cfg.bns for _ in range(nseg)])
+                statcs, o = [], 0
+                for bn in cfg.bns:
+                    n = bn.running_mean.numel()
+                    statcs.append(allc[o:o + nseg * n].view(nseg, n))
+                    o += nseg * n
         for l in range(L):
             Cout, Cin = Ws[l].shape
             bn = cfg.bns[l]
             tile = ETILE if l == 0 else _direct_tile(lib, ldp, Cout)
             Y = torch.empty((Cout, ldp), device=dev, dtype=f32)
             part = torch.empty((ldp // tile, 2, Cout), device=dev, dtype=f32) if cfg.training else None
-            # shift of the second moment: the running mean before this call, for every segment
-            statc = None
-            if cfg.training:
-                statc = bn.running_mean.detach().unsqueeze(0) if nseg == 1 else bn.running_mean.detach().repeat(nseg, 1)
+            statc = statcs[l] if cfg.training else None
             if l == 0:
                 _call("group_expand", 0.0, lib.o3d_group_expand_c, Z.data_ptr(), ldz, gp.data_ptr(), cball.data_ptr(),
                       cw.data_ptr(), _ptr(centers), Ws[0].data_ptr(), Cin0, C0, meta.data_ptr(), start1, ldp, Y.data_ptr(),
@@ -593,7 +601,8 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             if nseg == 1:
                 grads[3 * l + 1], grads[3 * l + 2] = coef[0, 0], coef[1, 0]
             else:        # the same affine parameters served both segments
-                grads[3 * l + 1], grads[3 * l + 2] = coef[0].sum(0), coef[1].sum(0)
+                gb = coef[:2].sum(1)
+                grads[3 * l + 1], grads[3 * l + 2] = gb[0], gb[1]
             A = (coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr())
             if l == 0:
                 S = torch.empty((Cout, ldz), device=dev, dtype=f32)
@@ -615,7 +624,8 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                           None, None, None, None, None, 0, 0, 0, 1.0, 1, Cin, Cout, ldz, nsl, wpart.data_ptr(),
                           dW.data_ptr(), side.cuda_stream)
                     if nxyz:      # the centre term of grouped_xyz = xyz[idx] - new_xyz
-                        dW[:, :3] -= T @ centers[:nballs]
+                        _call("center_term", 0.0, lib.o3d_center_term, T.data_ptr(), centers.data_ptr(), Cout, nballs, Cin,
+                              dW.data_ptr(), side.cuda_stream)
                 grads[0] = dW
                 if want_xyz or want_feats:
                     dX = torch.empty((Cin, ldz), device=dev, dtype=f32)

@@ -1,0 +1,77 @@
+"""The trackers' loss (models/base_model.py:122-164, models/bat.py:57-65,131-137, models/p2b.py:69-74)
+as ONE launch of csrc/loss.hip: the five loss terms, the weighted total and the gradients of the
+total w.r.t. the network outputs.  `MatchingBaseModel.compute_loss` (torch ops, ~110 launches
+forward+backward) stays as the specification the kernel is tested against (tests/test_model_gpu.py).
+"""
+import ctypes
+
+import torch
+
+from . import capi
+
+_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
+capi.register("o3d_track_loss", [_vp] * 8 + [_i] * 4 + [_f] * 5 + [_vp] * 6)
+
+_ON = {"on": True}
+KEYS = ("loss_objective", "loss_box", "loss_seg", "loss_vote", "loss_bc")
+
+
+def set_fused_loss(enabled):
+    _ON["on"] = bool(enabled)
+
+
+def enabled():
+    return _ON["on"]
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+class FusedTrackLoss(torch.autograd.Function):
+    """(weights, cla, vote, boxes, bc_pred | None, seg, box_label, centers, bc_label | None) -> losses[6]
+    = (total, objective, box, seg, vote, bc); only losses[0] carries gradient."""
+
+    @staticmethod
+    def forward(ctx, weights, cla, vote, boxes, bc_pred, seg, box_label, centers, bc_label):
+        lib = capi.load()
+        f32 = torch.float32
+        tensors = [cla, vote, boxes, bc_pred, seg, box_label, centers, bc_label]
+        cla, vote, boxes, bc_pred, seg, box_label, centers, bc_label = [
+            t.detach().contiguous().to(f32) if t is not None else None for t in tensors]
+        B, N = cla.shape
+        P = boxes.shape[1]
+        K = bc_pred.shape[2] if bc_pred is not None else 0
+        dev = cla.device
+        losses = torch.empty((6,), device=dev, dtype=f32)
+        need = any(ctx.needs_input_grad)
+        grads = [torch.empty_like(cla), torch.empty_like(vote), torch.empty_like(boxes),
+                 torch.empty_like(bc_pred) if bc_pred is not None else None] if need else [None] * 4
+        st = torch.cuda.current_stream(dev).cuda_stream
+        rc = lib.o3d_track_loss(cla.data_ptr(), seg.data_ptr(), vote.data_ptr(), box_label.data_ptr(),
+                                centers.data_ptr(), boxes.data_ptr(), _ptr(bc_pred), _ptr(bc_label), B, N, P, K,
+                                *[float(w) for w in weights], losses.data_ptr(), *[_ptr(g) for g in grads], st)
+        if rc != 0:
+            raise RuntimeError("o3d_track_loss failed: %d" % rc)
+        ctx.grads = grads
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        grads, ctx.grads = ctx.grads, None
+        live = [t for t in grads if t is not None]
+        scaled = iter(torch._foreach_mul(live, g[0]))            # one launch; only the total carries gradient
+        out = [next(scaled) if t is not None else None for t in grads]
+        return (None, out[0], out[1], out[2], out[3], None, None, None, None)
+
+
+def track_loss(config, data, output, with_bc):
+    """-> (total, {loss_*: 0-d tensors}) from the same dicts MatchingBaseModel.compute_loss takes"""
+    c = config
+    weights = (c.objectiveness_weight, c.box_weight, c.seg_weight, c.vote_weight, c.bc_weight if with_bc else 0.0)
+    losses = FusedTrackLoss.apply(weights, output["estimation_cla"], output["vote_xyz"], output["estimation_boxes"],
+                                  output["pred_search_bc"] if with_bc else None, data["seg_label"], data["box_label"],
+                                  output["center_xyz"], data["points2cc_dist_s"] if with_bc else None)
+    parts = losses.detach()
+    ld = {k: parts[i + 1] for i, k in enumerate(KEYS) if with_bc or k != "loss_bc"}
+    return losses[0], ld

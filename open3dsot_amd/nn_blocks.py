@@ -27,7 +27,7 @@ def pointwise_conv1d(conv, x):
     F.conv1d; on the MI355X the library convolution picks 60-90 us kernels for these 6144-column
     problems (rocprofv3, profiles/) where the plain GEMM takes ~10."""
     B, C, N = x.shape
-    h = torch.mm(conv.weight[:, :, 0], x.permute(1, 0, 2).reshape(C, B * N))
+    h = torch.mm(conv.weight.view(conv.out_channels, C), x.permute(1, 0, 2).reshape(C, B * N))
     if conv.bias is not None:
         h = h + conv.bias[:, None]
     return h.reshape(-1, B, N).permute(1, 0, 2).contiguous()
@@ -226,10 +226,12 @@ class Seq(nn.Sequential):
         B, C, N = x.shape
         h = x.permute(1, 0, 2).reshape(C, B * N)
         for conv, bn, act in units:
-            w = conv.weight[:, :, 0]
+            w = conv.weight.view(conv.out_channels, -1)      # (a view: indexing [:, :, 0] costs a zero-fill + copy in backward)
             if w.shape[0] < 32:     # hipBLASLt picks a 16-row macro tile (87 us per call, rocprofv3) for the
                 w = torch.nn.functional.pad(w, (0, 0, 0, 32 - w.shape[0]))   # 1/5/9-channel outputs: pad to 32
-            h = torch.mm(w, h)[:conv.out_channels]
+                h = torch.mm(w, h)[:conv.out_channels]
+            else:
+                h = torch.mm(w, h)
             if conv.bias is not None:
                 h = h + conv.bias[:, None]
             if bn is not None:

@@ -15,6 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
+from . import fused_loss
 from . import nn_blocks as pt_utils
 from .backbone import Pointnet_Backbone
 from .rpn import P2BVoteNetRPN
@@ -115,6 +116,8 @@ class P2B(MatchingBaseModel):
         n_seed = end_points["estimation_cla"].shape[1]
         data = dict(batch)
         data["seg_label"] = batch["seg_label"].gather(1, end_points["sample_idxs"][:, :n_seed].long())
+        if end_points["estimation_cla"].is_cuda and fused_loss.enabled():
+            return fused_loss.track_loss(self.config, data, end_points, with_bc=False)     # one launch (csrc/loss.hip)
         ld = self.compute_loss(data, end_points)
         c = self.config
         loss = (ld["loss_objective"] * c.objectiveness_weight + ld["loss_box"] * c.box_weight
@@ -173,6 +176,8 @@ class BAT(MatchingBaseModel):
         data["seg_label"] = batch["seg_label"].gather(1, sidx)
         data["points2cc_dist_s"] = batch["points2cc_dist_s"].gather(
             1, sidx[:, :, None].expand(-1, -1, self.config.bc_channel))
+        if end_points["estimation_cla"].is_cuda and fused_loss.enabled():
+            return fused_loss.track_loss(self.config, data, end_points, with_bc=True)      # one launch (csrc/loss.hip)
         ld = self.compute_loss(data, end_points)
         c = self.config
         loss = (ld["loss_objective"] * c.objectiveness_weight + ld["loss_box"] * c.box_weight

@@ -273,3 +273,44 @@ def test_fused_pointwise_chain_vs_fp64(mode, train):
     if train:
         for bn, rm, rv in zip(bns, rms[0::2], rms[1::2]):
             assert rel(bn.running_mean, rm) < 1e-5 and rel(bn.running_var, rv) < 1e-5
+
+
+@pytest.mark.parametrize("with_bc", [True, False])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_fused_track_loss_matches_compute_loss(with_bc, seed):
+    """csrc/loss.hip (one launch: five losses, weighted total, gradients) against the torch-op restatement of
+    models/base_model.py:122-164 + models/bat.py:57-65 evaluated in fp64."""
+    from open3dsot_amd import fused_loss, trackers
+    g = torch.Generator().manual_seed(seed)
+    B, N, P, K = 48, 128, 64, 9
+    model = trackers.get_model("BAT" if with_bc else "P2B")()
+    box_label = torch.randn(B, 4, generator=g) * 0.5
+    centers = box_label[:, None, :3] + torch.randn(B, P, 3, generator=g) * 0.35      # near / masked / far proposals
+    out = {"estimation_cla": torch.randn(B, N, generator=g) * 2, "vote_xyz": box_label[:, None, :3] + torch.randn(B, N, 3, generator=g),
+           "estimation_boxes": torch.cat([box_label[:, None, :] + torch.randn(B, P, 4, generator=g), torch.randn(B, P, 1, generator=g) * 2], 2),
+           "center_xyz": centers, "pred_search_bc": torch.randn(B, N, K, generator=g) * 1.5}
+    data = {"seg_label": (torch.rand(B, N, generator=g) < 0.3).float(), "box_label": box_label,
+            "points2cc_dist_s": torch.randn(B, N, K, generator=g)}
+    if seed == 1:      # empty denominators: no foreground seed, no proposal within 0.3 m
+        data["seg_label"].zero_()
+        out["center_xyz"] = centers + 5.0
+    names = ["estimation_cla", "vote_xyz", "estimation_boxes"] + (["pred_search_bc"] if with_bc else [])
+    o64 = {k: v.double().requires_grad_(k in names) for k, v in out.items()}
+    d64 = {k: v.double() for k, v in data.items()}
+    ld = model.compute_loss(d64, o64)
+    c = model.config
+    total = (ld["loss_objective"] * c.objectiveness_weight + ld["loss_box"] * c.box_weight + ld["loss_seg"] * c.seg_weight
+             + ld["loss_vote"] * c.vote_weight + (ld["loss_bc"] * c.bc_weight if with_bc else 0.0))
+    (total * 0.7).backward()
+    og = {k: v.cuda().requires_grad_(k in names) for k, v in out.items()}
+    dg = {k: v.cuda() for k, v in data.items()}
+    tot, parts = fused_loss.track_loss(c, dg, og, with_bc)
+    (tot * 0.7).backward()
+    assert abs(float(tot) - float(total)) <= 2e-6 * (1 + abs(float(total))), (float(tot), float(total))
+    for k, v in ld.items():
+        assert abs(float(parts[k]) - float(v)) <= 2e-6 * (1 + abs(float(v))), (k, float(parts[k]), float(v))
+    for k in names:
+        ref = o64[k].grad
+        err = float((og[k].grad.cpu().double() - ref).abs().max())
+        assert err <= 2e-6 * float(ref.abs().max()) + 1e-9, (k, err, float(ref.abs().max()))
+    assert og["center_xyz"].grad is None
