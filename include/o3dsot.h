@@ -280,7 +280,9 @@ int o3d_pool_fwd_c(const float* Y, long ldp, const float* scale, const float* sh
                    float* yarg, void* stream);
 
 /* Backward of the pool: D (C,ldp) = dense class-sum gradient (zero on live columns, D[c,argq] = dOut where
- * out > 0) and the BatchNorm-backward partials part [nseg][2][C] of the pooled layer. */
+ * out > 0) and the BatchNorm-backward partials of the pooled layer, O3D_POOL_BWD_SPLIT rows per segment:
+ * part [nseg][O3D_POOL_BWD_SPLIT][2][C]. */
+#define O3D_POOL_BWD_SPLIT 8
 int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t* argq, const float* yarg,
                    const float* mean, int B, int C, int npoint0, int npoint1, const int32_t* meta, long start1,
                    long ldp, float* D, float* part, void* stream);
@@ -319,15 +321,28 @@ int o3d_mlp_conv_wgrad2(const float* dN, const float* pk, int ns, const float* Y
                         const float* in_shift, int B, int Cin, int Cout, int P, float* scratch, float* dW,
                         void* stream);
 
+/* BatchNorm finalize / backward finalize of TWO segments in one launch (template + search cloud through a
+ * shared module, models/bat.py:89-90): partial rows [nparts0 | nparts1], stat_c / mean / invstd / scale /
+ * shift / A1..A3 laid out (2,C), meta (2,4) (NULL in the backward variant: every row live).  Same numbers as
+ * the one-segment entry points called for segment 0, then 1; dgamma / dbeta (C) are summed over the segments. */
+int o3d_bn_finalize_c2(const float* part, int nparts0, int nparts1, int C, double count0, double count1,
+                       const float* stat_c, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, float momentum, float eps, float* mean, float* invstd, float* scale,
+                       float* shift, const int32_t* meta, int tile, void* stream);
+int o3d_bn_bwd_finalize_c2(const float* part, int nparts0, int nparts1, int C, double count0, double count1,
+                           const float* gamma, const float* mean, const float* invstd, float* dgamma,
+                           float* dbeta, float* A1, float* A2, float* A3, const int32_t* meta, int tile,
+                           void* stream);
+
 /* ---- tracker losses (next row of SURVEY.md section 8f: the loss as one launch) ----------------------
  * MatchingBaseModel.compute_loss (models/base_model.py:122-164) + the BoxCloud term (models/bat.py:57-65)
  * + the weighted total (models/bat.py:131-137, models/p2b.py:69-74) and the gradients of the total.
  * losses[6] = {total, objective, box, seg, vote, bc}.  bc_pred == NULL: no BoxCloud term (P2B).
- * g_* == NULL: losses only. */
+ * g_* == NULL: losses only.  scratch: 512 floats. */
 int o3d_track_loss(const float* cla, const float* seg, const float* vote, const float* box_label,
                    const float* centers, const float* boxes, const float* bc_pred, const float* bc_label, int B,
                    int N, int P, int K, float w_obj, float w_box, float w_seg, float w_vote, float w_bc,
-                   float* losses, float* g_cla, float* g_vote, float* g_boxes, float* g_bc, void* stream);
+                   float* scratch, float* losses, float* g_cla, float* g_vote, float* g_boxes, float* g_bc, void* stream);
 
 #ifdef __cplusplus
 }

@@ -157,6 +157,7 @@ __global__ __launch_bounds__(256) void expand_c_kernel(const float* __restrict__
 //   workgroup = 32 balls x POOL_CH channels.
 // ---------------------------------------------------------------------------------------
 constexpr int POOL_CH = 8;
+constexpr int POOL_BWD_SPLIT = 8;       // = O3D_POOL_BWD_SPLIT (include/o3dsot.h)
 
 // pooled tensors are stored per segment in the reference's (B, C, npoint) layout, segment 1's block after
 // segment 0's: element (c, ball)
@@ -228,8 +229,9 @@ __global__ __launch_bounds__(256) void pool_scatter_c_kernel(const float* __rest
     if (out[o] > 0.f) D[(long)c * ldp + argq[o]] = dOut[o];
 }
 
-// BatchNorm-backward partials of the pooled layer, one row per segment: part[seg][0][c] = sum g,
-// part[seg][1][c] = sum g*(yarg - mean), g = dOut where out > 0.  grid (C, nseg).
+// BatchNorm-backward partials of the pooled layer, POOL_BWD_SPLIT rows per segment:
+// part[seg*SPLIT + k][0][c] = sum g, part[..][1][c] = sum g*(yarg - mean), g = dOut where out > 0, over the
+// k-th share of the segment's balls.  grid (C, nseg, SPLIT).
 __global__ __launch_bounds__(256) void pool_bwd_partials_c_kernel(const float* __restrict__ dOut,
                                                                   const float* __restrict__ out,
                                                                   const float* __restrict__ yarg,
@@ -237,8 +239,10 @@ __global__ __launch_bounds__(256) void pool_bwd_partials_c_kernel(const float* _
                                                                   int nballs, int seg1_ball, int np0, int np1,
                                                                   float* __restrict__ part) {
     __shared__ float sh[2][4];
-    const int c = blockIdx.x, seg = blockIdx.y;
-    const int b0 = seg ? seg1_ball : 0, b1 = seg ? nballs : seg1_ball;
+    const int c = blockIdx.x, seg = blockIdx.y, k = blockIdx.z;
+    const int s0 = seg ? seg1_ball : 0, s1 = seg ? nballs : seg1_ball;
+    const int share = (s1 - s0 + POOL_BWD_SPLIT - 1) / POOL_BWD_SPLIT;
+    const int b0 = s0 + k * share, b1 = min(b0 + share, s1);
     const float mu = mean[seg * C + c];
     float s = 0.f, q = 0.f;
     for (int ball = b0 + threadIdx.x; ball < b1; ball += 256) {
@@ -252,8 +256,9 @@ __global__ __launch_bounds__(256) void pool_bwd_partials_c_kernel(const float* _
     if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        part[((long)seg * 2 + 0) * C + c] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
-        part[((long)seg * 2 + 1) * C + c] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+        const long row = (long)seg * POOL_BWD_SPLIT + k;
+        part[(row * 2 + 0) * C + c] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        part[(row * 2 + 1) * C + c] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
     }
 }
 
@@ -442,7 +447,7 @@ extern "C" int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t
     hipStream_t s = o3d_stream(stream);
     const int nseg = npoint1 > 0 ? 2 : 1;
     const int seg1_ball = B * npoint0, nballs = B * (npoint0 + npoint1), np1 = npoint1 > 0 ? npoint1 : npoint0;
-    hipLaunchKernelGGL(pool_bwd_partials_c_kernel, dim3(C, nseg), dim3(256), 0, s, dOut, out, yarg, mean, C, nballs,
+    hipLaunchKernelGGL(pool_bwd_partials_c_kernel, dim3(C, nseg, POOL_BWD_SPLIT), dim3(256), 0, s, dOut, out, yarg, mean, C, nballs,
                        seg1_ball, npoint0, np1, part);
     hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)o3d_cdiv(ldp, 1024), C), dim3(256), 0, s, D, ldp, meta, start1);
     const long total = (long)C * nballs;

@@ -282,6 +282,9 @@ struct BnFinArgs {
     float* running_mean; float* running_var;  // updated in place when momentum >= 0 (may be NULL)
     float momentum, eps;
     float* mean; float* invstd; float* scale; float* shift;  // outputs (C each)
+    // second segment (nparts1 > 0): its partial rows follow segment 0's `nparts`, its outputs / stat_c sit at
+    // +C, its live count at meta[4]; the running statistics see segment 0's update first
+    int nparts1; double count1;
 };
 
 __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
@@ -290,37 +293,44 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
     __shared__ double sh[2][64][5];
     const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
     const int c = blockIdx.x * 4 + cl;
-    double s = 0.0, q = 0.0;
-    int nparts = a.nparts;
-    if (a.meta) { const int live = a.meta[0] / a.tile; nparts = live < nparts ? live : nparts; }
-    if (c < a.C) {
+    const int nseg = a.nparts1 > 0 ? 2 : 1;
+    for (int seg = 0; seg < nseg; ++seg) {
+        const float* part = a.part + (seg ? (long)a.nparts * 2 * a.C : 0);
+        const double count = seg ? a.count1 : a.count;
+        const int off = seg * a.C;
+        double s = 0.0, q = 0.0;
+        int nparts = seg ? a.nparts1 : a.nparts;
+        if (a.meta) { const int live = a.meta[4 * seg] / a.tile; nparts = live < nparts ? live : nparts; }
+        if (c < a.C) {
 #pragma unroll 8
-        for (int t = sl; t < nparts; t += 64) {
-            s += (double)a.part[((long)t * 2 + 0) * a.C + c];
-            q += (double)a.part[((long)t * 2 + 1) * a.C + c];
+            for (int t = sl; t < nparts; t += 64) {
+                s += (double)part[((long)t * 2 + 0) * a.C + c];
+                q += (double)part[((long)t * 2 + 1) * a.C + c];
+            }
         }
-    }
-    sh[0][sl][cl] = s;
-    sh[1][sl][cl] = q;
-    __syncthreads();
-    if (sl == 0 && c < a.C) {
-        s = 0.0; q = 0.0;
-        for (int i = 0; i < 64; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
-        const double cs = a.stat_c ? (double)a.stat_c[c] : 0.0;
-        const double mean = s / a.count;
-        double var = q / a.count - (mean - cs) * (mean - cs);
-        if (var < 0.0) var = 0.0;
-        const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
-        const float g = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
-        a.mean[c] = (float)mean;
-        a.invstd[c] = invstd;
-        const float sc = g * invstd;
-        a.scale[c] = sc;
-        a.shift[c] = bt - (float)mean * sc;
-        if (a.running_mean && a.momentum >= 0.f) {
-            const double unbiased = a.count > 1.0 ? var * a.count / (a.count - 1.0) : var;
-            a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
-            a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+        if (seg) __syncthreads();
+        sh[0][sl][cl] = s;
+        sh[1][sl][cl] = q;
+        __syncthreads();
+        if (sl == 0 && c < a.C) {
+            s = 0.0; q = 0.0;
+            for (int i = 0; i < 64; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
+            const double cs = a.stat_c ? (double)a.stat_c[off + c] : 0.0;
+            const double mean = s / count;
+            double var = q / count - (mean - cs) * (mean - cs);
+            if (var < 0.0) var = 0.0;
+            const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+            const float g = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
+            a.mean[off + c] = (float)mean;
+            a.invstd[off + c] = invstd;
+            const float sc = g * invstd;
+            a.scale[off + c] = sc;
+            a.shift[off + c] = bt - (float)mean * sc;
+            if (a.running_mean && a.momentum >= 0.f) {
+                const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+                a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+                a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
+            }
         }
     }
 }
@@ -434,36 +444,51 @@ struct BnBwdFinArgs {
     const int32_t* meta; int tile;
     const float* gamma; const float* mean; const float* invstd;
     float* dgamma; float* dbeta; float* A1; float* A2; float* A3;
+    // second segment (nparts1 > 0): partial rows after segment 0's, mean / invstd / A1..A3 at +C, live count at
+    // meta[4]; dgamma / dbeta (C each) are the SUM over the segments (the affine parameters are shared)
+    int nparts1; double count1;
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFinArgs a) {
     __shared__ double sh[2][64][5];
     const int cl = threadIdx.x & 3, sl = threadIdx.x >> 2;
     const int c = blockIdx.x * 4 + cl;
-    double s = 0.0, q = 0.0;
-    int nparts = a.nparts;
-    if (a.meta) { const int live = a.meta[0] / a.tile; nparts = live < nparts ? live : nparts; }
-    if (c < a.C) {
+    const int nseg = a.nparts1 > 0 ? 2 : 1;
+    double dg = 0.0, db = 0.0;
+    for (int seg = 0; seg < nseg; ++seg) {
+        const float* part = a.part + (seg ? (long)a.nparts * 2 * a.C : 0);
+        const double count = seg ? a.count1 : a.count;
+        const int off = seg * a.C;
+        double s = 0.0, q = 0.0;
+        int nparts = seg ? a.nparts1 : a.nparts;
+        if (a.meta) { const int live = a.meta[4 * seg] / a.tile; nparts = live < nparts ? live : nparts; }
+        if (c < a.C) {
 #pragma unroll 8
-        for (int t = sl; t < nparts; t += 64) {
-            s += (double)a.part[((long)t * 2 + 0) * a.C + c];
-            q += (double)a.part[((long)t * 2 + 1) * a.C + c];
+            for (int t = sl; t < nparts; t += 64) {
+                s += (double)part[((long)t * 2 + 0) * a.C + c];
+                q += (double)part[((long)t * 2 + 1) * a.C + c];
+            }
+        }
+        if (seg) __syncthreads();
+        sh[0][sl][cl] = s;
+        sh[1][sl][cl] = q;
+        __syncthreads();
+        if (sl == 0 && c < a.C) {
+            s = 0.0; q = 0.0;
+            for (int i = 0; i < 64; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
+            const double g = a.gamma ? (double)a.gamma[c] : 1.0;
+            const double is = (double)a.invstd[off + c], mu = (double)a.mean[off + c];
+            db += s;
+            dg += q * is;
+            const double a1 = g * is;
+            const double a2 = -a1 * is * is * q / count;
+            const double a3 = -a1 * s / count - a2 * mu;
+            a.A1[off + c] = (float)a1; a.A2[off + c] = (float)a2; a.A3[off + c] = (float)a3;
         }
     }
-    sh[0][sl][cl] = s;
-    sh[1][sl][cl] = q;
-    __syncthreads();
     if (sl == 0 && c < a.C) {
-        s = 0.0; q = 0.0;
-        for (int i = 0; i < 64; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
-        const double g = a.gamma ? (double)a.gamma[c] : 1.0;
-        const double is = (double)a.invstd[c], mu = (double)a.mean[c];
-        a.dbeta[c] = (float)s;
-        a.dgamma[c] = (float)(q * is);
-        const double a1 = g * is;
-        const double a2 = -a1 * is * is * q / a.count;
-        const double a3 = -a1 * s / a.count - a2 * mu;
-        a.A1[c] = (float)a1; a.A2[c] = (float)a2; a.A3[c] = (float)a3;
+        a.dbeta[c] = (float)db;
+        a.dgamma[c] = (float)dg;
     }
 }
 
@@ -1128,6 +1153,32 @@ extern "C" int o3d_bn_bwd_finalize_c(const float* part, int nparts, int C, doubl
         tile <= 0)
         return O3D_EINVAL;
     BnBwdFinArgs a = {part, nparts, C, count, meta, tile, gamma, mean, invstd, dgamma, dbeta, A1, A2, A3};
+    return launch(bn_bwd_finalize_kernel, dim3(o3d_cdiv(C, 4)), dim3(256), 0, o3d_stream(stream), a);
+}
+
+// Two segments in one launch (see BnFinArgs): partial rows [nparts0 | nparts1], stat_c / outputs (2, C),
+// meta (2, 4).  Equivalent to o3d_bn_finalize_c for segment 0 followed by segment 1.
+extern "C" int o3d_bn_finalize_c2(const float* part, int nparts0, int nparts1, int C, double count0, double count1,
+                                  const float* stat_c, const float* gamma, const float* beta, float* running_mean,
+                                  float* running_var, float momentum, float eps, float* mean, float* invstd,
+                                  float* scale, float* shift, const int32_t* meta, int tile, void* stream) {
+    if (!part || nparts0 <= 0 || nparts1 <= 0 || C <= 0 || !mean || !invstd || !scale || !shift || !meta || tile <= 0)
+        return O3D_EINVAL;
+    BnFinArgs a = {part, nparts0, C, meta, tile, count0, stat_c, gamma, beta, running_mean, running_var, momentum, eps,
+                   mean, invstd, scale, shift, nparts1, count1};
+    return launch(bn_finalize_kernel, dim3(o3d_cdiv(C, 4)), dim3(256), 0, o3d_stream(stream), a);
+}
+
+// Two segments in one launch; meta may be NULL (every partial row live).  dgamma / dbeta (C) = sum over segments.
+extern "C" int o3d_bn_bwd_finalize_c2(const float* part, int nparts0, int nparts1, int C, double count0, double count1,
+                                      const float* gamma, const float* mean, const float* invstd, float* dgamma,
+                                      float* dbeta, float* A1, float* A2, float* A3, const int32_t* meta, int tile,
+                                      void* stream) {
+    if (!part || nparts0 <= 0 || nparts1 <= 0 || C <= 0 || !mean || !invstd || !dgamma || !dbeta || !A1 || !A2 || !A3 ||
+        tile <= 0)
+        return O3D_EINVAL;
+    BnBwdFinArgs a = {part, nparts0, C, count0, meta, tile, gamma, mean, invstd, dgamma, dbeta, A1, A2, A3, nparts1,
+                      count1};
     return launch(bn_bwd_finalize_kernel, dim3(o3d_cdiv(C, 4)), dim3(256), 0, o3d_stream(stream), a);
 }
 

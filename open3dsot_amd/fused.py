@@ -47,6 +47,9 @@ capi.register("o3d_mlp_conv_wgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
 _l = ctypes.c_long
 capi.register("o3d_compact_build", [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_group_expand_c", [_vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _l, _vp, _vp, _vp, _vp])
+POOL_BWD_SPLIT = 8      # O3D_POOL_BWD_SPLIT of include/o3dsot.h
+capi.register("o3d_bn_finalize_c2", [_vp, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp])
+capi.register("o3d_bn_bwd_finalize_c2", [_vp, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp])
 capi.register("o3d_center_term", [_vp, _vp, _i, _i, _i, _vp, _vp])
 capi.register("o3d_pool_fwd_c", [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_bwd_c", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _l, _vp, _vp, _vp])
@@ -507,13 +510,16 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                       scales[-1].data_ptr(), shifts[-1].data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1,
                       tile, Y.data_ptr(), _ptr(part), _ptr(statc), st)
             vec = torch.empty((4, nseg, Cout), device=dev, dtype=f32)      # mean, invstd, scale, shift per segment
-            if cfg.training:
-                for s_ in range(nseg):       # in order: the running statistics see segment 0's update first
-                    _call("bn_finalize", 0.0, lib.o3d_bn_finalize_c, part[starts[s_] // tile:].data_ptr(), Pmaxs[s_] // tile,
-                          Cout, counts[s_], statc[s_].data_ptr(), gammas[l].data_ptr(), betas[l].data_ptr(),
-                          bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
-                          vec[0, s_].data_ptr(), vec[1, s_].data_ptr(), vec[2, s_].data_ptr(), vec[3, s_].data_ptr(),
-                          meta[s_].data_ptr(), tile, st)
+            if cfg.training and nseg == 1:
+                _call("bn_finalize", 0.0, lib.o3d_bn_finalize_c, part.data_ptr(), Pmaxs[0] // tile, Cout, counts[0],
+                      statc.data_ptr(), gammas[l].data_ptr(), betas[l].data_ptr(), bn.running_mean.data_ptr(),
+                      bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps), vec[0].data_ptr(), vec[1].data_ptr(),
+                      vec[2].data_ptr(), vec[3].data_ptr(), meta.data_ptr(), tile, st)
+            elif cfg.training:       # both segments in one launch; the running statistics see segment 0's update first
+                _call("bn_finalize", 0.0, lib.o3d_bn_finalize_c2, part.data_ptr(), Pmaxs[0] // tile, Pmaxs[1] // tile, Cout,
+                      counts[0], counts[1], statc.data_ptr(), gammas[l].data_ptr(), betas[l].data_ptr(),
+                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
+                      vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), meta.data_ptr(), tile, st)
             else:
                 vec[0].copy_(bn.running_mean)
                 vec[1].copy_(torch.rsqrt(bn.running_var + bn.eps))
@@ -571,7 +577,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                     dst.zero_()
                 else:
                     dst.copy_(dOuts[s_])
-        part = torch.empty((nseg, 2, Cl), device=dev, dtype=f32)
+        part = torch.empty((nseg, POOL_BWD_SPLIT, 2, Cl), device=dev, dtype=f32)
         dN = torch.empty((Cl, ldp), device=dev, dtype=f32)          # dense class-sum gradient of the pooled layer
         np1 = npoints[1] if nseg == 2 else 0
         _call("pool_bwd", 0.0, lib.o3d_pool_bwd_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
@@ -583,26 +589,27 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         seg_grads = [[None, None, None] for _ in range(nseg)]
         for l in range(L - 1, -1, -1):
             Cout, Cin = Ws[l].shape
-            coef = torch.empty((5, nseg, Cout), device=dev, dtype=f32)  # dgamma dbeta A1 A2 A3, per segment
-            for s_ in range(nseg):
-                if l == L - 1:
-                    _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize, part[s_].data_ptr(), 1, Cout, counts[s_],
-                          gammas[l].data_ptr(), means[l][s_].data_ptr(), invstds[l][s_].data_ptr(), coef[0, s_].data_ptr(),
-                          coef[1, s_].data_ptr(), coef[2, s_].data_ptr(), coef[3, s_].data_ptr(), coef[4, s_].data_ptr(),
-                          None, st)
+            coef = torch.empty((5, nseg, Cout), device=dev, dtype=f32)  # dgamma dbeta (row 0: all segments) A1 A2 A3
+            cp = [coef[k].data_ptr() for k in range(5)]
+            if l == L - 1:       # partials of the pool backward: POOL_BWD_SPLIT rows per segment, all live
+                if nseg == 1:
+                    _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize, part.data_ptr(), POOL_BWD_SPLIT, Cout, counts[0],
+                          gammas[l].data_ptr(), means[l].data_ptr(), invstds[l].data_ptr(), *cp, None, st)
                 else:
-                    _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize_c, part[starts[s_] // dtile:].data_ptr(),
-                          Pmaxs[s_] // dtile, Cout, counts[s_], gammas[l].data_ptr(), means[l][s_].data_ptr(),
-                          invstds[l][s_].data_ptr(), coef[0, s_].data_ptr(), coef[1, s_].data_ptr(), coef[2, s_].data_ptr(),
-                          coef[3, s_].data_ptr(), coef[4, s_].data_ptr(), meta[s_].data_ptr(), dtile, st)
+                    _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize_c2, part.data_ptr(), POOL_BWD_SPLIT, POOL_BWD_SPLIT,
+                          Cout, counts[0], counts[1], gammas[l].data_ptr(), means[l].data_ptr(), invstds[l].data_ptr(), *cp,
+                          None, 1, st)
+            elif nseg == 1:
+                _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize_c, part.data_ptr(), Pmaxs[0] // dtile, Cout, counts[0],
+                      gammas[l].data_ptr(), means[l].data_ptr(), invstds[l].data_ptr(), *cp, meta.data_ptr(), dtile, st)
+            else:
+                _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize_c2, part.data_ptr(), Pmaxs[0] // dtile,
+                      Pmaxs[1] // dtile, Cout, counts[0], counts[1], gammas[l].data_ptr(), means[l].data_ptr(),
+                      invstds[l].data_ptr(), *cp, meta.data_ptr(), dtile, st)
             if not cfg.training:
                 coef[3].zero_()
                 coef[4].zero_()
-            if nseg == 1:
-                grads[3 * l + 1], grads[3 * l + 2] = coef[0, 0], coef[1, 0]
-            else:        # the same affine parameters served both segments
-                gb = coef[:2].sum(1)
-                grads[3 * l + 1], grads[3 * l + 2] = gb[0], gb[1]
+            grads[3 * l + 1], grads[3 * l + 2] = coef[0, 0], coef[1, 0]      # summed over the segments by the kernel
             A = (coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr())
             if l == 0:
                 S = torch.empty((Cout, ldz), device=dev, dtype=f32)

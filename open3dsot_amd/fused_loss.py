@@ -10,7 +10,7 @@ import torch
 from . import capi
 
 _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
-capi.register("o3d_track_loss", [_vp] * 8 + [_i] * 4 + [_f] * 5 + [_vp] * 6)
+capi.register("o3d_track_loss", [_vp] * 8 + [_i] * 4 + [_f] * 5 + [_vp] * 7)
 
 _ON = {"on": True}
 KEYS = ("loss_objective", "loss_box", "loss_seg", "loss_vote", "loss_bc")
@@ -43,14 +43,15 @@ class FusedTrackLoss(torch.autograd.Function):
         P = boxes.shape[1]
         K = bc_pred.shape[2] if bc_pred is not None else 0
         dev = cla.device
-        losses = torch.empty((6,), device=dev, dtype=f32)
+        buf = torch.empty((512 + 6,), device=dev, dtype=f32)      # block sums + the six losses
+        losses = buf[512:]
         need = any(ctx.needs_input_grad)
         grads = [torch.empty_like(cla), torch.empty_like(vote), torch.empty_like(boxes),
                  torch.empty_like(bc_pred) if bc_pred is not None else None] if need else [None] * 4
         st = torch.cuda.current_stream(dev).cuda_stream
         rc = lib.o3d_track_loss(cla.data_ptr(), seg.data_ptr(), vote.data_ptr(), box_label.data_ptr(),
                                 centers.data_ptr(), boxes.data_ptr(), _ptr(bc_pred), _ptr(bc_label), B, N, P, K,
-                                *[float(w) for w in weights], losses.data_ptr(), *[_ptr(g) for g in grads], st)
+                                *[float(w) for w in weights], buf.data_ptr(), losses.data_ptr(), *[_ptr(g) for g in grads], st)
         if rc != 0:
             raise RuntimeError("o3d_track_loss failed: %d" % rc)
         ctx.grads = grads

@@ -13,7 +13,7 @@ import ctypes
 import torch
 
 from . import capi
-from .fused import _call, _const_vec, _ptr, _stream, TILE
+from .fused import _call, _const_vec, _ptr, _stream, POOL_BWD_SPLIT, TILE
 
 _vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
 capi.register("o3d_bn_relu_apply", [_vp, _vp, _vp, _i, _l, _vp, _vp])
@@ -121,11 +121,11 @@ class FusedPointwiseChain(torch.autograd.Function):
             nparts = ntiles
         else:
             dOut = dOut.contiguous()
-            part = torch.empty((1, 2, Cl), device=dev, dtype=f32)
+            part = torch.empty((POOL_BWD_SPLIT, 2, Cl), device=dev, dtype=f32)
             meta = _meta_full(dev, P, B)       # every column is live: one "ball" of N columns per cloud
             _call("pool_bwd", 0.0, lib.o3d_pool_bwd_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
                   means[-1].data_ptr(), B, Cl, 1, 0, meta.data_ptr(), 0, P, dN.data_ptr(), part.data_ptr(), st)
-            nparts = 1
+            nparts = POOL_BWD_SPLIT
         grads = [None] * (4 * L)
         dx = None
         for l in range(L - 1, -1, -1):

@@ -15,6 +15,8 @@ Two execution paths produce the same numbers (tests/test_fused_gpu.py):
 Differences from the reference, by design: no `.cuda()` H2D copy for the non-FPS prefix
 indices (:56 builds them on the host) -- they are created on the device.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -22,7 +24,15 @@ import torch.nn.functional as F
 from . import nn_blocks as pt_utils
 from . import ops as pointnet2_utils
 
-_FUSED = {"enabled": True, "paired": True}
+_FUSED = {"enabled": True, "paired": True, "fps_streams": os.environ.get("O3D_FPS_STREAMS", "0") == "1"}
+_STREAMS = {}
+
+
+def _fps_stream(dev):
+    key = str(dev)
+    if key not in _STREAMS:
+        _STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _STREAMS[key]
 
 
 def set_fused(enabled):
@@ -93,8 +103,21 @@ class _PointnetSAModuleBase(nn.Module):
         if (_FUSED["enabled"] and _FUSED["paired"] and xyz_a.is_cuda and len(self.groupers) == 1):
             from . import fused
             if fused.supports(self.groupers[0], self.mlps[0], features_a):
-                idx_a, new_a = self._sample(xyz_a, npoint_a)
-                idx_b, new_b = self._sample(xyz_b, npoint_b)
+                if self.use_fps and _FUSED["fps_streams"]:
+                    # the two farthest-point samplings are one workgroup per cloud each (48 of 256 CUs busy): b's on a
+                    # second stream beside a's.  OFF by default (O3D_FPS_STREAMS=1): measured on the MI355X the fork /
+                    # join inside the HIP graph costs more than the 0.09 ms overlap gains (8.54 vs 8.22 ms per step)
+                    main, side = torch.cuda.current_stream(), _fps_stream(xyz_b.device)
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        idx_b, new_b = self._sample(xyz_b, npoint_b)
+                    idx_a, new_a = self._sample(xyz_a, npoint_a)
+                    main.wait_stream(side)
+                    idx_b.record_stream(main)
+                    new_b.record_stream(main)
+                else:
+                    idx_a, new_a = self._sample(xyz_a, npoint_a)
+                    idx_b, new_b = self._sample(xyz_b, npoint_b)
                 outs = fused.sa_group_mlp_pool_pair(self.groupers[0], self.mlps[0], (xyz_a, new_a, features_a),
                                                     (xyz_b, new_b, features_b))
                 if outs is not None:
