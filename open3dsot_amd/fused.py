@@ -467,10 +467,15 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                   meta[s_].data_ptr(), st)
         # ---- layer 0 on the points: Z = W0 . [xyz * inv_radius ; feats], flat (C0, ldz)
         padded = any(n != npd for n, npd in zip(Ns, Npads))
-        X0n = (torch.zeros if padded else torch.empty)((Cin0, ldz), device=dev, dtype=f32)
+        # rows padded to a multiple of 16 (zero rows, zero weight columns): the per-point GEMM then runs on the
+        # direct MFMA kernel (csrc/mlp_direct.hip needs K % 16 == 0) instead of the generic LDS-staged one
+        Cin0p = -(-Cin0 // 16) * 16 if Cin0 > 16 else Cin0
+        X0n = (torch.zeros if padded else torch.empty)((Cin0p, ldz), device=dev, dtype=f32)
+        if Cin0p != Cin0 and not padded:
+            X0n[Cin0:].zero_()
         centers = None
         for s_, (xyz, new_xyz, feats, _) in enumerate(segs):
-            view = X0n[:, pt_bases[s_]:pt_bases[s_] + B * Npads[s_]].view(Cin0, B, Npads[s_])
+            view = X0n[:Cin0, pt_bases[s_]:pt_bases[s_] + B * Npads[s_]].view(Cin0, B, Npads[s_])
             if nxyz:
                 view[:3, :, :Ns[s_]] = xyz.detach().permute(2, 0, 1) if unit else xyz.detach().permute(2, 0, 1) * cfg.inv_radius
             if C:
@@ -480,8 +485,9 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             if not unit:
                 centers = centers * cfg.inv_radius
         Z = torch.empty((C0, ldz), device=dev, dtype=f32)
-        _call("conv_fwd_points", 2.0 * Cin0 * C0 * ldz, lib.o3d_mlp_conv_fwd, X0n.data_ptr(), Ws[0].data_ptr(),
-              None, None, 1, Cin0, C0, ldz, Z.data_ptr(), None, None, st)
+        W0p = Ws[0] if Cin0p == Cin0 else torch.nn.functional.pad(Ws[0], (0, Cin0p - Cin0))
+        _call("conv_fwd_points", 2.0 * Cin0p * C0 * ldz, lib.o3d_mlp_conv_fwd, X0n.data_ptr(), W0p.data_ptr(),
+              None, None, 1, Cin0p, C0, ldz, Z.data_ptr(), None, None, st)
         counts = [float(pm) for pm in Pmaxs]          # BatchNorm counts every slot (copies included)
         Ys, means, invstds, scales, shifts = [], [], [], [], []
         if cfg.training:       # shift of the second moment: the running means before this call, one row per segment
@@ -635,13 +641,15 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                               dW.data_ptr(), side.cuda_stream)
                 grads[0] = dW
                 if want_xyz or want_feats:
-                    dX = torch.empty((Cin, ldz), device=dev, dtype=f32)
-                    _call("conv_dgrad_points", 2.0 * Cin * Cout * ldz, lib.o3d_mlp_conv_dgrad_plain, S.data_ptr(),
-                          S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), Ws[0].data_ptr(), 1, Cin, Cout,
-                          ldz, dX.data_ptr(), st)
+                    # dX = W0^T . S as a plain forward GEMM on the direct MFMA kernel: rows padded to a multiple of 64
+                    Cinm = -(-Cin // 64) * 64
+                    W0t = torch.nn.functional.pad(Ws[0], (0, Cinm - Cin)).t().contiguous()          # (Cinm, Cout)
+                    dX = torch.empty((Cinm, ldz), device=dev, dtype=f32)
+                    _call("conv_dgrad_points", 2.0 * Cinm * Cout * ldz, lib.o3d_mlp_conv_fwd, S.data_ptr(), W0t.data_ptr(),
+                          None, None, 1, Cout, Cinm, ldz, dX.data_ptr(), None, None, st)
                     dnew_all = ((-cfg.inv_radius) * Ws[0][:, :3]).t() @ T if want_xyz else None       # (3, balls)
                     for s_ in range(nseg):
-                        view = dX[:, pt_bases[s_]:pt_bases[s_] + B * Npads[s_]].view(Cin, B, Npads[s_])
+                        view = dX[:Cin, pt_bases[s_]:pt_bases[s_] + B * Npads[s_]].view(Cin, B, Npads[s_])
                         if want_feats:
                             seg_grads[s_][2] = view[nxyz:, :, :Ns[s_]].permute(1, 0, 2)
                         if want_xyz:
