@@ -314,7 +314,8 @@ int o3d_gmax_fwd(const float* Y, const float* scale, const float* shift, int B, 
 /* Weight gradient of an aligned inner layer (Cin, Cout multiples of 64; P multiple of 128), workgroup
  * tile matched to the layer: dW (Cout,Cin) = sum dY * f(X), dY = A1*dN + A2*Y + A3 from dN (dense) or,
  * when dN == NULL, from the packed pooled source pk of o3d_pool_bwd_partials; f(x) =
- * max(x*in_scale+in_shift, 0).  scratch: o3d_mlp_conv_wgrad2_scratch(...) floats. */
+ * max(x*in_scale+in_shift, 0), or x when in_scale == in_shift == NULL.  scratch:
+ * o3d_mlp_conv_wgrad2_scratch(...) floats. */
 long o3d_mlp_conv_wgrad2_scratch(int B, int Cin, int Cout, int P);
 int o3d_mlp_conv_wgrad2(const float* dN, const float* pk, int ns, const float* Y, const float* A1,
                         const float* A2, const float* A3, const float* X, const float* in_scale,

@@ -87,8 +87,10 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
     const float* A1 = a.A1 + (seg ? a.Cout : 0);
     const float* A2 = a.A2 + (seg ? a.Cout : 0);
     const float* A3 = a.A3 + (seg ? a.Cout : 0);
-    const float* in_scale = a.in_scale + (seg ? a.Cin : 0);
-    const float* in_shift = a.in_shift + (seg ? a.Cin : 0);
+    const bool plain_x = a.in_scale == nullptr;          // X as stored (no BatchNorm + ReLU on load)
+    const float* in_scale = plain_x ? nullptr : a.in_scale + (seg ? a.Cin : 0);
+    const float* in_shift = plain_x ? nullptr : a.in_shift + (seg ? a.Cin : 0);
+    const float x_floor = plain_x ? -INFINITY : 0.f;
     const int chunks_per_b = a.P / CP;
     const int r0 = tid / F, c4 = tid % F;
     const int np = POOLED ? a.P / a.ns : 1;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
 #pragma unroll
     for (int i = 0; i < PB; ++i) {
         const int ci = ci0 + r0 + RPP * i;
-        ksc[i] = in_scale[ci]; ksh[i] = in_shift[ci];
+        ksc[i] = plain_x ? 1.f : in_scale[ci]; ksh[i] = plain_x ? 0.f : in_shift[ci];
     }
 
     float4 rg[PA], ry[PA], rx[PB];
@@ -151,8 +153,8 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
             float4 v = rx[i];
-            v.x = fmaxf(fmaf(v.x, ksc[i], ksh[i]), 0.f); v.y = fmaxf(fmaf(v.y, ksc[i], ksh[i]), 0.f);
-            v.z = fmaxf(fmaf(v.z, ksc[i], ksh[i]), 0.f); v.w = fmaxf(fmaf(v.w, ksc[i], ksh[i]), 0.f);
+            v.x = fmaxf(fmaf(v.x, ksc[i], ksh[i]), x_floor); v.y = fmaxf(fmaf(v.y, ksc[i], ksh[i]), x_floor);
+            v.z = fmaxf(fmaf(v.z, ksc[i], ksh[i]), x_floor); v.w = fmaxf(fmaf(v.w, ksc[i], ksh[i]), x_floor);
             *reinterpret_cast<float4*>(&Bs(buf)[(r0 + RPP * i) * LD + 4 * c4]) = v;
         }
     };
@@ -248,7 +250,7 @@ extern "C" long o3d_mlp_conv_wgrad2_scratch(int B, int Cin, int Cout, int P) {
 }
 
 // dW (Cout,Cin) = sum_{b,p} dY * f(X); dY from dN (dense) or pk (pooled, needs ns); X raw producer output
-// with (in_scale,in_shift).  Cin, Cout multiples of 64, P multiple of 128.
+// with (in_scale,in_shift) (both NULL: X as stored).  Cin, Cout multiples of 64, P multiple of 128.
 static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y, const float* A1, const float* A2,
                        const float* A3, const float* X, const float* in_scale, const float* in_shift, int B, int Cin,
                        int Cout, int P, const float* w, const int32_t* meta, long start1, float* scratch, float* dW,
@@ -277,7 +279,7 @@ static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y,
                        int Cout, int P, const float* w, const int32_t* meta, long start1, float* scratch, float* dW,
                        void* stream) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || P <= 0 || P % 128 || !Y || !A1 || !A2 || !A3 ||
-        !X || !in_scale || !in_shift || !scratch || !dW || (!dN && (!pk || ns < 4 || ns % 4)))
+        !X || (in_scale == nullptr) != (in_shift == nullptr) || !scratch || !dW || (!dN && (!pk || ns < 4 || ns % 4)))
         return O3D_EINVAL;
     int TM, TN, WK, CP, nsl;
     wgrad2_plan(Cin, Cout, B, P, TM, TN, WK, CP, nsl);

@@ -469,9 +469,11 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         padded = any(n != npd for n, npd in zip(Ns, Npads))
         # rows padded to a multiple of 16 (zero rows, zero weight columns): the per-point GEMM then runs on the
         # direct MFMA kernel (csrc/mlp_direct.hip needs K % 16 == 0) instead of the generic LDS-staged one
+        # (and the buffer itself to a multiple of 64 rows for the weight-gradient kernel of csrc/mlp_wgrad.hip)
         Cin0p = -(-Cin0 // 16) * 16 if Cin0 > 16 else Cin0
-        X0n = (torch.zeros if padded else torch.empty)((Cin0p, ldz), device=dev, dtype=f32)
-        if Cin0p != Cin0 and not padded:
+        Cin0m = -(-Cin0 // 64) * 64 if Cin0 > 16 else Cin0
+        X0n = (torch.zeros if padded else torch.empty)((Cin0m, ldz), device=dev, dtype=f32)
+        if Cin0m != Cin0 and not padded:
             X0n[Cin0:].zero_()
         centers = None
         for s_, (xyz, new_xyz, feats, _) in enumerate(segs):
@@ -624,21 +626,31 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                       gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), ball_off.data_ptr(), ball_cnt.data_ptr(), B, nseg,
                       npoints[0], Npads[0], npoints[-1], Npads[-1], Cout, S.data_ptr(), _ptr(T), st)
                 one, zero = _const_vec(dev, Cout, 1.0), _const_vec(dev, Cout, 0.0)
-                tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
-                total_chunks = ldz // 32
-                nsl = max(1, min(total_chunks // 4 if total_chunks >= 4 else 1, 768 // tiles))
-                wpart = torch.empty((nsl + 16, Cout, Cin), device=dev, dtype=f32)
-                dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
-                keep += [S, T, wpart, one, zero]
+                Cinm = X0n.shape[0]                  # rows of the padded per-point operand
+                keep += [S, T, one, zero]
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    _call("conv_wgrad_points", 2.0 * Cin * Cout * ldz, lib.o3d_mlp_conv_wgrad, S.data_ptr(), None, None,
-                          None, 4, S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(), None,
-                          None, None, None, None, None, 0, 0, 0, 1.0, 1, Cin, Cout, ldz, nsl, wpart.data_ptr(),
-                          dW.data_ptr(), side.cuda_stream)
+                    if Cinm % 64 == 0:       # aligned: the tile-matched MFMA weight-gradient kernel, X as stored
+                        wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cinm, Cout, ldz),), device=dev, dtype=f32)
+                        dWm = torch.empty((Cout, Cinm), device=dev, dtype=f32)
+                        _call("conv_wgrad_points", 2.0 * Cinm * Cout * ldz, lib.o3d_mlp_conv_wgrad2, S.data_ptr(), None, 4,
+                              S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(), None, None, 1,
+                              Cinm, Cout, ldz, wpart.data_ptr(), dWm.data_ptr(), side.cuda_stream)
+                    else:
+                        tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
+                        total_chunks = ldz // 32
+                        nsl = max(1, min(total_chunks // 4 if total_chunks >= 4 else 1, 768 // tiles))
+                        wpart = torch.empty((nsl + 16, Cout, Cin), device=dev, dtype=f32)
+                        dWm = torch.empty((Cout, Cin), device=dev, dtype=f32)
+                        _call("conv_wgrad_points", 2.0 * Cin * Cout * ldz, lib.o3d_mlp_conv_wgrad, S.data_ptr(), None, None,
+                              None, 4, S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(), None,
+                              None, None, None, None, None, 0, 0, 0, 1.0, 1, Cin, Cout, ldz, nsl, wpart.data_ptr(),
+                              dWm.data_ptr(), side.cuda_stream)
+                    keep += [wpart, dWm]
                     if nxyz:      # the centre term of grouped_xyz = xyz[idx] - new_xyz
-                        _call("center_term", 0.0, lib.o3d_center_term, T.data_ptr(), centers.data_ptr(), Cout, nballs, Cin,
-                              dW.data_ptr(), side.cuda_stream)
+                        _call("center_term", 0.0, lib.o3d_center_term, T.data_ptr(), centers.data_ptr(), Cout, nballs,
+                              dWm.shape[1], dWm.data_ptr(), side.cuda_stream)
+                    dW = dWm if dWm.shape[1] == Cin else dWm[:, :Cin].contiguous()
                 grads[0] = dW
                 if want_xyz or want_feats:
                     # dX = W0^T . S as a plain forward GEMM on the direct MFMA kernel: rows padded to a multiple of 64
