@@ -345,6 +345,14 @@ int o3d_track_loss(const float* cla, const float* seg, const float* vote, const 
                    int N, int P, int K, float w_obj, float w_box, float w_seg, float w_vote, float w_bc,
                    float* scratch, float* losses, float* g_cla, float* g_vote, float* g_boxes, float* g_bc, void* stream);
 
+/* ---- BoxCloud (next row of SURVEY.md section 8f-2) -------------------------------------------------
+ * get_point_to_box_distance (datasets/points_utils.py:127-143) with Box.corners (datasets/data_classes.py:
+ * 226-250): out (B,N,9) = distance of every point to the box centre (channel 0) and to the 8 corners
+ * (channels 1..8, the corner order of Box.corners).  wlh = (width, length, height); rot (B,3,3) row-major
+ * rotation matrix of the box orientation. */
+int o3d_boxcloud(const float* points, const float* center, const float* wlh, const float* rot, float wlh_factor,
+                 int B, int N, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

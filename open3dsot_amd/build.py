@@ -24,6 +24,7 @@ SOURCES = [
     ("compact.hip", []),
     ("pointwise.hip", []),
     ("loss.hip", []),
+    ("boxcloud.hip", []),
     ("capi_misc.hip", []),
 ]
 COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-atomics",

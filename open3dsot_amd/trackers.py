@@ -145,6 +145,18 @@ class BAT(MatchingBaseModel):
         self.rpn = P2BVoteNetRPN(c.feature_channel, vote_channel=c.vote_channel,
                                  num_proposal=c.num_proposal, normalize_xyz=c.normalize_xyz)
 
+    def prepare_input(self, template_points, search_points, template_box):
+        """Inference input of one frame (models/bat.py:41-55) built on the device: both clouds resampled to the
+        configured sizes (seed 1, the reference's draw) and the template BoxCloud from csrc/boxcloud.hip --
+        no host round trip.  template_points / search_points: (n,3) GPU tensors; template_box = (center,
+        wlh, rotation matrix) of the template's target box."""
+        from . import points_utils
+        tp, _ = points_utils.regularize_pc(template_points, self.config.template_size, seed=1)
+        sp, _ = points_utils.regularize_pc(search_points, self.config.search_size, seed=1)
+        tp, sp = tp.float(), sp.float()
+        bc = points_utils.get_point_to_box_distance(tp, *template_box)
+        return {"template_points": tp[None], "search_points": sp[None], "points2cc_dist_t": bc[None]}
+
     def compute_loss(self, data, output):
         out = super().compute_loss(data, output)
         loss_bc = F.smooth_l1_loss(output["pred_search_bc"], data["points2cc_dist_s"], reduction="none")
