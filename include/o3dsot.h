@@ -39,6 +39,12 @@ const char* o3d_version(void);
 int o3d_furthest_point_sampling(const float* xyz, int B, int N, int npoint, float* temp,
                                 int32_t* idx, void* stream);
 
+/* Two independent sets of B clouds in ONE launch (the template and the search cloud of a tracker step,
+ * models/bat.py:89-90: 2 x B one-wave workgroups side by side instead of back to back).  Each set's indices are
+ * bit-identical to o3d_furthest_point_sampling on it.  max(N0,N1) <= 2048, else O3D_EINVAL (make two calls). */
+int o3d_furthest_point_sampling_pair(const float* xyz0, int N0, int npoint0, int32_t* idx0, const float* xyz1,
+                                     int N1, int npoint1, int32_t* idx1, int B, void* stream);
+
 /* ---- gather ---------------------------------------------------------------------------
  * replaces _ext.gather_points(features, idx)              pointnet2_utils.py:92
  * feats (B,C,N), idx (B,npoint) -> out (B,C,npoint) */

@@ -19,6 +19,7 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 SIGNATURES = {
     "o3d_furthest_point_sampling": [_vp, _i, _i, _i, _vp, _vp, _vp],
     "o3d_furthest_point_sampling_shfl": [_vp, _i, _i, _i, _vp, _vp, _vp],
+    "o3d_furthest_point_sampling_pair": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp],
     "o3d_gather_points": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "o3d_gather_points_grad": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "o3d_ball_query": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],

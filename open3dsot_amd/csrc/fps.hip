@@ -62,20 +62,34 @@ __device__ __forceinline__ unsigned fps_rank(unsigned k, int bs_log2, unsigned c
     return rev * cpb + (k >> bs_log2);
 }
 
+// A second, independent set of clouds sampled by the same launch (workgroups >= B0): the template and the
+// search cloud of a tracker step are one wave per cloud each -- 2 x 48 workgroups on 256 CUs -- so the two
+// samplings run side by side instead of back to back.  xyz == NULL: one set.
+struct FpsSet1 {
+    const float* xyz;
+    int32_t* idx;
+    int N, npoint, bs_log2, cpb, B0;
+};
+
 // One workgroup (NW waves) per cloud, PPT points per lane in registers.  N <= 64*NW*PPT,
 // N < 65535.  LDS: N*3 floats (cloud copy) + 2*NW words (cross-wave exchange).
 template <int PPT, int NW, bool USE_DPP>
 __global__ __launch_bounds__(64 * NW) void fps_reg_kernel(const float* __restrict__ xyz, int N,
                                                           int npoint, int bs_log2, int cpb,
-                                                          int32_t* __restrict__ idx) {
+                                                          int32_t* __restrict__ idx, FpsSet1 s1) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    int cloud = blockIdx.x;
+    if (s1.xyz && cloud >= s1.B0) {
+        cloud -= s1.B0;
+        xyz = s1.xyz; idx = s1.idx; N = s1.N; npoint = s1.npoint; bs_log2 = s1.bs_log2; cpb = s1.cpb;
+    }
     float* s_xyz = smem;
     unsigned* s_x = reinterpret_cast<unsigned*>(smem + (size_t)N * 3);  // [2][NW]
     constexpr int T = 64 * NW;
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
-    const float* p = xyz + (size_t)blockIdx.x * N * 3;
-    int32_t* out = idx + (size_t)blockIdx.x * npoint;
+    const float* p = xyz + (size_t)cloud * N * 3;
+    int32_t* out = idx + (size_t)cloud * npoint;
 
     for (int t = tid; t < N * 3; t += T) s_xyz[t] = p[t];
     __syncthreads();
@@ -195,7 +209,27 @@ int launch_reg(const float* xyz, int B, int N, int npoint, int bs_log2, int cpb,
                hipStream_t s) {
     const size_t lds = (size_t)N * 3 * sizeof(float) + 2 * NW * sizeof(unsigned);
     hipLaunchKernelGGL((fps_reg_kernel<PPT, NW, USE_DPP>), dim3(B), dim3(64 * NW), lds, s, xyz, N,
-                       npoint, bs_log2, cpb, idx);
+                       npoint, bs_log2, cpb, idx, FpsSet1{});
+    return o3d_launch_status();
+}
+
+static void fps_rank_params(int N, int& bs_log2, int& cpb) {
+    bs_log2 = 0;
+    while ((2 << bs_log2) <= N && bs_log2 < 9) ++bs_log2;  // bs = opt_n_threads(N)
+    cpb = (N + (1 << bs_log2) - 1) >> bs_log2;
+}
+
+// both sets in one launch of the one-wave-per-cloud kernel sized for the larger cloud
+template <int PPT>
+int launch_pair(const float* xyz0, int N0, int np0, int32_t* idx0, const float* xyz1, int N1, int np1,
+                int32_t* idx1, int B, hipStream_t s) {
+    int l0, c0, l1, c1;
+    fps_rank_params(N0, l0, c0);
+    fps_rank_params(N1, l1, c1);
+    const int Nmax = N0 > N1 ? N0 : N1;
+    const size_t lds = (size_t)Nmax * 3 * sizeof(float) + 2 * sizeof(unsigned);
+    const FpsSet1 s1 = {xyz1, idx1, N1, np1, l1, c1, B};
+    hipLaunchKernelGGL((fps_reg_kernel<PPT, 1, true>), dim3(2 * B), dim3(64), lds, s, xyz0, N0, np0, l0, c0, idx0, s1);
     return o3d_launch_status();
 }
 
@@ -228,6 +262,22 @@ extern "C" int o3d_furthest_point_sampling(const float* xyz, int B, int N, int n
     if (B < 0 || N <= 0 || npoint < 0 || (B > 0 && npoint > 0 && (!xyz || !idx))) return O3D_EINVAL;
     if (B == 0 || npoint == 0) return O3D_OK;
     return fps_dispatch<true>(xyz, B, N, npoint, temp, idx, o3d_stream(stream));
+}
+
+// Two independent sets of B clouds (N0 / N1 points, npoint0 / npoint1 samples) in ONE launch; each set's
+// result is bit-identical to o3d_furthest_point_sampling on it.  max(N0, N1) <= 2048 (one wave per cloud),
+// npoint >= 1; otherwise O3D_EINVAL -- make the two calls.
+extern "C" int o3d_furthest_point_sampling_pair(const float* xyz0, int N0, int npoint0, int32_t* idx0,
+                                                const float* xyz1, int N1, int npoint1, int32_t* idx1, int B,
+                                                void* stream) {
+    const int Nmax = N0 > N1 ? N0 : N1;
+    if (B <= 0 || N0 <= 0 || N1 <= 0 || npoint0 <= 0 || npoint1 <= 0 || Nmax > 2048 || !xyz0 || !xyz1 || !idx0 || !idx1)
+        return O3D_EINVAL;
+    hipStream_t s = o3d_stream(stream);
+    if (Nmax <= 256) return launch_pair<4>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
+    if (Nmax <= 512) return launch_pair<8>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
+    if (Nmax <= 1024) return launch_pair<16>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
+    return launch_pair<32>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
 }
 
 // Test hook: same op through the ds_bpermute (__shfl_xor) reduction instead of DPP.

@@ -53,6 +53,24 @@ def furthest_point_sampling(xyz, npoint, _variant="dpp"):
     return out
 
 
+def furthest_point_sampling_pair(xyz_a, npoint_a, xyz_b, npoint_b):
+    """furthest_point_sampling of two independent sets of clouds (same batch size) in one launch -> (idx_a, idx_b),
+    each bit-identical to the single call; falls back to two launches beyond 2048 points per cloud."""
+    _chk_f(xyz_a, "xyz_a")
+    _chk_f(xyz_b, "xyz_b")
+    B, Na, _ = xyz_a.shape
+    Nb = xyz_b.shape[1]
+    if xyz_b.shape[0] != B or max(Na, Nb) > 2048 or min(int(npoint_a), int(npoint_b)) < 1 or B == 0:
+        return furthest_point_sampling(xyz_a, npoint_a), furthest_point_sampling(xyz_b, npoint_b)
+    out_a = torch.empty((B, int(npoint_a)), dtype=torch.int32, device=xyz_a.device)
+    out_b = torch.empty((B, int(npoint_b)), dtype=torch.int32, device=xyz_a.device)
+    with torch.cuda.device(xyz_a.device):
+        capi.check(capi.load().o3d_furthest_point_sampling_pair(xyz_a.data_ptr(), Na, int(npoint_a), out_a.data_ptr(),
+                                                                xyz_b.data_ptr(), Nb, int(npoint_b), out_b.data_ptr(), B,
+                                                                _stream()), "furthest_point_sampling_pair")
+    return out_a, out_b
+
+
 def gather_points(features, idx):
     """features (B,C,N), idx (B,npoint) -> (B,C,npoint)   [pointnet2_utils.py:92]"""
     _chk_f(features, "features")

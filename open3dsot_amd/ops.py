@@ -31,6 +31,12 @@ class FurthestPointSampling(Function):
 furthest_point_sample = FurthestPointSampling.apply
 
 
+def furthest_point_sample_pair(xyz_a, npoint_a, xyz_b, npoint_b):
+    """furthest_point_sample of two independent sets of clouds in one launch (indices: not differentiable)"""
+    with torch.no_grad():
+        return _ext.furthest_point_sampling_pair(xyz_a.contiguous(), npoint_a, xyz_b.contiguous(), npoint_b)
+
+
 class GatherOperation(Function):
     """features (B,C,N), idx (B,npoint) i32 -> (B,C,npoint); grad scatters back into (B,C,N)."""
 

@@ -115,6 +115,10 @@ class _PointnetSAModuleBase(nn.Module):
                     main.wait_stream(side)
                     idx_b.record_stream(main)
                     new_b.record_stream(main)
+                elif self.use_fps:       # both farthest-point samplings in one launch (one wave per cloud each)
+                    idx_a, idx_b = pointnet2_utils.furthest_point_sample_pair(xyz_a, npoint_a, xyz_b, npoint_b)
+                    new_a = pointnet2_utils.gather_operation(xyz_a.transpose(1, 2).contiguous(), idx_a).transpose(1, 2).contiguous()
+                    new_b = pointnet2_utils.gather_operation(xyz_b.transpose(1, 2).contiguous(), idx_b).transpose(1, 2).contiguous()
                 else:
                     idx_a, new_a = self._sample(xyz_a, npoint_a)
                     idx_b, new_b = self._sample(xyz_b, npoint_b)

@@ -179,3 +179,17 @@ def test_error_behaviour(ext):
         ext.group_points(torch.zeros(1, 2, 8).cuda(), torch.zeros(1, 2, 2).cuda())  # idx not int32
     with pytest.raises(RuntimeError):
         ext.ball_query(x.double(), x, 0.3, 4)                      # wrong dtype
+
+
+@pytest.mark.parametrize("Na,npa,Nb,npb", [(512, 256, 1024, 512), (1024, 512, 512, 256), (100, 33, 2048, 1024), (64, 64, 64, 1)])
+def test_fps_pair_launch_is_bit_identical(Na, npa, Nb, npb):
+    """o3d_furthest_point_sampling_pair: two sets of clouds in one launch = the two single calls"""
+    import torch
+    from open3dsot_amd import ext
+    g = torch.Generator().manual_seed(Na + Nb)
+    a = torch.randn(7, Na, 3, generator=g).cuda()
+    b = (torch.randn(7, Nb, 3, generator=g) * 3).cuda()
+    a[2, :5] = 0.0          # near-origin points are never selected (sampling_gpu.cu: mag <= 1e-3)
+    ia, ib = ext.furthest_point_sampling_pair(a, npa, b, npb)
+    assert torch.equal(ia, ext.furthest_point_sampling(a, npa))
+    assert torch.equal(ib, ext.furthest_point_sampling(b, npb))
