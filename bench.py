@@ -189,6 +189,10 @@ def main():
             if t.get("workload_batch") == args.batch and t.get("model") == args.model:
                 roofline["traffic"] = t["gemm_family_hbm_bytes_per_launch"]
                 roofline["traffic_source"] = t["source"]
+                # the same launches against the other roof: measured HBM bytes / measured time
+                gbs = roofline["traffic"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9
+                roofline["hbm_gbs"] = round(gbs, 1)
+                roofline["hbm_frac"] = round(gbs / PEAK_HBM_GBS, 4)
     if roofline is None:  # no instrumented kernels yet: whole-step algorithmic rate (labelled as such)
         flops = 3.0 * mlp_flops_per_pair(args.model) * args.batch
         ach = flops / (elapsed / args.steps) / 1e12

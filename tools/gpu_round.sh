@@ -23,5 +23,6 @@ F=$(find $OUT/trace_eager -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && c
 G=$(find $OUT/trace_graph -name "*kernel_trace.csv" | head -1); [ -n "$G" ] && python tools/trace_steps.py "$G" 20 80 > $OUT/steady_state_per_step.txt
 mkdir -p $OUT/pmc; find $OUT/pmc_fetch $OUT/pmc_write -name "*counter_collection.csv" | while read f; do cp "$f" $OUT/pmc/$(echo $f | grep -o "pmc_[a-z]*")_$(basename $f); done
 python tools/pmc_summary.py $OUT/pmc $OUT/pmc_summary.csv
+python tools/hbm_traffic.py $OUT/pmc_summary.csv $OUT/hbm_traffic.json BAT 48
 rm -rf $OUT/trace_eager $OUT/trace_graph $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc
 head -3 $OUT/steady_state_per_step.txt; cat $OUT/bench.json | cut -c1-600
