@@ -487,7 +487,11 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             if not unit:
                 centers = centers * cfg.inv_radius
         Z = torch.empty((C0, ldz), device=dev, dtype=f32)
-        W0p = Ws[0] if Cin0p == Cin0 else torch.nn.functional.pad(Ws[0], (0, Cin0p - Cin0))
+        if Cin0p == Cin0:
+            W0p = Ws[0]
+        else:       # zero-padded copy in a buffer kept on the module: one copy launch per step
+            W0p = _padded(cfg.bns[0], "_o3d_w0p", (C0, Cin0p), dev)
+            W0p[:, :Cin0].copy_(Ws[0])
         _call("conv_fwd_points", 2.0 * Cin0p * C0 * ldz, lib.o3d_mlp_conv_fwd, X0n.data_ptr(), W0p.data_ptr(),
               None, None, 1, Cin0p, C0, ldz, Z.data_ptr(), None, None, st)
         counts = [float(pm) for pm in Pmaxs]          # BatchNorm counts every slot (copies included)
@@ -655,7 +659,8 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                 if want_xyz or want_feats:
                     # dX = W0^T . S as a plain forward GEMM on the direct MFMA kernel: rows padded to a multiple of 64
                     Cinm = -(-Cin // 64) * 64
-                    W0t = torch.nn.functional.pad(Ws[0], (0, Cinm - Cin)).t().contiguous()          # (Cinm, Cout)
+                    W0t = _padded(cfg.bns[0], "_o3d_w0t", (Cinm, Cout), dev)                          # (Cinm, Cout), rows >= Cin zero
+                    W0t[:Cin].copy_(Ws[0].t())
                     dX = torch.empty((Cinm, ldz), device=dev, dtype=f32)
                     _call("conv_dgrad_points", 2.0 * Cinm * Cout * ldz, lib.o3d_mlp_conv_fwd, S.data_ptr(), W0t.data_ptr(),
                           None, None, 1, Cout, Cinm, ldz, dX.data_ptr(), None, None, st)
@@ -700,6 +705,16 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             gin += [seg_grads[s_][0] if needs[4 * s_] else None, seg_grads[s_][1] if needs[4 * s_ + 1] else None,
                     seg_grads[s_][2] if needs[4 * s_ + 2] else None, None]
         return (None, None, *gin, *gw)
+
+
+def _padded(owner, name, shape, dev):
+    """zero-initialised scratch kept on `owner` (a module of the layer): callers overwrite the live part each
+    step and rely on the padding staying zero"""
+    buf = getattr(owner, name, None)
+    if buf is None or tuple(buf.shape) != tuple(shape) or buf.device != dev:
+        buf = torch.zeros(shape, device=dev, dtype=torch.float32)
+        object.__setattr__(owner, name, buf)
+    return buf
 
 
 def _compact_ok(layers, npoint, ns, B):
