@@ -125,27 +125,48 @@ __global__ __launch_bounds__(256) void expand_c_kernel(const float* __restrict__
             cx[t] = c[0]; cy[t] = c[1]; cz[t] = c[2];
         }
     }
-    for (int co = wave; co < C0; co += 4) {
-        const float* z = Z + (long)co * ldz;
-        float w0 = 0.f, w1 = 0.f, w2 = 0.f;
-        if (centers) { const float* wr = W0 + (long)co * ldw; w0 = wr[0]; w1 = wr[1]; w2 = wr[2]; }
-        float4 y;
-        y.x = z[id.x] - fmaf(w2, cz[0], fmaf(w1, cy[0], w0 * cx[0]));
-        y.y = z[id.y] - fmaf(w2, cz[1], fmaf(w1, cy[1], w0 * cx[1]));
-        y.z = z[id.z] - fmaf(w2, cz[2], fmaf(w1, cy[2], w0 * cx[2]));
-        y.w = z[id.w] - fmaf(w2, cz[3], fmaf(w1, cy[3], w0 * cx[3]));
-        *reinterpret_cast<float4*>(&Y0[(long)co * ldp + q]) = y;
-        if (part) {
-            const float c = stat_c ? stat_c[co] : 0.f;
-            float s = fmaf(w.x, y.x, fmaf(w.y, y.y, fmaf(w.z, y.z, w.w * y.w)));
-            float v = w.x * (y.x - c) * (y.x - c) + w.y * (y.y - c) * (y.y - c) + w.z * (y.z - c) * (y.z - c) +
-                      w.w * (y.w - c) * (y.w - c);
+    // channels in groups of EG per wave: all 4*EG gathers in flight first, and the EG x 2 statistics butterflies
+    // interleave (one channel at a time the 12 dependent shuffles are a ~300-cycle chain per channel)
+    constexpr int EG = 8;
+    for (int g0 = wave; g0 < C0; g0 += 4 * EG) {
+        float4 y[EG];
 #pragma unroll
-            for (int m = 1; m < 64; m <<= 1) { s += __shfl_xor(s, m, 64); v += __shfl_xor(v, m, 64); }
-            if (lane == 0) {
-                part[((long)blockIdx.x * 2 + 0) * C0 + co] = s;
-                part[((long)blockIdx.x * 2 + 1) * C0 + co] = v;
-            }
+        for (int g = 0; g < EG; ++g) {
+            const int co = g0 + 4 * g < C0 ? g0 + 4 * g : C0 - 1;
+            const float* z = Z + (long)co * ldz;
+            y[g].x = z[id.x]; y[g].y = z[id.y]; y[g].z = z[id.z]; y[g].w = z[id.w];
+        }
+        float s[EG], v[EG];
+#pragma unroll
+        for (int g = 0; g < EG; ++g) {
+            const int co = g0 + 4 * g;
+            if (co >= C0) { s[g] = 0.f; v[g] = 0.f; continue; }
+            float w0 = 0.f, w1 = 0.f, w2 = 0.f;
+            if (centers) { const float* wr = W0 + (long)co * ldw; w0 = wr[0]; w1 = wr[1]; w2 = wr[2]; }
+            y[g].x -= fmaf(w2, cz[0], fmaf(w1, cy[0], w0 * cx[0]));
+            y[g].y -= fmaf(w2, cz[1], fmaf(w1, cy[1], w0 * cx[1]));
+            y[g].z -= fmaf(w2, cz[2], fmaf(w1, cy[2], w0 * cx[2]));
+            y[g].w -= fmaf(w2, cz[3], fmaf(w1, cy[3], w0 * cx[3]));
+            *reinterpret_cast<float4*>(&Y0[(long)co * ldp + q]) = y[g];
+            const float c = (part && stat_c) ? stat_c[co] : 0.f;
+            s[g] = fmaf(w.x, y[g].x, fmaf(w.y, y[g].y, fmaf(w.z, y[g].z, w.w * y[g].w)));
+            v[g] = w.x * (y[g].x - c) * (y[g].x - c) + w.y * (y[g].y - c) * (y[g].y - c) +
+                   w.z * (y[g].z - c) * (y[g].z - c) + w.w * (y[g].w - c) * (y[g].w - c);
+        }
+        if (part) {
+#pragma unroll
+            for (int m = 1; m < 64; m <<= 1)
+#pragma unroll
+                for (int g = 0; g < EG; ++g) { s[g] += __shfl_xor(s[g], m, 64); v[g] += __shfl_xor(v[g], m, 64); }
+            if (lane == 0)
+#pragma unroll
+                for (int g = 0; g < EG; ++g) {
+                    const int co = g0 + 4 * g;
+                    if (co < C0) {
+                        part[((long)blockIdx.x * 2 + 0) * C0 + co] = s[g];
+                        part[((long)blockIdx.x * 2 + 1) * C0 + co] = v[g];
+                    }
+                }
         }
     }
 }
@@ -327,39 +348,51 @@ __global__ __launch_bounds__(256) void reduce_c_kernel(const float* __restrict__
     // one lane per 8 cycles per CU, measured with tools/exp/group_probe.py).
     const int lane = threadIdx.x & 63;
     const int span = q1 - q0;
+    // column metadata of the next 256-column chunk is fetched while the current one is reduced; within a chunk
+    // all channel loads go out first and the CS segmented scans advance together (independent shuffle chains)
+    int qn = q0 + threadIdx.x;
+    int gpn = qn < q1 ? gp[qn] : 0, cbn = qn < q1 ? cball[qn] : -1;
+    float cwn = qn < q1 ? cw[qn] : 0.f;
     for (int i0 = 0; i0 < span; i0 += 256) {
         const int q = q0 + i0 + threadIdx.x;
         const bool live = q < q1;
-        const int n = live ? gp[q] - pbase : 0, j = live ? cball[q] - bbase : -1;
-        const float w = live ? cw[q] : 0.f;
-        unsigned same = 0;           // bit s: lane - 2^s belongs to the same ball
+        const int n = live ? gpn - pbase : 0, j = live ? cbn - bbase : -1;
+        const float w = cwn;
+        qn = q + 256;
+        if (i0 + 256 < span) {
+            gpn = qn < q1 ? gp[qn] : 0; cbn = qn < q1 ? cball[qn] : -1; cwn = qn < q1 ? cw[qn] : 0.f;
+        }
+        float dy[CS];
+#pragma unroll
+        for (int c = 0; c < CS; ++c) {
+            dy[c] = 0.f;
+            if (live && c0 + c < C0) {
+                const long o = (long)(c0 + c) * ldp + q;
+                dy[c] = fmaf(a1[c], dN[o], w * fmaf(a2[c], Y0[o], a3[c]));
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CS; ++c)
+            if (live && c0 + c < C0) atomicAdd(&acc[c * ld + n], dy[c]);
         if (T) {
+            unsigned same = 0;           // bit s: lane - 2^s belongs to the same ball
 #pragma unroll
             for (int sft = 0; sft < 6; ++sft) {
                 const int ju = __shfl_up(j, 1 << sft, 64);
                 if (lane >= (1 << sft) && ju == j) same |= 1u << sft;
             }
-        }
-        const int jn = __shfl_down(j, 1, 64);
-        const bool tail = live && (lane == 63 || jn != j);
+            const int jn = __shfl_down(j, 1, 64);
+            const bool tail = live && (lane == 63 || jn != j);
 #pragma unroll
-        for (int c = 0; c < CS; ++c) {
-            if (c0 + c >= C0) break;
-            float dy = 0.f;
-            if (live) {
-                const long o = (long)(c0 + c) * ldp + q;
-                dy = fmaf(a1[c], dN[o], w * fmaf(a2[c], Y0[o], a3[c]));
-                atomicAdd(&acc[c * ld + n], dy);
-            }
-            if (T) {
-                float run = dy;
+            for (int sft = 0; sft < 6; ++sft)
 #pragma unroll
-                for (int sft = 0; sft < 6; ++sft) {
-                    const float up = __shfl_up(run, 1 << sft, 64);
-                    if (same & (1u << sft)) run += up;
+                for (int c = 0; c < CS; ++c) {
+                    const float up = __shfl_up(dy[c], 1 << sft, 64);
+                    if (same & (1u << sft)) dy[c] += up;
                 }
-                if (tail) atomicAdd(&tacc[c * npoint + j], run);
-            }
+#pragma unroll
+            for (int c = 0; c < CS; ++c)
+                if (tail && c0 + c < C0) atomicAdd(&tacc[c * npoint + j], dy[c]);
         }
     }
     __syncthreads();
