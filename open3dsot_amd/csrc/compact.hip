@@ -342,57 +342,64 @@ __global__ __launch_bounds__(256) void reduce_c_kernel(const float* __restrict__
         const int cc = seg * C0 + (c0 + c < C0 ? c0 + c : C0 - 1);     // segment 1: its own BN-backward constants
         a1[c] = A1[cc]; a2[c] = A2[cc]; a3[c] = A3[cc];
     }
-    // A ball's columns are consecutive, so its sum T is a segmented reduction over lanes (inclusive
-    // segmented scan by ball id, the last lane of each run adds the run total once): per-element LDS
-    // atomics on T would pile the ~8 columns of a ball onto one address (ds_add_f32 retires roughly
-    // one lane per 8 cycles per CU, measured with tools/exp/group_probe.py).
-    const int lane = threadIdx.x & 63;
-    const int span = q1 - q0;
-    // column metadata of the next 256-column chunk is fetched while the current one is reduced; within a chunk
-    // all channel loads go out first and the CS segmented scans advance together (independent shuffle chains)
-    int qn = q0 + threadIdx.x;
-    int gpn = qn < q1 ? gp[qn] : 0, cbn = qn < q1 ? cball[qn] : -1;
-    float cwn = qn < q1 ? cw[qn] : 0.f;
-    for (int i0 = 0; i0 < span; i0 += 256) {
-        const int q = q0 + i0 + threadIdx.x;
-        const bool live = q < q1;
-        const int n = live ? gpn - pbase : 0, j = live ? cbn - bbase : -1;
-        const float w = cwn;
-        qn = q + 256;
-        if (i0 + 256 < span) {
-            gpn = qn < q1 ? gp[qn] : 0; cbn = qn < q1 ? cball[qn] : -1; cwn = qn < q1 ? cw[qn] : 0.f;
+    // lane = 4 consecutive columns (one dwordx4 per operand row and per metadata array): 1024 columns per pass,
+    // all 2*CS row loads in flight before the first LDS atomic.  A ball's columns are consecutive, so a lane first
+    // folds its own columns of the same ball into one term for the ball sum T (the ~8 columns of a ball piling onto
+    // one LDS address was the slow part: ds_add_f32 retires roughly one lane per 8 cycles per CU on a shared address).
+    for (int base = q0 & ~3; base < q1; base += 1024) {
+        const int q = base + 4 * threadIdx.x;
+        const bool any = q < q1;
+        int4 g4 = make_int4(0, 0, 0, 0), b4 = make_int4(0, 0, 0, 0);
+        float4 w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (any) {
+            g4 = *reinterpret_cast<const int4*>(&gp[q]);
+            b4 = *reinterpret_cast<const int4*>(&cball[q]);
+            w4 = *reinterpret_cast<const float4*>(&cw[q]);
         }
-        float dy[CS];
+        const int gq[4] = {g4.x, g4.y, g4.z, g4.w}, bq[4] = {b4.x, b4.y, b4.z, b4.w};
+        const float wq[4] = {w4.x, w4.y, w4.z, w4.w};
+        bool lv[4];
+        int n[4], j[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            lv[t] = q + t >= q0 && q + t < q1;
+            n[t] = lv[t] ? gq[t] - pbase : 0;
+            j[t] = lv[t] ? bq[t] - bbase : -1;
+        }
+        float dy[CS][4];
 #pragma unroll
         for (int c = 0; c < CS; ++c) {
-            dy[c] = 0.f;
-            if (live && c0 + c < C0) {
+            float4 d = make_float4(0.f, 0.f, 0.f, 0.f), y = d;
+            if (any && c0 + c < C0) {
                 const long o = (long)(c0 + c) * ldp + q;
-                dy[c] = fmaf(a1[c], dN[o], w * fmaf(a2[c], Y0[o], a3[c]));
+                d = *reinterpret_cast<const float4*>(&dN[o]);
+                y = *reinterpret_cast<const float4*>(&Y0[o]);
             }
+            const float dv[4] = {d.x, d.y, d.z, d.w}, yv[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) dy[c][t] = lv[t] ? fmaf(a1[c], dv[t], wq[t] * fmaf(a2[c], yv[t], a3[c])) : 0.f;
         }
 #pragma unroll
-        for (int c = 0; c < CS; ++c)
-            if (live && c0 + c < C0) atomicAdd(&acc[c * ld + n], dy[c]);
-        if (T) {
-            unsigned same = 0;           // bit s: lane - 2^s belongs to the same ball
+        for (int c = 0; c < CS; ++c) {
+            if (c0 + c >= C0) break;
 #pragma unroll
-            for (int sft = 0; sft < 6; ++sft) {
-                const int ju = __shfl_up(j, 1 << sft, 64);
-                if (lane >= (1 << sft) && ju == j) same |= 1u << sft;
-            }
-            const int jn = __shfl_down(j, 1, 64);
-            const bool tail = live && (lane == 63 || jn != j);
+            for (int t = 0; t < 4; ++t)
+                if (lv[t]) atomicAdd(&acc[c * ld + n[t]], dy[c][t]);
+            if (T) {
+                float run = dy[c][0];
+                int jr = j[0];
 #pragma unroll
-            for (int sft = 0; sft < 6; ++sft)
-#pragma unroll
-                for (int c = 0; c < CS; ++c) {
-                    const float up = __shfl_up(dy[c], 1 << sft, 64);
-                    if (same & (1u << sft)) dy[c] += up;
+                for (int t = 1; t < 4; ++t) {
+                    if (j[t] == jr) {
+                        run += dy[c][t];
+                    } else {
+                        if (jr >= 0) atomicAdd(&tacc[c * npoint + jr], run);
+                        jr = j[t];
+                        run = dy[c][t];
+                    }
                 }
-#pragma unroll
-            for (int c = 0; c < CS; ++c)
-                if (tail && c0 + c < C0) atomicAdd(&tacc[c * npoint + j], dy[c]);
+                if (jr >= 0) atomicAdd(&tacc[c * npoint + jr], run);
+            }
         }
     }
     __syncthreads();
