@@ -51,7 +51,7 @@ __global__ __launch_bounds__(1024) void compact_scan_kernel(const int32_t* __res
     sh[threadIdx.x] = local;
     __syncthreads();
     for (int off = 1; off < 1024; off <<= 1) {
-        const int v = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        const int v = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
         __syncthreads();
         sh[threadIdx.x] += v;
         __syncthreads();
