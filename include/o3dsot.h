@@ -39,6 +39,11 @@ const char* o3d_version(void);
 int o3d_furthest_point_sampling(const float* xyz, int B, int N, int npoint, float* temp,
                                 int32_t* idx, void* stream);
 
+/* Test hook: the same sampling with the wave arg-max through ds_bpermute shuffles instead of DPP (the two
+ * reductions must agree bit for bit, tests/test_index_ops_gpu.py). */
+int o3d_furthest_point_sampling_shfl(const float* xyz, int B, int N, int npoint, float* temp, int32_t* idx,
+                                     void* stream);
+
 /* Two independent sets of B clouds in ONE launch (the template and the search cloud of a tracker step,
  * models/bat.py:89-90: 2 x B one-wave workgroups side by side instead of back to back).  Each set's indices are
  * bit-identical to o3d_furthest_point_sampling on it.  max(N0,N1) <= 2048, else O3D_EINVAL (make two calls). */

@@ -57,3 +57,34 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(capi, "SO_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(capi.O3DError, match="no CPU fallback"):
         capi.load()
+
+
+def header_prototypes():
+    """name -> list of parameter kinds ('p' pointer, 'i' int, 'l' long, 'f' float, 'd' double) from include/o3dsot.h"""
+    src = open(os.path.join(ROOT, "include", "o3dsot.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = {}
+    for m in re.finditer(r"\b(?:int|long|const char\s*\*)\s+(o3d_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src):
+        params = [p.strip() for p in m.group(2).split(",") if p.strip() and p.strip() != "void"]
+        kinds = []
+        for p in params:
+            if "*" in p:
+                kinds.append("p")
+            else:
+                t = p.split()
+                kinds.append({"int": "i", "long": "l", "float": "f", "double": "d"}[t[-2] if len(t) > 1 else t[0]])
+        protos[m.group(1)] = kinds
+    return protos
+
+
+def test_ctypes_signatures_match_the_header():
+    """every argtypes list registered by the Python binding has the arity and the argument kinds of its
+    prototype in include/o3dsot.h (a silent ctypes mismatch corrupts arguments instead of failing)"""
+    from open3dsot_amd import capi, fused, fused_loss, fused_pointwise, points_utils  # noqa: F401  (they register)
+    protos = header_prototypes()
+    kind = {ctypes.c_void_p: "p", ctypes.c_int: "i", ctypes.c_long: "l", ctypes.c_float: "f", ctypes.c_double: "d"}
+    assert len(capi.SIGNATURES) >= 40
+    for name, argtypes in capi.SIGNATURES.items():
+        assert name in protos, "%s is bound but not declared in include/o3dsot.h" % name
+        got = [kind[a] for a in argtypes]
+        assert got == protos[name], (name, got, protos[name])
