@@ -290,9 +290,11 @@ bool o3d_direct_ok(int M, int K, int P) { return M % DT_M == 0 && K % 16 == 0 &&
 // M output rows: 64 while the expected number of waves (a quarter of the worst case is live after
 // compaction) does not fill the 256 CUs a few times over, else 128.
 extern "C" int o3d_direct_tile(long P, int M, int compact) {
-    const long live = compact ? P / 4 : P;
-    (void)live; (void)M;
-    return 128;   // measured (O3D_DIRECT_TILE=64 vs 128, batch 48): 64-column tiles lose 1.3 % -- more loads per MFMA
+    (void)M; (void)compact;
+    // measured on the MI355X (batch 48, same run A/B): 64-column tiles for every launch lose 1.3 % (more loads
+    // per MFMA); 64-column tiles only for the small launches (vote aggregation, BoxCloud xcorr: <= 64 K slots,
+    // too few 128-column tiles for the 256 CUs) gain 0.8 % (7.705 -> 7.642 ms per step)
+    return P <= 65536 ? 64 : 128;
 }
 
 // forward: Y = W . f(X), see o3d_mlp_conv_fwd

@@ -391,7 +391,12 @@ _USE_SIDE = {"on": _os.environ.get("O3D_SIDE_STREAM", "0") == "1"}
 
 def _direct_tile(lib, pmax, m):
     t = _os.environ.get("O3D_DIRECT_TILE")          # experiment switch: force 64 / 128 columns per wave tile
-    return int(t) if t else lib.o3d_direct_tile(pmax, m, 1)
+    if t:
+        return int(t)
+    small = _os.environ.get("O3D_DIRECT_TILE_SMALL")   # experiment switch: 64-column tiles up to this many slots
+    if small and pmax <= int(small):
+        return 64
+    return lib.o3d_direct_tile(pmax, m, 1)
 
 
 def _side_stream(dev):
