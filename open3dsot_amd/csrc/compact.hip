@@ -19,6 +19,7 @@
 //   gp[q]    = b*ld + idx[b,j,k]      source point, as a column of the per-point matrices (C, B*ld)
 //   cball[q] = b*npoint + j           ball id (dummy id B*npoint for the padding columns)
 //   cw[q]    = weight
+#include <cstdlib>
 #include "o3d_common.hpp"
 
 namespace {
@@ -553,8 +554,15 @@ extern "C" int o3d_group_reduce_c(const float* dN, const float* Y0, long ldp, co
     const long lds_row = (long)B * ld0 + (nseg == 2 ? (long)B * ld1 : 0);
     const int nballs = B * npoint0 + (nseg == 2 ? B * npoint1 : 0);
     const int span = (sp0.ld + sp0.npoint) > (sp1.ld + sp1.npoint) ? (sp0.ld + sp0.npoint) : (sp1.ld + sp1.npoint);
-    if ((long)B * nseg * C0 >= 8192 && sizeof(float) * 4 * (size_t)span <= 64 * 1024)
+    // channels per workgroup: 1 (measured on the MI355X, same run A/B, ms per step of this kernel: 4 channels
+    // 0.76, 2 channels 0.71, 1 channel 0.65 -- more, smaller workgroups win over amortising the column
+    // metadata loads; O3D_REDUCE_CS overrides for experiments)
+    static const int cs = [] { const char* e = getenv("O3D_REDUCE_CS"); return e ? atoi(e) : 1; }();
+    if (cs == 4 && sizeof(float) * 4 * (size_t)span <= 64 * 1024)
         return launch_reduce_c<4>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, ball_cnt, B, nseg, sp0, sp1, C0,
+                                  lds_row, nballs, S, T, s);
+    if (cs == 1)
+        return launch_reduce_c<1>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, ball_cnt, B, nseg, sp0, sp1, C0,
                                   lds_row, nballs, S, T, s);
     return launch_reduce_c<2>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, ball_cnt, B, nseg, sp0, sp1, C0, lds_row,
                               nballs, S, T, s);

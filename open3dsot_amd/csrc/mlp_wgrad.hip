@@ -235,7 +235,8 @@ static void wgrad2_plan(int Cin, int Cout, int B, int P, int& TM, int& TN, int& 
     CP = (TM + TN == 128) ? 64 : 32;
     const int ntile = (Cout / TM) * (Cin / TN);
     const long total = (long)B * (P / CP);
-    nsl = 512 / ntile;                 // one resident round: 2 workgroups per CU x 256 CUs
+    static const int wgs = [] { const char* e = getenv("O3D_WGRAD_WGS"); return e ? atoi(e) : 512; }();   // experiment switch
+    nsl = wgs / ntile;                 // 512: one resident round, 2 workgroups per CU x 256 CUs
     if (nsl < 8) nsl = 8;
     while (nsl > 8 && total / nsl < 4) nsl -= 8;
     if (nsl > total) nsl = (int)total;
