@@ -129,11 +129,13 @@ __global__ __launch_bounds__(256) void expand_c_kernel(const float* __restrict__
     // channels in groups of EG per wave: all 4*EG gathers in flight first, and the EG x 2 statistics butterflies
     // interleave (one channel at a time the 12 dependent shuffles are a ~300-cycle chain per channel)
     constexpr int EG = 8;
-    for (int g0 = wave; g0 < C0; g0 += 4 * EG) {
+    const int cper = (C0 + gridDim.y - 1) / gridDim.y;           // channel range of this workgroup
+    const int cbeg = blockIdx.y * cper, cend = cbeg + cper < C0 ? cbeg + cper : C0;
+    for (int g0 = cbeg + wave; g0 < cend; g0 += 4 * EG) {
         float4 y[EG];
 #pragma unroll
         for (int g = 0; g < EG; ++g) {
-            const int co = g0 + 4 * g < C0 ? g0 + 4 * g : C0 - 1;
+            const int co = g0 + 4 * g < cend ? g0 + 4 * g : cend - 1;
             const float* z = Z + (long)co * ldz;
             y[g].x = z[id.x]; y[g].y = z[id.y]; y[g].z = z[id.z]; y[g].w = z[id.w];
         }
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void expand_c_kernel(const float* __restrict__
 #pragma unroll
         for (int g = 0; g < EG; ++g) {
             const int co = g0 + 4 * g;
-            if (co >= C0) { s[g] = 0.f; v[g] = 0.f; continue; }
+            if (co >= cend) { s[g] = 0.f; v[g] = 0.f; continue; }
             float w0 = 0.f, w1 = 0.f, w2 = 0.f;
             if (centers) { const float* wr = W0 + (long)co * ldw; w0 = wr[0]; w1 = wr[1]; w2 = wr[2]; }
             y[g].x -= fmaf(w2, cz[0], fmaf(w1, cy[0], w0 * cx[0]));
@@ -163,7 +165,7 @@ __global__ __launch_bounds__(256) void expand_c_kernel(const float* __restrict__
 #pragma unroll
                 for (int g = 0; g < EG; ++g) {
                     const int co = g0 + 4 * g;
-                    if (co < C0) {
+                    if (co < cend) {
                         part[((long)blockIdx.x * 2 + 0) * C0 + co] = s[g];
                         part[((long)blockIdx.x * 2 + 1) * C0 + co] = v[g];
                     }
@@ -178,7 +180,6 @@ __global__ __launch_bounds__(256) void expand_c_kernel(const float* __restrict__
 //   consecutive balls, i.e. one nearly contiguous row segment; first-maximum arg-max via 3 shuffles.
 //   workgroup = 32 balls x POOL_CH channels.
 // ---------------------------------------------------------------------------------------
-constexpr int POOL_CH = 8;
 constexpr int POOL_BWD_SPLIT = 8;       // = O3D_POOL_BWD_SPLIT (include/o3dsot.h)
 
 // pooled tensors are stored per segment in the reference's (B, C, npoint) layout, segment 1's block after
@@ -190,6 +191,7 @@ __device__ __forceinline__ long pool_index(int c, int ball, int C, int seg1_ball
     return (s1 ? (long)seg1_ball * C : 0) + ((long)b * C + c) * np + j;
 }
 
+template <int POOL_CH>
 __global__ __launch_bounds__(256) void pool_c_kernel(const float* __restrict__ Y, long ldp,
                                                      const float* __restrict__ scale,
                                                      const float* __restrict__ shift,
@@ -479,7 +481,11 @@ extern "C" int o3d_group_expand_c(const float* Z, long ldz, const int32_t* gp, c
     if (!Z || !gp || !cball || !cw || !meta || !Y0 || C0 <= 0 || ldp <= 0 || ldp % 256 != 0 || start1 < 0 ||
         start1 % 256 != 0 || (centers && (!W0 || ldw < 3)))
         return O3D_EINVAL;
-    hipLaunchKernelGGL(expand_c_kernel, dim3((unsigned)(ldp / 256)), dim3(256), 0, o3d_stream(stream), Z, ldz, gp,
+    // channel ranges per column tile: measured on the MI355X (same run A/B, ms per step of this kernel) 1 range
+    // 0.26, 2 ranges 0.20, 4 ranges 0.19; a range keeps >= 32 channels = one full pass of its 4 waves
+    static const int ysplit_env = [] { const char* e = getenv("O3D_EXPAND_SPLIT"); return e ? atoi(e) : 0; }();
+    const int ysplit = ysplit_env > 0 ? ysplit_env : (C0 >= 128 ? 4 : C0 >= 64 ? 2 : 1);
+    hipLaunchKernelGGL(expand_c_kernel, dim3((unsigned)(ldp / 256), ysplit), dim3(256), 0, o3d_stream(stream), Z, ldz, gp,
                        cball, cw, centers, W0, ldw, C0, meta, start1, ldp, Y0, part, stat_c);
     return o3d_launch_status();
 }
@@ -493,7 +499,21 @@ extern "C" int o3d_pool_fwd_c(const float* Y, long ldp, const float* scale, cons
         (argq && !yarg))
         return O3D_EINVAL;
     const int seg1_ball = B * npoint0, nballs = B * (npoint0 + npoint1);
-    hipLaunchKernelGGL(pool_c_kernel, dim3(o3d_cdiv(nballs, 32), o3d_cdiv(C, POOL_CH)), dim3(256), 0,
+    static const int pch = [] { const char* e = getenv("O3D_POOL_CH"); return e ? atoi(e) : 8; }();   // experiment switch
+    if (pch == 4) {
+        hipLaunchKernelGGL(pool_c_kernel<4>, dim3(o3d_cdiv(nballs, 32), o3d_cdiv(C, 4)), dim3(256), 0, o3d_stream(stream), Y,
+                           ldp, scale, shift, ball_off, ball_cnt, C, seg1_ball, npoint0, npoint1 > 0 ? npoint1 : npoint0,
+                           nballs, out, argq, yarg);
+        return o3d_launch_status();
+    }
+    if (pch == 16) {
+        hipLaunchKernelGGL(pool_c_kernel<16>, dim3(o3d_cdiv(nballs, 32), o3d_cdiv(C, 16)), dim3(256), 0, o3d_stream(stream), Y,
+                           ldp, scale, shift, ball_off, ball_cnt, C, seg1_ball, npoint0, npoint1 > 0 ? npoint1 : npoint0,
+                           nballs, out, argq, yarg);
+        return o3d_launch_status();
+    }
+    constexpr int POOL_CH = 8;
+    hipLaunchKernelGGL(pool_c_kernel<8>, dim3(o3d_cdiv(nballs, 32), o3d_cdiv(C, POOL_CH)), dim3(256), 0,
                        o3d_stream(stream), Y, ldp, scale, shift, ball_off, ball_cnt, C, seg1_ball, npoint0,
                        npoint1 > 0 ? npoint1 : npoint0, nballs, out, argq, yarg);
     return o3d_launch_status();
