@@ -24,7 +24,7 @@ import torch.nn.functional as F
 from . import nn_blocks as pt_utils
 from . import ops as pointnet2_utils
 
-_FUSED = {"enabled": True, "paired": True, "fps_streams": os.environ.get("O3D_FPS_STREAMS", "0") == "1"}
+_FUSED = {"enabled": True, "paired": os.environ.get("O3D_PAIRED", "1") != "0", "fps_streams": os.environ.get("O3D_FPS_STREAMS", "0") == "1"}
 _STREAMS = {}
 
 
