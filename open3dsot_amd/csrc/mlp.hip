@@ -1069,8 +1069,9 @@ extern "C" int o3d_mlp_conv_fwd(const float* X, const float* W, const float* in_
                                 float* part, const float* stat_c, void* stream) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || P <= 0 || P % BN_POS != 0 || !X || !W || !Y) return O3D_EINVAL;
     if (o3d_direct_ok(Cout, Cin, P) && (in_scale == nullptr) == (in_shift == nullptr))
-        return o3d_direct_fwd(X, W, in_scale, in_shift, B, Cin, Cout, P, Y, part, stat_c, nullptr, nullptr, 0, 128,
-                              o3d_stream(stream));
+        // (the statistics partials are one row per 128 columns by contract: narrower tiles only without them)
+        return o3d_direct_fwd(X, W, in_scale, in_shift, B, Cin, Cout, P, Y, part, stat_c, nullptr, nullptr, 0,
+                              part ? 128 : o3d_direct_tile((long)B * P, Cout, 0), o3d_stream(stream));
     FwdArgs a = {};
     a.X = X; a.W = W; a.Y = Y; a.in_scale = in_scale; a.in_shift = in_shift; a.part = part; a.stat_c = stat_c;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = P; a.ns = 4; a.inv_radius = 1.f;

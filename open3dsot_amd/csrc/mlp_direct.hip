@@ -294,7 +294,8 @@ extern "C" int o3d_direct_tile(long P, int M, int compact) {
     // measured on the MI355X (batch 48, same run A/B): 64-column tiles for every launch lose 1.3 % (more loads
     // per MFMA); 64-column tiles only for the small launches (vote aggregation, BoxCloud xcorr: <= 64 K slots,
     // too few 128-column tiles for the 256 CUs) gain 0.8 % (7.705 -> 7.642 ms per step)
-    return P <= 65536 ? 64 : 128;
+    static const long max64 = [] { const char* e = getenv("O3D_TILE64_MAX"); return e ? atol(e) : 65536L; }();   // experiment switch
+    return P <= max64 ? 64 : 128;
 }
 
 // forward: Y = W . f(X), see o3d_mlp_conv_fwd
