@@ -316,8 +316,8 @@ __global__ __launch_bounds__(256) void pool_bwd_partials_c_kernel(const float* _
 struct SegParams { int npoint, ld, pt_base, ball_base; };   // per segment: balls / points per cloud, first point
                                                              // column and first ball of the segment
 
-template <int CS>
-__global__ __launch_bounds__(256) void reduce_c_kernel(const float* __restrict__ dN, const float* __restrict__ Y0,
+template <int CS, int BT>
+__global__ __launch_bounds__(BT) void reduce_c_kernel(const float* __restrict__ dN, const float* __restrict__ Y0,
                                                        long ldp, const float* __restrict__ A1,
                                                        const float* __restrict__ A2,
                                                        const float* __restrict__ A3,
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void reduce_c_kernel(const float* __restrict__
     const int npoint = sp.npoint, ld = sp.ld;
     const int pbase = sp.pt_base + b * ld, bbase = sp.ball_base + b * npoint;
     float* tacc = acc + CS * ld;
-    for (int i = threadIdx.x; i < CS * (ld + npoint); i += 256) acc[i] = 0.f;
+    for (int i = threadIdx.x; i < CS * (ld + npoint); i += BT) acc[i] = 0.f;
     __syncthreads();
     const int q0 = ball_off[bbase], q1 = ball_off[bbase + npoint - 1] + ball_cnt[bbase + npoint - 1];
     float a1[CS], a2[CS], a3[CS];
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(256) void reduce_c_kernel(const float* __restrict__
     // all 2*CS row loads in flight before the first LDS atomic.  A ball's columns are consecutive, so a lane first
     // folds its own columns of the same ball into one term for the ball sum T (the ~8 columns of a ball piling onto
     // one LDS address was the slow part: ds_add_f32 retires roughly one lane per 8 cycles per CU on a shared address).
-    for (int base = q0 & ~3; base < q1; base += 1024) {
+    for (int base = q0 & ~3; base < q1; base += 4 * BT) {
         const int q = base + 4 * threadIdx.x;
         const bool any = q < q1;
         int4 g4 = make_int4(0, 0, 0, 0), b4 = make_int4(0, 0, 0, 0);
@@ -406,12 +406,12 @@ __global__ __launch_bounds__(256) void reduce_c_kernel(const float* __restrict__
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < CS * ld; i += 256) {
+    for (int i = threadIdx.x; i < CS * ld; i += BT) {
         const int c = i / ld, n = i - c * ld;
         if (c0 + c < C0) S[(long)(c0 + c) * lds_row + pbase + n] = acc[i];
     }
     if (T)
-        for (int i = threadIdx.x; i < CS * npoint; i += 256) {
+        for (int i = threadIdx.x; i < CS * npoint; i += BT) {
             const int c = i / npoint, j = i - c * npoint;
             if (c0 + c < C0) T[(long)(c0 + c) * nballs + bbase + j] = tacc[i];
         }
@@ -539,7 +539,7 @@ extern "C" int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t
     return o3d_launch_status();
 }
 
-template <int CS>
+template <int CS, int BT = 256>
 static int launch_reduce_c(const float* dN, const float* Y0, long ldp, const float* A1, const float* A2,
                            const float* A3, const int32_t* gp, const int32_t* cball, const float* cw,
                            const int32_t* ball_off, const int32_t* ball_cnt, int B, int nseg, SegParams sp0,
@@ -549,11 +549,11 @@ static int launch_reduce_c(const float* dN, const float* Y0, long ldp, const flo
     const size_t lds = sizeof(float) * CS * (size_t)span;
     if (lds > 64 * 1024) return O3D_EINVAL;
     if (lds > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(reduce_c_kernel<CS>),
+        hipFuncSetAttribute(reinterpret_cast<const void*>(reduce_c_kernel<CS, BT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return O3D_ELAUNCH;
     const int slabs = (C0 + CS - 1) / CS;
-    hipLaunchKernelGGL(reduce_c_kernel<CS>, dim3(B * nseg * slabs), dim3(256), lds, s, dN, Y0, ldp, A1, A2, A3, gp, cball,
+    hipLaunchKernelGGL((reduce_c_kernel<CS, BT>), dim3(B * nseg * slabs), dim3(BT), lds, s, dN, Y0, ldp, A1, A2, A3, gp, cball,
                        cw, ball_off, ball_cnt, B, sp0, sp1, C0, lds_row, S, T, nballs);
     return o3d_launch_status();
 }
@@ -581,6 +581,13 @@ extern "C" int o3d_group_reduce_c(const float* dN, const float* Y0, long ldp, co
     if (cs == 4 && sizeof(float) * 4 * (size_t)span <= 64 * 1024)
         return launch_reduce_c<4>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, ball_cnt, B, nseg, sp0, sp1, C0,
                                   lds_row, nballs, S, T, s);
+    static const int bt = [] { const char* e = getenv("O3D_REDUCE_BT"); return e ? atoi(e) : 256; }();   // experiment switch
+    if (cs == 1 && bt == 128)
+        return launch_reduce_c<1, 128>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, ball_cnt, B, nseg, sp0, sp1, C0,
+                                       lds_row, nballs, S, T, s);
+    if (cs == 1 && bt == 512)
+        return launch_reduce_c<1, 512>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, ball_cnt, B, nseg, sp0, sp1, C0,
+                                       lds_row, nballs, S, T, s);
     if (cs == 1)
         return launch_reduce_c<1>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, ball_cnt, B, nseg, sp0, sp1, C0,
                                   lds_row, nballs, S, T, s);
