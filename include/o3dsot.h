@@ -298,6 +298,13 @@ int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t* argq, con
                    const float* mean, int B, int C, int npoint0, int npoint1, const int32_t* meta, long start1,
                    long ldp, float* D, float* part, void* stream);
 
+/* Per-point operand of layer 0 (QueryAndGroup's inputs before the gather, pointnet2_utils.py:318-333):
+ * X0 (rows, ldz), ldz = B*(ld0 + ld1): rows [0,nxyz) = xyz^T * inv_radius, rows [nxyz, nxyz+C) = feats, further
+ * rows zero; cloud b of segment s occupies columns [base_s + b*ld_s, +N_s), padded to ld_s by zeros.
+ * xyz_s (B,N_s,3), feats_s (B,C,N_s); N1 = 0: one segment. */
+int o3d_pack_points(const float* xyz0, const float* feats0, int N0, int ld0, const float* xyz1, const float* feats1,
+                    int N1, int ld1, int B, int nxyz, int C, float inv_radius, int rows, float* X0, void* stream);
+
 /* Centre term of the layer-0 weight gradient (grouped_xyz = xyz[idx] - new_xyz, pointnet2_utils.py:322-324):
  * dW (C0,ldw) columns 0..2 -= T (C0,nballs) . centers (nballs,3) */
 int o3d_center_term(const float* T, const float* centers, int C0, int nballs, int ldw, float* dW, void* stream);

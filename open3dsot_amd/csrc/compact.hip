@@ -449,6 +449,29 @@ __global__ __launch_bounds__(1024) void center_term_kernel(const float* __restri
     }
 }
 
+// Per-point operand of layer 0: X0 (rows, ldz) = [xyz * inv_radius ; feats ; zero rows] with every cloud's N points
+// padded to ld columns by zeros, for one or two segments side by side (segment 1's columns start at B*ld0).
+// Replaces a zero fill and up to four strided torch copies per SA call.
+struct PackSeg { const float* xyz; const float* feats; int N, ld; };
+
+__global__ __launch_bounds__(256) void pack_points_kernel(PackSeg s0, PackSeg s1, int B, int nxyz, int C, float inv_radius,
+                                                          long ldz, float* __restrict__ X0) {
+    const long col = (long)blockIdx.x * 256 + threadIdx.x;
+    if (col >= ldz) return;
+    const int r = blockIdx.y;
+    const long base1 = (long)B * s0.ld;
+    const bool second = col >= base1;
+    const PackSeg sg = second ? s1 : s0;
+    const long local = second ? col - base1 : col;
+    const int b = (int)(local / sg.ld), n = (int)(local - (long)b * sg.ld);
+    float v = 0.f;
+    if (n < sg.N) {
+        if (r < nxyz) v = sg.xyz[((long)b * sg.N + n) * 3 + r] * inv_radius;
+        else if (r < nxyz + C) v = sg.feats[((long)b * C + (r - nxyz)) * sg.N + n];
+    }
+    X0[(long)r * ldz + col] = v;
+}
+
 }  // namespace
 
 static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
@@ -600,5 +623,21 @@ extern "C" int o3d_center_term(const float* T, const float* centers, int C0, int
                                void* stream) {
     if (!T || !centers || !dW || C0 <= 0 || nballs <= 0 || ldw < 3) return O3D_EINVAL;
     hipLaunchKernelGGL(center_term_kernel, dim3(C0), dim3(1024), 0, o3d_stream(stream), T, centers, nballs, ldw, dW);
+    return o3d_launch_status();
+}
+
+// X0 (rows, ldz), ldz = B*(ld0 + ld1): rows [0,nxyz) = xyz^T * inv_radius, [nxyz, nxyz+C) = feats, the rest zero;
+// columns of cloud b of segment s: [base_s + b*ld_s, +N_s) live, the padding up to ld_s zero.  xyz_s (B,N_s,3) (NULL
+// when nxyz == 0), feats_s (B,C,N_s) (NULL when C == 0); N1 = 0: one segment.
+extern "C" int o3d_pack_points(const float* xyz0, const float* feats0, int N0, int ld0, const float* xyz1,
+                               const float* feats1, int N1, int ld1, int B, int nxyz, int C, float inv_radius, int rows,
+                               float* X0, void* stream) {
+    if (!X0 || B <= 0 || N0 <= 0 || ld0 < N0 || N1 < 0 || (N1 > 0 && ld1 < N1) || (nxyz != 0 && nxyz != 3) || C < 0 ||
+        rows < nxyz + C || (nxyz && (!xyz0 || (N1 > 0 && !xyz1))) || (C && (!feats0 || (N1 > 0 && !feats1))))
+        return O3D_EINVAL;
+    const long ldz = (long)B * ld0 + (N1 > 0 ? (long)B * ld1 : 0);
+    const PackSeg s0 = {xyz0, feats0, N0, ld0}, s1 = {xyz1, feats1, N1, N1 > 0 ? ld1 : 1};
+    hipLaunchKernelGGL(pack_points_kernel, dim3((unsigned)o3d_cdiv(ldz, 256), rows), dim3(256), 0, o3d_stream(stream), s0, s1,
+                       B, nxyz, C, inv_radius, ldz, X0);
     return o3d_launch_status();
 }

@@ -50,6 +50,7 @@ capi.register("o3d_group_expand_c", [_vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _
 POOL_BWD_SPLIT = 8      # O3D_POOL_BWD_SPLIT of include/o3dsot.h
 capi.register("o3d_bn_finalize_c2", [_vp, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp])
 capi.register("o3d_bn_bwd_finalize_c2", [_vp, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp])
+capi.register("o3d_pack_points", [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp])
 capi.register("o3d_center_term", [_vp, _vp, _i, _i, _i, _vp, _vp])
 capi.register("o3d_pool_fwd_c", [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_bwd_c", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _l, _vp, _vp, _vp])
@@ -477,16 +478,13 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         # (and the buffer itself to a multiple of 64 rows for the weight-gradient kernel of csrc/mlp_wgrad.hip)
         Cin0p = -(-Cin0 // 16) * 16 if Cin0 > 16 else Cin0
         Cin0m = -(-Cin0 // 64) * 64 if Cin0 > 16 else Cin0
-        X0n = (torch.zeros if padded else torch.empty)((Cin0m, ldz), device=dev, dtype=f32)
-        if Cin0m != Cin0 and not padded:
-            X0n[Cin0:].zero_()
+        X0n = torch.empty((Cin0m, ldz), device=dev, dtype=f32)
+        xs = [sg[0].detach().contiguous() if nxyz else None for sg in segs]
+        fs = [sg[2].detach().contiguous() if C else None for sg in segs]
+        _call("pack_points", 0.0, lib.o3d_pack_points, _ptr(xs[0]), _ptr(fs[0]), Ns[0], Npads[0],
+              _ptr(xs[-1]) if nseg == 2 else None, _ptr(fs[-1]) if nseg == 2 else None, Ns[-1] if nseg == 2 else 0,
+              Npads[-1] if nseg == 2 else 0, B, nxyz, C, float(cfg.inv_radius), Cin0m, X0n.data_ptr(), st)
         centers = None
-        for s_, (xyz, new_xyz, feats, _) in enumerate(segs):
-            view = X0n[:Cin0, pt_bases[s_]:pt_bases[s_] + B * Npads[s_]].view(Cin0, B, Npads[s_])
-            if nxyz:
-                view[:3, :, :Ns[s_]] = xyz.detach().permute(2, 0, 1) if unit else xyz.detach().permute(2, 0, 1) * cfg.inv_radius
-            if C:
-                view[nxyz:, :, :Ns[s_]] = feats.detach().permute(1, 0, 2)
         if nxyz:       # ball centres of every segment + the dummy ball (origin) of the padding columns: one launch
             centers = torch.cat([sg[1].detach().reshape(-1, 3) for sg in segs] + [_const_vec(dev, 3, 0.0).view(1, 3)])
             if not unit:
