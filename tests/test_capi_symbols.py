@@ -88,3 +88,24 @@ def test_ctypes_signatures_match_the_header():
         assert name in protos, "%s is bound but not declared in include/o3dsot.h" % name
         got = [kind[a] for a in argtypes]
         assert got == protos[name], (name, got, protos[name])
+
+
+def test_entry_points_reject_bad_arguments_before_touching_the_device():
+    """argument validation comes first in every entry point: NULL pointers / impossible sizes return O3D_EINVAL (-1)
+    without a launch -- checkable without a GPU (no compute call is made)"""
+    from open3dsot_amd import capi, fused, fused_loss, points_utils  # noqa: F401  (they register argtypes)
+    lib = capi.load()
+    EINVAL = lib.o3d_boxcloud(None, None, None, None, 1.0, 1, 8, None, None)
+    assert EINVAL != 0
+    assert lib.o3d_boxcloud(None, None, None, None, 1.0, 0, 8, None, None) == 0            # empty batch: nothing to do
+    assert lib.o3d_track_loss(*([None] * 8), 2, 8, 4, 9, 1.0, 1.0, 1.0, 1.0, 1.0, *([None] * 7)) == EINVAL
+    assert lib.o3d_pack_points(None, None, 8, 8, None, None, 0, 0, 1, 3, 0, 1.0, 3, None, None) == EINVAL
+    assert lib.o3d_furthest_point_sampling_pair(None, 8, 4, None, None, 8, 4, None, 1, None) == EINVAL
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    assert lib.o3d_furthest_point_sampling_pair(p, 4096, 4, p, p, 8, 4, p, 1, None) == EINVAL     # > 2048 points: two calls
+    assert lib.o3d_compact_build(None, 1, 8, 4, 8, 0, 0, 0, 8, *([None] * 7)) == EINVAL
+    assert lib.o3d_compact_build(p, 1, 8, 3, 8, 0, 0, 0, 8, p, p, p, p, p, p, None) == EINVAL       # nsample not a power of two
+    assert lib.o3d_pool_fwd_c(None, 256, None, None, None, None, 1, 8, 8, 0, None, None, None, None) == EINVAL
+    assert lib.o3d_center_term(None, None, 8, 8, 3, None, None) == EINVAL
+    assert lib.o3d_bn_finalize_c2(None, 1, 1, 8, 1.0, 1.0, *([None] * 5), 0.1, 1e-5, *([None] * 5), 128, None) == EINVAL
