@@ -125,7 +125,9 @@ class DataParallelStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: other threads of the process (the RCCL watchdog of torch.distributed polls events) may
+        # keep calling the runtime while this thread captures
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self._static_loss = self._forward_backward(self._static)
         self._static_grads = [p.grad for p in self.grads.params]
         self.graph = g
