@@ -298,6 +298,16 @@ int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t* argq, con
                    const float* mean, int B, int C, int npoint0, int npoint1, const int32_t* meta, long start1,
                    long ldp, float* D, float* part, void* stream);
 
+/* The same sums as o3d_group_reduce_c without float atomics: the cloud's columns are sorted by (column chunk,
+ * point) once per call (perm: ldp ints; poff: o3d_group_reduce_gather_scratch(...) ints, -1 = shape not covered,
+ * use o3d_group_reduce_c) and every sum is a gather from an LDS-staged chunk in a fixed order (bitwise
+ * reproducible).  spanmax = npoint*nsample of the largest segment.  Experimental (O3D_REDUCE_GATHER=1). */
+long o3d_group_reduce_gather_scratch(int B, int nseg, int npoint0, int ld0, int npoint1, int ld1, int spanmax);
+int o3d_group_reduce_gather(const float* dN, const float* Y0, long ldp, const float* A1, const float* A2,
+                            const float* A3, const int32_t* gp, const float* cw, const int32_t* ball_off,
+                            const int32_t* ball_cnt, int B, int nseg, int npoint0, int ld0, int npoint1, int ld1, int C0,
+                            int spanmax, int32_t* perm, int32_t* poff, float* S, float* T, void* stream);
+
 /* Per-point operand of layer 0 (QueryAndGroup's inputs before the gather, pointnet2_utils.py:318-333):
  * X0 (rows, ldz), ldz = B*(ld0 + ld1): rows [0,nxyz) = xyz^T * inv_radius, rows [nxyz, nxyz+C) = feats, further
  * rows zero; cloud b of segment s occupies columns [base_s + b*ld_s, +N_s), padded to ld_s by zeros.

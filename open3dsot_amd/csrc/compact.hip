@@ -417,6 +417,173 @@ __global__ __launch_bounds__(BT) void reduce_c_kernel(const float* __restrict__ 
         }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same reduce WITHOUT float atomics (tools/exp/reduce_gather_probe.hip: 138.6 vs 297.7 us on the SA1 shape).
+//   csr_build_kernel   per cloud, once per SA call: the cloud's columns sorted by (column chunk, point, column) in
+//                      `perm` (counting sort in LDS, lists sorted -> fixed summation order) and the list starts
+//                      poff[cloud][chunk*ld + n] (relative to the cloud's first column), total at [nchunk*ld].
+//   reduce_gather_kernel  per (cloud, RG_CS channels): the chunk's dY staged in LDS with plain stores; thread n
+//                      gathers its own list, thread j sums its ball's contiguous range.
+// Behind O3D_REDUCE_GATHER=1 (open3dsot_amd/fused.py) until it has been through the GPU parity tests.
+// ---------------------------------------------------------------------------------------
+constexpr int RG_CH = 2048;     // columns per chunk (16-bit list entries: <= 65536)
+constexpr int RG_CS = 2;        // channels per workgroup
+
+__global__ __launch_bounds__(1024) void csr_build_kernel(const int32_t* __restrict__ gp,
+                                                         const int32_t* __restrict__ ball_off,
+                                                         const int32_t* __restrict__ ball_cnt, int B, SegParams sp0,
+                                                         SegParams sp1, int nchunk, int poff_stride,
+                                                         int32_t* __restrict__ perm, int32_t* __restrict__ poff) {
+    extern __shared__ int csr_sh[];         // cnt[nchunk*ld + 1], scan scratch [1024]
+    const int cloud = blockIdx.x;
+    const int seg = cloud >= B ? 1 : 0, b = cloud - seg * B;
+    const SegParams sp = seg ? sp1 : sp0;
+    const int npoint = sp.npoint, ld = sp.ld;
+    const int pbase = sp.pt_base + b * ld, bbase = sp.ball_base + b * npoint;
+    const int q0 = ball_off[bbase], q1 = ball_off[bbase + npoint - 1] + ball_cnt[bbase + npoint - 1];
+    const int q0a = q0 & ~3;                // chunk 0 starts at the float4-aligned column at or before q0
+    const int nbin = nchunk * ld;
+    int* cnt = csr_sh;
+    int* part = csr_sh + nbin + 1;
+    for (int i = threadIdx.x; i <= nbin; i += 1024) cnt[i] = 0;
+    __syncthreads();
+    for (int q = q0 + threadIdx.x; q < q1; q += 1024) atomicAdd(&cnt[((q - q0a) / RG_CH) * ld + (gp[q] - pbase)], 1);
+    __syncthreads();
+    const int per = (nbin + 1023) / 1024, i0 = threadIdx.x * per;       // exclusive scan of the bin counts
+    int local = 0;
+    for (int i = i0; i < i0 + per && i < nbin; ++i) local += cnt[i];
+    part[threadIdx.x] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0;
+        __syncthreads();
+        part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = part[threadIdx.x] - local;
+    for (int i = i0; i < i0 + per && i < nbin; ++i) {
+        const int c = cnt[i];
+        cnt[i] = run;
+        run += c;
+    }
+    if (threadIdx.x == 1023) cnt[nbin] = part[1023];
+    __syncthreads();
+    int32_t* po = poff + (long)cloud * poff_stride;
+    for (int i = threadIdx.x; i <= nbin; i += 1024) po[i] = cnt[i];
+    __syncthreads();
+    for (int q = q0 + threadIdx.x; q < q1; q += 1024) {      // fill; the order inside a list is restored below
+        const int k = atomicAdd(&cnt[((q - q0a) / RG_CH) * ld + (gp[q] - pbase)], 1);
+        perm[q0 + k] = q;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbin; i += 1024) {         // insertion sort of each (short) list
+        const int s0 = po[i], e = po[i + 1];
+        for (int a = s0 + 1; a < e; ++a) {
+            const int v = perm[q0 + a];
+            int t = a - 1;
+            while (t >= s0 && perm[q0 + t] > v) { perm[q0 + t + 1] = perm[q0 + t]; --t; }
+            perm[q0 + t + 1] = v;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_gather_kernel(const float* __restrict__ dN, const float* __restrict__ Y0,
+                                                            long ldp, const float* __restrict__ A1,
+                                                            const float* __restrict__ A2, const float* __restrict__ A3,
+                                                            const float* __restrict__ cw,
+                                                            const int32_t* __restrict__ ball_off,
+                                                            const int32_t* __restrict__ ball_cnt,
+                                                            const int32_t* __restrict__ perm,
+                                                            const int32_t* __restrict__ poff, int poff_stride, int B,
+                                                            SegParams sp0, SegParams sp1, int C0, long lds_row,
+                                                            float* __restrict__ S, float* __restrict__ T, int nballs) {
+    extern __shared__ float rg_sm[];        // dy[CS][CH], sacc[CS][ld], tacc[CS][npoint], offs[ld+1] ints, list[CH] u16
+    constexpr int CS = RG_CS, CH = RG_CH;
+    const int slabs = (C0 + CS - 1) / CS;
+    const int cloud = blockIdx.x / slabs, c0 = (blockIdx.x - cloud * slabs) * CS;
+    const int seg = cloud >= B ? 1 : 0, b = cloud - seg * B;
+    const SegParams sp = seg ? sp1 : sp0;
+    const int npoint = sp.npoint, ld = sp.ld;
+    const int pbase = sp.pt_base + b * ld, bbase = sp.ball_base + b * npoint;
+    float* dy = rg_sm;
+    float* sacc = dy + CS * CH;
+    float* tacc = sacc + CS * ld;
+    int* offs = reinterpret_cast<int*>(tacc + CS * npoint);
+    uint16_t* lst = reinterpret_cast<uint16_t*>(offs + ld + 1);
+    const int q0 = ball_off[bbase], q1 = ball_off[bbase + npoint - 1] + ball_cnt[bbase + npoint - 1];
+    const int q0a = q0 & ~3;
+    const int32_t* po = poff + (long)cloud * poff_stride;
+    for (int i = threadIdx.x; i < CS * (ld + npoint); i += 256) sacc[i] = 0.f;
+    float a1[CS], a2[CS], a3[CS];
+    int crow[CS];                            // channel rows (clamped: an odd C0 repeats its last row, never stored)
+#pragma unroll
+    for (int c = 0; c < CS; ++c) {
+        crow[c] = c0 + c < C0 ? c0 + c : C0 - 1;
+        const int cc = seg * C0 + crow[c];   // segment 1: its own BatchNorm-backward constants
+        a1[c] = A1[cc]; a2[c] = A2[cc]; a3[c] = A3[cc];
+    }
+    for (int k = 0, lo = q0a; lo < q1; ++k, lo += CH) {
+        const int hi = lo + CH < q1 ? lo + CH : q1;
+        __syncthreads();                    // previous chunk fully consumed (first pass: the zero fill)
+        for (int i = 4 * threadIdx.x; i < CH; i += 1024) {        // phase A: dY of the chunk, plain LDS stores
+            const int q = lo + i;
+            if (q >= hi) break;
+            const float4 w4 = *reinterpret_cast<const float4*>(&cw[q]);
+#pragma unroll
+            for (int c = 0; c < CS; ++c) {
+                const float4 d = *reinterpret_cast<const float4*>(&dN[(long)crow[c] * ldp + q]);
+                const float4 y = *reinterpret_cast<const float4*>(&Y0[(long)crow[c] * ldp + q]);
+                float4 o;
+                o.x = fmaf(a1[c], d.x, w4.x * fmaf(a2[c], y.x, a3[c]));
+                o.y = fmaf(a1[c], d.y, w4.y * fmaf(a2[c], y.y, a3[c]));
+                o.z = fmaf(a1[c], d.z, w4.z * fmaf(a2[c], y.z, a3[c]));
+                o.w = fmaf(a1[c], d.w, w4.w * fmaf(a2[c], y.w, a3[c]));
+                *reinterpret_cast<float4*>(&dy[c * CH + i]) = o;
+            }
+        }
+        const int l0 = po[k * ld], l1 = po[(k + 1) * ld];         // this chunk's slice of perm
+        for (int i = threadIdx.x; i < l1 - l0; i += 256) lst[i] = (uint16_t)(perm[q0 + l0 + i] - lo);
+        for (int i = threadIdx.x; i <= ld; i += 256) offs[i] = po[k * ld + i] - l0;
+        __syncthreads();
+        for (int n = threadIdx.x; n < ld; n += 256) {             // phase B: thread n walks its own list
+            float s[CS];
+#pragma unroll
+            for (int c = 0; c < CS; ++c) s[c] = 0.f;
+            for (int a = offs[n]; a < offs[n + 1]; ++a) {
+                const int i = lst[a];
+#pragma unroll
+                for (int c = 0; c < CS; ++c) s[c] += dy[c * CH + i];
+            }
+#pragma unroll
+            for (int c = 0; c < CS; ++c) sacc[c * ld + n] += s[c];
+        }
+        if (T)
+            for (int j = threadIdx.x; j < npoint; j += 256) {     // thread j: its ball's part of the chunk
+                const int b0 = ball_off[bbase + j], b1 = b0 + ball_cnt[bbase + j];
+                const int s0 = b0 > lo ? b0 : lo, s1 = b1 < hi ? b1 : hi;
+                if (s0 >= s1) continue;
+                float t[CS];
+#pragma unroll
+                for (int c = 0; c < CS; ++c) t[c] = 0.f;
+                for (int q = s0; q < s1; ++q)
+#pragma unroll
+                    for (int c = 0; c < CS; ++c) t[c] += dy[c * CH + (q - lo)];
+#pragma unroll
+                for (int c = 0; c < CS; ++c) tacc[c * npoint + j] += t[c];
+            }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < CS * ld; i += 256) {
+        const int c = i / ld, n = i - c * ld;
+        if (c0 + c < C0) S[(long)(c0 + c) * lds_row + pbase + n] = sacc[i];
+    }
+    if (T)
+        for (int i = threadIdx.x; i < CS * npoint; i += 256) {
+            const int c = i / npoint, j = i - c * npoint;
+            if (c0 + c < C0) T[(long)(c0 + c) * nballs + bbase + j] = tacc[i];
+        }
+}
+
 // dW[c, 0..2] -= sum over balls of T[c, ball] * centers[ball, :]: the centre term of
 // grouped_xyz = xyz[idx] - new_xyz (pointnet2_utils.py:322-324) in the layer-0 weight gradient.
 // One 1024-thread workgroup per channel, fixed summation order.
@@ -639,5 +806,56 @@ extern "C" int o3d_pack_points(const float* xyz0, const float* feats0, int N0, i
     const PackSeg s0 = {xyz0, feats0, N0, ld0}, s1 = {xyz1, feats1, N1, N1 > 0 ? ld1 : 1};
     hipLaunchKernelGGL(pack_points_kernel, dim3((unsigned)o3d_cdiv(ldz, 256), rows), dim3(256), 0, o3d_stream(stream), s0, s1,
                        B, nxyz, C, inv_radius, ldz, X0);
+    return o3d_launch_status();
+}
+
+// ---- the reduce through a transposed index (see csr_build_kernel); same result as o3d_group_reduce_c ----------
+static int rg_nchunk(int spanmax) { return (spanmax + 4 + RG_CH - 1) / RG_CH; }
+
+// int32 elements of `poff` scratch for o3d_group_reduce_gather, or -1 when the shape does not fit its LDS budget
+// (the caller then uses o3d_group_reduce_c).  spanmax = npoint*nsample of the largest segment.
+extern "C" long o3d_group_reduce_gather_scratch(int B, int nseg, int npoint0, int ld0, int npoint1, int ld1, int spanmax) {
+    if (B <= 0 || (nseg != 1 && nseg != 2) || npoint0 <= 0 || ld0 <= 0 || spanmax <= 0 ||
+        (nseg == 2 && (npoint1 <= 0 || ld1 <= 0)))
+        return -1;
+    const int ldm = nseg == 2 && ld1 > ld0 ? ld1 : ld0, npm = nseg == 2 && npoint1 > npoint0 ? npoint1 : npoint0;
+    const long nbin = (long)rg_nchunk(spanmax) * ldm;
+    const size_t lds_csr = ((size_t)nbin + 1 + 1024) * 4;
+    const size_t lds_red = ((size_t)RG_CS * RG_CH + (size_t)RG_CS * (ldm + npm)) * 4 + ((size_t)ldm + 1) * 4 + (size_t)RG_CH * 2 + 8;
+    if (lds_csr > 128 * 1024 || lds_red > 64 * 1024) return -1;
+    return (long)B * nseg * (nbin + 1);
+}
+
+extern "C" int o3d_group_reduce_gather(const float* dN, const float* Y0, long ldp, const float* A1, const float* A2,
+                                       const float* A3, const int32_t* gp, const float* cw, const int32_t* ball_off,
+                                       const int32_t* ball_cnt, int B, int nseg, int npoint0, int ld0, int npoint1,
+                                       int ld1, int C0, int spanmax, int32_t* perm, int32_t* poff, float* S, float* T,
+                                       void* stream) {
+    if (!dN || !Y0 || !A1 || !A2 || !A3 || !gp || !cw || !ball_off || !ball_cnt || !perm || !poff || !S || C0 <= 0 ||
+        ldp <= 0 || ldp % 4 != 0 || o3d_group_reduce_gather_scratch(B, nseg, npoint0, ld0, npoint1, ld1, spanmax) < 0)
+        return O3D_EINVAL;
+    hipStream_t s = o3d_stream(stream);
+    const SegParams sp0 = {npoint0, ld0, 0, 0};
+    const SegParams sp1 = nseg == 2 ? SegParams{npoint1, ld1, B * ld0, B * npoint0} : sp0;
+    const long lds_row = (long)B * ld0 + (nseg == 2 ? (long)B * ld1 : 0);
+    const int nballs = B * npoint0 + (nseg == 2 ? B * npoint1 : 0);
+    const int ldm = nseg == 2 && ld1 > ld0 ? ld1 : ld0, npm = nseg == 2 && npoint1 > npoint0 ? npoint1 : npoint0;
+    const int nchunk = rg_nchunk(spanmax);
+    const int stride = nchunk * ldm + 1;
+    const size_t lds_csr = ((size_t)nchunk * ldm + 1 + 1024) * 4;
+    const size_t lds_red = ((size_t)RG_CS * RG_CH + (size_t)RG_CS * (ldm + npm)) * 4 + ((size_t)ldm + 1) * 4 + (size_t)RG_CH * 2 + 8;
+    if (lds_csr > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(csr_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds_csr) != hipSuccess)
+        return O3D_ELAUNCH;
+    if (lds_red > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(reduce_gather_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_red) != hipSuccess)
+        return O3D_ELAUNCH;
+    hipLaunchKernelGGL(csr_build_kernel, dim3(B * nseg), dim3(1024), lds_csr, s, gp, ball_off, ball_cnt, B, sp0, sp1, nchunk,
+                       stride, perm, poff);
+    const int slabs = (C0 + RG_CS - 1) / RG_CS;
+    hipLaunchKernelGGL(reduce_gather_kernel, dim3(B * nseg * slabs), dim3(256), lds_red, s, dN, Y0, ldp, A1, A2, A3, cw,
+                       ball_off, ball_cnt, perm, poff, stride, B, sp0, sp1, C0, lds_row, S, T, nballs);
     return o3d_launch_status();
 }

@@ -50,6 +50,9 @@ capi.register("o3d_group_expand_c", [_vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _
 POOL_BWD_SPLIT = 8      # O3D_POOL_BWD_SPLIT of include/o3dsot.h
 capi.register("o3d_bn_finalize_c2", [_vp, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp])
 capi.register("o3d_bn_bwd_finalize_c2", [_vp, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp])
+capi.register("o3d_group_reduce_gather_scratch", [_i, _i, _i, _i, _i, _i, _i])
+capi.register("o3d_group_reduce_gather", [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp,
+                                          _vp, _vp, _vp, _vp])
 capi.register("o3d_pack_points", [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp])
 capi.register("o3d_center_term", [_vp, _vp, _i, _i, _i, _vp, _vp])
 capi.register("o3d_pool_fwd_c", [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
@@ -629,9 +632,20 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             if l == 0:
                 S = torch.empty((Cout, ldz), device=dev, dtype=f32)
                 T = torch.empty((Cout, nballs), device=dev, dtype=f32) if nxyz else None
-                _call("group_reduce", 0.0, lib.o3d_group_reduce_c, dN.data_ptr(), Ys[0].data_ptr(), ldp, A[0], A[1], A[2],
-                      gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), ball_off.data_ptr(), ball_cnt.data_ptr(), B, nseg,
-                      npoints[0], Npads[0], npoints[-1], Npads[-1], Cout, S.data_ptr(), _ptr(T), st)
+                spanmax = max(npoints) * ns
+                npo = lib.o3d_group_reduce_gather_scratch(B, nseg, npoints[0], Npads[0], npoints[-1], Npads[-1],
+                                                          spanmax) if _REDUCE_GATHER["on"] else -1
+                if npo >= 0:     # experimental: gather through a transposed index, no float atomics
+                    perm = torch.empty((ldp,), device=dev, dtype=torch.int32)
+                    poff = torch.empty((npo,), device=dev, dtype=torch.int32)
+                    _call("group_reduce", 0.0, lib.o3d_group_reduce_gather, dN.data_ptr(), Ys[0].data_ptr(), ldp, A[0], A[1],
+                          A[2], gp.data_ptr(), cw.data_ptr(), ball_off.data_ptr(), ball_cnt.data_ptr(), B, nseg, npoints[0],
+                          Npads[0], npoints[-1], Npads[-1], Cout, spanmax, perm.data_ptr(), poff.data_ptr(), S.data_ptr(),
+                          _ptr(T), st)
+                else:
+                    _call("group_reduce", 0.0, lib.o3d_group_reduce_c, dN.data_ptr(), Ys[0].data_ptr(), ldp, A[0], A[1], A[2],
+                          gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), ball_off.data_ptr(), ball_cnt.data_ptr(), B, nseg,
+                          npoints[0], Npads[0], npoints[-1], Npads[-1], Cout, S.data_ptr(), _ptr(T), st)
                 one, zero = _const_vec(dev, Cout, 1.0), _const_vec(dev, Cout, 0.0)
                 Cinm = X0n.shape[0]                  # rows of the padded per-point operand
                 keep += [S, T, one, zero]
@@ -708,6 +722,15 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             gin += [seg_grads[s_][0] if needs[4 * s_] else None, seg_grads[s_][1] if needs[4 * s_ + 1] else None,
                     seg_grads[s_][2] if needs[4 * s_ + 2] else None, None]
         return (None, None, *gin, *gw)
+
+
+# layer-0 backward reduce as an LDS gather through a transposed index (csrc/compact.hip::reduce_gather_kernel):
+# 2.1x on the stand-alone probe; OFF until it has been through the GPU parity tests (O3D_REDUCE_GATHER=1 enables)
+_REDUCE_GATHER = {"on": _os.environ.get("O3D_REDUCE_GATHER", "0") == "1"}
+
+
+def set_reduce_gather(enabled):
+    _REDUCE_GATHER["on"] = bool(enabled)
 
 
 def _padded(owner, name, shape, dev):

@@ -7,6 +7,8 @@ values differ by 1e-6 can route a gradient differently at a near-tie; an fp32-vs
 comparison is therefore noisy (measured on the GPU box: torch's own CPU fp32 backward is 2e-2
 away from its fp64 run on some RPN weights, tools/diag_grad2.py).  Criterion: relative L2 error
 <= 5e-4 and max error <= 1e-2 of the tensor scale, against fp64."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -276,6 +278,31 @@ def test_paired_backbone_matches_sequential():
             assert torch.equal(x, y)
     for (n1, b1), (_, b2) in zip(net.named_buffers(), ref.named_buffers()):
         assert rel(b1.float(), b2.float()) < 1e-5, n1
+
+
+@pytest.mark.skipif(os.environ.get("O3D_TEST_REDUCE_GATHER") != "1",
+                    reason="experimental kernel (DESIGN.md 9.2): run with O3D_TEST_REDUCE_GATHER=1 once it is being integrated")
+@pytest.mark.parametrize("kind", ["sa1", "sa2", "sa3", "rpn"])
+def test_reduce_gather_matches_atomic_reduce(kind):
+    """o3d_group_reduce_gather (transposed index + LDS gather) against o3d_group_reduce_c (LDS atomics): same S / T,
+    i.e. the same input and layer-0 weight gradients"""
+    import copy
+    from open3dsot_amd import fused
+    grouper, mlp, xyz, new_xyz, feats = make_case(kind)
+    grads = []
+    for gather in (False, True):
+        fused.set_reduce_gather(gather)
+        try:
+            m = copy.deepcopy(mlp)
+            leaves = [t.clone().requires_grad_(True) if t is not None else None for t in (xyz, new_xyz, feats)]
+            out = fused.sa_group_mlp_pool(grouper, m, *leaves)
+            go = torch.randn(out.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+            out.backward(go)
+            grads.append([p.grad for p in m.parameters()] + [t.grad for t in leaves if t is not None])
+        finally:
+            fused.set_reduce_gather(False)
+    for a, b in zip(*grads):
+        assert l2rel(a, b) < 1e-5, l2rel(a, b)
 
 
 def test_slotwise_fallback_path_matches_fp64():
