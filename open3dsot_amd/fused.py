@@ -725,7 +725,8 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
 
 
 # layer-0 backward reduce as an LDS gather through a transposed index (csrc/compact.hip::reduce_gather_kernel):
-# 2.1x on the stand-alone probe; OFF until it has been through the GPU parity tests (O3D_REDUCE_GATHER=1 enables)
+# 2.1x on the stand-alone probe, passes test_reduce_gather_matches_atomic_reduce on the MI355X (single segment);
+# OFF until the paired-segment parity run and the bench have been done (O3D_REDUCE_GATHER=1 enables)
 _REDUCE_GATHER = {"on": _os.environ.get("O3D_REDUCE_GATHER", "0") == "1"}
 
 
