@@ -305,6 +305,35 @@ def test_reduce_gather_matches_atomic_reduce(kind):
         assert l2rel(a, b) < 1e-5, l2rel(a, b)
 
 
+@pytest.mark.skipif(os.environ.get("O3D_TEST_REDUCE_GATHER") != "1",
+                    reason="experimental kernel (DESIGN.md 9.2): run with O3D_TEST_REDUCE_GATHER=1 once it is being integrated")
+@pytest.mark.parametrize("kind", ["sa1", "sa2"])
+def test_reduce_gather_matches_atomic_reduce_paired(kind):
+    """the same comparison through the two-segment (template + search) call"""
+    import copy
+    from open3dsot_amd import fused
+    grouper, mlp, xyz_s, new_s, feats_s = make_case(kind)
+    N, npoint = xyz_s.shape[1], new_s.shape[1]
+    xyz_t = (xyz_s[:, :N // 2, :] * 0.9 + 0.05).contiguous()
+    new_t = xyz_t[:, :npoint // 2, :].contiguous()
+    feats_t = torch.randn(feats_s.shape[0], feats_s.shape[1], N // 2, device="cuda") if feats_s is not None else None
+    grads = []
+    for gather in (False, True):
+        fused.set_reduce_gather(gather)
+        try:
+            m = copy.deepcopy(mlp)
+            segs = [[t.clone().requires_grad_(True) if t is not None else None for t in sg]
+                    for sg in ((xyz_t, new_t, feats_t), (xyz_s, new_s, feats_s))]
+            outs = fused.sa_group_mlp_pool_pair(grouper, m, tuple(segs[0]), tuple(segs[1]))
+            gen = torch.Generator(device="cuda").manual_seed(4)
+            torch.autograd.backward(list(outs), [torch.randn(o.shape, device="cuda", generator=gen) for o in outs])
+            grads.append([p.grad for p in m.parameters()] + [t.grad for sg in segs for t in sg if t is not None])
+        finally:
+            fused.set_reduce_gather(False)
+    for a, b in zip(*grads):
+        assert l2rel(a, b) < 1e-5, l2rel(a, b)
+
+
 def test_slotwise_fallback_path_matches_fp64():
     """the slot-per-neighbour layout (used when the compact layout does not apply: nsample > 64 or more than
     65536 balls) stays correct: same SA block, compact layout switched off"""
