@@ -1,0 +1,34 @@
+"""Deterministic, storage-free parameter values shared by tests/golden/make_golden_trackers.py (run on the reference's
+own BAT / P2B classes) and tests/test_golden_trackers.py (run on the host mirror): every tensor of a state_dict is a
+closed-form function of its key and shape, so the 1.4 M weights need not be stored in the fixture."""
+import zlib
+
+import torch
+
+
+def fill_state_dict(module):
+    sd = module.state_dict()
+    new = {}
+    for key in sorted(sd):
+        t = sd[key]
+        if not t.dtype.is_floating_point:          # num_batches_tracked
+            new[key] = torch.zeros_like(t)
+            continue
+        n = t.numel()
+        phase = (zlib.crc32(key.encode()) % 1000) * 0.0173
+        i = torch.arange(n, dtype=torch.float64)
+        wave = torch.cos(0.7310 * i + phase) * 0.6 + torch.sin(0.1937 * i * 1.618 + 2.0 * phase) * 0.4
+        if key.endswith("running_var"):
+            v = 1.0 + 0.4 * wave
+        elif key.endswith("running_mean"):
+            v = 0.1 * wave
+        elif key.endswith("bn.weight") or key.endswith("bn.bn.weight"):
+            v = 1.0 + 0.3 * wave
+        elif key.endswith("bias"):
+            v = 0.05 * wave
+        else:                                      # conv weights: variance-preserving scale
+            fan_in = max(1, n // t.shape[0])
+            v = wave * (1.7 / fan_in) ** 0.5
+        new[key] = v.to(t.dtype).reshape(t.shape)
+    module.load_state_dict(new, strict=True)
+    return module
