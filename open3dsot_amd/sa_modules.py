@@ -70,14 +70,7 @@ class _PointnetSAModuleBase(nn.Module):
     def forward(self, xyz, features, npoint, return_idx=False):
         """xyz (B,N,3), features (B,C,N) | None -> new_xyz (B,npoint,3), (B,sum(mlp[-1]),npoint)"""
         self.npoint = npoint
-        if self.use_fps:
-            sample_idxs = pointnet2_utils.furthest_point_sample(xyz, npoint)
-            new_xyz = pointnet2_utils.gather_operation(
-                xyz.transpose(1, 2).contiguous(), sample_idxs).transpose(1, 2).contiguous()
-        else:
-            # reference: arange(npoint) indices, i.e. the first npoint points (:56-62)
-            sample_idxs = torch.arange(npoint, dtype=torch.int32, device=xyz.device).repeat(xyz.size(0), 1)
-            new_xyz = xyz[:, :npoint, :].contiguous()
+        sample_idxs, new_xyz = self._sample(xyz, npoint)
         outs = [self._group_mlp_pool(i, xyz, new_xyz, features) for i in range(len(self.groupers))]
         feats = torch.cat(outs, dim=1) if len(outs) > 1 else outs[0]
         if return_idx:
@@ -86,6 +79,11 @@ class _PointnetSAModuleBase(nn.Module):
 
 
     def _sample(self, xyz, npoint):
+        """centres of the balls: FPS, or the reference's arange(npoint) prefix (pointnet2_modules.py:52-62)"""
+        if not self.use_fps and npoint > xyz.size(1):
+            # upstream gathers arange(npoint) out of bounds here (undefined values and, in backward, an out-of-bounds
+            # scatter): e.g. num_proposal 64 with a 256-point search cloud (256 / 8 = 32 seeds)
+            raise ValueError("npoint (%d) exceeds the number of points (%d)" % (npoint, xyz.size(1)))
         if self.use_fps:
             sample_idxs = pointnet2_utils.furthest_point_sample(xyz, npoint)
             new_xyz = pointnet2_utils.gather_operation(
