@@ -126,5 +126,17 @@ for name in ("BAT", "P2B"):
         model({k: v.clone() for k, v in batch.items()})
     for k, v in captured.items():
         out["%s.eval.%s" % (name, k)] = v.detach().numpy().copy()
+    # the optimizer step the reference would take next (models/base_model.py:28-36: Adam betas (0.5, 0.999), eps 1e-6,
+    # StepLR): hyper-parameters and the parameters after ONE step from the gradients above
+    conf = model.configure_optimizers()
+    opt, sched = conf["optimizer"], conf["lr_scheduler"]
+    grp = opt.param_groups[0]
+    out["%s.opt.hyper" % name] = np.array([grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"],
+                                            sched.step_size, sched.gamma], dtype=np.float64)
+    opt.step()
+    named = dict(model.named_parameters())
+    for k in GRAD_KEYS:
+        if k in named:
+            out["%s.stepped.%s" % (name, k)] = named[k].detach().numpy().copy()
 np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_trackers.npz"), **out)
 print("wrote ref_trackers.npz:", len(out), "arrays")

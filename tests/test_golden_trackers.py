@@ -96,3 +96,31 @@ def test_eval_forward_matches_reference_class(gold, cpu_ext, name):
             assert np.array_equal(got, want), k
         else:
             assert rel(got, want) < 2e-4, (k, rel(got, want))
+
+
+@pytest.mark.parametrize("name", ["BAT", "P2B"])
+def test_optimizer_step_matches_reference_class(gold, cpu_ext, name):
+    """configure_optimizers (models/base_model.py:28-36): hyper-parameters, and the parameters after one step"""
+    model, batch, _ = run(name, True)
+    loss, _ = model.training_loss(batch)
+    loss.backward()
+    conf = model.configure_optimizers()
+    opt, sched = conf["optimizer"], conf["lr_scheduler"]
+    grp = opt.param_groups[0]
+    got = [grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"], sched.step_size, sched.gamma]
+    assert np.allclose(got, gold[name + ".opt.hyper"], rtol=0, atol=1e-12), got
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    opt.step()
+    named = dict(model.named_parameters())
+    for k in [k for k in gold.files if k.startswith(name + ".stepped.")]:
+        key = k.split(".stepped.")[1]
+        g_ref = gold["%s.grad.%s" % (name, key)]
+        if np.abs(g_ref).max() < 1e-4:      # gradient = rounding noise (bias in front of a BatchNorm): Adam's first
+            continue                        # step, lr * g / (|g| + eps), is then noise as well
+        mine = (named[key].detach() - before[key]).numpy().ravel()
+        ref = (torch.from_numpy(gold[k]) - before[key]).numpy().ravel()
+        assert np.abs(mine).max() <= grp["lr"] * 1.01 and np.abs(ref).max() <= grp["lr"] * 1.01, key
+        firm = np.abs(g_ref.ravel()) > 1e-3 * np.abs(g_ref).max()          # elements with a well-defined direction
+        assert np.mean(np.sign(mine[firm]) == np.sign(ref[firm])) > 0.99, key
+        big = np.abs(g_ref.ravel()) > 0.2 * np.abs(g_ref).max()            # far from a sign change under 5 % gradient noise
+        assert np.abs(mine[big] - ref[big]).max() < 0.05 * grp["lr"], key
