@@ -35,7 +35,7 @@ const char* o3d_version(void);
  * xyz (B,N,3) f32 -> idx (B,npoint) i32.  Iterative FPS from index 0; points with
  * |p|^2 <= 1e-3 are never selected; tie order identical to the upstream thread-block
  * reduction (block = opt_n_threads(N)).  `temp` is a (B,N) f32 scratch that is only
- * touched when N > 16384 (may be NULL otherwise). */
+ * touched when N > 8192 (may be NULL otherwise). */
 int o3d_furthest_point_sampling(const float* xyz, int B, int N, int npoint, float* temp,
                                 int32_t* idx, void* stream);
 

@@ -6,6 +6,7 @@ purpose: torch brings its own ROCm runtime (libamdhip64.so.7) and the kernels mu
 the same runtime instance that owns torch's device pointers and streams.
 """
 import ctypes
+import functools
 import os
 
 import torch  # noqa: F401  (must be loaded before the HIP library, see above)
@@ -81,3 +82,19 @@ def check(rc, what):
 
 def version():
     return load().o3d_version().decode()
+
+
+def on_tensor_device(fn):
+    """Run `fn` with the CUDA device of its first GPU-tensor argument current: the launch stream, the scratch
+    allocations and the kernel launches of the fused operators then all belong to the device that owns the
+    pointers, whichever device the caller left current (a model on cuda:1 while cuda:0 is current)."""
+    @functools.wraps(fn)
+    def wrapped(*args):
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.is_cuda:
+                if a.device.index == torch.cuda.current_device():
+                    break
+                with torch.cuda.device(a.device):
+                    return fn(*args)
+        return fn(*args)
+    return wrapped

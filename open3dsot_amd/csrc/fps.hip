@@ -10,8 +10,8 @@
 //     round touches no memory except one uniform 12-byte LDS read of the new centre.
 //   * N <= 2048: ONE wave per cloud, no barrier anywhere in the round loop; the arg-max
 //     is a DPP row reduction (quad_perm / row_half_mirror / row_mirror) + 4 v_readlane.
-//     2048 < N <= 16384: 8 waves per cloud, two LDS hand-offs per round.
-//     N > 16384: generic strided kernel with the min-distance array in caller scratch.
+//     2048 < N <= 8192: 8 waves per cloud, two LDS hand-offs per round.
+//     N > 8192: generic strided kernel with the min-distance array in caller scratch.
 //   * bit-identical indices: the upstream winner among equal maxima is decided by its
 //     thread-strided scan + tree reduction, i.e. by
 //         rank(k) = bitrev_L(k mod bs) * ceil(N/bs) + (k div bs),  bs = opt_n_threads(N),
@@ -248,7 +248,8 @@ int fps_dispatch(const float* xyz, int B, int N, int npoint, float* temp, int32_
     if (N <= 2048) return launch_reg<32, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
     if (N <= 4096) return launch_reg<8, 8, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
     if (N <= 8192) return launch_reg<16, 8, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
-    if (N <= 16384) return launch_reg<32, 8, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
+    // beyond 8192 points the cloud no longer fits the LDS staging of the register kernels (N*12 B against
+    // 160 KB per CU from N = 13649 on): generic kernel, running min-distance in the caller's `temp`
     if (!temp) return O3D_EINVAL;
     hipLaunchKernelGGL(fps_generic_kernel, dim3(B), dim3(1024), 0, s, xyz, N, npoint, bs_log2, cpb,
                        temp, idx);

@@ -92,7 +92,11 @@ class DataParallelStep:
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0)
         self.grads = FlatGrads(model.parameters())
-        self.optimizer = optimizer if optimizer is not None else model.configure_optimizers()["optimizer"]
+        self.scheduler = None
+        if optimizer is None:
+            conf = model.configure_optimizers()
+            optimizer, self.scheduler = conf["optimizer"], conf.get("lr_scheduler")   # StepLR of base_model.py:34-35
+        self.optimizer = optimizer
         self.graph_requested = bool(graph) and torch.cuda.is_available()
         self.graph_warmup = graph_warmup
         self.graph = None
@@ -118,12 +122,18 @@ class DataParallelStep:
 
     def _capture(self, batch):
         self._static = {k: v.clone() for k, v in batch.items()}
+        # the allocator warm-up pass below is NOT a training step: the BatchNorm running statistics and
+        # num_batches_tracked it touches are put back, so a graph run sees exactly one update per step()
+        buffers = list(self.model.buffers())
+        saved = [b.clone() for b in buffers]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):      # one more eager pass on the capture stream's allocator
             self._forward_backward(self._static)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        for b, v in zip(buffers, saved):
+            b.copy_(v)
         g = torch.cuda.CUDAGraph()
         # thread_local: other threads of the process (the RCCL watchdog of torch.distributed polls events) may
         # keep calling the runtime while this thread captures
@@ -139,7 +149,7 @@ class DataParallelStep:
             self.graph.replay()
             for p, g in zip(self.grads.params, self._static_grads):   # replay rewrote these buffers in place
                 p.grad = g
-            loss = self._static_loss
+            loss = self._static_loss.clone()      # the graph rewrites its own buffer at the next replay
         else:
             if self.graph_requested and self._eager_steps >= self.graph_warmup:
                 try:
@@ -156,3 +166,15 @@ class DataParallelStep:
         self.reduce_gradients()
         self.optimizer.step()
         return loss
+
+    def epoch_end(self):
+        """step the learning-rate schedule (the reference's Lightning loop steps StepLR once per epoch)"""
+        if self.scheduler is not None:
+            self.scheduler.step()
+
+    def sync_buffers(self):
+        """BatchNorm statistics are per rank during training (no sync-BN in the reference; its DDP wrapper
+        re-broadcasts rank 0's buffers every forward): call before checkpointing so every rank holds rank 0's"""
+        if self.world > 1:
+            for b in self.model.buffers():
+                dist.broadcast(b.data, src=0)

@@ -44,7 +44,7 @@ def furthest_point_sampling(xyz, npoint, _variant="dpp"):
     B, N, _ = xyz.shape
     npoint = int(npoint)
     out = torch.empty((B, npoint), dtype=torch.int32, device=xyz.device)
-    temp = torch.empty((B, N), dtype=torch.float32, device=xyz.device) if N > 16384 else None
+    temp = torch.empty((B, N), dtype=torch.float32, device=xyz.device) if N > 8192 else None
     lib = capi.load()
     fn = lib.o3d_furthest_point_sampling if _variant == "dpp" else lib.o3d_furthest_point_sampling_shfl
     with torch.cuda.device(xyz.device):

@@ -114,9 +114,14 @@ def profile_step(step_fn, peak_tflops, repeats=3):
     finally:
         _PROF["on"] = False
     agg = {}
+    live_cols = slot_cols = 0.0
     for name, flops, e0, e1 in _PROF["events"]:
-        if isinstance(flops, tuple):       # (per-column FLOPs, meta): the live column count is data dependent
-            flops = flops[0] * float(flops[1].view(-1, 4)[:, 0].sum().item())      # live columns of every segment
+        if isinstance(flops, tuple):       # (per-column FLOPs, meta, slots): the live column count is data dependent
+            live = float(flops[1].view(-1, 4)[:, 0].sum().item())      # live columns of every segment
+            if name == "conv_fwd":
+                live_cols += live
+                slot_cols += float(flops[2])
+            flops = flops[0] * live
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += flops
@@ -137,6 +142,9 @@ def profile_step(step_fn, peak_tflops, repeats=3):
             "kernel": "fp32-MFMA grouped-MLP GEMM kernels (direct_gemm_kernel fwd/dgrad of csrc/mlp_direct.hip, "
                       "wgrad2_kernel of csrc/mlp_wgrad.hip, conv_*_kernel of csrc/mlp.hip for the unaligned "
                       "per-point layer 0); executed FLOPs per launch / HIP-event time of the launch",
+            # share of the ball slots (B*npoint*nsample, what the reference's kernels process) that hold a DISTINCT
+            # neighbour and are therefore computed here: data dependent -- `value` scales with it (bench.py --dense = 1.0)
+            "live_fraction": round(live_cols / slot_cols, 4) if slot_cols else None,
             "launches_per_step": launches // repeats, "avg_launch_ms": round(ms / launches, 5),
             "gemm_ms_per_step": round(ms / repeats, 4), "gemm_gflop_per_step": round(flops / repeats / 1e9, 2),
             "fused_kernels_ms_per_step": round(sum(v[2] for v in agg.values()) / repeats, 4),
@@ -196,6 +204,7 @@ class FusedGroupedMLP(torch.autograd.Function):
     """(xyz, new_xyz, feats, idx, cfg, W0,g0,b0, W1,g1,b1, ...) -> pooled (B, C_last, npoint)"""
 
     @staticmethod
+    @capi.on_tensor_device
     def forward(ctx, xyz, new_xyz, feats, idx, cfg, *params):
         lib = capi.load()
         L = len(params) // 3
@@ -276,6 +285,7 @@ class FusedGroupedMLP(torch.autograd.Function):
         return out
 
     @staticmethod
+    @capi.on_tensor_device
     def backward(ctx, dOut):
         lib = capi.load()
         cfg = ctx.cfg
@@ -433,6 +443,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
     apply(cfg, nseg, xyz_0, new_xyz_0, feats_0, idx_0, [xyz_1, ...], W0,g0,b0, W1,...) -> pooled_0 [, pooled_1]"""
 
     @staticmethod
+    @capi.on_tensor_device
     def forward(ctx, cfg, nseg, *args):
         lib = capi.load()
         segs = [args[4 * s:4 * s + 4] for s in range(nseg)]
@@ -524,7 +535,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                       cw.data_ptr(), _ptr(centers), Ws[0].data_ptr(), Cin0, C0, meta.data_ptr(), start1, ldp, Y.data_ptr(),
                       _ptr(part), _ptr(statc), st)
             else:
-                _call("conv_fwd", (2.0 * Cin * Cout, meta), lib.o3d_mlp_conv_fwd_c, Ys[-1].data_ptr(), Ws[l].data_ptr(),
+                _call("conv_fwd", (2.0 * Cin * Cout, meta, ldp), lib.o3d_mlp_conv_fwd_c, Ys[-1].data_ptr(), Ws[l].data_ptr(),
                       scales[-1].data_ptr(), shifts[-1].data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1,
                       tile, Y.data_ptr(), _ptr(part), _ptr(statc), st)
             vec = torch.empty((4, nseg, Cout), device=dev, dtype=f32)      # mean, invstd, scale, shift per segment
@@ -565,6 +576,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         return outs if nseg > 1 else outs[0]
 
     @staticmethod
+    @capi.on_tensor_device
     def backward(ctx, *dOuts):
         lib = capi.load()
         cfg = ctx.cfg
@@ -692,7 +704,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                             seg_grads[s_][1] = dnew_all[:, ball_bases[s_]:ball_bases[s_] + nballs_s[s_]].reshape(
                                 3, B, npoints[s_]).permute(1, 2, 0)
                 continue
-            flops = (2.0 * Cin * Cout, meta)      # executed FLOPs = per live column (count read back when profiling)
+            flops = (2.0 * Cin * Cout, meta, ldp)      # executed FLOPs = per live column (count read back when profiling)
             dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
             wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, ldp),), device=dev, dtype=f32)
             keep += [dN, wpart, coef]
@@ -732,6 +744,10 @@ _REDUCE_GATHER = {"on": _os.environ.get("O3D_REDUCE_GATHER", "0") == "1"}
 
 def set_reduce_gather(enabled):
     _REDUCE_GATHER["on"] = bool(enabled)
+
+
+def reduce_gather_enabled():
+    return _REDUCE_GATHER["on"]
 
 
 def _padded(owner, name, shape, dev):

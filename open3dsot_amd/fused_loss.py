@@ -33,6 +33,7 @@ class FusedTrackLoss(torch.autograd.Function):
     = (total, objective, box, seg, vote, bc); only losses[0] carries gradient."""
 
     @staticmethod
+    @capi.on_tensor_device
     def forward(ctx, weights, cla, vote, boxes, bc_pred, seg, box_label, centers, bc_label):
         lib = capi.load()
         f32 = torch.float32
@@ -58,6 +59,7 @@ class FusedTrackLoss(torch.autograd.Function):
         return losses
 
     @staticmethod
+    @capi.on_tensor_device
     def backward(ctx, g):
         grads, ctx.grads = ctx.grads, None
         live = [t for t in grads if t is not None]

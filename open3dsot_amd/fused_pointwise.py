@@ -35,6 +35,7 @@ class FusedPointwiseChain(torch.autograd.Function):
     """(x (B,Cin,N), cfg, W0,b0,g0,beta0, W1,...) -> act (B,C_L,N) | pooled (B,C_L)"""
 
     @staticmethod
+    @capi.on_tensor_device
     def forward(ctx, x, cfg, *params):
         lib = capi.load()
         L = len(params) // 4
@@ -102,6 +103,7 @@ class FusedPointwiseChain(torch.autograd.Function):
         return out
 
     @staticmethod
+    @capi.on_tensor_device
     def backward(ctx, dOut):
         lib = capi.load()
         cfg = ctx.cfg

@@ -43,8 +43,9 @@ def get_point_to_box_distance(points, center, wlh, rot, wlh_factor=1.0):
     if not (c.shape[0] == s.shape[0] == r.shape[0] == B):
         raise ValueError("one box per cloud expected")
     out = torch.empty((B, N, 9), device=dev, dtype=torch.float32)
-    rc = capi.load().o3d_boxcloud(pts.data_ptr(), c.data_ptr(), s.data_ptr(), r.data_ptr(), float(wlh_factor), B, N,
-                                  out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
+    with torch.cuda.device(dev):
+        rc = capi.load().o3d_boxcloud(pts.data_ptr(), c.data_ptr(), s.data_ptr(), r.data_ptr(), float(wlh_factor), B, N,
+                                      out.data_ptr(), torch.cuda.current_stream(dev).cuda_stream)
     if rc != 0:
         raise RuntimeError("o3d_boxcloud failed: %d" % rc)
     return out[0] if single else out

@@ -100,6 +100,27 @@ def make_batch(first_index, batch_size, template_size=512, search_size=1024, see
     return {k: np.stack([it[k] for it in items], 0) for k in items[0]}
 
 
+def make_dense_batch(first_index, batch_size, template_size=512, search_size=1024, seed0=1234):
+    """Worst case of the data-dependent work: the same pairs with both clouds replaced by distinct points inside a
+    17 cm cube (diagonal 0.294 m < the smallest ball radius 0.3 m, away from the origin so the FPS near-origin rule
+    of Appendix A.1 skips nothing): every ball of every set-abstraction level is full of DISTINCT neighbours, so the
+    distinct-neighbour layout of csrc/compact.hip compacts nothing (live fraction 1.0).  Labels / BoxClouds are
+    recomputed for the new points; used by `bench.py --dense` only."""
+    out = make_batch(first_index, batch_size, template_size, search_size, seed0)
+    for i in range(batch_size):
+        rng = np.random.default_rng(seed0 + 7919 * (int(first_index) + i) + 1)
+        wlh = out["bbox_size"][i].astype(np.float64)
+        t = (np.array([0.5, 0.3, 0.2]) + rng.uniform(-0.085, 0.085, (template_size, 3))).astype(np.float32)
+        c = out["box_label"][i]
+        rot, center = _rotz(c[3]), c[:3].astype(np.float64)
+        sp = (center + np.array([0.5, 0.3, 0.2]) + rng.uniform(-0.085, 0.085, (search_size, 3))).astype(np.float32)
+        out["template_points"][i], out["search_points"][i] = t, sp
+        out["points2cc_dist_t"][i] = boxcloud(t, np.zeros(3), np.eye(3), wlh)
+        out["points2cc_dist_s"][i] = boxcloud(sp, center, rot, wlh)
+        out["seg_label"][i] = 1.0
+    return out
+
+
 def make_motion_batch(first_index, batch_size, point_sample_size=1024, seed0=4321):
     """Synthetic M2-Track input (datasets/sampler.py::motion_processing :143-179): two consecutive
     frames of one target, each resampled to `point_sample_size` points, stacked as

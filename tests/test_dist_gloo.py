@@ -1,7 +1,8 @@
 """world_size-2 gloo test of the data-parallel step (CPU): two ranks on disjoint shards must
 end with identical parameters, equal to a single process that averages the two shard
 gradients itself.  Uses a small stand-in model with the tracker's `training_loss` protocol
-(the real tracker needs the GPU operator set)."""
+(the real tracker needs the GPU operator set); a second test drives the REAL BAT tracker through the
+same step with the oracle's operator shim standing in for the HIP library (test only)."""
 import os
 import socket
 
@@ -98,3 +99,89 @@ def test_shards_are_disjoint():
             assert not (ids & seen)
             seen |= ids
     assert len(seen) == 3 * 4 * 48
+
+
+# ---- the real tracker (BAT, small clouds) through DataParallelStep, world_size 2 ----------------------------
+def _patch_ext_with_oracle():
+    """what tests/conftest.py::cpu_ext does, for a spawned worker: the oracle's CPU operators stand in for the HIP
+    library (TEST ONLY) and the fused kernels are off"""
+    from oracle import ext_shim, ops as oops
+    import open3dsot_amd.ext as ext
+    from open3dsot_amd import sa_modules
+    for name in ("furthest_point_sampling", "gather_points", "gather_points_grad", "three_nn", "three_interpolate",
+                 "three_interpolate_grad", "ball_query", "group_points", "group_points_grad"):
+        setattr(ext, name, getattr(ext_shim, name))
+    ext.knn = lambda q, r, k: torch.from_numpy(oops.knn(q.detach().numpy(), r.detach().numpy(), k))
+    sa_modules.set_fused(False)
+
+
+def _bat_batch(first, n):
+    from open3dsot_amd import synth
+    return synth.to_torch(synth.make_batch(first, n, 128, 256))
+
+
+def _bat_model(seed):
+    from open3dsot_amd import trackers
+    torch.manual_seed(seed)
+    return trackers.BAT(trackers.make_config(trackers.BAT_CAR, num_proposal=32, optimizer="sgd", lr=0.01)).train()
+
+
+def _bat_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    _patch_ext_with_oracle()
+    from open3dsot_amd import dist as D
+    r, _, w = D.init_distributed("gloo")
+    model = _bat_model(7 + rank)          # different init per rank: the constructor's broadcast must fix it
+    trainer = D.DataParallelStep(model)
+    assert trainer.scheduler is not None  # StepLR of configure_optimizers is kept (base_model.py:34-35)
+    losses = []
+    for step in range(2):
+        first, n = D.shard_indices(step, r, w, 2)
+        losses.append(float(trainer.step(_bat_batch(first, n))))
+    trainer.epoch_end()
+    torch.save({"sd": {k: v.clone() for k, v in model.state_dict().items()}, "losses": losses,
+                "lr": trainer.optimizer.param_groups[0]["lr"]}, os.path.join(out, "bat%d.pt" % rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_real_tracker(tmp_path):
+    port = _free_port()
+    mp.spawn(_bat_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "bat0.pt"), torch.load(tmp_path / "bat1.pt")
+    stat = lambda k: "running" in k or "num_batches" in k
+    for k in r0["sd"]:
+        if not stat(k):
+            assert torch.equal(r0["sd"][k], r1["sd"][k]), k          # replicas stay identical
+    assert any(not torch.equal(r0["sd"][k], r1["sd"][k]) for k in r0["sd"] if "running_mean" in k)   # per-rank BN
+    assert r0["lr"] == r1["lr"] and r0["lr"] > 0
+    # single-process emulation: rank 0's initial weights, mean of the two shard gradients, the same Adam
+    _patch_ext_with_oracle()
+    try:
+        import copy
+        from open3dsot_amd import dist as D
+        ref = _bat_model(7)
+        opt = ref.configure_optimizers()["optimizer"]
+        reps = [copy.deepcopy(ref) for _ in range(2)]               # per-rank BatchNorm buffers
+        for step in range(2):
+            grads = []
+            for r in range(2):
+                reps[r].load_state_dict({k: (v if stat(k) else ref.state_dict()[k]) for k, v in reps[r].state_dict().items()})
+                reps[r].zero_grad(set_to_none=True)
+                first, n = D.shard_indices(step, r, 2, 2)
+                loss, _ = reps[r].training_loss(_bat_batch(first, n))
+                loss.backward()
+                if r == 0:
+                    assert abs(float(loss) - r0["losses"][step]) < 1e-4 * (1 + abs(float(loss)))
+                grads.append([p.grad.clone() if p.grad is not None else torch.zeros_like(p) for p in reps[r].parameters()])
+            for p, g0, g1 in zip(ref.parameters(), *grads):
+                p.grad = (g0 + g1) / 2
+            opt.step()
+        for k, p in ref.named_parameters():
+            # (SGD configuration of base_model.py:29-31 on purpose: Adam normalises every step to +-lr, which turns
+            # the rounding noise of near-zero gradients into sign flips of whole steps)
+            assert torch.allclose(r0["sd"][k], p.detach(), rtol=1e-4, atol=1e-5), k
+    finally:
+        from open3dsot_amd import sa_modules
+        sa_modules.set_fused(True)

@@ -125,8 +125,9 @@ def test_bn_finalize_matches_torch(lib, B, C, P):
     assert rel(rm, bn.running_mean) < 1e-5 and rel(rv, bn.running_var) < 1e-5
 
 
-def make_case(kind, B=3, train=True, seed=0):
-    """(grouper, mlp, xyz, new_xyz, feats) on the GPU for a layer shape family of the tracker"""
+def make_case(kind, B=3, train=True, seed=0, full=False):
+    """(grouper, mlp, xyz, new_xyz, feats) on the GPU for a layer shape family of the tracker; `full`: the SEARCH
+    branch's point counts at BASELINE config 2 (1024-point search cloud) instead of the half-size test clouds"""
     from open3dsot_amd import nn_blocks, ops, synth
     torch.manual_seed(seed)
     if kind == "sa1":
@@ -139,9 +140,11 @@ def make_case(kind, B=3, train=True, seed=0):
         N, npoint, ns, r, C, spec = 128, 64, 16, 0.3, 257, [260, 256, 256, 256]
     else:
         raise ValueError(kind)
+    if full and kind != "rpn":
+        N, npoint = 2 * N, 2 * npoint
     b = synth.make_batch(900 + seed, B, 512, 1024)
     xyz = torch.from_numpy(b["search_points"][:, :N, :]).cuda()
-    if kind != "sa1":
+    if kind != "sa1" and not full:
         xyz = xyz * 0.5
     new_xyz = xyz[:, :npoint, :].contiguous()
     feats = torch.randn(B, C, N, device="cuda") if C else None
@@ -202,14 +205,27 @@ def test_fused_sa_matches_composed(kind, train):
 
 
 @pytest.mark.parametrize("kind", ["sa1", "sa2", "sa3"])
+def test_paired_segments_full_size_batch48(kind):
+    """BASELINE config 2 itself: 48 pairs, template 512 / search 1024 points -- the per-level column counts of the
+    benchmarked step (search SA1 48*512*32 = 786 432 slots), where the launch geometry differs from the small cases
+    (128-column wave tiles above 65 536 slots, segment 1 at a non-zero `start1`, the weight-gradient slice plan):
+    forward <= 2e-5, every gradient <= 5e-4 L2 against the fp64 shadow, running statistics <= 1e-5."""
+    _paired_case(kind, True, B=48, full=True)
+
+
+@pytest.mark.parametrize("kind", ["sa1", "sa2", "sa3"])
 @pytest.mark.parametrize("train", [True, False])
 def test_paired_segments_match_two_calls(kind, train):
     """The template and the search cloud through one shared SA module in ONE set of launches
     (fused.sa_group_mlp_pool_pair) = two consecutive calls, template first: separate batch statistics,
     running statistics updated in order, parameter gradients summed (models/bat.py:89-90)."""
+    _paired_case(kind, train)
+
+
+def _paired_case(kind, train, B=3, full=False):
     import copy
     from open3dsot_amd import fused
-    grouper, mlp, xyz_s, new_s, feats_s = make_case(kind, train=train)
+    grouper, mlp, xyz_s, new_s, feats_s = make_case(kind, B=B, train=train, full=full)
     N, npoint = xyz_s.shape[1], new_s.shape[1]
     xyz_t = (xyz_s[:, :N // 2, :] * 0.9 + 0.05).contiguous()          # the template: half the points
     new_t = xyz_t[:, :npoint // 2, :].contiguous()
@@ -280,8 +296,6 @@ def test_paired_backbone_matches_sequential():
         assert rel(b1.float(), b2.float()) < 1e-5, n1
 
 
-@pytest.mark.skipif(os.environ.get("O3D_TEST_REDUCE_GATHER") != "1",
-                    reason="experimental kernel (DESIGN.md 9.2): run with O3D_TEST_REDUCE_GATHER=1 once it is being integrated")
 @pytest.mark.parametrize("kind", ["sa1", "sa2", "sa3", "rpn"])
 def test_reduce_gather_matches_atomic_reduce(kind):
     """o3d_group_reduce_gather (transposed index + LDS gather) against o3d_group_reduce_c (LDS atomics): same S / T,
@@ -290,6 +304,7 @@ def test_reduce_gather_matches_atomic_reduce(kind):
     from open3dsot_amd import fused
     grouper, mlp, xyz, new_xyz, feats = make_case(kind)
     grads = []
+    was = fused.reduce_gather_enabled()
     for gather in (False, True):
         fused.set_reduce_gather(gather)
         try:
@@ -300,24 +315,24 @@ def test_reduce_gather_matches_atomic_reduce(kind):
             out.backward(go)
             grads.append([p.grad for p in m.parameters()] + [t.grad for t in leaves if t is not None])
         finally:
-            fused.set_reduce_gather(False)
+            fused.set_reduce_gather(was)
     for a, b in zip(*grads):
         assert l2rel(a, b) < 1e-5, l2rel(a, b)
 
 
-@pytest.mark.skipif(os.environ.get("O3D_TEST_REDUCE_GATHER") != "1",
-                    reason="experimental kernel (DESIGN.md 9.2): run with O3D_TEST_REDUCE_GATHER=1 once it is being integrated")
-@pytest.mark.parametrize("kind", ["sa1", "sa2"])
-def test_reduce_gather_matches_atomic_reduce_paired(kind):
-    """the same comparison through the two-segment (template + search) call"""
+@pytest.mark.parametrize("kind,B,full", [("sa1", 3, False), ("sa2", 3, False), ("sa3", 3, False), ("sa1", 48, True),
+                                         ("sa2", 48, True)])
+def test_reduce_gather_matches_atomic_reduce_paired(kind, B, full):
+    """the same comparison through the two-segment (template + search) call, also at BASELINE config 2's sizes"""
     import copy
     from open3dsot_amd import fused
-    grouper, mlp, xyz_s, new_s, feats_s = make_case(kind)
+    grouper, mlp, xyz_s, new_s, feats_s = make_case(kind, B=B, full=full)
     N, npoint = xyz_s.shape[1], new_s.shape[1]
     xyz_t = (xyz_s[:, :N // 2, :] * 0.9 + 0.05).contiguous()
     new_t = xyz_t[:, :npoint // 2, :].contiguous()
     feats_t = torch.randn(feats_s.shape[0], feats_s.shape[1], N // 2, device="cuda") if feats_s is not None else None
     grads = []
+    was = fused.reduce_gather_enabled()
     for gather in (False, True):
         fused.set_reduce_gather(gather)
         try:
@@ -329,7 +344,7 @@ def test_reduce_gather_matches_atomic_reduce_paired(kind):
             torch.autograd.backward(list(outs), [torch.randn(o.shape, device="cuda", generator=gen) for o in outs])
             grads.append([p.grad for p in m.parameters()] + [t.grad for sg in segs for t in sg if t is not None])
         finally:
-            fused.set_reduce_gather(False)
+            fused.set_reduce_gather(was)
     for a, b in zip(*grads):
         assert l2rel(a, b) < 1e-5, l2rel(a, b)
 

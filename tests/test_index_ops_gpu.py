@@ -60,7 +60,8 @@ def test_fps_golden(ext, golden_index, variant):
 @pytest.mark.parametrize("variant", ["dpp", "shfl"])
 @pytest.mark.parametrize("N,npoint", [(1, 1), (2, 2), (5, 3), (63, 40), (64, 64), (65, 10), (100, 100), (255, 128),
                                       (512, 256), (777, 300), (1024, 512), (1500, 200), (2048, 1024),
-                                      (3000, 64), (5000, 100), (9000, 50), (20000, 40)])
+                                      (3000, 64), (5000, 100), (8192, 30), (9000, 50), (14000, 40), (16384, 30),
+                                      (20000, 40)])
 def test_fps_sizes_and_ties(ext, variant, N, npoint):
     for kind in ("normal", "dup", "grid", "origin", "zero"):
         B = 3 if N <= 2048 else 2
