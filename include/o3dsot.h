@@ -363,6 +363,47 @@ int o3d_bn_bwd_finalize_c2(const float* part, int nparts0, int nparts1, int C, d
                            float* dbeta, float* A1, float* A2, float* A3, const int32_t* meta, int tile,
                            void* stream);
 
+/* ---- 1-D conv stacks of the heads on the flat (C, P = B*N) layout -------------------------------------
+ * Replaces pt_utils.Seq / Conv1d (+BatchNorm1d +ReLU) stacks, pointnet2/utils/pytorch_utils.py:124-155,300-457, as
+ * used by models/head/rpn.py:16-39 (FC_layer_cla, vote_layer, FC_proposal), models/head/xcorr.py:14-17 (fea_layer)
+ * and models/bat.py:22-26 (conv_final, mlp_bc): hidden layers conv -> BatchNorm -> ReLU (BatchNorm + ReLU applied
+ * by the consumer on load, statistics partials from the producer), last layer conv + bias.
+ * P % 64 == 0; contraction sizes % 16 == 0 and output rows % 64 == 0 (callers zero-pad, see o3d_pack_rows /
+ * o3d_prep_weights).  Statistics partial rows are per o3d_pw_tile(P) columns. */
+typedef struct { const float* p; long sb, sc, sn; int C; } o3d_rows_src;
+
+/* X (rows, B*N) <- up to 4 sources of shape (B, C_i, N) with arbitrary strides (in floats) stacked along the rows
+ * (torch.cat(dim=1) of e.g. [xyz^T ; features]: rpn.py:50, bat.py:94); rows beyond sum C_i are zero.
+ * srcs: HOST array. */
+int o3d_pack_rows(const o3d_rows_src* srcs, int nsrc, int B, int N, int rows, float* X, void* stream);
+
+/* Every padded / transposed weight copy of a step in one launch.  jobs: DEVICE array of njobs x 6 longs
+ * {src ptr, dst ptr, rows, cols, dst_ld, transpose}: src (rows, cols) row-major -> dst[r*ld + c], or
+ * dst[c*ld + r] when transpose != 0; the padding of dst is not written. */
+int o3d_prep_weights(const long* jobs, int njobs, void* stream);
+
+/* out (C) = row sums of G (C, P): bias gradient of a plain Conv1d layer. */
+int o3d_row_sum(const float* G, int C, long P, float* out, void* stream);
+
+int o3d_pw_tile(long P);
+
+/* Y (Cout, P) = W (Cout, Cin) . f(X),  f = relu(x*in_scale + in_shift) per input row, or identity (both NULL).
+ * part != NULL: BatchNorm statistics partials [P/tile][2][Cout] = {sum y, sum (y - stat_c)^2};
+ * part == NULL: Y += bias[row] + resid (Cout, P), either may be NULL (last layer of a stack; the residual is the
+ * `seeds + vote_layer(seeds)` of rpn.py:53). */
+int o3d_pw_fwd(const float* X, const float* W, const float* in_scale, const float* in_shift, const float* bias,
+               const float* resid, int Cin, int Cout, long P, float* Y, float* part, const float* stat_c,
+               void* stream);
+
+/* dNprev (Cin, P) = Wt (Cin, Cout) . dY,  dY = dN (Y == NULL) or A1*dN + A2*Y + A3.
+ * Yprev != NULL: masked by relu(Yprev*scale_p + shift_p) > 0, BatchNorm-backward partials of the producer
+ * [P/tile][2][Cin] = {sum g, sum g*(Yprev - mean_p)} in `part`;
+ * Yprev == NULL: plain store (+ resid (Cin, P)): the gradient of the stack's input. */
+int o3d_pw_dgrad(const float* dN, const float* Y, const float* A1, const float* A2, const float* A3,
+                 const float* Wt, int Cin, int Cout, long P, const float* Yprev, const float* scale_p,
+                 const float* shift_p, const float* mean_p, const float* resid, float* dNprev, float* part,
+                 void* stream);
+
 /* ---- tracker losses (next row of SURVEY.md section 8f: the loss as one launch) ----------------------
  * MatchingBaseModel.compute_loss (models/base_model.py:122-164) + the BoxCloud term (models/bat.py:57-65)
  * + the weighted total (models/bat.py:131-137, models/p2b.py:69-74) and the gradients of the total.

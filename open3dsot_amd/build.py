@@ -23,6 +23,7 @@ SOURCES = [
     ("group.hip", []),
     ("compact.hip", []),
     ("pointwise.hip", []),
+    ("heads.hip", []),
     ("loss.hip", []),
     ("boxcloud.hip", []),
     ("capi_misc.hip", []),

@@ -1,0 +1,105 @@
+// heads.hip -- adapters of the trackers' 1-D conv stacks (models/head/rpn.py:16-39, models/head/xcorr.py:14-17,
+// models/bat.py:22-26) to the flat (C, P = B*N) layout of the GEMM kernels.
+//
+//   pack_rows_kernel     X (rows, P) <- up to four (B, C_i, N) sources with ARBITRARY strides stacked along the
+//                        rows (the reference's torch.cat along dim 1 of e.g. [xyz^T ; features], rpn.py:50,
+//                        bat.py:94), zero rows up to `rows` (the GEMM kernels want K % 16 == 0, the weight-gradient
+//                        kernel K % 64 == 0).  One launch instead of transpose + contiguous + cat + permute.
+//   prep_weights_kernel  every padded / transposed weight copy of a step (W zero-padded to aligned shapes, W^T for
+//                        the data-gradient GEMMs) in ONE launch from a job table in device memory; the weights only
+//                        change in the optimizer step, so the table is static and the launch is graph-capturable.
+#include "o3d_common.hpp"
+
+namespace {
+
+struct PackRowsArgs {
+    o3d_rows_src s[4];
+    int nsrc, B, N, rows;
+    float* X;
+};
+
+__global__ __launch_bounds__(256) void pack_rows_kernel(PackRowsArgs a) {
+    const long P = (long)a.B * a.N;
+    const long col = (long)blockIdx.x * 256 + threadIdx.x;
+    if (col >= P) return;
+    const int b = (int)(col / a.N), n = (int)(col - (long)b * a.N);
+    int r = blockIdx.y;
+    float v = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (i < a.nsrc) {
+            if (r >= 0 && r < a.s[i].C) v = a.s[i].p[b * a.s[i].sb + r * a.s[i].sc + n * a.s[i].sn];
+            r -= a.s[i].C;
+        }
+    }
+    a.X[(long)blockIdx.y * P + col] = v;
+}
+
+// job = {src, dst, rows, cols, dst_ld, transpose}: src (rows, cols) row-major ->
+//   dst[r*ld + c] (transpose == 0)  or  dst[c*ld + r] (transpose != 0); padding of dst is never written
+__global__ __launch_bounds__(256) void prep_weights_kernel(const long* __restrict__ jobs) {
+    const long* j = jobs + 6L * blockIdx.x;
+    const float* src = reinterpret_cast<const float*>(j[0]);
+    float* dst = reinterpret_cast<float*>(j[1]);
+    const long rows = j[2], cols = j[3], ld = j[4], tr = j[5];
+    const long n = rows * cols;
+    for (long o = (long)blockIdx.y * 256 + threadIdx.x; o < n; o += 256L * gridDim.y) {
+        if (tr) {
+            const long c = o / rows, r = o - c * rows;
+            dst[c * ld + r] = src[r * cols + c];
+        } else {
+            const long r = o / cols, c = o - r * cols;
+            dst[r * ld + c] = src[o];
+        }
+    }
+}
+
+// row sums of a (C, P) matrix: the bias gradient of a plain Conv1d layer.  One workgroup per row, fixed order.
+__global__ __launch_bounds__(256) void row_sum_kernel(const float* __restrict__ G, long P, float* __restrict__ out) {
+    __shared__ float sh[4];
+    const float* g = G + (long)blockIdx.x * P;
+    float s = 0.f;
+    for (long p = 4L * threadIdx.x; p < P; p += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(&g[p]);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+
+}  // namespace
+
+// X (rows, B*N): rows [0, sum C_i) = the sources stacked in order, element (b, c, n) of source i read at
+// p + b*sb + c*sc + n*sn (strides in floats); remaining rows zero.  srcs is a HOST array of nsrc <= 4 entries.
+extern "C" int o3d_pack_rows(const o3d_rows_src* srcs, int nsrc, int B, int N, int rows, float* X, void* stream) {
+    if (!srcs || nsrc < 1 || nsrc > 4 || B <= 0 || N <= 0 || rows <= 0 || !X) return O3D_EINVAL;
+    PackRowsArgs a = {};
+    int total = 0;
+    for (int i = 0; i < nsrc; ++i) {
+        if (!srcs[i].p || srcs[i].C <= 0) return O3D_EINVAL;
+        a.s[i] = srcs[i];
+        total += srcs[i].C;
+    }
+    if (total > rows) return O3D_EINVAL;
+    a.nsrc = nsrc; a.B = B; a.N = N; a.rows = rows; a.X = X;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)o3d_cdiv((long)B * N, 256), rows), dim3(256), 0,
+                       o3d_stream(stream), a);
+    return o3d_launch_status();
+}
+
+// jobs: DEVICE array of njobs x 6 longs {src, dst, rows, cols, dst_ld, transpose} (see prep_weights_kernel)
+extern "C" int o3d_prep_weights(const long* jobs, int njobs, void* stream) {
+    if (!jobs || njobs <= 0) return O3D_EINVAL;
+    hipLaunchKernelGGL(prep_weights_kernel, dim3(njobs, 16), dim3(256), 0, o3d_stream(stream), jobs);
+    return o3d_launch_status();
+}
+
+// out (C) = row sums of G (C, P); P % 4 == 0
+extern "C" int o3d_row_sum(const float* G, int C, long P, float* out, void* stream) {
+    if (!G || !out || C <= 0 || P <= 0 || P % 4 != 0) return O3D_EINVAL;
+    hipLaunchKernelGGL(row_sum_kernel, dim3(C), dim3(256), 0, o3d_stream(stream), G, P, out);
+    return o3d_launch_status();
+}

@@ -74,6 +74,9 @@ struct DirectArgs {
     float* part;           // [B*P/(32*NT)][2][M] or NULL
     const float* stat_c;   // forward: shift of the second moment
     const float* Yprev; const float* scale_p; const float* shift_p; const float* mean_p;  // dgrad mask
+    // EPI 2 (plain layer of a 1-D conv stack): out = acc + bias[m] + resid[m, p]   (either may be NULL)
+    const float* bias;     // (M)
+    const float* resid;    // (M, P), same layout as Out
 };
 
 template <int MODE, int NT>
@@ -131,6 +134,8 @@ __device__ __forceinline__ void compute_group(const RawB<NT>& f, const float4& a
 
 // EPI 0: forward (store raw output, statistics {sum y, sum (y-c)^2})
 // EPI 1: data gradient (mask by the producer's ReLU, store, statistics {sum g, sum g*(yprev-mean)})
+// EPI 2: plain store + per-row bias + residual tensor, no statistics (last layer of a Conv1d stack,
+//        pytorch_utils.py:124-155 with bn=False / activation=None, and the input gradient of a stack)
 // NT = 4: 128 columns per wave (one dwordx4 B load per k row); NT = 2: 64 columns (dwordx2) -- twice the waves
 // of half the length for launches that do not fill the chip (everything after compaction at batch 48).
 template <int WAVES, int MODE, int EPI, int NT>
@@ -225,6 +230,14 @@ void direct_gemm_kernel(DirectArgs a) {
                     acc[i][t][r] = v[t];
                     sum += v[t];
                 }
+            } else if (EPI == 2) {
+                const float bm = a.bias ? a.bias[m] : 0.f;
+                float rs[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) rs[t] = 0.f;
+                if (a.resid) ldv<NT>(rs, a.resid + o);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) v[t] = (v[t] + bm) + rs[t];
             } else {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) sum = fmaf(wv[t], v[t], sum);
@@ -232,7 +245,7 @@ void direct_gemm_kernel(DirectArgs a) {
             stv<NT>(a.Out + o, v);
             red[i * 16 + r] = sum;
         }
-    if (!a.part) return;
+    if (EPI == 2 || !a.part) return;
     // lane l31 of half h ends up owning value index l31 -> (i = l31>>4, r = l31&15)
     float* dst = a.part + (long)tile * 2 * a.M + m0 + 32 * (l31 >> 4) + acc_row(l31 & 15, h);
     reduce_scatter32(red, l31);
@@ -321,4 +334,52 @@ int o3d_direct_dgrad(const float* dN, const float* pk, int ns,
     a.Out = dNprev; a.M = Cin; a.K = Cout; a.P = P; a.B = B; a.part = part;
     a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p;
     return dN ? launch_direct<B_DY, 1>(a, tile, st) : launch_direct<B_DYPOOL, 1>(a, tile, st);
+}
+
+// ---- 1-D conv stacks (the trackers' heads) on the flat (C, P) layout, P = B*N columns -------------------------
+// Same kernels, two more operand / epilogue combinations.  P % 64 == 0, Cin % 16 == 0, Cout % 64 == 0 (callers
+// zero-pad); 64-column wave tiles while the problem is small (o3d_direct_tile).
+
+// Y (Cout, P) = W (Cout, Cin) . f(X) [+ bias + resid];  f = relu(x*in_scale+in_shift) or identity (both NULL).
+// part != NULL: BatchNorm statistics partials [P/tile][2][Cout] (then bias / resid must be NULL);
+// returns the tile (64 | 128) through *tile_out so the caller sizes `part` = P / tile rows.
+extern "C" int o3d_pw_tile(long P) { return (int)o3d_direct_tile(P, 0, 0); }
+
+extern "C" int o3d_pw_fwd(const float* X, const float* W, const float* in_scale, const float* in_shift,
+                          const float* bias, const float* resid, int Cin, int Cout, long P, float* Y, float* part,
+                          const float* stat_c, void* stream) {
+    if (!X || !W || !Y || P <= 0 || P > 0x7fffffff || P % 64 != 0 || Cin <= 0 || Cin % 16 != 0 || Cout <= 0 ||
+        Cout % DT_M != 0 || (in_scale == nullptr) != (in_shift == nullptr) || (part && (bias || resid)))
+        return O3D_EINVAL;
+    const int tile = o3d_direct_tile(P, Cout, 0);
+    if (tile == 128 && P % 128 != 0) return O3D_EINVAL;
+    DirectArgs a = {};
+    a.A = W; a.X = X; a.c1 = in_scale; a.c2 = in_shift; a.Out = Y; a.M = Cout; a.K = Cin; a.P = (int)P; a.B = 1;
+    a.part = part; a.stat_c = stat_c; a.ns = 4; a.bias = bias; a.resid = resid;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (part || (!bias && !resid))
+        return in_scale ? launch_direct<B_XFORM, 0>(a, tile, st) : launch_direct<B_PLAIN, 0>(a, tile, st);
+    return in_scale ? launch_direct<B_XFORM, 2>(a, tile, st) : launch_direct<B_PLAIN, 2>(a, tile, st);
+}
+
+// dNprev (Cin, P) = Wt (Cin, Cout) . dY,  dY = dN (Y == NULL) or A1*dN + A2*Y + A3 (BatchNorm backward folded);
+// Yprev != NULL: masked by the producer's ReLU (relu(Yprev*scale_p+shift_p) > 0) with its BatchNorm-backward
+// partials in `part` [P/tile][2][Cin]; Yprev == NULL: plain store (+ resid): the gradient of the stack's input.
+extern "C" int o3d_pw_dgrad(const float* dN, const float* Y, const float* A1, const float* A2, const float* A3,
+                            const float* Wt, int Cin, int Cout, long P, const float* Yprev, const float* scale_p,
+                            const float* shift_p, const float* mean_p, const float* resid, float* dNprev, float* part,
+                            void* stream) {
+    if (!dN || !Wt || !dNprev || P <= 0 || P > 0x7fffffff || P % 64 != 0 || Cin <= 0 || Cin % DT_M != 0 ||
+        Cout <= 0 || Cout % 16 != 0 || (Y && (!A1 || !A2 || !A3)) ||
+        (Yprev && (!scale_p || !shift_p || !mean_p || !part || resid)) || (!Yprev && part))
+        return O3D_EINVAL;
+    const int tile = o3d_direct_tile(P, Cin, 0);
+    if (tile == 128 && P % 128 != 0) return O3D_EINVAL;
+    DirectArgs a = {};
+    a.A = Wt; a.X = dN; a.Y = Y; a.c1 = A1; a.c2 = A2; a.c3 = A3; a.ns = 4;
+    a.Out = dNprev; a.M = Cin; a.K = Cout; a.P = (int)P; a.B = 1; a.part = part;
+    a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p; a.resid = resid;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (Yprev) return Y ? launch_direct<B_DY, 1>(a, tile, st) : launch_direct<B_PLAIN, 1>(a, tile, st);
+    return Y ? launch_direct<B_DY, 2>(a, tile, st) : launch_direct<B_PLAIN, 2>(a, tile, st);
 }

@@ -244,14 +244,14 @@ static void wgrad2_plan(int Cin, int Cout, int B, int P, int& TM, int& TN, int& 
 
 // floats of scratch needed by o3d_mlp_conv_wgrad2 (partial tiles + second-stage groups)
 extern "C" long o3d_mlp_conv_wgrad2_scratch(int B, int Cin, int Cout, int P) {
-    if (Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || P <= 0 || P % 128 || B <= 0) return -1;
+    if (Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || P <= 0 || P % 64 || B <= 0) return -1;
     int TM, TN, WK, CP, nsl;
     wgrad2_plan(Cin, Cout, B, P, TM, TN, WK, CP, nsl);
     return ((long)nsl * WK + 16) * Cout * Cin;
 }
 
 // dW (Cout,Cin) = sum_{b,p} dY * f(X); dY from dN (dense) or pk (pooled, needs ns); X raw producer output
-// with (in_scale,in_shift) (both NULL: X as stored).  Cin, Cout multiples of 64, P multiple of 128.
+// with (in_scale,in_shift) (both NULL: X as stored).  Cin, Cout, P multiples of 64 (the staged chunks are 32 / 64 columns).
 static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y, const float* A1, const float* A2,
                        const float* A3, const float* X, const float* in_scale, const float* in_shift, int B, int Cin,
                        int Cout, int P, const float* w, const int32_t* meta, long start1, float* scratch, float* dW,
@@ -279,7 +279,7 @@ static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y,
                        const float* A3, const float* X, const float* in_scale, const float* in_shift, int B, int Cin,
                        int Cout, int P, const float* w, const int32_t* meta, long start1, float* scratch, float* dW,
                        void* stream) {
-    if (B <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || P <= 0 || P % 128 || !Y || !A1 || !A2 || !A3 ||
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || P <= 0 || P % 64 || !Y || !A1 || !A2 || !A3 ||
         !X || (in_scale == nullptr) != (in_shift == nullptr) || !scratch || !dW || (!dN && (!pk || ns < 4 || ns % 4)))
         return O3D_EINVAL;
     int TM, TN, WK, CP, nsl;

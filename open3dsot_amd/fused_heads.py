@@ -1,0 +1,385 @@
+"""The trackers' 1-D conv stacks on the library's GEMM kernels, flat (C, P = B*N) layout end to end.
+
+What it replaces (same numbers within fp32 rounding, tests/test_heads_gpu.py):
+  pt_utils.Seq of Conv1d(+BatchNorm1d+ReLU) units   pointnet2/utils/pytorch_utils.py:124-155,300-457
+    FC_layer_cla, vote_layer (+ the residual `seeds + vote_layer(seeds)`), FC_proposal   models/head/rpn.py:16-39,50-54
+    fea_layer                                          models/head/xcorr.py:14-17
+    mlp_bc, conv_final                                 models/bat.py:22-26,91-94
+The reference runs each unit as conv1d -> batch_norm -> relu on (B,C,N) tensors with torch.cat / transpose
+around them; here a stack is: ONE pack launch that stacks its (arbitrarily strided) sources into the zero-padded
+(K, P) operand, then per layer one fp32-MFMA GEMM (csrc/mlp_direct.hip; BatchNorm + ReLU of the producer
+applied on load, statistics partials in the epilogue, bias / residual in the last layer's epilogue) and one
+BatchNorm finalize; the backward mirrors it (data gradient with the BatchNorm-backward constants folded in,
+tile-matched weight gradient of csrc/mlp_wgrad.hip).  Parameters stay in the caller's modules.
+
+`WeightPrep`: every zero-padded / transposed weight copy the GEMMs need (K % 16, M % 64, W^T for the data
+gradient) is a job in one table; inside a `prep_scope` all jobs of the device are refreshed by ONE launch at scope
+entry (the weights only change in the optimizer step) instead of one small copy per layer per step.
+"""
+import contextlib
+import ctypes
+import weakref
+
+import torch
+
+from . import capi
+from .fused import _call, _const_vec, _ptr, _stream
+
+_vp, _i, _l, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
+capi.register("o3d_pack_rows", [_vp, _i, _i, _i, _i, _vp, _vp])
+capi.register("o3d_prep_weights", [_vp, _i, _vp])
+capi.register("o3d_row_sum", [_vp, _i, _l, _vp, _vp])
+capi.register("o3d_pw_tile", [_l])
+capi.register("o3d_pw_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp])
+capi.register("o3d_pw_dgrad", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+
+_ON = {"on": True}
+
+
+def set_fused_heads(enabled):
+    """1-D conv stacks on the library's kernels (default) or on torch ops (the specification they are tested against)"""
+    _ON["on"] = bool(enabled)
+
+
+def enabled():
+    return _ON["on"]
+
+
+def _up(v, m):
+    return -(-v // m) * m
+
+
+class _RowsSrc(ctypes.Structure):
+    _fields_ = [("p", ctypes.c_void_p), ("sb", ctypes.c_long), ("sc", ctypes.c_long), ("sn", ctypes.c_long),
+                ("C", ctypes.c_int)]
+
+
+def pack_rows(sources, rows):
+    """[(B,C_i,N) tensors, any strides] -> X (rows, B*N): the sources stacked along the rows, zero rows below"""
+    lib = capi.load()
+    B, _, N = sources[0].shape
+    X = torch.empty((rows, B * N), device=sources[0].device, dtype=torch.float32)
+    arr = (_RowsSrc * len(sources))()
+    for i, t in enumerate(sources):
+        sb, sc, sn = t.stride()
+        arr[i].p, arr[i].sb, arr[i].sc, arr[i].sn, arr[i].C = t.data_ptr(), sb, sc, sn, t.shape[1]
+    _call("pack_rows", 0.0, lib.o3d_pack_rows, ctypes.addressof(arr), len(sources), B, N, rows, X.data_ptr(), _stream())
+    return X
+
+
+def _as_flat(t):
+    """(B,C,N) view of a contiguous (C,B,N) buffer -> that buffer as (C, B*N), else None"""
+    p = t.permute(1, 0, 2)
+    return p.reshape(p.shape[0], -1) if p.is_contiguous() else None
+
+
+# ---- weight preparation ------------------------------------------------------------------------------------
+class _Job:
+    __slots__ = ("ref", "dst", "rows", "cols", "transpose", "src_ptr")
+
+
+class WeightPrep:
+    def __init__(self, dev):
+        self.dev = dev
+        self.jobs = {}
+        self.table = None
+        self.dirty = False
+        self.active = False
+        self.fresh = set()
+
+    @staticmethod
+    def _copy_now(job, param):
+        src = param.detach().reshape(job.rows, job.cols)
+        if job.transpose:
+            job.dst[:job.cols, :job.rows].copy_(src.t())
+        else:
+            job.dst[:job.rows, :job.cols].copy_(src)
+
+    def get(self, param, rows_p, cols_p, transpose=False):
+        """param viewed as (param.shape[0], rest) -> zero-padded (rows_p, cols_p) copy of it (or of its transpose)"""
+        rows = param.shape[0] if param.dim() > 1 else 1
+        if not transpose and (rows, param.numel() // rows) == (rows_p, cols_p):
+            return param.detach().reshape(rows_p, cols_p)           # already in shape: no copy at all
+        key = (id(param), rows_p, cols_p, bool(transpose))
+        job = self.jobs.get(key)
+        if job is None or job.ref() is not param:
+            job = _Job()
+            job.ref = weakref.ref(param)
+            job.rows = param.shape[0] if param.dim() > 1 else 1
+            job.cols = param.numel() // job.rows
+            job.transpose = bool(transpose)
+            job.dst = torch.zeros((rows_p, cols_p), device=param.device, dtype=torch.float32)
+            job.src_ptr = param.data_ptr()
+            self.jobs[key] = job
+            self.dirty = True
+            self._copy_now(job, param)
+        elif not (self.active and key in self.fresh) or job.src_ptr != param.data_ptr():
+            self._copy_now(job, param)
+        return job.dst
+
+    def refresh(self):
+        """all registered copies in one launch"""
+        for key in [k for k, j in self.jobs.items() if j.ref() is None]:
+            del self.jobs[key]
+            self.dirty = True
+        for j in self.jobs.values():
+            ptr = j.ref().data_ptr()
+            if ptr != j.src_ptr:
+                j.src_ptr, self.dirty = ptr, True
+        if not self.jobs:
+            return
+        if self.dirty or self.table is None:
+            rows = [[j.src_ptr, j.dst.data_ptr(), j.rows, j.cols, j.dst.shape[1], int(j.transpose)] for j in self.jobs.values()]
+            self.table = torch.tensor(rows, dtype=torch.int64, device=self.dev)       # only while the job set changes
+            self.dirty = False
+        with torch.cuda.device(self.dev):
+            _call("prep_weights", 0.0, capi.load().o3d_prep_weights, self.table.data_ptr(), self.table.shape[0],
+                  torch.cuda.current_stream(self.dev).cuda_stream)
+        self.fresh = set(self.jobs)
+
+
+_PREP = {}
+
+
+def prep_for(dev):
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _PREP:
+        _PREP[key] = WeightPrep(torch.device(*key))
+    return _PREP[key]
+
+
+@contextlib.contextmanager
+def prep_scope(dev):
+    """Between entry and exit the weights do not change (one forward of a tracker): every prepared copy of the
+    device is refreshed by one launch now and `get` hands the buffers out without further copies."""
+    if dev.type != "cuda" or not _ON["on"]:
+        yield
+        return
+    prep = prep_for(dev)
+    if prep.active:          # nested scopes: the outer one did the work
+        yield
+        return
+    prep.refresh()
+    prep.active = True
+    try:
+        yield
+    finally:
+        prep.active = False
+
+
+# ---- the stack ---------------------------------------------------------------------------------------------
+class _Cfg:
+    __slots__ = ("bns", "training", "residual", "nsrc")
+
+
+def chain_supported(sources, units):
+    """sources: [(B,C_i,N) GPU tensors]; units: [(conv1d, batchnorm1d | None, activation | None)]"""
+    if not _ON["on"] or not units:
+        return False
+    x = sources[0]
+    if not x.is_cuda or any(t.dtype != torch.float32 or t.dim() != 3 or t.shape[0] != x.shape[0] or
+                            t.shape[2] != x.shape[2] for t in sources) or len(sources) > 4:
+        return False
+    B, _, N = x.shape
+    P = B * N
+    if P == 0 or P % 64 or (P > 65536 and P % 128):
+        return False
+    if sum(t.shape[1] for t in sources) != units[0][0].in_channels:
+        return False
+    for i, (conv, bn, act) in enumerate(units):
+        if conv.kernel_size != (1,) or conv.stride != (1,) or conv.padding != (0,) or conv.groups != 1:
+            return False
+        last = i == len(units) - 1
+        if last:
+            if bn is not None or act is not None:
+                return False
+        else:
+            if bn is None or not isinstance(act, torch.nn.ReLU) or conv.bias is not None or conv.out_channels % 64 or \
+                    not bn.affine or not bn.track_running_stats or bn.momentum is None:
+                return False
+    return True
+
+
+class FlatChain(torch.autograd.Function):
+    """apply(cfg, src_0..src_{nsrc-1}, [W, bias | None, gamma | None, beta | None] per layer) -> (B, Cout, N) view of the
+    flat (Cout_pad, B*N) output.  Hidden layers: conv -> BatchNorm -> ReLU; last layer: conv + bias (+ residual)."""
+
+    @staticmethod
+    @capi.on_tensor_device
+    def forward(ctx, cfg, *tensors):
+        lib = capi.load()
+        srcs, params = tensors[:cfg.nsrc], tensors[cfg.nsrc:]
+        L = len(params) // 4
+        B, _, N = srcs[0].shape
+        P = B * N
+        dev, f32 = srcs[0].device, torch.float32
+        st = _stream()
+        prep = prep_for(dev)
+        K0 = sum(t.shape[1] for t in srcs)
+        K0p = _up(K0, 64)
+        X0 = _as_flat(srcs[0].detach()) if (cfg.nsrc == 1 and K0 == K0p) else None
+        if X0 is None:
+            X0 = pack_rows([t.detach() for t in srcs], K0p)
+        need_bwd = any(ctx.needs_input_grad)
+        tile = lib.o3d_pw_tile(P)
+        nparts = P // tile
+        Ys, vecs, Wts = [], [], []
+        Kp = K0p
+        for l in range(L):
+            W, bias, gamma, beta = params[4 * l:4 * l + 4]
+            Cout = W.shape[0]
+            Mp = _up(Cout, 64)
+            Wp = prep.get(W, Mp, Kp)
+            if need_bwd:
+                Wts.append(prep.get(W, Kp, Mp, transpose=True))
+            src = X0 if l == 0 else Ys[-1]
+            sc = None if l == 0 else vecs[-1][2].data_ptr()
+            sh = None if l == 0 else vecs[-1][3].data_ptr()
+            Y = torch.empty((Mp, P), device=dev, dtype=f32)
+            if l < L - 1:
+                bn = cfg.bns[l]
+                vec = torch.empty((4, Mp), device=dev, dtype=f32)            # mean, invstd, scale, shift
+                if cfg.training:
+                    part = torch.empty((nparts, 2, Mp), device=dev, dtype=f32)
+                    _call("pw_conv_fwd", 2.0 * Kp * Mp * P, lib.o3d_pw_fwd, src.data_ptr(), Wp.data_ptr(), sc, sh, None, None,
+                          Kp, Mp, P, Y.data_ptr(), part.data_ptr(), bn.running_mean.data_ptr(), st)
+                    fold = torch.empty((64, Mp), device=dev, dtype=f32)
+                    _call("bn_finalize", 0.0, lib.o3d_bn_finalize, part.data_ptr(), nparts, Mp, float(P),
+                          bn.running_mean.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(),
+                          bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps), vec[0].data_ptr(), vec[1].data_ptr(),
+                          vec[2].data_ptr(), vec[3].data_ptr(), fold.data_ptr(), st)
+                else:
+                    _call("pw_conv_fwd", 2.0 * Kp * Mp * P, lib.o3d_pw_fwd, src.data_ptr(), Wp.data_ptr(), sc, sh, None, None,
+                          Kp, Mp, P, Y.data_ptr(), None, None, st)
+                    vec[0].copy_(bn.running_mean)
+                    vec[1].copy_(torch.rsqrt(bn.running_var + bn.eps))
+                    vec[2].copy_(gamma.detach() * vec[1])
+                    vec[3].copy_(beta.detach() - vec[0] * vec[2])
+                vecs.append(vec)
+            else:
+                bp = prep.get(bias, 1, Mp) if bias is not None else None
+                if cfg.residual and Mp != K0p:
+                    raise ValueError("residual stack: padded output rows %d != padded input rows %d" % (Mp, K0p))
+                if bp is None and not cfg.residual:       # plain store without statistics
+                    bp = _const_vec(dev, Mp, 0.0)
+                _call("pw_conv_fwd", 2.0 * Kp * Mp * P, lib.o3d_pw_fwd, src.data_ptr(), Wp.data_ptr(), sc, sh, _ptr(bp),
+                      X0.data_ptr() if cfg.residual else None, Kp, Mp, P, Y.data_ptr(), None, None, st)
+            Ys.append(Y)
+            Kp = Mp
+        if cfg.training and L > 1:
+            torch._foreach_add_([bn.num_batches_tracked for bn in cfg.bns[:L - 1]], 1)
+        Cl = params[4 * (L - 1)].shape[0]
+        if need_bwd:
+            ctx.cfg = cfg
+            ctx.geom = (B, N, L, K0, K0p, tile, [t.shape[1] for t in srcs])
+            ctx.versions = [(p, p._version) for p in params if p is not None]
+            ctx.saved = (X0, Ys, vecs, Wts, [params[4 * l + 2] for l in range(L)], [params[4 * l] for l in range(L)])
+        return Ys[-1][:Cl].view(Cl, B, N).permute(1, 0, 2)
+
+    @staticmethod
+    @capi.on_tensor_device
+    def backward(ctx, dOut):
+        lib = capi.load()
+        cfg = ctx.cfg
+        B, N, L, K0, K0p, tile, src_C = ctx.geom
+        for p, v in ctx.versions:
+            if p._version != v:
+                raise RuntimeError("a parameter of a fused conv stack was modified in place between forward and backward")
+        X0, Ys, vecs, Wts, gammas, Ws = ctx.saved
+        P = B * N
+        dev, f32 = dOut.device, torch.float32
+        st = _stream()
+        nparts = P // tile
+        Cl = Ws[-1].shape[0]
+        Mp = Ys[-1].shape[0]
+        G = _as_flat(dOut) if Cl == Mp else None
+        if G is None:
+            G = pack_rows([dOut], Mp)
+        grads = [None] * (4 * L)
+        want_x = any(ctx.needs_input_grad[1:1 + cfg.nsrc])
+        one, zero = _const_vec(dev, Mp, 1.0), _const_vec(dev, Mp, 0.0)
+        dX0 = None
+
+        def wgrad(l, dN, Y, A, Cout_p):
+            Xs = X0 if l == 0 else Ys[l - 1]
+            Kp = Xs.shape[0]
+            sc = None if l == 0 else vecs[l - 1][2].data_ptr()
+            sh = None if l == 0 else vecs[l - 1][3].data_ptr()
+            dW = torch.empty((Cout_p, Kp), device=dev, dtype=f32)
+            scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Kp, Cout_p, P),), device=dev, dtype=f32)
+            _call("pw_conv_wgrad", 2.0 * Kp * Cout_p * P, lib.o3d_mlp_conv_wgrad2, dN.data_ptr(), None, 4, Y.data_ptr(),
+                  A[0], A[1], A[2], Xs.data_ptr(), sc, sh, 1, Kp, Cout_p, P, scratch.data_ptr(), dW.data_ptr(), st)
+            Wl = Ws[l]
+            Cout, Cin = Wl.shape[0], Wl.shape[1]
+            return (dW if (Cout, Cin) == (Cout_p, Kp) else dW[:Cout, :Cin]).reshape(Wl.shape)
+
+        # ---- last layer: plain conv (+ bias, + residual)
+        l = L - 1
+        if ctx.needs_input_grad[1 + cfg.nsrc + 4 * l + 1]:
+            db = torch.empty((Mp,), device=dev, dtype=f32)
+            _call("row_sum", 0.0, lib.o3d_row_sum, G.data_ptr(), Mp, P, db.data_ptr(), st)
+            grads[4 * l + 1] = db[:Cl]
+        grads[4 * l] = wgrad(l, G, G, (one.data_ptr(), zero.data_ptr(), zero.data_ptr()), Mp)
+        dN, part = None, None
+        if L > 1:
+            Cp = Ys[l - 1].shape[0]
+            dN = torch.empty((Cp, P), device=dev, dtype=f32)
+            part = torch.empty((nparts, 2, Cp), device=dev, dtype=f32)
+            v = vecs[l - 1]
+            _call("pw_conv_dgrad", 2.0 * Cp * Mp * P, lib.o3d_pw_dgrad, G.data_ptr(), None, None, None, None,
+                  Wts[l].data_ptr(), Cp, Mp, P, Ys[l - 1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(), v[0].data_ptr(), None,
+                  dN.data_ptr(), part.data_ptr(), st)
+        elif want_x:
+            dX0 = torch.empty((K0p, P), device=dev, dtype=f32)
+            _call("pw_conv_dgrad", 2.0 * K0p * Mp * P, lib.o3d_pw_dgrad, G.data_ptr(), None, None, None, None,
+                  Wts[0].data_ptr(), K0p, Mp, P, None, None, None, None, G.data_ptr() if cfg.residual else None,
+                  dX0.data_ptr(), None, st)
+        # ---- hidden layers: conv -> BatchNorm -> ReLU
+        for l in range(L - 2, -1, -1):
+            Cp = Ys[l].shape[0]
+            v = vecs[l]
+            coef = torch.empty((5, Cp), device=dev, dtype=f32)          # dgamma dbeta A1 A2 A3
+            fold = torch.empty((64, Cp), device=dev, dtype=f32)
+            _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize, part.data_ptr(), nparts, Cp, float(P),
+                  gammas[l].data_ptr(), v[0].data_ptr(), v[1].data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
+                  coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr(), fold.data_ptr(), st)
+            if not cfg.training:
+                coef[3].zero_()
+                coef[4].zero_()
+            grads[4 * l + 2], grads[4 * l + 3] = coef[0], coef[1]
+            A = (coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr())
+            grads[4 * l] = wgrad(l, dN, Ys[l], A, Cp)
+            if l > 0:
+                Cq = Ys[l - 1].shape[0]
+                dNp = torch.empty((Cq, P), device=dev, dtype=f32)
+                part = torch.empty((nparts, 2, Cq), device=dev, dtype=f32)
+                vp = vecs[l - 1]
+                _call("pw_conv_dgrad", 2.0 * Cq * Cp * P, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
+                      Wts[l].data_ptr(), Cq, Cp, P, Ys[l - 1].data_ptr(), vp[2].data_ptr(), vp[3].data_ptr(), vp[0].data_ptr(),
+                      None, dNp.data_ptr(), part.data_ptr(), st)
+                dN = dNp
+            elif want_x:
+                dX0 = torch.empty((K0p, P), device=dev, dtype=f32)
+                _call("pw_conv_dgrad", 2.0 * K0p * Cp * P, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1], A[2],
+                      Wts[0].data_ptr(), K0p, Cp, P, None, None, None, None, G.data_ptr() if cfg.residual else None,
+                      dX0.data_ptr(), None, st)
+        gsrc, off = [], 0
+        for i, C in enumerate(src_C):
+            gsrc.append(dX0[off:off + C].view(C, B, N).permute(1, 0, 2) if (dX0 is not None and ctx.needs_input_grad[1 + i])
+                        else None)
+            off += C
+        return (None, *gsrc, *grads)
+
+
+def run_chain(sources, units, residual=False):
+    """sources [(B,C_i,N)] stacked along the channels -> the Conv1d stack `units` -> (B,Cout,N) (+ sources when
+    `residual`).  Caller has checked chain_supported."""
+    cfg = _Cfg()
+    cfg.nsrc = len(sources)
+    cfg.training = bool(units[0][1].training) if units[0][1] is not None else False
+    cfg.residual = bool(residual)
+    cfg.bns = [bn for _, bn, _ in units]
+    params = []
+    for conv, bn, _ in units:
+        params += [conv.weight, conv.bias, bn.weight if bn is not None else None, bn.bias if bn is not None else None]
+    return FlatChain.apply(cfg, *sources, *params)

@@ -23,14 +23,32 @@ def set_flat_pointwise(enabled):
 
 
 def pointwise_conv1d(conv, x):
-    """nn.Conv1d with kernel 1 on (B,C,N) as ONE (Cout,Cin) x (Cin,B*N) GEMM.  Same arithmetic as
-    F.conv1d; on the MI355X the library convolution picks 60-90 us kernels for these 6144-column
-    problems (rocprofv3, profiles/) where the plain GEMM takes ~10."""
+    """nn.Conv1d with kernel 1 on (B,C,N) as ONE (Cout,Cin) x (Cin,B*N) GEMM: on the GPU the library's fp32-MFMA
+    kernel on the flat layout (open3dsot_amd/fused_heads.py), else torch.mm.  Same arithmetic as F.conv1d."""
+    if _FLAT["on"] and x.is_cuda:
+        from . import fused_heads
+        units = [(conv, None, None)]
+        if fused_heads.chain_supported([x], units):
+            return fused_heads.run_chain([x], units)
     B, C, N = x.shape
     h = torch.mm(conv.weight.view(conv.out_channels, C), x.permute(1, 0, 2).reshape(C, B * N))
     if conv.bias is not None:
         h = h + conv.bias[:, None]
     return h.reshape(-1, B, N).permute(1, 0, 2).contiguous()
+
+
+def seq_apply(seq, parts, residual=False):
+    """seq(torch.cat(parts, dim=1)) (+ the concatenated input when `residual`: `seeds + vote_layer(seeds)`,
+    models/head/rpn.py:50-54) for a pt_utils.Seq of kernel-1 Conv1d units.  On the GPU the parts go straight into the
+    stack's packed operand (no cat, no transposes: parts may be any strided (B,C_i,N) views)."""
+    units = seq._flat_units() if (_FLAT["on"] and isinstance(seq, Seq)) else None
+    if units is not None and parts[0].is_cuda:
+        from . import fused_heads
+        if fused_heads.chain_supported(parts, units):
+            return fused_heads.run_chain(parts, units, residual)
+    x = parts[0] if len(parts) == 1 else torch.cat(parts, dim=1)
+    y = seq(x)
+    return x + y if residual else y
 
 
 _CONV = {1: nn.Conv1d, 2: nn.Conv2d, 3: nn.Conv3d}
@@ -221,6 +239,10 @@ class Seq(nn.Sequential):
         units = self._flat_units() if (_FLAT["on"] and x.dim() == 3) else None
         if units is None:
             return super().forward(x)
+        if x.is_cuda:
+            from . import fused_heads
+            if fused_heads.chain_supported([x], units):
+                return fused_heads.run_chain([x], units)
         # flat layout (C, B*N): each layer is one GEMM; BatchNorm1d sees (1, C, B*N), i.e. the same
         # per-channel statistics over all B*N positions
         B, C, N = x.shape

@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import fused_loss
+from . import fused_heads, fused_loss
 from . import nn_blocks as pt_utils
 from .backbone import Pointnet_Backbone
 from .rpn import P2BVoteNetRPN
@@ -102,6 +102,10 @@ class P2B(MatchingBaseModel):
                                  num_proposal=c.num_proposal, normalize_xyz=c.normalize_xyz)
 
     def forward(self, input_dict):
+        with fused_heads.prep_scope(input_dict["search_points"].device):
+            return self._forward(input_dict)
+
+    def _forward(self, input_dict):
         template, search = input_dict["template_points"], input_dict["search_points"]
         M, N = template.shape[1], search.shape[1]
         (template_xyz, template_feature, _), (search_xyz, search_feature, sample_idxs) = self.backbone.forward_pair(
@@ -165,6 +169,10 @@ class BAT(MatchingBaseModel):
         return out
 
     def forward(self, input_dict):
+        with fused_heads.prep_scope(input_dict["search_points"].device):
+            return self._forward(input_dict)
+
+    def _forward(self, input_dict):
         template, search = input_dict["template_points"], input_dict["search_points"]
         template_bc = input_dict["points2cc_dist_t"]
         M, N = template.shape[1], search.shape[1]
@@ -172,7 +180,7 @@ class BAT(MatchingBaseModel):
             self.backbone.forward_pair(template, [M // 2, M // 4, M // 8], search, [N // 2, N // 4, N // 8])
         template_feature = pt_utils.pointwise_conv1d(self.conv_final, template_feature)
         search_feature = pt_utils.pointwise_conv1d(self.conv_final, search_feature)
-        pred_search_bc = self.mlp_bc(torch.cat([search_xyz.transpose(1, 2), search_feature], dim=1))
+        pred_search_bc = pt_utils.seq_apply(self.mlp_bc, [search_xyz.transpose(1, 2), search_feature])
         pred_search_bc = pred_search_bc.transpose(1, 2)                                    # (B,N/8,9)
         t_idx = sample_idxs_t[:, :M // 8, None].long().expand(-1, -1, self.config.bc_channel)
         template_bc = template_bc.gather(dim=1, index=t_idx)                               # (B,M/8,9)

@@ -231,6 +231,7 @@ def _paired_case(kind, train, B=3, full=False):
     new_t = xyz_t[:, :npoint // 2, :].contiguous()
     feats_t = torch.randn(feats_s.shape[0], feats_s.shape[1], N // 2, device="cuda") if feats_s is not None else None
     mlp_ref = copy.deepcopy(mlp)
+    mlp_ref0 = copy.deepcopy(mlp)
     want_xyz = kind == "sa2"
     segs, refs, outs64 = [], [], []
     for xyz, new_xyz, feats in ((xyz_t, new_t, feats_t), (xyz_s, new_s, feats_s)):
@@ -264,12 +265,37 @@ def _paired_case(kind, train, B=3, full=False):
     for o64, go in zip(outs64, gos):
         o64.backward(go.double())
     tol = 5e-4 if train else 6e-3      # eval: nothing damps an argmax flip, and two clouds contribute flips
+    yard = {}
+    if full:
+        # At 48 pairs a weight gradient sums 16x more terms than in the small cases and fp32 rounding grows with it
+        # (measured on the MI355X: 0.8-2e-3 L2 on the layer-0 tensors).  The yardstick is torch's own fp32 evaluation
+        # (MIOpen convolutions + BatchNorm on the same HIP index operators, the two module calls in order) against
+        # the same fp64 shadow: the fused kernels must stay within 5e-4 or twice that error, whichever is larger.
+        m32 = copy.deepcopy(mlp_ref0)
+        segs32 = [[t.detach().clone().requires_grad_(t.requires_grad) if t is not None else None for t in sg] for sg in segs]
+        outs32 = [composed(grouper, m32, *sg) for sg in segs32]
+        torch.autograd.backward(outs32, gos)
+        for n1, p32 in m32.named_parameters():
+            yard[n1] = l2rel(p32.grad, refs[0][n1].grad + refs[1][n1].grad)
+        for si, (sg, l64) in enumerate(zip(segs32, refs)):
+            for nm, a in zip(("xyz", "new_xyz", "feats"), sg):
+                if a is not None and a.requires_grad:
+                    yard["%d.%s" % (si, nm)] = l2rel(a.grad, l64[nm].grad)
+    report = {}
     for n1, p1 in mlp.named_parameters():
-        assert_grad_close(p1.grad, refs[0][n1].grad + refs[1][n1].grad, n1, l2tol=tol, maxtol=1e-2 if train else 2e-2)
-    for sg, l64 in zip(segs, refs):
+        want = refs[0][n1].grad + refs[1][n1].grad
+        report[n1] = (l2rel(p1.grad, want), yard.get(n1))
+        assert_grad_close(p1.grad, want, n1, l2tol=max(tol, 2 * yard.get(n1, 0.0)), maxtol=1e-2 if train else 2e-2)
+    for si, (sg, l64) in enumerate(zip(segs, refs)):
         for nm, a in zip(("xyz", "new_xyz", "feats"), sg):
             if a is not None and a.requires_grad:
-                assert_grad_close(a.grad, l64[nm].grad, nm, l2tol=tol, maxtol=1e-2 if train else 4e-2)
+                key = "%d.%s" % (si, nm)
+                report[key] = (l2rel(a.grad, l64[nm].grad), yard.get(key))
+                assert_grad_close(a.grad, l64[nm].grad, nm, l2tol=max(tol, 2 * yard.get(key, 0.0)),
+                                  maxtol=1e-2 if train else 4e-2)
+    if full:
+        print("B=%d %s gradient L2 error vs fp64 (fused, torch fp32):" % (B, kind),
+              {k: ("%.1e" % v[0], "%.1e" % v[1]) for k, v in report.items()})
 
 
 def test_paired_backbone_matches_sequential():
@@ -345,8 +371,8 @@ def test_reduce_gather_matches_atomic_reduce_paired(kind, B, full):
             grads.append([p.grad for p in m.parameters()] + [t.grad for sg in segs for t in sg if t is not None])
         finally:
             fused.set_reduce_gather(was)
-    for a, b in zip(*grads):
-        assert l2rel(a, b) < 1e-5, l2rel(a, b)
+    for a, b in zip(*grads):      # two fp32 summation orders of the same terms: grows with the number of terms
+        assert l2rel(a, b) < (1e-5 if B <= 4 else 5e-5), l2rel(a, b)
 
 
 def test_slotwise_fallback_path_matches_fp64():

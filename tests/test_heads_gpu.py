@@ -1,0 +1,151 @@
+"""GPU parity of the flat-layout 1-D conv stacks (open3dsot_amd/fused_heads.py on csrc/mlp_direct.hip,
+csrc/mlp_wgrad.hip, csrc/heads.hip) against the same pt_utils.Seq modules evaluated by torch in fp64
+(pointnet2/utils/pytorch_utils.py:124-155,300-457; the stacks of models/head/rpn.py:16-39, models/head/xcorr.py:14-17,
+models/bat.py:22-26).  Forward 1e-4 of the tensor scale (north_star; measured ~1e-6), gradients 5e-4 L2 / 1e-2 max."""
+import copy
+import ctypes
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-20))
+
+
+def l2rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-20))
+
+
+def test_pack_rows_matches_cat():
+    from open3dsot_amd import fused_heads
+    g = torch.Generator(device="cuda").manual_seed(0)
+    B, N = 3, 40
+    xyz = torch.randn(B, N, 3, device="cuda", generator=g)
+    flat = torch.randn(7, B, N, device="cuda", generator=g)              # a flat (C,B,N) buffer seen as (B,C,N)
+    wide = torch.randn(B, 12, 2 * N, device="cuda", generator=g)[:, 2:7, ::2]      # strided slice
+    parts = [xyz.transpose(1, 2), flat.permute(1, 0, 2), wide]
+    X = fused_heads.pack_rows(parts, 64)
+    want = torch.cat([p.contiguous() for p in parts], dim=1).permute(1, 0, 2).reshape(15, B * N)
+    assert torch.equal(X[:15], want) and float(X[15:].abs().max()) == 0.0
+
+
+def test_prep_weights_pads_and_transposes():
+    from open3dsot_amd import fused_heads
+    dev = torch.device("cuda", 0)
+    prep = fused_heads.WeightPrep(dev)
+    w = torch.nn.Parameter(torch.randn(9, 259, 1, device=dev))
+    b = torch.nn.Parameter(torch.randn(9, device=dev))
+    wp, wt, bp = prep.get(w, 64, 320), prep.get(w, 320, 64, transpose=True), prep.get(b, 1, 64)
+
+    def check():
+        assert torch.equal(wp[:9, :259], w.detach()[:, :, 0]) and float(wp[9:].abs().max()) == 0 and float(wp[:, 259:].abs().max()) == 0
+        assert torch.equal(wt[:259, :9], w.detach()[:, :, 0].t()) and float(wt[259:].abs().max()) == 0 and float(wt[:, 9:].abs().max()) == 0
+        assert torch.equal(bp[0, :9], b.detach()) and float(bp[0, 9:].abs().max()) == 0
+    check()
+    with torch.no_grad():
+        w.mul_(2.0).add_(1.0)
+        b.add_(3.0)
+    prep.refresh()              # one launch for the three jobs
+    check()
+    same = torch.nn.Parameter(torch.randn(256, 256, 1, device=dev))
+    assert prep.get(same, 256, 256).data_ptr() == same.data_ptr()        # already aligned: handed out as is
+
+
+CASES = {
+    # name: (channels of the sources, widths, residual)
+    "cla": ([256], [256, 256, 1], False),                 # FC_layer_cla        rpn.py:16-22
+    "vote": ([3, 256], [256, 256, 259], True),            # vote_layer + seeds  rpn.py:23-28,50-54
+    "proposal": ([256], [256, 256, 5], False),            # FC_proposal         rpn.py:34-39
+    "mlp_bc": ([3, 256], [256, 256, 9], False),           # mlp_bc              bat.py:23-26,94
+    "fea": ([256], [256, 256], False),                    # fea_layer           xcorr.py:15-17
+}
+
+
+def build_seq(widths, cin, seed):
+    from open3dsot_amd import nn_blocks
+    torch.manual_seed(seed)
+    seq = nn_blocks.Seq(cin)
+    for i, w in enumerate(widths):
+        seq = seq.conv1d(w, bn=True) if i < len(widths) - 1 else seq.conv1d(w, activation=None)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m in seq.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.copy_(torch.empty(m.weight.shape).uniform_(0.5, 1.5, generator=g))
+                m.bias.copy_(torch.empty(m.bias.shape).normal_(0, 0.2, generator=g))
+                m.running_mean.copy_(torch.empty(m.bias.shape).normal_(0, 0.2, generator=g))
+                m.running_var.copy_(torch.empty(m.bias.shape).uniform_(0.5, 1.5, generator=g))
+            if isinstance(m, torch.nn.Conv1d) and m.bias is not None:
+                m.bias.copy_(torch.empty(m.bias.shape).normal_(0, 0.3, generator=g))
+    return seq.cuda()
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("B,N", [(4, 64), (48, 128)])
+def test_flat_chain_vs_fp64(name, train, B, N):
+    from open3dsot_amd import fused_heads, nn_blocks
+    src_C, widths, residual = CASES[name]
+    seq = build_seq(widths, sum(src_C), 3).train(train)
+    ref = copy.deepcopy(seq).double()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    parts = []
+    for C in src_C:     # xyz arrives as a transposed (B,N,3) tensor, features as (B,C,N)
+        t = torch.randn(B, N, C, device="cuda", generator=g).transpose(1, 2) if C == 3 else \
+            torch.randn(B, C, N, device="cuda", generator=g)
+        parts.append(t.requires_grad_(True))
+    parts64 = [t.detach().double().requires_grad_(True) for t in parts]
+    assert fused_heads.chain_supported(parts, seq._flat_units())
+    out = nn_blocks.seq_apply(seq, parts, residual)
+    x64 = torch.cat(parts64, dim=1)
+    ref_out = ref(x64) + (x64 if residual else 0)
+    assert out.shape == ref_out.shape
+    assert rel(out, ref_out) < 2e-5, rel(out, ref_out)
+    ct = torch.randn(out.shape, device="cuda", generator=g)
+    (out * ct).sum().backward()
+    (ref_out * ct.double()).sum().backward()
+    for a, b in zip(parts, parts64):
+        assert l2rel(a.grad, b.grad) < 5e-4 and rel(a.grad, b.grad) < 1e-2, ("input", l2rel(a.grad, b.grad))
+    for (n1, p), (_, q) in zip(seq.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, n1
+        assert p.grad.shape == p.shape
+        assert l2rel(p.grad, q.grad) < 5e-4 and rel(p.grad, q.grad) < 1e-2, (n1, l2rel(p.grad, q.grad), rel(p.grad, q.grad))
+    if train:
+        for (n1, b1), (_, b2) in zip(seq.named_buffers(), ref.named_buffers()):
+            if b1.dtype.is_floating_point:
+                assert rel(b1, b2) < 1e-5, n1
+            else:
+                assert int(b1) == int(b2) == 1, n1
+
+
+@pytest.mark.parametrize("B,N", [(4, 64), (48, 64), (48, 128)])
+def test_conv_final_flat(B, N):
+    """nn.Conv1d(256, 256, 1) with bias (models/bat.py:22, :91-92) through the same kernels"""
+    from open3dsot_amd import nn_blocks
+    torch.manual_seed(1)
+    conv = torch.nn.Conv1d(256, 256, 1).cuda()
+    ref = copy.deepcopy(conv).double()
+    x = torch.randn(B, 256, N, device="cuda", requires_grad=True)
+    x64 = x.detach().double().requires_grad_(True)
+    out = nn_blocks.pointwise_conv1d(conv, x)
+    want = ref(x64)
+    assert rel(out, want) < 2e-5
+    ct = torch.randn(out.shape, device="cuda")
+    (out * ct).sum().backward()
+    (want * ct.double()).sum().backward()
+    assert l2rel(x.grad, x64.grad) < 5e-4
+    assert l2rel(conv.weight.grad, ref.weight.grad) < 5e-4 and l2rel(conv.bias.grad, ref.bias.grad) < 5e-4
+
+
+def test_flat_chain_falls_back_when_unaligned():
+    """B*N not a multiple of 64: the torch path (same numbers) runs instead"""
+    from open3dsot_amd import fused_heads, nn_blocks
+    seq = build_seq([256, 256, 5], 256, 2).train()
+    x = torch.randn(3, 256, 30, device="cuda")
+    assert not fused_heads.chain_supported([x], seq._flat_units())
+    assert nn_blocks.seq_apply(seq, [x]).shape == (3, 5, 30)
