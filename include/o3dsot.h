@@ -404,6 +404,22 @@ int o3d_pw_dgrad(const float* dN, const float* Y, const float* A1, const float* 
                  const float* shift_p, const float* mean_p, const float* resid, float* dNprev, float* part,
                  void* stream);
 
+/* ---- P2B template<->search fusion, layer 0 (models/head/xcorr.py:25-53) ---------------------------------
+ * The reference materialises x_ij = [cos_sim(t_i, s_j) ; xyz_i ; feat_i] for all M*N (template, search) pairs and
+ * runs SharedMLP + max over the template axis.  Only channel 0 depends on j, so with Z = W0[:,1:].[xyz;feat]
+ * (a GEMM over the M template points):   Y0[c, q] = Z[c, b*M + i] + W0[c*ldw] * sim[q],   q = (b*N + j)*M + i.
+ * M a power of two in [4, 64], (M*N) % 1024 == 0, C0 % 16 == 0.  part [P/256][2][C0] = {sum y, sum (y-stat_c)^2}. */
+int o3d_xcorr_expand(const float* Z, long ldz, const float* sim, const float* W0, int ldw, int B, int M, int N, int C0,
+                     float* Y0, float* part, const float* stat_c, void* stream);
+
+/* Backward of the above with dY0 = A1*dN + A2*Y0 + A3:  S (C0, lds) = sum over j (-> dW0[:,1:], d[xyz;feat] through
+ * the per-point GEMMs), dsim_part (o3d_xcorr_reduce_groups(C0), P) = per-channel-group partial sums of
+ * W0[c,0]*dY0 (the caller adds the rows), dw_part (B, C0) = per-cloud partial sums of dY0*sim (-> dW0[:,0]). */
+long o3d_xcorr_reduce_groups(int C0);
+int o3d_xcorr_reduce(const float* dN, const float* Y0, const float* A1, const float* A2, const float* A3,
+                     const float* sim, const float* W0, int ldw, int B, int M, int N, int C0, float* S, long lds,
+                     float* dsim_part, float* dw_part, void* stream);
+
 /* ---- tracker losses (next row of SURVEY.md section 8f: the loss as one launch) ----------------------
  * MatchingBaseModel.compute_loss (models/base_model.py:122-164) + the BoxCloud term (models/bat.py:57-65)
  * + the weighted total (models/bat.py:131-137, models/p2b.py:69-74) and the gradients of the total.

@@ -24,6 +24,7 @@ SOURCES = [
     ("compact.hip", []),
     ("pointwise.hip", []),
     ("heads.hip", []),
+    ("xcorr.hip", []),
     ("loss.hip", []),
     ("boxcloud.hip", []),
     ("capi_misc.hip", []),

@@ -98,10 +98,10 @@ __device__ __forceinline__ void load_b(const DirectArgs& a, const float* xb, con
     }
 }
 
-// one group: 8 k's (4 per half-wave) x (2 m-tiles x NT n-tiles) = 8*NT MFMAs
-template <int MODE, int NT>
+// one group: 8 k's (4 per half-wave) x (MT m-tiles x NT n-tiles) = 4*MT*NT MFMAs
+template <int MODE, int NT, int MT>
 __device__ __forceinline__ void compute_group(const RawB<NT>& f, const float4& a0v, const float4& a1v, int kk,
-                                              const float (&wv)[NT], f32x16 (&acc)[2][NT]) {
+                                              const float (&wv)[NT], f32x16 (&acc)[MT][NT]) {
     const float a0[4] = {a0v.x, a0v.y, a0v.z, a0v.w}, a1[4] = {a1v.x, a1v.y, a1v.z, a1v.w};
     const float c1[4] = {f.c1.x, f.c1.y, f.c1.z, f.c1.w}, c2[4] = {f.c2.x, f.c2.y, f.c2.z, f.c2.w};
     const float c3[4] = {f.c3.x, f.c3.y, f.c3.z, f.c3.w};
@@ -127,7 +127,7 @@ __device__ __forceinline__ void compute_group(const RawB<NT>& f, const float4& a
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             acc[0][t] = mfma32(a0[s], bv[t], acc[0][t]);
-            acc[1][t] = mfma32(a1[s], bv[t], acc[1][t]);
+            if constexpr (MT == 2) acc[1][t] = mfma32(a1[s], bv[t], acc[1][t]);
         }
     }
 }
@@ -138,10 +138,13 @@ __device__ __forceinline__ void compute_group(const RawB<NT>& f, const float4& a
 //        pytorch_utils.py:124-155 with bn=False / activation=None, and the input gradient of a stack)
 // NT = 4: 128 columns per wave (one dwordx4 B load per k row); NT = 2: 64 columns (dwordx2) -- twice the waves
 // of half the length for launches that do not fill the chip (everything after compaction at batch 48).
-template <int WAVES, int MODE, int EPI, int NT>
+// MT = 2: 64 output rows per wave; MT = 1: 32 rows -- half the MFMA chain per wave for the launch-latency-bound
+// problems of the heads (256 x 256 x 6144: 96 column tiles; a 64x64 wave tile is a 512-MFMA = 14 us serial chain).
+template <int WAVES, int MODE, int EPI, int NT, int MT = 2>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ? 2 : 4)))
 void direct_gemm_kernel(DirectArgs a) {
     constexpr int POS = 32 * NT;
+    constexpr int DT_MW = 32 * MT;      // output rows per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int tiles_per_b = a.P / POS;
@@ -159,7 +162,7 @@ void direct_gemm_kernel(DirectArgs a) {
             if (a.scale_p) { a.scale_p += a.M; a.shift_p += a.M; a.mean_p += a.M; }
         }
     }
-    const int m0 = (blockIdx.y * WAVES + wave) * DT_M;
+    const int m0 = (blockIdx.y * WAVES + wave) * DT_MW;
     const int p = p0 + NT * l31;
     float wv[NT];
 #pragma unroll
@@ -179,9 +182,9 @@ void direct_gemm_kernel(DirectArgs a) {
         pool_base = (long)b * a.K * np + j;
     }
 
-    f32x16 acc[2][NT];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -194,24 +197,27 @@ void direct_gemm_kernel(DirectArgs a) {
         const int kb = 8 * g + 4 * h;
         load_b<MODE, NT>(a, xb, yb, rowP, kb, pool_base, np, f[st]);
         wa0[st] = *reinterpret_cast<const float4*>(wa + 8 * g);
-        wa1[st] = *reinterpret_cast<const float4*>(wa + 8 * g + wstep);
+        if constexpr (MT == 2) wa1[st] = *reinterpret_cast<const float4*>(wa + 8 * g + wstep);
+        else wa1[st] = wa0[st];
     };
     load(0, 0);
     for (int g = 0; g < G; g += 2) {
         load(1, g + 1);
         __builtin_amdgcn_sched_barrier(0);
-        compute_group<MODE, NT>(f[0], wa0[0], wa1[0], kk, wv, acc);
+        compute_group<MODE, NT, MT>(f[0], wa0[0], wa1[0], kk, wv, acc);
         __builtin_amdgcn_sched_barrier(0);
         load(0, g + 2 < G ? g + 2 : G - 1);       // tail: harmless re-load of the last group
         __builtin_amdgcn_sched_barrier(0);
-        compute_group<MODE, NT>(f[1], wa0[1], wa1[1], kk, wv, acc);
+        compute_group<MODE, NT, MT>(f[1], wa0[1], wa1[1], kk, wv, acc);
         __builtin_amdgcn_sched_barrier(0);
     }
 
     // ---------------- epilogue: store, then the two statistics one at a time (32 live values each)
     float red[32];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int r = 0; r < 32; ++r) red[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + 32 * i + acc_row(r, h);
@@ -248,10 +254,13 @@ void direct_gemm_kernel(DirectArgs a) {
     if (EPI == 2 || !a.part) return;
     // lane l31 of half h ends up owning value index l31 -> (i = l31>>4, r = l31&15)
     float* dst = a.part + (long)tile * 2 * a.M + m0 + 32 * (l31 >> 4) + acc_row(l31 & 15, h);
+    const bool owner = (l31 >> 4) < MT;
     reduce_scatter32(red, l31);
-    dst[0] = red[0];
+    if (owner) dst[0] = red[0];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int r = 0; r < 32; ++r) red[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = m0 + 32 * i + acc_row(r, h);
@@ -270,24 +279,32 @@ void direct_gemm_kernel(DirectArgs a) {
             red[i * 16 + r] = q;
         }
     reduce_scatter32(red, l31);
-    dst[a.M] = red[0];
+    if (owner) dst[a.M] = red[0];
 }
 
 // All M/64 row slabs of a position tile run as the waves of ONE workgroup: they read the same B rows,
 // so those come from HBM once and from L1/L2 for the other slabs (rocprofv3 FETCH_SIZE of the
 // two-workgroup variant showed every slab re-reading HBM: 604 MB instead of 350 MB per launch).
-template <int MODE, int EPI, int NT>
+template <int MODE, int EPI, int NT, int MT = 2>
 int launch_direct_nt(const DirectArgs& a, hipStream_t st) {
     const int tiles = a.B * (a.P / (32 * NT));
-    const int slabs = a.M / DT_M;
+    const int slabs = a.M / (32 * MT);
     if (slabs % 4 == 0) {
-        hipLaunchKernelGGL((direct_gemm_kernel<4, MODE, EPI, NT>), dim3(tiles, slabs / 4), dim3(256), 0, st, a);
+        hipLaunchKernelGGL((direct_gemm_kernel<4, MODE, EPI, NT, MT>), dim3(tiles, slabs / 4), dim3(256), 0, st, a);
     } else if (slabs % 2 == 0) {
-        hipLaunchKernelGGL((direct_gemm_kernel<2, MODE, EPI, NT>), dim3(tiles, slabs / 2), dim3(128), 0, st, a);
+        hipLaunchKernelGGL((direct_gemm_kernel<2, MODE, EPI, NT, MT>), dim3(tiles, slabs / 2), dim3(128), 0, st, a);
     } else {
-        hipLaunchKernelGGL((direct_gemm_kernel<1, MODE, EPI, NT>), dim3(tiles, slabs), dim3(64), 0, st, a);
+        hipLaunchKernelGGL((direct_gemm_kernel<1, MODE, EPI, NT, MT>), dim3(tiles, slabs), dim3(64), 0, st, a);
     }
     return o3d_launch_status();
+}
+
+// the heads' launches: 64-column tiles, and 32-row wave tiles while the whole problem is a few waves per SIMD
+template <int MODE, int EPI>
+int launch_direct_small(const DirectArgs& a, int tile, hipStream_t st) {
+    static const long small_max = [] { const char* e = getenv("O3D_PW_SMALL_MAX"); return e ? atol(e) : (4L << 20); }();
+    if (tile == 64 && (long)a.M * a.P <= small_max) return launch_direct_nt<MODE, EPI, 2, 1>(a, st);
+    return tile == 64 ? launch_direct_nt<MODE, EPI, 2>(a, st) : launch_direct_nt<MODE, EPI, 4>(a, st);
 }
 
 template <int MODE, int EPI>
@@ -358,8 +375,8 @@ extern "C" int o3d_pw_fwd(const float* X, const float* W, const float* in_scale,
     a.part = part; a.stat_c = stat_c; a.ns = 4; a.bias = bias; a.resid = resid;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (part || (!bias && !resid))
-        return in_scale ? launch_direct<B_XFORM, 0>(a, tile, st) : launch_direct<B_PLAIN, 0>(a, tile, st);
-    return in_scale ? launch_direct<B_XFORM, 2>(a, tile, st) : launch_direct<B_PLAIN, 2>(a, tile, st);
+        return in_scale ? launch_direct_small<B_XFORM, 0>(a, tile, st) : launch_direct_small<B_PLAIN, 0>(a, tile, st);
+    return in_scale ? launch_direct_small<B_XFORM, 2>(a, tile, st) : launch_direct_small<B_PLAIN, 2>(a, tile, st);
 }
 
 // dNprev (Cin, P) = Wt (Cin, Cout) . dY,  dY = dN (Y == NULL) or A1*dN + A2*Y + A3 (BatchNorm backward folded);
@@ -380,6 +397,6 @@ extern "C" int o3d_pw_dgrad(const float* dN, const float* Y, const float* A1, co
     a.Out = dNprev; a.M = Cin; a.K = Cout; a.P = (int)P; a.B = 1; a.part = part;
     a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p; a.resid = resid;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (Yprev) return Y ? launch_direct<B_DY, 1>(a, tile, st) : launch_direct<B_PLAIN, 1>(a, tile, st);
-    return Y ? launch_direct<B_DY, 2>(a, tile, st) : launch_direct<B_PLAIN, 2>(a, tile, st);
+    if (Yprev) return Y ? launch_direct_small<B_DY, 1>(a, tile, st) : launch_direct_small<B_PLAIN, 1>(a, tile, st);
+    return Y ? launch_direct_small<B_DY, 2>(a, tile, st) : launch_direct_small<B_PLAIN, 2>(a, tile, st);
 }

@@ -9,7 +9,10 @@ MI355X differences, results identical up to the documented tie rule:
   * BoxAwareXCorr selects the k nearest by the stable HIP kNN kernel (squared distance,
     ties -> lowest template index) instead of cdist + a full argsort of 64 (:81,:87 --
     torch.argsort's tie order is unspecified);
-  * the grouped (B,f+12,N,k) tensor goes through the fused gather+MLP+max path when enabled.
+  * the grouped (B,f+12,N,k) tensor goes through the fused gather+MLP+max path when enabled;
+  * P2B_XCorr's (B,f+4,M,N) fusion tensor is never built: its SharedMLP + max over the template axis run on the
+    library's kernels with layer 0 split into a per-template-point GEMM and the similarity term
+    (open3dsot_amd/fused_xcorr.py, csrc/xcorr.hip).
 """
 import torch
 from torch import nn
@@ -38,6 +41,13 @@ class P2B_XCorr(BaseXCorr):
         """template_feature (B,f,M), search_feature (B,f,N), template_xyz (B,M,3) -> (B,out,N)"""
         B, f, n1 = template_feature.shape
         n2 = search_feature.size(2)
+        if sa_modules.fused_enabled() and template_feature.is_cuda:
+            from . import fused_xcorr
+            if fused_xcorr.supported(self.mlp, template_feature, search_feature):
+                # layer 0 split into a per-template-point GEMM + the similarity term (csrc/xcorr.hip): the
+                # (B,4+f,M,N) fusion tensor is never built
+                fusion = fused_xcorr.p2b_xcorr_mlp_pool(self.mlp, template_feature, search_feature, template_xyz)
+                return self.fea_layer(fusion)
         # cosine similarity without materialising the two (B,f,M,N) expansions:
         # sim = <t,s> / (max(|t|,eps) * max(|s|,eps))   (nn.CosineSimilarity, eps=1e-8)
         tn = template_feature.norm(dim=1).clamp_min(1e-8)                      # (B,M)

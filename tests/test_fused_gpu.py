@@ -270,7 +270,8 @@ def _paired_case(kind, train, B=3, full=False):
         # At 48 pairs a weight gradient sums 16x more terms than in the small cases and fp32 rounding grows with it
         # (measured on the MI355X: 0.8-2e-3 L2 on the layer-0 tensors).  The yardstick is torch's own fp32 evaluation
         # (MIOpen convolutions + BatchNorm on the same HIP index operators, the two module calls in order) against
-        # the same fp64 shadow: the fused kernels must stay within 5e-4 or twice that error, whichever is larger.
+        # the same fp64 shadow: the fused kernels must stay within 5e-4 or three times that error, whichever is larger
+        # (the same yardstick rule as tests/test_model_gpu.py::test_backward_random_cotangent).
         m32 = copy.deepcopy(mlp_ref0)
         segs32 = [[t.detach().clone().requires_grad_(t.requires_grad) if t is not None else None for t in sg] for sg in segs]
         outs32 = [composed(grouper, m32, *sg) for sg in segs32]
@@ -285,13 +286,13 @@ def _paired_case(kind, train, B=3, full=False):
     for n1, p1 in mlp.named_parameters():
         want = refs[0][n1].grad + refs[1][n1].grad
         report[n1] = (l2rel(p1.grad, want), yard.get(n1))
-        assert_grad_close(p1.grad, want, n1, l2tol=max(tol, 2 * yard.get(n1, 0.0)), maxtol=1e-2 if train else 2e-2)
+        assert_grad_close(p1.grad, want, n1, l2tol=max(tol, 3 * yard.get(n1, 0.0)), maxtol=1e-2 if train else 2e-2)
     for si, (sg, l64) in enumerate(zip(segs, refs)):
         for nm, a in zip(("xyz", "new_xyz", "feats"), sg):
             if a is not None and a.requires_grad:
                 key = "%d.%s" % (si, nm)
                 report[key] = (l2rel(a.grad, l64[nm].grad), yard.get(key))
-                assert_grad_close(a.grad, l64[nm].grad, nm, l2tol=max(tol, 2 * yard.get(key, 0.0)),
+                assert_grad_close(a.grad, l64[nm].grad, nm, l2tol=max(tol, 3 * yard.get(key, 0.0)),
                                   maxtol=1e-2 if train else 4e-2)
     if full:
         print("B=%d %s gradient L2 error vs fp64 (fused, torch fp32):" % (B, kind),

@@ -149,3 +149,49 @@ def test_flat_chain_falls_back_when_unaligned():
     x = torch.randn(3, 256, 30, device="cuda")
     assert not fused_heads.chain_supported([x], seq._flat_units())
     assert nn_blocks.seq_apply(seq, [x]).shape == (3, 5, 30)
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("B,M,N", [(2, 32, 64), (4, 64, 128)])
+def test_p2b_xcorr_fused_vs_fp64(train, B, M, N):
+    """P2B_XCorr (models/head/xcorr.py:25-53) on the split layer-0 kernels of csrc/xcorr.hip against the module's
+    own torch formulation (the materialised (B,4+f,M,N) fusion tensor) evaluated in fp64"""
+    from open3dsot_amd import fused_xcorr, sa_modules, xcorr
+    torch.manual_seed(2)
+    mod = xcorr.P2B_XCorr(256, 256, 256).cuda().train(train)
+    g = torch.Generator().manual_seed(4)
+    with torch.no_grad():
+        for m in mod.modules():
+            if isinstance(m, (torch.nn.BatchNorm1d, torch.nn.BatchNorm2d)):
+                m.weight.copy_(torch.empty(m.weight.shape).uniform_(0.5, 1.5, generator=g))
+                m.bias.copy_(torch.empty(m.bias.shape).normal_(0, 0.2, generator=g))
+                m.running_mean.copy_(torch.empty(m.bias.shape).normal_(0, 0.2, generator=g))
+                m.running_var.copy_(torch.empty(m.bias.shape).uniform_(0.5, 1.5, generator=g))
+    ref = copy.deepcopy(mod).double()
+    gg = torch.Generator(device="cuda").manual_seed(6)
+    t_feat = torch.randn(B, 256, M, device="cuda", generator=gg).requires_grad_(True)
+    s_feat = torch.randn(B, 256, N, device="cuda", generator=gg).requires_grad_(True)
+    t_xyz = torch.randn(B, M, 3, device="cuda", generator=gg).requires_grad_(True)
+    leaves = (t_feat, s_feat, t_xyz)
+    leaves64 = [t.detach().double().requires_grad_(True) for t in leaves]
+    assert fused_xcorr.supported(mod.mlp, t_feat, s_feat)
+    out = mod(*leaves)
+    sa_modules.set_fused(False)
+    try:
+        want = ref(*leaves64)
+    finally:
+        sa_modules.set_fused(True)
+    assert rel(out, want) < 5e-5, rel(out, want)
+    ct = torch.randn(out.shape, device="cuda", generator=gg)
+    (out * ct).sum().backward()
+    (want * ct.double()).sum().backward()
+    tol = 5e-4 if train else 3e-3        # eval: no normalisation damps a max-pool routing flip
+    for a, b in zip(leaves, leaves64):
+        assert l2rel(a.grad, b.grad) < tol and rel(a.grad, b.grad) < 2e-2, (l2rel(a.grad, b.grad), rel(a.grad, b.grad))
+    for (n1, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None and p.grad.shape == p.shape, n1
+        assert l2rel(p.grad, q.grad) < tol and rel(p.grad, q.grad) < 2e-2, (n1, l2rel(p.grad, q.grad), rel(p.grad, q.grad))
+    if train:
+        for (n1, b1), (_, b2) in zip(mod.named_buffers(), ref.named_buffers()):
+            if b1.dtype.is_floating_point:
+                assert rel(b1, b2) < 1e-5, n1

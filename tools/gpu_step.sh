@@ -6,7 +6,7 @@ OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 if [ -n "$KEXPR" ]; then
-  timeout 1200 python -m pytest tests -m gpu -q --timeout=900 -p no:cacheprovider -x -k "$KEXPR" > $OUT/pytest.log 2>&1
+  timeout 1200 python -m pytest tests -m gpu -q --timeout=900 -p no:cacheprovider -k "$KEXPR" > $OUT/pytest.log 2>&1
 else
   timeout 1500 python -m pytest tests -m gpu -q --timeout=900 -p no:cacheprovider > $OUT/pytest.log 2>&1
 fi
