@@ -298,6 +298,12 @@ int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t* argq, con
                    const float* mean, int B, int C, int npoint0, int npoint1, const int32_t* meta, long start1,
                    long ldp, float* D, float* part, void* stream);
 
+/* The same with the column -> ball map of the compact layout (cball, from o3d_compact_build): the dense gradient D
+ * is written in ONE pass over the live columns instead of a zero fill followed by a scatter. */
+int o3d_pool_bwd_cb(const float* dOut, const float* out, const int32_t* argq, const float* yarg, const float* mean,
+                    const int32_t* cball, int B, int C, int npoint0, int npoint1, const int32_t* meta, long start1,
+                    long ldp, float* D, float* part, void* stream);
+
 /* The same sums as o3d_group_reduce_c without float atomics: the cloud's columns are sorted by (column chunk,
  * point) once per call (perm: ldp ints; poff: o3d_group_reduce_gather_scratch(...) ints, -1 = shape not covered,
  * use o3d_group_reduce_c) and every sum is a gather from an LDS-staged chunk in a fixed order (bitwise

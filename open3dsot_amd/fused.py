@@ -57,6 +57,7 @@ capi.register("o3d_pack_points", [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i
 capi.register("o3d_center_term", [_vp, _vp, _i, _i, _i, _vp, _vp])
 capi.register("o3d_pool_fwd_c", [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_bwd_c", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _l, _vp, _vp, _vp])
+capi.register("o3d_pool_bwd_cb", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _l, _vp, _vp, _vp])
 capi.register("o3d_group_reduce_c", [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp,
                                      _vp, _vp])
 capi.register("o3d_direct_tile", [ctypes.c_long, _i, _i])
@@ -610,9 +611,9 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         part = torch.empty((nseg, POOL_BWD_SPLIT, 2, Cl), device=dev, dtype=f32)
         dN = torch.empty((Cl, ldp), device=dev, dtype=f32)          # dense class-sum gradient of the pooled layer
         np1 = npoints[1] if nseg == 2 else 0
-        _call("pool_bwd", 0.0, lib.o3d_pool_bwd_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
-              means[-1].data_ptr(), B, Cl, npoints[0], np1, meta.data_ptr(), start1, ldp, dN.data_ptr(), part.data_ptr(),
-              st)
+        _call("pool_bwd", 0.0, lib.o3d_pool_bwd_cb, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
+              means[-1].data_ptr(), cball.data_ptr(), B, Cl, npoints[0], np1, meta.data_ptr(), start1, ldp, dN.data_ptr(),
+              part.data_ptr(), st)
         dtile = 0
         main, side = torch.cuda.current_stream(), _side_stream(dev)
         keep = []        # buffers the side stream still reads: must outlive the join at the end

@@ -109,12 +109,25 @@ def test_flat_chain_vs_fp64(name, train, B, N):
     ct = torch.randn(out.shape, device="cuda", generator=g)
     (out * ct).sum().backward()
     (ref_out * ct.double()).sum().backward()
+    # ReLU masks are discrete: a pre-activation within fp32 rounding of zero (|z| < ~3e-7: about one in 3e6
+    # activations, i.e. ~0.5 per 256-channel layer at 6144 columns) is routed differently than in fp64, which changes
+    # that ONE column's gradient by O(1) and every parameter gradient by ~1/sqrt(columns) (measured on the MI355X,
+    # profiles/r02_relu_flip_diag.txt: one such column at (48,128), none at (4,64); everything else agrees to 5e-7).
+    # So at the large size: inputs must agree to 1e-3 of the rms on all but 0.1 % of the elements, parameters to
+    # 3e-3 L2; at the small size the tight bounds apply.
+    big = B * N > 1024
     for a, b in zip(parts, parts64):
-        assert l2rel(a.grad, b.grad) < 5e-4 and rel(a.grad, b.grad) < 1e-2, ("input", l2rel(a.grad, b.grad))
+        if big:
+            err = (a.grad.double() - b.grad).abs()
+            assert float((err > 1e-3 * b.grad.pow(2).mean().sqrt()).double().mean()) < 1e-3, "input"
+            assert float(err.median() / b.grad.abs().max()) < 1e-5, "input (median)"
+        else:
+            assert l2rel(a.grad, b.grad) < 5e-4 and rel(a.grad, b.grad) < 1e-2, ("input", l2rel(a.grad, b.grad))
     for (n1, p), (_, q) in zip(seq.named_parameters(), ref.named_parameters()):
         assert p.grad is not None, n1
         assert p.grad.shape == p.shape
-        assert l2rel(p.grad, q.grad) < 5e-4 and rel(p.grad, q.grad) < 1e-2, (n1, l2rel(p.grad, q.grad), rel(p.grad, q.grad))
+        assert l2rel(p.grad, q.grad) < (3e-3 if big else 5e-4) and rel(p.grad, q.grad) < (3e-2 if big else 1e-2), \
+            (n1, l2rel(p.grad, q.grad), rel(p.grad, q.grad))
     if train:
         for (n1, b1), (_, b2) in zip(seq.named_buffers(), ref.named_buffers()):
             if b1.dtype.is_floating_point:
@@ -154,8 +167,9 @@ def test_flat_chain_falls_back_when_unaligned():
 @pytest.mark.parametrize("train", [True, False])
 @pytest.mark.parametrize("B,M,N", [(2, 32, 64), (4, 64, 128)])
 def test_p2b_xcorr_fused_vs_fp64(train, B, M, N):
-    """P2B_XCorr (models/head/xcorr.py:25-53) on the split layer-0 kernels of csrc/xcorr.hip against the module's
-    own torch formulation (the materialised (B,4+f,M,N) fusion tensor) evaluated in fp64"""
+    """P2B_XCorr's SharedMLP + max over the template axis (models/head/xcorr.py:37-49) on the split layer-0 kernels of
+    csrc/xcorr.hip against the reference formulation -- the materialised (B,4+f,M,N) fusion tensor through the same
+    SharedMLP module -- evaluated in fp64; then the whole module (fea_layer behind it) in forward."""
     from open3dsot_amd import fused_xcorr, sa_modules, xcorr
     torch.manual_seed(2)
     mod = xcorr.P2B_XCorr(256, 256, 256).cuda().train(train)
@@ -173,25 +187,35 @@ def test_p2b_xcorr_fused_vs_fp64(train, B, M, N):
     s_feat = torch.randn(B, 256, N, device="cuda", generator=gg).requires_grad_(True)
     t_xyz = torch.randn(B, M, 3, device="cuda", generator=gg).requires_grad_(True)
     leaves = (t_feat, s_feat, t_xyz)
-    leaves64 = [t.detach().double().requires_grad_(True) for t in leaves]
+    tf, sf, tx = [t.detach().double().requires_grad_(True) for t in leaves]
     assert fused_xcorr.supported(mod.mlp, t_feat, s_feat)
-    out = mod(*leaves)
-    sa_modules.set_fused(False)
-    try:
-        want = ref(*leaves64)
-    finally:
-        sa_modules.set_fused(True)
-    assert rel(out, want) < 5e-5, rel(out, want)
+    out = fused_xcorr.p2b_xcorr_mlp_pool(mod.mlp, t_feat, s_feat, t_xyz)
+    sim = torch.nn.functional.cosine_similarity(tf.unsqueeze(-1).expand(B, 256, M, N),
+                                                sf.unsqueeze(2).expand(B, 256, M, N), dim=1)          # xcorr.py:37-38
+    x = torch.cat((sim.unsqueeze(1), tx.transpose(1, 2).unsqueeze(-1).expand(B, 3, M, N),
+                   tf.unsqueeze(-1).expand(B, 256, M, N)), dim=1)                                      # :40-45
+    want = ref.mlp(x).max(dim=2)[0]                                                                    # :47-49
+    assert out.shape == want.shape
+    assert rel(out, want) < 2e-5, rel(out, want)
     ct = torch.randn(out.shape, device="cuda", generator=gg)
     (out * ct).sum().backward()
     (want * ct.double()).sum().backward()
     tol = 5e-4 if train else 3e-3        # eval: no normalisation damps a max-pool routing flip
-    for a, b in zip(leaves, leaves64):
+    for a, b in zip(leaves, (tf, sf, tx)):
         assert l2rel(a.grad, b.grad) < tol and rel(a.grad, b.grad) < 2e-2, (l2rel(a.grad, b.grad), rel(a.grad, b.grad))
-    for (n1, p), (_, q) in zip(mod.named_parameters(), ref.named_parameters()):
+    for (n1, p), (_, q) in zip(mod.mlp.named_parameters(), ref.mlp.named_parameters()):
         assert p.grad is not None and p.grad.shape == p.shape, n1
         assert l2rel(p.grad, q.grad) < tol and rel(p.grad, q.grad) < 2e-2, (n1, l2rel(p.grad, q.grad), rel(p.grad, q.grad))
     if train:
-        for (n1, b1), (_, b2) in zip(mod.named_buffers(), ref.named_buffers()):
+        for (n1, b1), (_, b2) in zip(mod.mlp.named_buffers(), ref.mlp.named_buffers()):
             if b1.dtype.is_floating_point:
                 assert rel(b1, b2) < 1e-5, n1
+    # the whole module: fused stage + fea_layer (its BatchNorm over only B*N columns amplifies rounding: 5e-4)
+    mod2 = copy.deepcopy(ref).float().train(train)
+    sa_modules.set_fused(False)
+    try:
+        whole = ref(tf.detach(), sf.detach(), tx.detach())
+    finally:
+        sa_modules.set_fused(True)
+    got = mod2(t_feat.detach(), s_feat.detach(), t_xyz.detach())
+    assert rel(got, whole) < 5e-4, rel(got, whole)
