@@ -393,6 +393,12 @@ int o3d_row_sum(const float* G, int C, long P, float* out, void* stream);
 
 int o3d_pw_tile(long P);
 
+/* Eval-mode BatchNorm constants in one launch: vec (4, nrep, C) = {mean, invstd, scale, shift} with
+ * invstd = 1/sqrt(running_var + eps), scale = gamma*invstd, shift = beta - mean*scale (pytorch_utils.py:56-59 in
+ * eval mode); conv_bias (C) or NULL is a bias of the convolution in front, folded into the mean. */
+int o3d_bn_eval_consts(const float* running_mean, const float* running_var, const float* gamma, const float* beta,
+                       const float* conv_bias, float eps, int C, int nrep, float* vec, void* stream);
+
 /* Y (Cout, P) = W (Cout, Cin) . f(X),  f = relu(x*in_scale + in_shift) per input row, or identity (both NULL).
  * part != NULL: BatchNorm statistics partials [P/tile][2][Cout] = {sum y, sum (y - stat_c)^2};
  * part == NULL: Y += bias[row] + resid (Cout, P), either may be NULL (last layer of a stack; the residual is the

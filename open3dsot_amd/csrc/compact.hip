@@ -506,19 +506,12 @@ __global__ __launch_bounds__(1024) void csr_build_kernel(const int32_t* __restri
     int32_t* po = poff + (long)cloud * poff_stride;
     for (int i = threadIdx.x; i <= nbin; i += 1024) po[i] = cnt[i];
     __syncthreads();
-    for (int q = q0 + threadIdx.x; q < q1; q += 1024) {      // fill; the order inside a list is restored below
-        const int k = atomicAdd(&cnt[((q - q0a) / RG_CH) * ld + (gp[q] - pbase)], 1);
-        perm[q0 + k] = q;
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < nbin; i += 1024) {         // insertion sort of each (short) list
-        const int s0 = po[i], e = po[i + 1];
-        for (int a = s0 + 1; a < e; ++a) {
-            const int v = perm[q0 + a];
-            int t = a - 1;
-            while (t >= s0 && perm[q0 + t] > v) { perm[q0 + t + 1] = perm[q0 + t]; --t; }
-            perm[q0 + t + 1] = v;
-        }
+    // fill: entry = (point << 16) | (column - chunk start); the order inside a list is whatever the LDS atomics
+    // hand out (all entries of a list belong to the same point, so only the summation order depends on it)
+    for (int q = q0 + threadIdx.x; q < q1; q += 1024) {
+        const int ch = (q - q0a) / RG_CH, n = gp[q] - pbase;
+        const int k = atomicAdd(&cnt[ch * ld + n], 1);
+        perm[q0 + k] = (n << 16) | (q - q0a - ch * RG_CH);
     }
 }
 
@@ -532,7 +525,7 @@ __global__ __launch_bounds__(256) void reduce_gather_kernel(const float* __restr
                                                             const int32_t* __restrict__ poff, int poff_stride, int B,
                                                             SegParams sp0, SegParams sp1, int C0, long lds_row,
                                                             float* __restrict__ S, float* __restrict__ T, int nballs) {
-    extern __shared__ float rg_sm[];        // dy[CS][CH], sacc[CS][ld], tacc[CS][npoint], offs[ld+1] ints, list[CH] u16
+    extern __shared__ float rg_sm[];        // dy[CS][CH], sacc[CS][ld], tacc[CS][npoint], list[CH] packed (point, column)
     constexpr int CS = RG_CS, CH = RG_CH;
     const int slabs = (C0 + CS - 1) / CS;
     const int cloud = blockIdx.x / slabs, c0 = (blockIdx.x - cloud * slabs) * CS;
@@ -543,8 +536,7 @@ __global__ __launch_bounds__(256) void reduce_gather_kernel(const float* __restr
     float* dy = rg_sm;
     float* sacc = dy + CS * CH;
     float* tacc = sacc + CS * ld;
-    int* offs = reinterpret_cast<int*>(tacc + CS * npoint);
-    uint16_t* lst = reinterpret_cast<uint16_t*>(offs + ld + 1);
+    int* lst = reinterpret_cast<int*>(tacc + CS * npoint);
     const int q0 = ball_off[bbase], q1 = ball_off[bbase + npoint - 1] + ball_cnt[bbase + npoint - 1];
     const int q0a = q0 & ~3;
     const int32_t* po = poff + (long)cloud * poff_stride;
@@ -576,21 +568,38 @@ __global__ __launch_bounds__(256) void reduce_gather_kernel(const float* __restr
                 *reinterpret_cast<float4*>(&dy[c * CH + i]) = o;
             }
         }
-        const int l0 = po[k * ld], l1 = po[(k + 1) * ld];         // this chunk's slice of perm
-        for (int i = threadIdx.x; i < l1 - l0; i += 256) lst[i] = (uint16_t)(perm[q0 + l0 + i] - lo);
-        for (int i = threadIdx.x; i <= ld; i += 256) offs[i] = po[k * ld + i] - l0;
+        const int l0 = po[k * ld], l1 = po[(k + 1) * ld];         // this chunk's slice of perm (sorted by point)
+        const int cnt = l1 - l0;
+        for (int i = threadIdx.x; i < cnt; i += 256) lst[i] = perm[q0 + l0 + i];
         __syncthreads();
-        for (int n = threadIdx.x; n < ld; n += 256) {             // phase B: thread n walks its own list
-            float s[CS];
+        // phase B, balanced: every thread takes an equal share of the chunk's entries (a point referenced by hundreds
+        // of balls no longer serialises on one thread) and flushes a run of equal points with one LDS atomic
+        {
+            const int per = (cnt + 255) / 256;
+            const int e0 = threadIdx.x * per, e1 = e0 + per < cnt ? e0 + per : cnt;
+            int cur = -1;
+            float sr[CS];
 #pragma unroll
-            for (int c = 0; c < CS; ++c) s[c] = 0.f;
-            for (int a = offs[n]; a < offs[n + 1]; ++a) {
-                const int i = lst[a];
+            for (int c = 0; c < CS; ++c) sr[c] = 0.f;
+            for (int a = e0; a < e1; ++a) {
+                const int e = lst[a];
+                const int n = e >> 16, i = e & 0xffff;
+                if (n != cur) {
+                    if (cur >= 0) {
 #pragma unroll
-                for (int c = 0; c < CS; ++c) s[c] += dy[c * CH + i];
+                        for (int c = 0; c < CS; ++c) atomicAdd(&sacc[c * ld + cur], sr[c]);
+                    }
+                    cur = n;
+#pragma unroll
+                    for (int c = 0; c < CS; ++c) sr[c] = 0.f;
+                }
+#pragma unroll
+                for (int c = 0; c < CS; ++c) sr[c] += dy[c * CH + i];
             }
+            if (cur >= 0) {
 #pragma unroll
-            for (int c = 0; c < CS; ++c) sacc[c * ld + n] += s[c];
+                for (int c = 0; c < CS; ++c) atomicAdd(&sacc[c * ld + cur], sr[c]);
+            }
         }
         if (T)
             for (int j = threadIdx.x; j < npoint; j += 256) {     // thread j: its ball's part of the chunk
@@ -874,7 +883,7 @@ extern "C" long o3d_group_reduce_gather_scratch(int B, int nseg, int npoint0, in
     const int ldm = nseg == 2 && ld1 > ld0 ? ld1 : ld0, npm = nseg == 2 && npoint1 > npoint0 ? npoint1 : npoint0;
     const long nbin = (long)rg_nchunk(spanmax) * ldm;
     const size_t lds_csr = ((size_t)nbin + 1 + 1024) * 4;
-    const size_t lds_red = ((size_t)RG_CS * RG_CH + (size_t)RG_CS * (ldm + npm)) * 4 + ((size_t)ldm + 1) * 4 + (size_t)RG_CH * 2 + 8;
+    const size_t lds_red = ((size_t)RG_CS * RG_CH + (size_t)RG_CS * (ldm + npm)) * 4 + (size_t)RG_CH * 4 + 8;
     if (lds_csr > 128 * 1024 || lds_red > 64 * 1024) return -1;
     return (long)B * nseg * (nbin + 1);
 }
@@ -896,7 +905,7 @@ extern "C" int o3d_group_reduce_gather(const float* dN, const float* Y0, long ld
     const int nchunk = rg_nchunk(spanmax);
     const int stride = nchunk * ldm + 1;
     const size_t lds_csr = ((size_t)nchunk * ldm + 1 + 1024) * 4;
-    const size_t lds_red = ((size_t)RG_CS * RG_CH + (size_t)RG_CS * (ldm + npm)) * 4 + ((size_t)ldm + 1) * 4 + (size_t)RG_CH * 2 + 8;
+    const size_t lds_red = ((size_t)RG_CS * RG_CH + (size_t)RG_CS * (ldm + npm)) * 4 + (size_t)RG_CH * 4 + 8;
     if (lds_csr > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(csr_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_csr) != hipSuccess)

@@ -70,7 +70,40 @@ __global__ __launch_bounds__(256) void row_sum_kernel(const float* __restrict__ 
     if (threadIdx.x == 0) out[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
 }
 
+// eval-mode BatchNorm as the four per-channel vectors the fused kernels consume (one launch instead of four
+// elementwise torch launches per layer): mean = running_mean - bias_shift, invstd, scale = gamma*invstd,
+// shift = beta - mean*scale
+__global__ __launch_bounds__(256) void bn_eval_consts_kernel(const float* __restrict__ rm, const float* __restrict__ rv,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ conv_bias, float eps, int C,
+                                                             int nrep, float* __restrict__ vec) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float mu = rm[c] - (conv_bias ? conv_bias[c] : 0.f);
+    const float is = 1.0f / sqrtf(rv[c] + eps);
+    const float sc = gamma[c] * is, sh = beta[c] - mu * sc;
+    for (int r = 0; r < nrep; ++r) {            // vec laid out (4, nrep, C): one copy per segment
+        vec[((long)0 * nrep + r) * C + c] = mu;
+        vec[((long)1 * nrep + r) * C + c] = is;
+        vec[((long)2 * nrep + r) * C + c] = sc;
+        vec[((long)3 * nrep + r) * C + c] = sh;
+    }
+}
+
 }  // namespace
+
+// vec (4, nrep, C) = {mean, invstd, scale, shift} of an eval-mode BatchNorm (F.batch_norm with training=False,
+// pytorch_utils.py:56-59): invstd = 1/sqrt(running_var + eps).  conv_bias (C) or NULL: a bias of the convolution in
+// front, folded into the mean.
+extern "C" int o3d_bn_eval_consts(const float* running_mean, const float* running_var, const float* gamma,
+                                  const float* beta, const float* conv_bias, float eps, int C, int nrep, float* vec,
+                                  void* stream) {
+    if (!running_mean || !running_var || !gamma || !beta || !vec || C <= 0 || nrep <= 0) return O3D_EINVAL;
+    hipLaunchKernelGGL(bn_eval_consts_kernel, dim3(o3d_cdiv(C, 256)), dim3(256), 0, o3d_stream(stream), running_mean,
+                       running_var, gamma, beta, conv_bias, eps, C, nrep, vec);
+    return o3d_launch_status();
+}
 
 // X (rows, B*N): rows [0, sum C_i) = the sources stacked in order, element (b, c, n) of source i read at
 // p + b*sb + c*sc + n*sn (strides in floats); remaining rows zero.  srcs is a HOST array of nsrc <= 4 entries.

@@ -14,7 +14,7 @@ import ctypes
 import torch
 
 from . import capi
-from .fused import _call, _const_vec, _layers, _ptr, _stream, POOL_BWD_SPLIT
+from .fused import _call, _const_vec, _layers, _ptr, _stream
 from .fused_heads import _up, pack_rows, prep_for
 
 _vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
@@ -119,18 +119,21 @@ class FusedP2BXCorr(torch.autograd.Function):
         if cfg.training:
             torch._foreach_add_([bn.num_batches_tracked for bn in cfg.bns], 1)
         Cl = Ws[-1].shape[0]
-        out = torch.empty((B, Cl, N), device=dev, dtype=f32)
-        argq = torch.empty((B, Cl, N), device=dev, dtype=torch.int32) if need_bwd else None
-        yarg = torch.empty((B, Cl, N), device=dev, dtype=f32) if need_bwd else None
-        _call("pool_fwd", 0.0, lib.o3d_pool_fwd_c, Ys[-1].data_ptr(), P, vecs[-1][2].data_ptr(), vecs[-1][3].data_ptr(),
-              ball_off.data_ptr(), ball_cnt.data_ptr(), B, Cl, N, 0, out.data_ptr(), _ptr(argq), _ptr(yarg), st)
+        # max over the template axis = over the M contiguous columns of a ball: the regular (slot) pooling kernel on the
+        # flat layout (one "cloud" of B*N balls); the pooled tensor comes out flat (Cl, B*N), the layout the
+        # fea_layer stack consumes without a pack launch
+        out = torch.empty((Cl, B * N), device=dev, dtype=f32)
+        argq = torch.empty((Cl, B * N), device=dev, dtype=torch.int32) if need_bwd else None
+        yarg = torch.empty((Cl, B * N), device=dev, dtype=f32) if need_bwd else None
+        _call("pool_fwd", 0.0, lib.o3d_bn_relu_maxpool_fwd, Ys[-1].data_ptr(), vecs[-1][2].data_ptr(), vecs[-1][3].data_ptr(),
+              1, Cl, B * N, M, out.data_ptr(), _ptr(argq), _ptr(yarg), st)
         if need_bwd:
             ctx.cfg = cfg
             ctx.geom = (B, N, M, f, K0, K0p, tile)
             ctx.versions = [(p, p._version) for p in params]
             W0t = prep.get(params[0], K0p, C0, transpose=True)
             ctx.saved = (X0, simf, Ys, vecs, Ws, Wts, W0t, gammas, meta, out.detach(), argq, yarg)
-        return out
+        return out.view(Cl, B, N).permute(1, 0, 2)
 
     @staticmethod
     @capi.on_tensor_device
@@ -147,12 +150,16 @@ class FusedP2BXCorr(torch.autograd.Function):
         dev, f32 = dOut.device, torch.float32
         st = _stream()
         Cl = Ws[-1].shape[0]
-        dOut = dOut.contiguous()
-        part = torch.empty((1, POOL_BWD_SPLIT, 2, Cl), device=dev, dtype=f32)
-        dN = torch.empty((Cl, P), device=dev, dtype=f32)
-        _call("pool_bwd", 0.0, lib.o3d_pool_bwd_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
-              vecs[-1][0].data_ptr(), B, Cl, N, 0, meta.data_ptr(), 0, P, dN.data_ptr(), part.data_ptr(), st)
-        nparts = POOL_BWD_SPLIT
+        g = dOut.permute(1, 0, 2)
+        g = g.reshape(Cl, B * N) if g.is_contiguous() else g.contiguous().view(Cl, B * N)
+        # the dense (Cl, P) gradient of the pooled layer (one non-zero per ball and channel) is never written: the last
+        # layer's data / weight gradient kernels read the packed {masked gradient, arg-max slot} pairs
+        part = torch.empty((1, 2, Cl), device=dev, dtype=f32)
+        pk = torch.empty((Cl, B * N, 2), device=dev, dtype=f32)
+        _call("pool_bwd", 0.0, lib.o3d_pool_bwd_partials, g.data_ptr(), out.data_ptr(), yarg.data_ptr(),
+              vecs[-1][0].data_ptr(), 1, Cl, B * N, part.data_ptr(), argq.data_ptr(), pk.data_ptr(), st)
+        nparts = 1
+        dN = None
         grads = [None] * (3 * L)
         dsim = dxyz = dfeat = None
         for l in range(L - 1, -1, -1):
@@ -196,17 +203,25 @@ class FusedP2BXCorr(torch.autograd.Function):
                 continue
             dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
             scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, P),), device=dev, dtype=f32)
-            _call("conv_wgrad", 2.0 * Cin * Cout * P, lib.o3d_mlp_conv_wgrad2, dN.data_ptr(), None, 4, Ys[l].data_ptr(), A[0], A[1],
-                  A[2], Ys[l - 1].data_ptr(), vecs[l - 1][2].data_ptr(), vecs[l - 1][3].data_ptr(), 1, Cin, Cout, P,
-                  scratch.data_ptr(), dW.data_ptr(), st)
+            _call("conv_wgrad", 2.0 * Cin * Cout * P, lib.o3d_mlp_conv_wgrad2, _ptr(dN), pk.data_ptr() if dN is None else None,
+                  M if dN is None else 4, Ys[l].data_ptr(), A[0], A[1], A[2], Ys[l - 1].data_ptr(), vecs[l - 1][2].data_ptr(),
+                  vecs[l - 1][3].data_ptr(), 1, Cin, Cout, P, scratch.data_ptr(), dW.data_ptr(), st)
             grads[3 * l] = dW
             dNp = torch.empty((Cin, P), device=dev, dtype=f32)
-            part = torch.empty((P // tile, 2, Cin), device=dev, dtype=f32)
             vp = vecs[l - 1]
-            _call("conv_dgrad", 2.0 * Cin * Cout * P, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
-                  Wts[l - 1].data_ptr(), Cin, Cout, P, Ys[l - 1].data_ptr(), vp[2].data_ptr(), vp[3].data_ptr(), vp[0].data_ptr(),
-                  None, dNp.data_ptr(), part.data_ptr(), st)
-            nparts = P // tile
+            if dN is None:         # pooled source: 128-column tiles (one statistics partial row each)
+                part = torch.empty((P // 128, 2, Cin), device=dev, dtype=f32)
+                _call("conv_dgrad", 2.0 * Cin * Cout * P, lib.o3d_mlp_conv_dgrad_wt, None, g.data_ptr(), out.data_ptr(),
+                      argq.data_ptr(), M, Ys[l].data_ptr(), A[0], A[1], A[2], Ws[l].data_ptr(), Wts[l - 1].data_ptr(),
+                      pk.data_ptr(), 1, Cin, Cout, P, Ys[l - 1].data_ptr(), vp[2].data_ptr(), vp[3].data_ptr(), vp[0].data_ptr(),
+                      dNp.data_ptr(), part.data_ptr(), st)
+                nparts = P // 128
+            else:
+                part = torch.empty((P // tile, 2, Cin), device=dev, dtype=f32)
+                _call("conv_dgrad", 2.0 * Cin * Cout * P, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
+                      Wts[l - 1].data_ptr(), Cin, Cout, P, Ys[l - 1].data_ptr(), vp[2].data_ptr(), vp[3].data_ptr(),
+                      vp[0].data_ptr(), None, dNp.data_ptr(), part.data_ptr(), st)
+                nparts = P // tile
             dN = dNp
         gw = []
         for l in range(L):
