@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--pool", type=int, default=4, help="distinct resident synthetic batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of host time the CPU baseline may take")
+    ap.add_argument("--infer", action="store_true", help="tracking-inference latency instead of the training step: eval-mode "
+                    "forward of one frame (SURVEY.md section 8f-4, models/base_model.py:59-86), one HIP graph replay per frame")
+    ap.add_argument("--infer-batch", type=int, default=1, help="frames per forward in --infer mode (the reference tracks at 1)")
     ap.add_argument("--dense", action="store_true", help="worst-case clouds: every ball full of distinct neighbours "
                     "(live_fraction 1.0) instead of the KITTI-like crops")
     ap.add_argument("--composed", action="store_true", help="disable the fused kernels (debug A/B only)")
@@ -167,7 +170,75 @@ def main():
     run(args)
 
 
+def run_infer(args):
+    """`--infer`: eval-mode forward latency of one tracked frame.  The reference's per-frame loop (models/base_model.py:
+    59-86) is strictly sequential (frame t's search region depends on frame t-1's box), so the figure of merit is the
+    latency of ONE batch-1 forward: BatchNorm on running statistics, no autograd, the whole forward (FPS, ball queries,
+    fused MLPs, xcorr, heads) replayed as one HIP graph.  Inputs resident in HBM; `steps` frames are timed."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library is the only compute path (no CPU fallback)")
+    from open3dsot_amd import capi
+    capi.load()
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1234)
+    model = trackers.get_model(args.model if args.model != "M2TRACK" else "BAT")().to(dev).eval()
+    B = args.infer_batch
+    frames = [synth.to_torch(synth.make_batch(100 + i * B, B), dev) for i in range(max(2, args.pool))]
+
+    def fwd(b):
+        with torch.no_grad():
+            out = model(b)
+            return out["estimation_boxes"], out["estimation_cla"]
+
+    for i in range(max(args.warmup, 3)):
+        fwd(frames[i % len(frames)])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_eager = min(args.steps, 100)
+    for i in range(n_eager):
+        fwd(frames[i % len(frames)])
+    torch.cuda.synchronize()
+    eager_ms = (time.perf_counter() - t0) / n_eager * 1e3
+    static = {k: v.clone() for k, v in frames[0].items()}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fwd(static)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fwd(static)
+    torch.cuda.synchronize()
+    ref = [t.clone() for t in fwd(frames[1])]
+    for k, v in frames[1].items():
+        static[k].copy_(v)
+    g.replay()
+    torch.cuda.synchronize()
+    same = all(torch.allclose(a, b, rtol=1e-5, atol=1e-6) for a, b in zip(out, ref))
+    for i in range(args.warmup):
+        g.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        for k, v in frames[i % len(frames)].items():
+            static[k].copy_(v, non_blocking=True)
+        g.replay()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    print(json.dumps({
+        "metric": "tracked frames/sec (eval forward, %s KITTI-Car 512/1024 pts, batch %d)" % (model.__class__.__name__, B),
+        "value": round(B / ms * 1e3, 1), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic KITTI-Car-like pairs (open3dsot_amd/synth.py), random-init weights, BatchNorm on running statistics",
+        "config": {"workload": "%s_Car.yaml tracking inference, template 512 / search 1024 pts, batch %d, eval forward only, "
+                               "fp32" % (model.__class__.__name__, B), "hip_graph": True, "eager_ms_per_frame": round(eager_ms, 4),
+                   "graph_replay_matches_eager": bool(same)}}))
+
+
 def run(args):
+    if args.infer:
+        return run_infer(args)
     rank, local_rank, world = D.init_distributed()
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run "

@@ -151,6 +151,11 @@ int o3d_pool_bwd_partials(const float* dOut, const float* out, const float* yarg
                           int B, int C, int npoint, float* part, const int32_t* arg, float* pk,
                           void* stream);
 
+/* The same for ONE cloud of npoint balls in the flat (C, npoint) layout (the P2B fusion: npoint = B*N), the balls of
+ * a channel split over nsplit workgroups: part [nsplit][2][C]. */
+int o3d_pool_bwd_partials_split(const float* dOut, const float* out, const float* yarg, const float* mean, int C,
+                                int npoint, int nsplit, float* part, const int32_t* arg, float* pk, void* stream);
+
 /* BatchNorm backward from partials {sum dN, sum dN*(Y-mean)}: dgamma, dbeta and the per-channel
  * coefficients of dY = A1*dN + A2*Y + A3. */
 int o3d_bn_bwd_finalize(const float* part, int nparts, int C, double count, const float* gamma,
@@ -298,11 +303,6 @@ int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t* argq, con
                    const float* mean, int B, int C, int npoint0, int npoint1, const int32_t* meta, long start1,
                    long ldp, float* D, float* part, void* stream);
 
-/* The same with the column -> ball map of the compact layout (cball, from o3d_compact_build): the dense gradient D
- * is written in ONE pass over the live columns instead of a zero fill followed by a scatter. */
-int o3d_pool_bwd_cb(const float* dOut, const float* out, const int32_t* argq, const float* yarg, const float* mean,
-                    const int32_t* cball, int B, int C, int npoint0, int npoint1, const int32_t* meta, long start1,
-                    long ldp, float* D, float* part, void* stream);
 
 /* The same sums as o3d_group_reduce_c without float atomics: the cloud's columns are sorted by (column chunk,
  * point) once per call (perm: ldp ints; poff: o3d_group_reduce_gather_scratch(...) ints, -1 = shape not covered,
@@ -375,7 +375,7 @@ int o3d_bn_bwd_finalize_c2(const float* part, int nparts0, int nparts1, int C, d
  * and models/bat.py:22-26 (conv_final, mlp_bc): hidden layers conv -> BatchNorm -> ReLU (BatchNorm + ReLU applied
  * by the consumer on load, statistics partials from the producer), last layer conv + bias.
  * P % 64 == 0; contraction sizes % 16 == 0 and output rows % 64 == 0 (callers zero-pad, see o3d_pack_rows /
- * o3d_prep_weights).  Statistics partial rows are per o3d_pw_tile(P) columns. */
+ * o3d_prep_weights).  Statistics partial rows are per o3d_pw_tile(P, output rows) columns. */
 typedef struct { const float* p; long sb, sc, sn; int C; } o3d_rows_src;
 
 /* X (rows, B*N) <- up to 4 sources of shape (B, C_i, N) with arbitrary strides (in floats) stacked along the rows
@@ -391,7 +391,7 @@ int o3d_prep_weights(const long* jobs, int njobs, void* stream);
 /* out (C) = row sums of G (C, P): bias gradient of a plain Conv1d layer. */
 int o3d_row_sum(const float* G, int C, long P, float* out, void* stream);
 
-int o3d_pw_tile(long P);
+int o3d_pw_tile(long P, int M);
 
 /* Eval-mode BatchNorm constants in one launch: vec (4, nrep, C) = {mean, invstd, scale, shift} with
  * invstd = 1/sqrt(running_var + eps), scale = gamma*invstd, shift = beta - mean*scale (pytorch_utils.py:56-59 in

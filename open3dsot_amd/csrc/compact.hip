@@ -275,41 +275,6 @@ __global__ __launch_bounds__(256) void pool_scatter_c_kernel(const float* __rest
     if (out[o] > 0.f) D[(long)c * ldp + argq[o]] = dOut[o];
 }
 
-// The two kernels above in ONE pass over the live columns: D[c, q] = dOut[c, ball(q)] where q is the ball's arg-max
-// column and out > 0, else 0.  Thread = 4 consecutive columns x PD_CH channels (the column's ball id is read once);
-// the pooled arrays are gathered through L2 (one int per column and channel, the value only at the arg-max).
-constexpr int PD_CH = 8;
-__global__ __launch_bounds__(256) void pool_bwd_dense_kernel(const float* __restrict__ dOut,
-                                                             const float* __restrict__ out,
-                                                             const int32_t* __restrict__ argq,
-                                                             const int32_t* __restrict__ cball, int C, int nballs,
-                                                             int seg1_ball, int np0, int np1,
-                                                             const int32_t* __restrict__ meta, long start1, long ldp,
-                                                             float* __restrict__ D) {
-    const long q = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (q >= ldp) return;
-    const int seg = (start1 > 0 && q >= start1) ? 1 : 0;
-    if (q - (seg ? start1 : 0) >= meta[4 * seg]) return;
-    const int4 b4 = *reinterpret_cast<const int4*>(&cball[q]);
-    const int ball[4] = {b4.x, b4.y, b4.z, b4.w};
-    const int c0 = blockIdx.y * PD_CH;
-#pragma unroll
-    for (int cc = 0; cc < PD_CH; ++cc) {
-        const int c = c0 + cc;
-        if (c >= C) break;
-        float v[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            v[t] = 0.f;
-            if (ball[t] < nballs) {                       // (padding columns carry the dummy ball id)
-                const long o = pool_index(c, ball[t], C, seg1_ball, np0, np1);
-                if (argq[o] == (int)(q + t) && out[o] > 0.f) v[t] = dOut[o];
-            }
-        }
-        *reinterpret_cast<float4*>(&D[(long)c * ldp + q]) = make_float4(v[0], v[1], v[2], v[3]);
-    }
-}
-
 // BatchNorm-backward partials of the pooled layer, POOL_BWD_SPLIT rows per segment:
 // part[seg*SPLIT + k][0][c] = sum g, part[..][1][c] = sum g*(yarg - mean), g = dOut where out > 0, over the
 // k-th share of the segment's balls.  grid (C, nseg, SPLIT).
@@ -770,24 +735,6 @@ extern "C" int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t
     const long total = (long)C * nballs;
     hipLaunchKernelGGL(pool_scatter_c_kernel, dim3(o3d_cdiv(total, 256)), dim3(256), 0, s, dOut, out, argq, C, nballs,
                        seg1_ball, npoint0, np1, total, ldp, D);
-    return o3d_launch_status();
-}
-
-// Same as o3d_pool_bwd_c with the column -> ball map of the compact layout at hand (cball, csrc/compact.hip):
-// the dense gradient is written in one pass instead of a zero fill + a scatter.
-extern "C" int o3d_pool_bwd_cb(const float* dOut, const float* out, const int32_t* argq, const float* yarg,
-                               const float* mean, const int32_t* cball, int B, int C, int npoint0, int npoint1,
-                               const int32_t* meta, long start1, long ldp, float* D, float* part, void* stream) {
-    if (!dOut || !out || !argq || !yarg || !mean || !cball || !meta || !D || !part || B <= 0 || C <= 0 || npoint0 <= 0 ||
-        npoint1 < 0 || ldp <= 0 || ldp % 4 != 0)
-        return O3D_EINVAL;
-    hipStream_t s = o3d_stream(stream);
-    const int nseg = npoint1 > 0 ? 2 : 1;
-    const int seg1_ball = B * npoint0, nballs = B * (npoint0 + npoint1), np1 = npoint1 > 0 ? npoint1 : npoint0;
-    hipLaunchKernelGGL(pool_bwd_partials_c_kernel, dim3(C, nseg, POOL_BWD_SPLIT), dim3(256), 0, s, dOut, out, yarg, mean, C, nballs,
-                       seg1_ball, npoint0, np1, part);
-    hipLaunchKernelGGL(pool_bwd_dense_kernel, dim3((unsigned)o3d_cdiv(ldp, 1024), o3d_cdiv(C, PD_CH)), dim3(256), 0, s, dOut,
-                       out, argq, cball, C, nballs, seg1_ball, npoint0, np1, meta, start1, ldp, D);
     return o3d_launch_status();
 }
 

@@ -440,6 +440,38 @@ __global__ __launch_bounds__(256) void pool_bwd_partials_kernel(const float* __r
     }
 }
 
+// The same for ONE cloud of many balls (the flat (C, npoint) layout of the P2B fusion: npoint = B*N balls): a channel's
+// balls are split over gridDim.y workgroups, part [gridDim.y][2][C].
+__global__ __launch_bounds__(256) void pool_bwd_partials_split_kernel(const float* __restrict__ dOut,
+                                                                      const float* __restrict__ out,
+                                                                      const float* __restrict__ yarg,
+                                                                      const float* __restrict__ mean, int C, int npoint,
+                                                                      float* __restrict__ part,
+                                                                      const int32_t* __restrict__ arg,
+                                                                      float2* __restrict__ pk) {
+    __shared__ float sh[2][4];
+    const int c = blockIdx.x, k = blockIdx.y;
+    const int share = (npoint + gridDim.y - 1) / gridDim.y;
+    const int j0 = k * share, j1 = min(j0 + share, npoint);
+    const float mu = mean[c];
+    float s = 0.f, q = 0.f;
+    for (int j = j0 + threadIdx.x; j < j1; j += 256) {
+        const long i = (long)c * npoint + j;
+        const float g = out[i] > 0.f ? dOut[i] : 0.f;
+        if (pk) pk[i] = make_float2(g, __int_as_float(arg[i]));
+        s += g;
+        q += g * (yarg[i] - mu);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { s += __shfl_xor(s, off, 64); q += __shfl_xor(q, off, 64); }
+    if ((threadIdx.x & 63) == 0) { sh[0][threadIdx.x >> 6] = s; sh[1][threadIdx.x >> 6] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        part[((long)k * 2 + 0) * C + c] = (sh[0][0] + sh[0][1]) + (sh[0][2] + sh[0][3]);
+        part[((long)k * 2 + 1) * C + c] = (sh[1][0] + sh[1][1]) + (sh[1][2] + sh[1][3]);
+    }
+}
+
 // BatchNorm backward finalize: partials {sum dN, sum dN*(Y-mean)} -> dgamma, dbeta and the
 // coefficients of dY = A1*dN + A2*Y + A3 (per channel).
 struct BnBwdFinArgs {
@@ -1126,6 +1158,17 @@ extern "C" int o3d_pool_bwd_partials(const float* dOut, const float* out, const 
     hipLaunchKernelGGL(pool_bwd_partials_kernel, dim3(o3d_cdiv((long)B * C, 4)), dim3(256), 0,
                        o3d_stream(stream), dOut, out, yarg, mean, B, C, npoint, part, arg,
                        reinterpret_cast<float2*>(pk));
+    return o3d_launch_status();
+}
+
+// one cloud of npoint balls (flat (C, npoint) pooled tensors): part [nsplit][2][C], pk (C, npoint, 2) or NULL
+extern "C" int o3d_pool_bwd_partials_split(const float* dOut, const float* out, const float* yarg, const float* mean,
+                                           int C, int npoint, int nsplit, float* part, const int32_t* arg, float* pk,
+                                           void* stream) {
+    if (C <= 0 || npoint <= 0 || nsplit <= 0 || nsplit > 64 || !dOut || !out || !yarg || !mean || !part || (pk && !arg))
+        return O3D_EINVAL;
+    hipLaunchKernelGGL(pool_bwd_partials_split_kernel, dim3(C, nsplit), dim3(256), 0, o3d_stream(stream), dOut, out, yarg,
+                       mean, C, npoint, part, arg, reinterpret_cast<float2*>(pk));
     return o3d_launch_status();
 }
 

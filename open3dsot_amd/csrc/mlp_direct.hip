@@ -34,15 +34,18 @@ __device__ __forceinline__ void ldv(float (&d)[NT], const float* p) {
     if constexpr (NT == 4) {
         const float4 t = *reinterpret_cast<const float4*>(p);
         d[0] = t.x; d[1] = t.y; d[2] = t.z; d[3] = t.w;
-    } else {
+    } else if constexpr (NT == 2) {
         const float2 t = *reinterpret_cast<const float2*>(p);
         d[0] = t.x; d[1] = t.y;
+    } else {
+        d[0] = *p;
     }
 }
 template <int NT>
 __device__ __forceinline__ void stv(float* p, const float (&d)[NT]) {
-    if constexpr (NT == 4) *reinterpret_cast<float4*>(p) = make_float4(d[0], d[1], d[2], d[3]);
-    else                   *reinterpret_cast<float2*>(p) = make_float2(d[0], d[1]);
+    if constexpr (NT == 4)      *reinterpret_cast<float4*>(p) = make_float4(d[0], d[1], d[2], d[3]);
+    else if constexpr (NT == 2) *reinterpret_cast<float2*>(p) = make_float2(d[0], d[1]);
+    else                        *p = d[0];
 }
 
 // raw B operand of one group of 8 k's (this lane: 4 of them) x NT consecutive positions
@@ -86,7 +89,7 @@ __device__ __forceinline__ void load_b(const DirectArgs& a, const float* xb, con
     for (int s = 0; s < 4; ++s) {
         if (MODE != B_DYPOOL) ldv<NT>(f.v[s], xb + (long)(kb + s) * rowP);
         if (MODE >= B_DY) ldv<NT>(f.y[s], yb + (long)(kb + s) * rowP);
-        if (MODE == B_DYPOOL) {
+        if constexpr (MODE == B_DYPOOL && NT >= 2) {
             const float2 t = a.pk[pool_base + (long)(kb + s) * np];
             f.v[s][0] = t.x; f.v[s][1] = t.y;
         }
@@ -108,7 +111,7 @@ __device__ __forceinline__ void compute_group(const RawB<NT>& f, const float4& a
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
         float bv[NT];
-        if (MODE == B_DYPOOL) {
+        if constexpr (MODE == B_DYPOOL && NT >= 2) {
             const float go = f.v[s][0];
             const int ak = __float_as_int(f.v[s][1]);
 #pragma unroll
@@ -299,11 +302,25 @@ int launch_direct_nt(const DirectArgs& a, hipStream_t st) {
     return o3d_launch_status();
 }
 
-// the heads' launches: 64-column tiles, and 32-row wave tiles while the whole problem is a few waves per SIMD
+// the heads' launches: 64-column tiles, and 32-row (x 32-column, O3D_PW_NT1=1) wave tiles while the whole problem is
+// a few waves per SIMD
+static long pw_small_max() {
+    static const long v = [] { const char* e = getenv("O3D_PW_SMALL_MAX"); return e ? atol(e) : (4L << 20); }();
+    return v;
+}
+static bool pw_nt1() {
+    static const bool v = [] { const char* e = getenv("O3D_PW_NT1"); return e && atoi(e) != 0; }();
+    return v;
+}
+static int pw_tile(long P, int M) {
+    const int t = o3d_direct_tile(P, M, 0);
+    return (t == 64 && pw_nt1() && P % 32 == 0 && (long)M * P <= pw_small_max()) ? 32 : t;
+}
+
 template <int MODE, int EPI>
 int launch_direct_small(const DirectArgs& a, int tile, hipStream_t st) {
-    static const long small_max = [] { const char* e = getenv("O3D_PW_SMALL_MAX"); return e ? atol(e) : (4L << 20); }();
-    if (tile == 64 && (long)a.M * a.P <= small_max) return launch_direct_nt<MODE, EPI, 2, 1>(a, st);
+    if (tile == 32) return launch_direct_nt<MODE, EPI, 1, 1>(a, st);
+    if (tile == 64 && (long)a.M * a.P <= pw_small_max()) return launch_direct_nt<MODE, EPI, 2, 1>(a, st);
     return tile == 64 ? launch_direct_nt<MODE, EPI, 2>(a, st) : launch_direct_nt<MODE, EPI, 4>(a, st);
 }
 
@@ -358,9 +375,9 @@ int o3d_direct_dgrad(const float* dN, const float* pk, int ns,
 // zero-pad); 64-column wave tiles while the problem is small (o3d_direct_tile).
 
 // Y (Cout, P) = W (Cout, Cin) . f(X) [+ bias + resid];  f = relu(x*in_scale+in_shift) or identity (both NULL).
-// part != NULL: BatchNorm statistics partials [P/tile][2][Cout] (then bias / resid must be NULL);
-// returns the tile (64 | 128) through *tile_out so the caller sizes `part` = P / tile rows.
-extern "C" int o3d_pw_tile(long P) { return (int)o3d_direct_tile(P, 0, 0); }
+// part != NULL: BatchNorm statistics partials [P/tile][2][Cout] (then bias / resid must be NULL), tile =
+// o3d_pw_tile(P, rows of the output) columns per partial row.
+extern "C" int o3d_pw_tile(long P, int M) { return pw_tile(P, M); }
 
 extern "C" int o3d_pw_fwd(const float* X, const float* W, const float* in_scale, const float* in_shift,
                           const float* bias, const float* resid, int Cin, int Cout, long P, float* Y, float* part,
@@ -368,7 +385,7 @@ extern "C" int o3d_pw_fwd(const float* X, const float* W, const float* in_scale,
     if (!X || !W || !Y || P <= 0 || P > 0x7fffffff || P % 64 != 0 || Cin <= 0 || Cin % 16 != 0 || Cout <= 0 ||
         Cout % DT_M != 0 || (in_scale == nullptr) != (in_shift == nullptr) || (part && (bias || resid)))
         return O3D_EINVAL;
-    const int tile = o3d_direct_tile(P, Cout, 0);
+    const int tile = pw_tile(P, Cout);
     if (tile == 128 && P % 128 != 0) return O3D_EINVAL;
     DirectArgs a = {};
     a.A = W; a.X = X; a.c1 = in_scale; a.c2 = in_shift; a.Out = Y; a.M = Cout; a.K = Cin; a.P = (int)P; a.B = 1;
@@ -390,7 +407,7 @@ extern "C" int o3d_pw_dgrad(const float* dN, const float* Y, const float* A1, co
         Cout <= 0 || Cout % 16 != 0 || (Y && (!A1 || !A2 || !A3)) ||
         (Yprev && (!scale_p || !shift_p || !mean_p || !part || resid)) || (!Yprev && part))
         return O3D_EINVAL;
-    const int tile = o3d_direct_tile(P, Cin, 0);
+    const int tile = pw_tile(P, Cin);
     if (tile == 128 && P % 128 != 0) return O3D_EINVAL;
     DirectArgs a = {};
     a.A = Wt; a.X = dN; a.Y = Y; a.c1 = A1; a.c2 = A2; a.c3 = A3; a.ns = 4;

@@ -57,10 +57,10 @@ capi.register("o3d_pack_points", [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i
 capi.register("o3d_center_term", [_vp, _vp, _i, _i, _i, _vp, _vp])
 capi.register("o3d_pool_fwd_c", [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_bwd_c", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _l, _vp, _vp, _vp])
-capi.register("o3d_pool_bwd_cb", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _l, _vp, _vp, _vp])
 capi.register("o3d_group_reduce_c", [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp,
                                      _vp, _vp])
 capi.register("o3d_direct_tile", [ctypes.c_long, _i, _i])
+capi.register("o3d_bn_eval_consts", [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _vp, _vp])
 capi.register("o3d_mlp_conv_fwd_c", [_vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_dgrad_c", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp])
@@ -94,6 +94,12 @@ def _call(name, flops, fn, *args):
     else:
         rc = fn(*args)
     capi.check(rc, name)
+
+
+def _eval_consts(lib, bn, gamma, beta, vec, nrep, st, conv_bias=None):
+    """eval-mode BatchNorm -> vec (4, nrep, C) = mean, invstd, scale, shift (one launch, csrc/heads.hip)"""
+    _call("bn_eval_consts", 0.0, lib.o3d_bn_eval_consts, bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
+          gamma.data_ptr(), beta.data_ptr(), _ptr(conv_bias), float(bn.eps), bn.running_mean.numel(), nrep, vec.data_ptr(), st)
 
 
 GEMM_KERNELS = ("conv_fwd", "conv_fwd_points", "conv_dgrad", "conv_dgrad_points", "conv_wgrad", "conv_wgrad_points",
@@ -262,10 +268,7 @@ class FusedGroupedMLP(torch.autograd.Function):
                       bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps), vec[0].data_ptr(),
                       vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), fold.data_ptr(), st)
             else:
-                vec[0].copy_(bn.running_mean)
-                vec[1].copy_(torch.rsqrt(bn.running_var + bn.eps))
-                vec[2].copy_(gammas[l] * vec[1])
-                vec[3].copy_(betas[l] - vec[0] * vec[2])
+                _eval_consts(lib, bn, gammas[l], betas[l], vec, 1, st)
             Ys.append(Y)
             means.append(vec[0]); invstds.append(vec[1]); scales.append(vec[2]); shifts.append(vec[3])
         if cfg.training:
@@ -551,10 +554,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                       bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
                       vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), meta.data_ptr(), tile, st)
             else:
-                vec[0].copy_(bn.running_mean)
-                vec[1].copy_(torch.rsqrt(bn.running_var + bn.eps))
-                vec[2].copy_(gammas[l] * vec[1, 0])
-                vec[3].copy_(betas[l] - vec[0, 0] * vec[2, 0])
+                _eval_consts(lib, bn, gammas[l], betas[l], vec, nseg, st)
             Ys.append(Y)
             means.append(vec[0]); invstds.append(vec[1]); scales.append(vec[2]); shifts.append(vec[3])
         if cfg.training:
@@ -611,9 +611,9 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         part = torch.empty((nseg, POOL_BWD_SPLIT, 2, Cl), device=dev, dtype=f32)
         dN = torch.empty((Cl, ldp), device=dev, dtype=f32)          # dense class-sum gradient of the pooled layer
         np1 = npoints[1] if nseg == 2 else 0
-        _call("pool_bwd", 0.0, lib.o3d_pool_bwd_cb, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
-              means[-1].data_ptr(), cball.data_ptr(), B, Cl, npoints[0], np1, meta.data_ptr(), start1, ldp, dN.data_ptr(),
-              part.data_ptr(), st)
+        _call("pool_bwd", 0.0, lib.o3d_pool_bwd_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
+              means[-1].data_ptr(), B, Cl, npoints[0], np1, meta.data_ptr(), start1, ldp, dN.data_ptr(), part.data_ptr(),
+              st)
         dtile = 0
         main, side = torch.cuda.current_stream(), _side_stream(dev)
         keep = []        # buffers the side stream still reads: must outlive the join at the end
@@ -737,10 +737,13 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         return (None, None, *gin, *gw)
 
 
-# layer-0 backward reduce as an LDS gather through a transposed index (csrc/compact.hip::reduce_gather_kernel):
-# 2.1x on the stand-alone probe, passes test_reduce_gather_matches_atomic_reduce on the MI355X (single segment);
-# OFF until the paired-segment parity run and the bench have been done (O3D_REDUCE_GATHER=1 enables)
-_REDUCE_GATHER = {"on": _os.environ.get("O3D_REDUCE_GATHER", "0") == "1"}
+# layer-0 backward reduce as an LDS gather through a transposed index (csrc/compact.hip::reduce_gather_kernel) instead
+# of one LDS float atomic per column and channel.  Round-2 measurements on the MI355X (BAT, batch 48, same run A/B):
+# the first version (thread n walks point n's list) was 3x SLOWER than the atomics on real crops (1.96 vs 0.65 ms per
+# step: a point referenced by hundreds of balls serialised on one thread, and the per-list insertion sort was
+# quadratic); the balanced walk (equal shares of the sorted entries per thread, one atomic per run of equal points)
+# takes 0.50 ms including the index build.  ON by default; O3D_REDUCE_GATHER=0 selects the atomic kernel.
+_REDUCE_GATHER = {"on": _os.environ.get("O3D_REDUCE_GATHER", "1") != "0"}
 
 
 def set_reduce_gather(enabled):

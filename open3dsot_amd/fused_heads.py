@@ -23,13 +23,13 @@ import weakref
 import torch
 
 from . import capi
-from .fused import _call, _const_vec, _ptr, _stream
+from .fused import _call, _const_vec, _eval_consts, _ptr, _stream
 
 _vp, _i, _l, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 capi.register("o3d_pack_rows", [_vp, _i, _i, _i, _i, _vp, _vp])
 capi.register("o3d_prep_weights", [_vp, _i, _vp])
 capi.register("o3d_row_sum", [_vp, _i, _l, _vp, _vp])
-capi.register("o3d_pw_tile", [_l])
+capi.register("o3d_pw_tile", [_l, _i])
 capi.register("o3d_pw_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp])
 capi.register("o3d_pw_dgrad", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 
@@ -221,8 +221,6 @@ class FlatChain(torch.autograd.Function):
         if X0 is None:
             X0 = pack_rows([t.detach() for t in srcs], K0p)
         need_bwd = any(ctx.needs_input_grad)
-        tile = lib.o3d_pw_tile(P)
-        nparts = P // tile
         Ys, vecs, Wts = [], [], []
         Kp = K0p
         for l in range(L):
@@ -240,6 +238,7 @@ class FlatChain(torch.autograd.Function):
                 bn = cfg.bns[l]
                 vec = torch.empty((4, Mp), device=dev, dtype=f32)            # mean, invstd, scale, shift
                 if cfg.training:
+                    nparts = P // lib.o3d_pw_tile(P, Mp)
                     part = torch.empty((nparts, 2, Mp), device=dev, dtype=f32)
                     _call("pw_conv_fwd", 2.0 * Kp * Mp * P, lib.o3d_pw_fwd, src.data_ptr(), Wp.data_ptr(), sc, sh, None, None,
                           Kp, Mp, P, Y.data_ptr(), part.data_ptr(), bn.running_mean.data_ptr(), st)
@@ -251,10 +250,7 @@ class FlatChain(torch.autograd.Function):
                 else:
                     _call("pw_conv_fwd", 2.0 * Kp * Mp * P, lib.o3d_pw_fwd, src.data_ptr(), Wp.data_ptr(), sc, sh, None, None,
                           Kp, Mp, P, Y.data_ptr(), None, None, st)
-                    vec[0].copy_(bn.running_mean)
-                    vec[1].copy_(torch.rsqrt(bn.running_var + bn.eps))
-                    vec[2].copy_(gamma.detach() * vec[1])
-                    vec[3].copy_(beta.detach() - vec[0] * vec[2])
+                    _eval_consts(lib, bn, gamma, beta, vec, 1, st)
                 vecs.append(vec)
             else:
                 bp = prep.get(bias, 1, Mp) if bias is not None else None
@@ -271,7 +267,7 @@ class FlatChain(torch.autograd.Function):
         Cl = params[4 * (L - 1)].shape[0]
         if need_bwd:
             ctx.cfg = cfg
-            ctx.geom = (B, N, L, K0, K0p, tile, [t.shape[1] for t in srcs])
+            ctx.geom = (B, N, L, K0, K0p, [t.shape[1] for t in srcs])
             ctx.versions = [(p, p._version) for p in params if p is not None]
             ctx.saved = (X0, Ys, vecs, Wts, [params[4 * l + 2] for l in range(L)], [params[4 * l] for l in range(L)])
         return Ys[-1][:Cl].view(Cl, B, N).permute(1, 0, 2)
@@ -281,7 +277,7 @@ class FlatChain(torch.autograd.Function):
     def backward(ctx, dOut):
         lib = capi.load()
         cfg = ctx.cfg
-        B, N, L, K0, K0p, tile, src_C = ctx.geom
+        B, N, L, K0, K0p, src_C = ctx.geom
         for p, v in ctx.versions:
             if p._version != v:
                 raise RuntimeError("a parameter of a fused conv stack was modified in place between forward and backward")
@@ -289,7 +285,7 @@ class FlatChain(torch.autograd.Function):
         P = B * N
         dev, f32 = dOut.device, torch.float32
         st = _stream()
-        nparts = P // tile
+        nparts = 0
         Cl = Ws[-1].shape[0]
         Mp = Ys[-1].shape[0]
         G = _as_flat(dOut) if Cl == Mp else None
@@ -324,6 +320,7 @@ class FlatChain(torch.autograd.Function):
         if L > 1:
             Cp = Ys[l - 1].shape[0]
             dN = torch.empty((Cp, P), device=dev, dtype=f32)
+            nparts = P // lib.o3d_pw_tile(P, Cp)
             part = torch.empty((nparts, 2, Cp), device=dev, dtype=f32)
             v = vecs[l - 1]
             _call("pw_conv_dgrad", 2.0 * Cp * Mp * P, lib.o3d_pw_dgrad, G.data_ptr(), None, None, None, None,
@@ -352,12 +349,13 @@ class FlatChain(torch.autograd.Function):
             if l > 0:
                 Cq = Ys[l - 1].shape[0]
                 dNp = torch.empty((Cq, P), device=dev, dtype=f32)
-                part = torch.empty((nparts, 2, Cq), device=dev, dtype=f32)
+                nparts_next = P // lib.o3d_pw_tile(P, Cq)
+                part_next = torch.empty((nparts_next, 2, Cq), device=dev, dtype=f32)
                 vp = vecs[l - 1]
                 _call("pw_conv_dgrad", 2.0 * Cq * Cp * P, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
                       Wts[l].data_ptr(), Cq, Cp, P, Ys[l - 1].data_ptr(), vp[2].data_ptr(), vp[3].data_ptr(), vp[0].data_ptr(),
-                      None, dNp.data_ptr(), part.data_ptr(), st)
-                dN = dNp
+                      None, dNp.data_ptr(), part_next.data_ptr(), st)
+                dN, part, nparts = dNp, part_next, nparts_next
             elif want_x:
                 dX0 = torch.empty((K0p, P), device=dev, dtype=f32)
                 _call("pw_conv_dgrad", 2.0 * K0p * Cp * P, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1], A[2],

@@ -13,7 +13,7 @@ import ctypes
 import torch
 
 from . import capi
-from .fused import _call, _const_vec, _ptr, _stream, POOL_BWD_SPLIT, TILE
+from .fused import _call, _const_vec, _eval_consts, _ptr, _stream, POOL_BWD_SPLIT, TILE
 
 _vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
 capi.register("o3d_bn_relu_apply", [_vp, _vp, _vp, _i, _l, _vp, _vp])
@@ -71,11 +71,7 @@ class FusedPointwiseChain(torch.autograd.Function):
                 if b is not None:       # statistics were taken without the bias: mean(Y + b) = mean(Y) + b
                     bn.running_mean.add_(b, alpha=float(bn.momentum))
             else:
-                mu = bn.running_mean - b if b is not None else bn.running_mean
-                vec[0].copy_(mu)
-                vec[1].copy_(torch.rsqrt(bn.running_var + bn.eps))
-                vec[2].copy_(gammas[l] * vec[1])
-                vec[3].copy_(betas[l] - vec[0] * vec[2])
+                _eval_consts(lib, bn, gammas[l], betas[l], vec, 1, st, conv_bias=b)
             Ys.append(Y)
             means.append(vec[0]); invstds.append(vec[1]); scales.append(vec[2]); shifts.append(vec[3])
         if cfg.training:

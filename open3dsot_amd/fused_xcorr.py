@@ -14,12 +14,13 @@ import ctypes
 import torch
 
 from . import capi
-from .fused import _call, _const_vec, _layers, _ptr, _stream
+from .fused import _call, _const_vec, _eval_consts, _layers, _ptr, _stream
 from .fused_heads import _up, pack_rows, prep_for
 
 _vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
 capi.register("o3d_xcorr_expand", [_vp, _l, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_xcorr_reduce_groups", [_i])
+capi.register("o3d_pool_bwd_partials_split", [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_xcorr_reduce", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _l, _vp, _vp, _vp])
 
 
@@ -85,7 +86,7 @@ class FusedP2BXCorr(torch.autograd.Function):
         _call("conv_fwd_points", 2.0 * K0p * C0 * Pm, lib.o3d_pw_fwd, X0.data_ptr(), W0p.data_ptr(), None, None, None, None,
               K0p, C0, Pm, Z.data_ptr(), None, None, st)
         Ys, vecs, Wts = [], [], []
-        tile = lib.o3d_pw_tile(P)
+        tile = lib.o3d_pw_tile(P, 256)          # the xcorr stage has far more than 65536 columns: 128, whatever the rows
         for l in range(L):
             Cout, Cin = Ws[l].shape
             bn = cfg.bns[l]
@@ -110,10 +111,7 @@ class FusedP2BXCorr(torch.autograd.Function):
                       float(bn.momentum), float(bn.eps), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
                       vec[3].data_ptr(), fold.data_ptr(), st)
             else:
-                vec[0].copy_(bn.running_mean)
-                vec[1].copy_(torch.rsqrt(bn.running_var + bn.eps))
-                vec[2].copy_(gammas[l] * vec[1])
-                vec[3].copy_(betas[l] - vec[0] * vec[2])
+                _eval_consts(lib, bn, gammas[l], betas[l], vec, 1, st)
             Ys.append(Y)
             vecs.append(vec)
         if cfg.training:
@@ -154,11 +152,11 @@ class FusedP2BXCorr(torch.autograd.Function):
         g = g.reshape(Cl, B * N) if g.is_contiguous() else g.contiguous().view(Cl, B * N)
         # the dense (Cl, P) gradient of the pooled layer (one non-zero per ball and channel) is never written: the last
         # layer's data / weight gradient kernels read the packed {masked gradient, arg-max slot} pairs
-        part = torch.empty((1, 2, Cl), device=dev, dtype=f32)
+        nparts = 8
+        part = torch.empty((nparts, 2, Cl), device=dev, dtype=f32)
         pk = torch.empty((Cl, B * N, 2), device=dev, dtype=f32)
-        _call("pool_bwd", 0.0, lib.o3d_pool_bwd_partials, g.data_ptr(), out.data_ptr(), yarg.data_ptr(),
-              vecs[-1][0].data_ptr(), 1, Cl, B * N, part.data_ptr(), argq.data_ptr(), pk.data_ptr(), st)
-        nparts = 1
+        _call("pool_bwd", 0.0, lib.o3d_pool_bwd_partials_split, g.data_ptr(), out.data_ptr(), yarg.data_ptr(),
+              vecs[-1][0].data_ptr(), Cl, B * N, nparts, part.data_ptr(), argq.data_ptr(), pk.data_ptr(), st)
         dN = None
         grads = [None] * (3 * L)
         dsim = dxyz = dfeat = None

@@ -386,3 +386,47 @@ def test_fused_track_loss_matches_compute_loss(with_bc, seed):
         err = float((og[k].grad.cpu().double() - ref).abs().max())
         assert err <= 2e-6 * float(ref.abs().max()) + 1e-9, (k, err, float(ref.abs().max()))
     assert og["center_xyz"].grad is None
+
+
+@pytest.mark.parametrize("model_name", ["BAT", "P2B"])
+def test_inference_graph_replay_matches_eager_and_oracle(model_name):
+    """the tracking-inference path -- eval mode (BatchNorm on running statistics), batch 1,
+    template 512 / search 1024 points, no autograd -- captured as ONE HIP graph and replayed on new frames:
+    replay == eager launch-by-launch == fp32 CPU oracle (1e-4), sampling indices equal (models/base_model.py:59-86)."""
+    from open3dsot_amd import synth
+    dev = torch.device("cuda", 0)
+    model = make_model(model_name, 7, train=False)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    hosts = [synth.make_batch(700 + i, 1) for i in range(3)]
+    frames = [synth.to_torch(h, dev) for h in hosts]
+    keys = [k for k in OUT_KEYS if model_name == "BAT" or k != "pred_search_bc"]
+
+    def fwd(b):
+        with torch.no_grad():
+            out = model(b)
+        return [out[k] for k in keys] + [out["sample_idxs"]]
+
+    eager = [[t.clone() for t in fwd(f)] for f in frames]
+    static = {k: v.clone() for k, v in frames[0].items()}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fwd(static)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        outs = fwd(static)
+    for h, f, e in zip(hosts, frames, eager):
+        for k, v in f.items():
+            static[k].copy_(v)
+        g.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(outs, e):
+            assert torch.equal(a, b)                                   # the same kernels on the same data: bitwise
+        ref = (torch_ref.bat_forward if model_name == "BAT" else torch_ref.p2b_forward)(sd, synth.to_torch(h), False)
+        assert np.array_equal(outs[-1].cpu().numpy(), ref["sample_idxs"].numpy())
+        for k, a in zip(keys, outs):
+            assert rel(a, ref[k]) < 1e-4, (k, rel(a, ref[k]))
+    for k, v in model.state_dict().items():                            # eval mode leaves every buffer untouched
+        assert torch.equal(v.cpu(), sd[k]), k
