@@ -23,6 +23,7 @@
 // Software pipeline: ring of 2 fragment sets per wave, loop unrolled by 2, loads clamped instead of
 // predicated (branch-free, so the compiler can count vmcnt exactly), sched_barriers keep the
 // prefetch ahead of the MFMAs; 2 waves per SIMD (<= 256 VGPRs incl. 128 accumulators).
+#include <type_traits>
 #include "mlp_common.hpp"
 
 namespace {
@@ -193,26 +194,57 @@ void direct_gemm_kernel(DirectArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
 
-    const int G = a.K / 8;       // even (K % 16 == 0)
-    RawB<NT> f[2];
-    float4 wa0[2], wa1[2];
-    auto load = [&](int st, int g) {
+    // Ring of R fragment sets, R-1 groups of loads in flight ahead of the MFMAs.  A group of 8 k's is 8*MT*NT/2 MFMAs
+    // of 64 cycles; with 2 waves per SIMD and 64-row tiles (MT = 2) one group ahead covers a ~2000-cycle miss, the
+    // 32-row tiles of the heads' small launches (one wave per SIMD, 8 MFMAs = 512 cycles per group) were bound by
+    // load latency x groups (measured: 15-20 us for a 256x256x6144 GEMM, 15 us even at K = 64): they run 3 ahead.
+    constexpr int R = MT == 1 ? 4 : 2;
+    const int G = a.K / 8;       // multiple of R (K % 16 == 0; K % 32 == 0 for MT == 1)
+    RawB<NT> f[R];
+    float4 wa0[R], wa1[R];
+    auto load = [&](auto stc, int g) {
+        constexpr int st = decltype(stc)::value;
         const int kb = 8 * g + 4 * h;
         load_b<MODE, NT>(a, xb, yb, rowP, kb, pool_base, np, f[st]);
         wa0[st] = *reinterpret_cast<const float4*>(wa + 8 * g);
         if constexpr (MT == 2) wa1[st] = *reinterpret_cast<const float4*>(wa + 8 * g + wstep);
         else wa1[st] = wa0[st];
     };
-    load(0, 0);
-    for (int g = 0; g < G; g += 2) {
-        load(1, g + 1);
-        __builtin_amdgcn_sched_barrier(0);
-        compute_group<MODE, NT, MT>(f[0], wa0[0], wa1[0], kk, wv, acc);
-        __builtin_amdgcn_sched_barrier(0);
-        load(0, g + 2 < G ? g + 2 : G - 1);       // tail: harmless re-load of the last group
-        __builtin_amdgcn_sched_barrier(0);
-        compute_group<MODE, NT, MT>(f[1], wa0[1], wa1[1], kk, wv, acc);
-        __builtin_amdgcn_sched_barrier(0);
+    if constexpr (R == 2) {
+        load(std::integral_constant<int, 0>{}, 0);
+        for (int g = 0; g < G; g += 2) {
+            load(std::integral_constant<int, 1>{}, g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group<MODE, NT, MT>(f[0], wa0[0], wa1[0], kk, wv, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            load(std::integral_constant<int, 0>{}, g + 2 < G ? g + 2 : G - 1);       // tail: harmless re-load of the last group
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group<MODE, NT, MT>(f[1], wa0[1], wa1[1], kk, wv, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    } else {
+        const int last = G - 1;
+        load(std::integral_constant<int, 0>{}, 0);
+        load(std::integral_constant<int, 1>{}, 1 < last ? 1 : last);
+        load(std::integral_constant<int, 2>{}, 2 < last ? 2 : last);
+        for (int g = 0; g < G; g += 4) {
+            load(std::integral_constant<int, 3>{}, g + 3 < last ? g + 3 : last);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group<MODE, NT, MT>(f[0], wa0[0], wa1[0], kk, wv, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            load(std::integral_constant<int, 0>{}, g + 4 < last ? g + 4 : last);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group<MODE, NT, MT>(f[1], wa0[1], wa1[1], kk, wv, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            load(std::integral_constant<int, 1>{}, g + 5 < last ? g + 5 : last);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group<MODE, NT, MT>(f[2], wa0[2], wa1[2], kk, wv, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            load(std::integral_constant<int, 2>{}, g + 6 < last ? g + 6 : last);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group<MODE, NT, MT>(f[3], wa0[3], wa1[3], kk, wv, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
     }
 
     // ---------------- epilogue: store, then the two statistics one at a time (32 live values each)
@@ -319,8 +351,10 @@ static int pw_tile(long P, int M) {
 
 template <int MODE, int EPI>
 int launch_direct_small(const DirectArgs& a, int tile, hipStream_t st) {
-    if (tile == 32) return launch_direct_nt<MODE, EPI, 1, 1>(a, st);
-    if (tile == 64 && (long)a.M * a.P <= pw_small_max()) return launch_direct_nt<MODE, EPI, 2, 1>(a, st);
+    if (a.K % 32 == 0) {        // the 32-row tiles keep 3 groups of 8 k in flight: whole rounds of 4 groups
+        if (tile == 32) return launch_direct_nt<MODE, EPI, 1, 1>(a, st);
+        if (tile == 64 && (long)a.M * a.P <= pw_small_max()) return launch_direct_nt<MODE, EPI, 2, 1>(a, st);
+    }
     return tile == 64 ? launch_direct_nt<MODE, EPI, 2>(a, st) : launch_direct_nt<MODE, EPI, 4>(a, st);
 }
 

@@ -102,6 +102,19 @@ def _eval_consts(lib, bn, gamma, beta, vec, nrep, st, conv_bias=None):
           gamma.data_ptr(), beta.data_ptr(), _ptr(conv_bias), float(bn.eps), bn.running_mean.numel(), nrep, vec.data_ptr(), st)
 
 
+def _versions(params):
+    """[(tensor, version)]: the fused functions keep detached views of the live parameter storage for their backward
+    (no copy), so autograd's own in-place check does not see them -- `_check_versions` restores it"""
+    return [(p, p._version) for p in params if isinstance(p, torch.Tensor)]
+
+
+def _check_versions(saved, what):
+    for p, v in saved:
+        if p._version != v:
+            raise RuntimeError("%s: a parameter was modified in place between forward and backward (its saved view "
+                               "would silently yield wrong gradients)" % what)
+
+
 GEMM_KERNELS = ("conv_fwd", "conv_fwd_points", "conv_dgrad", "conv_dgrad_points", "conv_wgrad", "conv_wgrad_points",
                 "pw_conv_fwd", "pw_conv_dgrad", "pw_conv_wgrad")
 
@@ -281,6 +294,7 @@ class FusedGroupedMLP(torch.autograd.Function):
               shifts[-1].data_ptr(), B, Cl, npoint, ns, out.data_ptr(), _ptr(arg), _ptr(yarg), st)
         if need_bwd:
             ctx.cfg = cfg
+            ctx.versions = _versions(params)
             ctx.dims = (B, N, C, npoint, ns, L)
             # NB: `out` itself must not be stored on ctx (out.grad_fn is this node: a reference cycle
             # that keeps the whole graph -- and last step's AccumulateGrad nodes -- alive until the GC runs)
@@ -293,6 +307,7 @@ class FusedGroupedMLP(torch.autograd.Function):
     def backward(ctx, dOut):
         lib = capi.load()
         cfg = ctx.cfg
+        _check_versions(ctx.versions, "FusedGroupedMLP")
         B, N, C, npoint, ns, L = ctx.dims
         X0n, new_c, Z, GY, idx, Ws, gammas, Ys, means, invstds, scales, shifts, out, arg, yarg = ctx.saved
         Npad = X0n.shape[2]
@@ -569,6 +584,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
               ball_off.data_ptr(), ball_cnt.data_ptr(), B, Cl, npoints[0], np1, out.data_ptr(), _ptr(argq), _ptr(yarg), st)
         if need_bwd:
             ctx.cfg = cfg
+            ctx.versions = _versions(params)
             ctx.geom = (B, ns, C, nseg, Ns, Npads, npoints, Pmaxs, starts, pt_bases, ball_bases, nballs_s)
             ctx.saved = (X0n, centers, ball_off, ball_cnt, gp, cball, cw, meta, Ws, gammas, Ys, means, invstds, scales,
                          shifts, out.detach(), argq, yarg)
@@ -581,6 +597,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
     def backward(ctx, *dOuts):
         lib = capi.load()
         cfg = ctx.cfg
+        _check_versions(ctx.versions, "FusedGroupedMLPCompact")
         B, ns, C, nseg, Ns, Npads, npoints, Pmaxs, starts, pt_bases, ball_bases, nballs_s = ctx.geom
         (X0n, centers, ball_off, ball_cnt, gp, cball, cw, meta, Ws, gammas, Ys, means, invstds, scales, shifts, out,
          argq, yarg) = ctx.saved

@@ -61,7 +61,7 @@ class FusedTrackLoss(torch.autograd.Function):
     @staticmethod
     @capi.on_tensor_device
     def backward(ctx, g):
-        grads, ctx.grads = ctx.grads, None
+        grads = ctx.grads            # kept: a second backward (retain_graph=True) scales the same tensors again
         live = [t for t in grads if t is not None]
         scaled = iter(torch._foreach_mul(live, g[0]))            # one launch; only the total carries gradient
         out = [next(scaled) if t is not None else None for t in grads]

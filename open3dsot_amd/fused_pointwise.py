@@ -13,7 +13,7 @@ import ctypes
 import torch
 
 from . import capi
-from .fused import _call, _const_vec, _eval_consts, _ptr, _stream, POOL_BWD_SPLIT, TILE
+from .fused import _call, _check_versions, _const_vec, _eval_consts, _ptr, _stream, _versions, POOL_BWD_SPLIT, TILE
 
 _vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
 capi.register("o3d_bn_relu_apply", [_vp, _vp, _vp, _i, _l, _vp, _vp])
@@ -92,6 +92,7 @@ class FusedPointwiseChain(torch.autograd.Function):
                   N, out.data_ptr(), _ptr(argq), _ptr(yarg), st)
         if need_bwd:
             ctx.cfg = cfg
+            ctx.versions = _versions(params)
             ctx.dims = (B, N, L)
             ctx.has_bias = [b is not None for b in biases]
             ctx.saved = (X0, Ws, gammas, Ys, means, invstds, scales, shifts, out.detach() if cfg.mode != "act" else None,
@@ -103,6 +104,7 @@ class FusedPointwiseChain(torch.autograd.Function):
     def backward(ctx, dOut):
         lib = capi.load()
         cfg = ctx.cfg
+        _check_versions(ctx.versions, "FusedPointwiseChain")
         B, N, L = ctx.dims
         X0, Ws, gammas, Ys, means, invstds, scales, shifts, out, argq, yarg = ctx.saved
         P = B * N

@@ -554,3 +554,28 @@ def test_compact_build(lib, ns):
     pad = slice(tot, int(meta[0]))
     assert bool((cw_c[pad] == 0).all()) and bool((cball_c[pad] == nballs).all())
     assert abs(float(cw_c[:tot].sum()) - Pmax) < 0.5      # the weights account for every slot
+
+
+def test_in_place_weight_update_between_forward_and_backward_is_refused():
+    """the fused functions keep views of the live parameter storage for backward: an in-place update in between must
+    raise (as autograd's version counter does for saved tensors) instead of yielding wrong gradients"""
+    from open3dsot_amd import fused
+    grouper, mlp, xyz, new_xyz, feats = make_case("sa2")
+    out = fused.sa_group_mlp_pool(grouper, mlp, xyz, new_xyz, feats.clone().requires_grad_(True))
+    with torch.no_grad():
+        next(mlp.parameters()).mul_(1.5)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        out.sum().backward()
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (the round-end scaling node has them)")
+def test_fused_path_on_a_non_current_device():
+    """a module on cuda:1 while cuda:0 is the current device: streams, scratch and launches follow the tensors"""
+    from open3dsot_amd import fused
+    grouper, mlp, xyz, new_xyz, feats = make_case("sa2")
+    dev1 = torch.device("cuda", 1)
+    mlp1 = __import__("copy").deepcopy(mlp).to(dev1)
+    want = fused.sa_group_mlp_pool(grouper, mlp, xyz, new_xyz, feats)
+    assert torch.cuda.current_device() == 0
+    got = fused.sa_group_mlp_pool(grouper, mlp1, xyz.to(dev1), new_xyz.to(dev1), feats.to(dev1))
+    assert got.device == dev1 and rel(got, want) < 1e-6

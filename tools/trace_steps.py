@@ -1,11 +1,13 @@
 """Steady-state per-step kernel breakdown from a rocprofv3 kernel trace of bench.py (graph mode):
-the window between the FPS launch of step -(n+1) and the FPS launch of the last step.
+the window between the loss-kernel launch of step -(n+1) and the loss-kernel launch of the last step.
 usage: trace_steps.py <kernel_trace.csv> [n_steps=20] [top=60]"""
 import csv, sys, collections
 F = sys.argv[1]; steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20; top = int(sys.argv[3]) if len(sys.argv) > 3 else 60
 rows = list(csv.DictReader(open(F)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-fps = [r for r in rows if "fps_reg_kernel<16" in r["Kernel_Name"]]
+fps = [r for r in rows if "track_loss_sums_kernel" in r["Kernel_Name"]]      # one per training step (BAT and P2B)
+if len(fps) <= steps:
+    fps = [r for r in rows if "fps_reg_kernel<16" in r["Kernel_Name"]]
 start = int(fps[-steps - 1]["Start_Timestamp"]); end = int(fps[-1]["Start_Timestamp"])
 agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
