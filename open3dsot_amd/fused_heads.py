@@ -33,7 +33,21 @@ capi.register("o3d_pw_tile", [_l, _i])
 capi.register("o3d_pw_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp])
 capi.register("o3d_pw_dgrad", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 
+import os as _os
+
 _ON = {"on": True}
+# Weight gradients (and bias gradients) of a stack on a second HIP stream beside the data-gradient chain: the heads'
+# launches are latency bound (15-18 us each whatever their size on the MI355X, a 256x256x6144 GEMM is 8 us of MFMA
+# work), the weight-gradient branch is off the critical path (nothing in the backward consumes it), and inside the
+# captured HIP graph the fork / join are plain edges.  O3D_HEADS_SIDE_STREAM=0 serialises them (A/B switch).
+_SIDE = {"on": _os.environ.get("O3D_HEADS_SIDE_STREAM", "1") != "0", "streams": {}}
+
+
+def _side_stream(dev):
+    key = (dev.type, dev.index)
+    if key not in _SIDE["streams"]:
+        _SIDE["streams"][key] = torch.cuda.Stream(device=dev)
+    return _SIDE["streams"][key]
 
 
 def set_fused_heads(enabled):
@@ -296,24 +310,38 @@ class FlatChain(torch.autograd.Function):
         one, zero = _const_vec(dev, Mp, 1.0), _const_vec(dev, Mp, 0.0)
         dX0 = None
 
-        def wgrad(l, dN, Y, A, Cout_p):
+        main = torch.cuda.current_stream()
+        side = _side_stream(dev) if _SIDE["on"] else main
+        keep = []            # buffers the side stream reads or writes: alive until the join below
+
+        def wgrad(l, dN, Y, A, Cout_p, coef=None):
             Xs = X0 if l == 0 else Ys[l - 1]
             Kp = Xs.shape[0]
             sc = None if l == 0 else vecs[l - 1][2].data_ptr()
             sh = None if l == 0 else vecs[l - 1][3].data_ptr()
-            dW = torch.empty((Cout_p, Kp), device=dev, dtype=f32)
-            scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Kp, Cout_p, P),), device=dev, dtype=f32)
-            _call("pw_conv_wgrad", 2.0 * Kp * Cout_p * P, lib.o3d_mlp_conv_wgrad2, dN.data_ptr(), None, 4, Y.data_ptr(),
-                  A[0], A[1], A[2], Xs.data_ptr(), sc, sh, 1, Kp, Cout_p, P, scratch.data_ptr(), dW.data_ptr(), st)
-            Wl = Ws[l]
-            Cout, Cin = Wl.shape[0], Wl.shape[1]
-            return (dW if (Cout, Cin) == (Cout_p, Kp) else dW[:Cout, :Cin]).reshape(Wl.shape)
+            if side is not main:
+                side.wait_stream(main)           # dN and the BatchNorm-backward constants of this layer are ready
+            with torch.cuda.stream(side):
+                dW = torch.empty((Cout_p, Kp), device=dev, dtype=f32)
+                scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Kp, Cout_p, P),), device=dev, dtype=f32)
+                _call("pw_conv_wgrad", 2.0 * Kp * Cout_p * P, lib.o3d_mlp_conv_wgrad2, dN.data_ptr(), None, 4, Y.data_ptr(),
+                      A[0], A[1], A[2], Xs.data_ptr(), sc, sh, 1, Kp, Cout_p, P, scratch.data_ptr(), dW.data_ptr(),
+                      side.cuda_stream)
+                Wl = Ws[l]
+                Cout, Cin = Wl.shape[0], Wl.shape[1]
+                out = (dW if (Cout, Cin) == (Cout_p, Kp) else dW[:Cout, :Cin]).reshape(Wl.shape)
+            keep.extend((dN, Y, scratch, dW, coef, out))
+            return out
 
         # ---- last layer: plain conv (+ bias, + residual)
         l = L - 1
         if ctx.needs_input_grad[1 + cfg.nsrc + 4 * l + 1]:
-            db = torch.empty((Mp,), device=dev, dtype=f32)
-            _call("row_sum", 0.0, lib.o3d_row_sum, G.data_ptr(), Mp, P, db.data_ptr(), st)
+            if side is not main:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                db = torch.empty((Mp,), device=dev, dtype=f32)
+                _call("row_sum", 0.0, lib.o3d_row_sum, G.data_ptr(), Mp, P, db.data_ptr(), side.cuda_stream)
+            keep.extend((G, db))
             grads[4 * l + 1] = db[:Cl]
         grads[4 * l] = wgrad(l, G, G, (one.data_ptr(), zero.data_ptr(), zero.data_ptr()), Mp)
         dN, part = None, None
@@ -345,7 +373,7 @@ class FlatChain(torch.autograd.Function):
                 coef[4].zero_()
             grads[4 * l + 2], grads[4 * l + 3] = coef[0], coef[1]
             A = (coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr())
-            grads[4 * l] = wgrad(l, dN, Ys[l], A, Cp)
+            grads[4 * l] = wgrad(l, dN, Ys[l], A, Cp, coef)
             if l > 0:
                 Cq = Ys[l - 1].shape[0]
                 dNp = torch.empty((Cq, P), device=dev, dtype=f32)
@@ -361,6 +389,9 @@ class FlatChain(torch.autograd.Function):
                 _call("pw_conv_dgrad", 2.0 * K0p * Cp * P, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1], A[2],
                       Wts[0].data_ptr(), K0p, Cp, P, None, None, None, None, G.data_ptr() if cfg.residual else None,
                       dX0.data_ptr(), None, st)
+        if side is not main:
+            main.wait_stream(side)       # join: every weight gradient is complete before autograd hands it on
+        del keep
         gsrc, off = [], 0
         for i, C in enumerate(src_C):
             gsrc.append(dX0[off:off + C].view(C, B, N).permute(1, 0, 2) if (dX0 is not None and ctx.needs_input_grad[1 + i])
