@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--infer", action="store_true", help="tracking-inference latency instead of the training step: eval-mode "
                     "forward of one frame (SURVEY.md section 8f-4, models/base_model.py:59-86), one HIP graph replay per frame")
     ap.add_argument("--infer-batch", type=int, default=1, help="frames per forward in --infer mode (the reference tracks at 1)")
+    ap.add_argument("--search-size", type=int, default=1024, help="search-cloud points (BASELINE config 5, BAT_CAR_NUSCENES: 2048)")
     ap.add_argument("--dense", action="store_true", help="worst-case clouds: every ball full of distinct neighbours "
                     "(live_fraction 1.0) instead of the KITTI-like crops")
     ap.add_argument("--composed", action="store_true", help="disable the fused kernels (debug A/B only)")
@@ -260,7 +261,8 @@ def run(args):
         args.no_cpu_baseline = True
     else:
         model = trackers.get_model(args.model)().to(dev).train()
-        make = synth.make_dense_batch if args.dense else synth.make_batch
+        base_make = synth.make_dense_batch if args.dense else synth.make_batch
+        make = lambda first, n: base_make(first, n, 512, args.search_size)
     sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     trainer = D.DataParallelStep(model, world=world, graph=not args.no_graph, graph_warmup=2)
 
@@ -309,7 +311,7 @@ def run(args):
             roofline = fused.profile_step(eager_step, PEAK_FP32_MFMA_TFLOPS)
     except ImportError:
         roofline = None
-    if roofline is not None and args.model != "M2TRACK":
+    if roofline is not None and args.model != "M2TRACK" and args.search_size == 1024:
         # the reference gathers first (layer 0 on npoint*nsample positions): rate in those terms as well
         ref_gflop = 3.0 * mlp_flops_per_pair(args.model) * args.batch / 1e9
         roofline["reference_formula_gflop_per_step"] = round(ref_gflop, 2)
@@ -320,10 +322,12 @@ def run(args):
             if t.get("workload_batch") == args.batch and t.get("model") == args.model:
                 roofline["traffic"] = t["gemm_family_hbm_bytes_per_launch"]
                 roofline["traffic_source"] = t["source"]
-                # the same launches against the other roof: measured HBM bytes / measured time
+                # the same launches against the other roof.  FETCH_SIZE / WRITE_SIZE count the L2's memory-side (fabric)
+                # requests, Infinity-Cache hits included (MI355X_MICROARCH.md, HBM section): an UPPER bound of the HBM
+                # bytes, so the fraction below is "fabric traffic against the HBM peak", not proven HBM bandwidth
                 gbs = roofline["traffic"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9
-                roofline["hbm_gbs"] = round(gbs, 1)
-                roofline["hbm_frac"] = round(gbs / PEAK_HBM_GBS, 4)
+                roofline["fabric_gbs"] = round(gbs, 1)
+                roofline["fabric_frac_of_hbm_peak"] = round(gbs / PEAK_HBM_GBS, 4)
     if roofline is None:  # no instrumented kernels yet: whole-step algorithmic rate (labelled as such)
         flops = 3.0 * mlp_flops_per_pair(args.model) * args.batch
         ach = flops / (elapsed / args.steps) / 1e12
@@ -334,8 +338,8 @@ def run(args):
     if rank == 0:
         pairs = world * args.batch * args.steps
         line = {
-            "metric": {"BAT": "template/search pairs/sec (fwd+bwd), BAT KITTI-Car 512/1024 pts",
-                       "P2B": "template/search pairs/sec (fwd+bwd), P2B KITTI-Car 512/1024 pts",
+            "metric": {"BAT": "template/search pairs/sec (fwd+bwd), BAT KITTI-Car 512/%d pts" % args.search_size,
+                       "P2B": "template/search pairs/sec (fwd+bwd), P2B KITTI-Car 512/%d pts" % args.search_size,
                        "M2TRACK": "frame pairs/sec (fwd+bwd), M2-Track KITTI 2x1024 pts"}[args.model],
             "value": round(pairs / elapsed, 2), "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
@@ -345,14 +349,15 @@ def run(args):
                     "synthetic KITTI-Car-like pairs (open3dsot_amd/synth.py, seed 1234+index), random-init weights",
             "config": {"workload": ("M2_track_kitti.yaml, 2x1024 pts, batch %d per GPU, fwd+bwd+Adam, fp32" % args.batch)
                        if args.model == "M2TRACK" else
-                       "%s_Car.yaml KITTI-Car, template 512 / search 1024 pts, batch %d per GPU, "
-                       "fwd+bwd+Adam, fp32" % (args.model, args.batch),
+                       "%s KITTI-Car, template 512 / search %d pts, batch %d per GPU, fwd+bwd+Adam, fp32" % (
+                           "%s_Car.yaml" % args.model if args.search_size == 1024 else "BAT_CAR_NUSCENES.yaml shapes,",
+                           args.search_size, args.batch),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "fused_kernels": bool(sa_modules.fused_enabled()),
                        "hip_graph": trainer.graph is not None},
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline and world == 1:
+        if not args.no_cpu_baseline and world == 1 and args.search_size == 1024:
             line["cpu_baseline"] = cpu_baseline(args.model, sd_cpu, args.batch, args.cpu_budget)
         print(json.dumps(line))
     if world > 1:

@@ -36,11 +36,13 @@ capi.register("o3d_pw_dgrad", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _v
 import os as _os
 
 _ON = {"on": True}
-# Weight gradients (and bias gradients) of a stack on a second HIP stream beside the data-gradient chain: the heads'
-# launches are latency bound (15-18 us each whatever their size on the MI355X, a 256x256x6144 GEMM is 8 us of MFMA
-# work), the weight-gradient branch is off the critical path (nothing in the backward consumes it), and inside the
-# captured HIP graph the fork / join are plain edges.  O3D_HEADS_SIDE_STREAM=0 serialises them (A/B switch).
-_SIDE = {"on": _os.environ.get("O3D_HEADS_SIDE_STREAM", "1") != "0", "streams": {}}
+# Weight gradients (and bias gradients) of a stack on a second HIP stream beside the data-gradient chain.  The heads'
+# launches are latency bound (15-18 us each on the MI355X whatever their size -- a 256x256x6144 GEMM is 8 us of MFMA
+# work, and neither 32-column tiles nor a 4-deep operand ring moved that) and the weight-gradient branch is off the
+# critical path, so overlap looked free.  Measured (BAT, batch 48, same run A/B): 7.39 ms per step with the side
+# stream against 6.98 without -- the fork / join edges inside the captured HIP graph cost more than the overlap
+# gains, as for the set-abstraction levels in round 1.  OFF by default; O3D_HEADS_SIDE_STREAM=1 enables it.
+_SIDE = {"on": _os.environ.get("O3D_HEADS_SIDE_STREAM", "0") == "1", "streams": {}}
 
 
 def _side_stream(dev):

@@ -11,6 +11,7 @@ import sys
 src, dst = sys.argv[1], sys.argv[2]
 model = sys.argv[3] if len(sys.argv) > 3 else "BAT"
 batch = int(sys.argv[4]) if len(sys.argv) > 4 else 48
+steps = int(sys.argv[5]) if len(sys.argv) > 5 else 5          # eager steps in the profiled run (warm-up + timed)
 PRIMARY = ("direct_gemm_kernel", "wgrad2_kernel", "conv_fwd_kernel", "conv_dgrad_kernel", "conv_wgrad_kernel")
 EXTRA = ("wgrad_reduce",)
 tot_bytes, launches, per = 0.0, 0, {}
@@ -30,8 +31,10 @@ for r in csv.DictReader(open(src)):
     per[short] = {"dispatches": n, "read_bytes": int(rd), "write_bytes": int(wr)}
 json.dump({"model": model, "workload_batch": batch,
            "gemm_family_hbm_bytes_per_launch": int(tot_bytes / max(launches, 1)),
-           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/gpu_round.sh), FETCH_SIZE "
-                     "doubled per MI355X_MICROARCH.md (gfx950 counts wide reads at half size); average over the %d "
-                     "GEMM-family dispatches of the eager steps of that run (tools/hbm_traffic.py)" % launches,
+           "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/gpu_round2.sh): the L2's "
+                     "memory-side (fabric) request bytes, Infinity-Cache hits INCLUDED (an upper bound of HBM bytes); "
+                     "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts wide reads at half size); average over "
+                     "the %d GEMM-family dispatches of the eager steps of that run (tools/hbm_traffic.py)" % launches,
+           "gemm_family_bytes_per_step": int(tot_bytes / max(steps, 1)),
            "per_kernel": per}, open(dst, "w"), indent=1)
 print("gemm family: %d launches, %.1f MB per launch" % (launches, tot_bytes / max(launches, 1) / 1e6))
