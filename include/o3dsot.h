@@ -303,6 +303,23 @@ int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t* argq, con
                    const float* mean, int B, int C, int npoint0, int npoint1, const int32_t* meta, long start1,
                    long ldp, float* D, float* part, void* stream);
 
+/* Backward of the pool WITHOUT the dense gradient of the pooled layer: part as above, and pkc (C, nballs + 1) pairs
+ * {dOut where out > 0, bits(arg-max column)} per (channel, ball); entry [c][nballs] = {0, -1} serves the padding
+ * columns (cball = nballs).  Consumed by o3d_mlp_conv_dgrad_cp / o3d_mlp_conv_wgrad2_cp. */
+int o3d_pool_bwd_pk(const float* dOut, const float* out, const int32_t* argq, const float* yarg, const float* mean, int B,
+                    int C, int npoint0, int npoint1, float* part, float* pkc, void* stream);
+
+/* o3d_mlp_conv_dgrad_c / o3d_mlp_conv_wgrad2_c for the pooled (last) layer of the compact layout: dN[c, q] =
+ * pkc[c][cball[q]].value where pkc[c][cball[q]].arg == q, else 0 -- gathered on the fly, never materialised. */
+int o3d_mlp_conv_dgrad_cp(const float* pkc, const int32_t* cball, int nb1, const float* Y, const float* A1,
+                          const float* A2, const float* A3, const float* Wt, int Cin, int Cout, long ldp, const float* w,
+                          const int32_t* meta, long start1, int tile, const float* Yprev, const float* scale_p,
+                          const float* shift_p, const float* mean_p, float* dNprev, float* part, void* stream);
+int o3d_mlp_conv_wgrad2_cp(const float* pkc, const int32_t* cball, int nb1, const float* Y, const float* A1,
+                           const float* A2, const float* A3, const float* X, const float* in_scale,
+                           const float* in_shift, int Cin, int Cout, long ldp, const float* w, const int32_t* meta,
+                           long start1, float* scratch, float* dW, void* stream);
+
 
 /* The same sums as o3d_group_reduce_c without float atomics: the cloud's columns are sorted by (column chunk,
  * point) once per call (perm: ldp ints; poff: o3d_group_reduce_gather_scratch(...) ints, -1 = shape not covered,

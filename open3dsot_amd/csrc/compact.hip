@@ -283,9 +283,14 @@ __global__ __launch_bounds__(256) void pool_bwd_partials_c_kernel(const float* _
                                                                   const float* __restrict__ yarg,
                                                                   const float* __restrict__ mean, int C,
                                                                   int nballs, int seg1_ball, int np0, int np1,
-                                                                  float* __restrict__ part) {
+                                                                  float* __restrict__ part,
+                                                                  const int32_t* __restrict__ argq,
+                                                                  float2* __restrict__ pkc) {
     __shared__ float sh[2][4];
     const int c = blockIdx.x, seg = blockIdx.y, k = blockIdx.z;
+    // pkc (C, nballs + 1): {gradient where out > 0, bits(arg-max column)} per (channel, ball) -- the pooled layer's
+    // gradient as the data / weight gradient kernels gather it; the dummy ball of the padding columns holds {0, -1}
+    if (pkc && seg == 0 && k == 0 && threadIdx.x == 0) pkc[(long)c * (nballs + 1) + nballs] = make_float2(0.f, __int_as_float(-1));
     const int s0 = seg ? seg1_ball : 0, s1 = seg ? nballs : seg1_ball;
     const int share = (s1 - s0 + POOL_BWD_SPLIT - 1) / POOL_BWD_SPLIT;
     const int b0 = s0 + k * share, b1 = min(b0 + share, s1);
@@ -294,6 +299,7 @@ __global__ __launch_bounds__(256) void pool_bwd_partials_c_kernel(const float* _
     for (int ball = b0 + threadIdx.x; ball < b1; ball += 256) {
         const long o = pool_index(c, ball, C, seg1_ball, np0, np1);
         const float g = out[o] > 0.f ? dOut[o] : 0.f;
+        if (pkc) pkc[(long)c * (nballs + 1) + ball] = make_float2(g, __int_as_float(argq[o]));
         s += g;
         q += g * (yarg[o] - mu);
     }
@@ -730,11 +736,27 @@ extern "C" int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t
     const int nseg = npoint1 > 0 ? 2 : 1;
     const int seg1_ball = B * npoint0, nballs = B * (npoint0 + npoint1), np1 = npoint1 > 0 ? npoint1 : npoint0;
     hipLaunchKernelGGL(pool_bwd_partials_c_kernel, dim3(C, nseg, POOL_BWD_SPLIT), dim3(256), 0, s, dOut, out, yarg, mean, C, nballs,
-                       seg1_ball, npoint0, np1, part);
+                       seg1_ball, npoint0, np1, part, nullptr, nullptr);
     hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)o3d_cdiv(ldp, 1024), C), dim3(256), 0, s, D, ldp, meta, start1);
     const long total = (long)C * nballs;
     hipLaunchKernelGGL(pool_scatter_c_kernel, dim3(o3d_cdiv(total, 256)), dim3(256), 0, s, dOut, out, argq, C, nballs,
                        seg1_ball, npoint0, np1, total, ldp, D);
+    return o3d_launch_status();
+}
+
+// Backward of the pool WITHOUT the dense gradient: the BatchNorm-backward partials as in o3d_pool_bwd_c plus
+// pkc (C, nballs + 1) = {masked gradient, bits(arg-max column)} per (channel, ball), which o3d_mlp_conv_dgrad_cp /
+// o3d_mlp_conv_wgrad2_cp gather through the column -> ball map.  Replaces a zero fill + a scatter of a (C, live columns)
+// tensor that the two gradient kernels then read back (about 1.5 GB of traffic per BAT step at batch 48).
+extern "C" int o3d_pool_bwd_pk(const float* dOut, const float* out, const int32_t* argq, const float* yarg,
+                               const float* mean, int B, int C, int npoint0, int npoint1, float* part, float* pkc,
+                               void* stream) {
+    if (!dOut || !out || !argq || !yarg || !mean || !part || !pkc || B <= 0 || C <= 0 || npoint0 <= 0 || npoint1 < 0)
+        return O3D_EINVAL;
+    const int nseg = npoint1 > 0 ? 2 : 1;
+    const int seg1_ball = B * npoint0, nballs = B * (npoint0 + npoint1), np1 = npoint1 > 0 ? npoint1 : npoint0;
+    hipLaunchKernelGGL(pool_bwd_partials_c_kernel, dim3(C, nseg, POOL_BWD_SPLIT), dim3(256), 0, o3d_stream(stream), dOut, out,
+                       yarg, mean, C, nballs, seg1_ball, npoint0, np1, part, argq, reinterpret_cast<float2*>(pkc));
     return o3d_launch_status();
 }
 

@@ -1298,6 +1298,26 @@ extern "C" int o3d_mlp_conv_dgrad_c(const float* dN, const float* Y, const float
 
 // dX (B,Cin,P) = W^T dY with dY = A1*dN + A2*Y + A3, no mask, no statistics: the gradient w.r.t. an
 // operand that is not the BN+ReLU output of a previous layer (the per-point operand of layer 0).
+int o3d_direct_dgrad_pooled_c(const float* pkc, const int32_t* cball, int nb1, const float* Y, const float* A1,
+                              const float* A2, const float* A3, const float* Wt, int Cin, int Cout, int P,
+                              const float* Yprev, const float* scale_p, const float* shift_p, const float* mean_p,
+                              float* dNprev, float* part, const float* w, const int32_t* meta, long start1, int tile,
+                              hipStream_t st);
+
+// o3d_mlp_conv_dgrad_c for the pooled (last) layer: its gradient comes from the pooled tensors (o3d_pool_bwd_pk)
+extern "C" int o3d_mlp_conv_dgrad_cp(const float* pkc, const int32_t* cball, int nb1, const float* Y, const float* A1,
+                                     const float* A2, const float* A3, const float* Wt, int Cin, int Cout, long ldp,
+                                     const float* w, const int32_t* meta, long start1, int tile, const float* Yprev,
+                                     const float* scale_p, const float* shift_p, const float* mean_p, float* dNprev,
+                                     float* part, void* stream) {
+    if (!pkc || !cball || nb1 <= 0 || !Y || !A1 || !A2 || !A3 || !Wt || !w || !meta || !Yprev || !scale_p || !shift_p ||
+        !mean_p || !dNprev || !part || ldp <= 0 || ldp > 0x7fffffff || !o3d_direct_ok(Cin, Cout, (int)ldp) ||
+        (tile != 64 && tile != 128))
+        return O3D_EINVAL;
+    return o3d_direct_dgrad_pooled_c(pkc, cball, nb1, Y, A1, A2, A3, Wt, Cin, Cout, (int)ldp, Yprev, scale_p, shift_p,
+                                     mean_p, dNprev, part, w, meta, start1, tile, o3d_stream(stream));
+}
+
 extern "C" int o3d_mlp_conv_dgrad_plain(const float* dN, const float* Y, const float* A1, const float* A2,
                                         const float* A3, const float* W, int B, int Cin, int Cout, int P,
                                         float* dX, void* stream) {

@@ -54,10 +54,11 @@ template <int NT>
 struct RawB {
     float v[4][NT];   // the main tensor (X, or dN); pooled: v[s][0..1] = {dOut masked by out > 0, bits(arg)}
     float y[4][NT];   // DY: raw conv output Y
+    float ar[4][NT];  // compact pooled source: bits of the ball's arg-max column, per (k row, column)
     float4 c1, c2, c3;  // per-k constants: (scale, shift, -) or (A1, A2, A3)
 };
 
-enum BMode { B_PLAIN = 0, B_XFORM = 1, B_DY = 2, B_DYPOOL = 3 };
+enum BMode { B_PLAIN = 0, B_XFORM = 1, B_DY = 2, B_DYPOOL = 3, B_DYPOOLC = 4 };
 
 struct DirectArgs {
     const float* A;        // (M, K) row-major: W for forward, W^T for the data gradient
@@ -65,6 +66,9 @@ struct DirectArgs {
     const float* Y;        // DY modes: raw output of this layer (B, K, P)
     const float* c1; const float* c2; const float* c3;   // per-k constants (K each)
     const float2* pk; int ns;   // pooled source (B, K, P/ns): {dOut masked by out > 0, bits(arg)}
+    // pooled source of the COMPACT layout (B_DYPOOLC): pk = (K, nb1) pairs {masked dOut, bits(arg-max column)} per
+    // (channel, ball), cball (P) = ball of every column (padding columns: the dummy ball nb1 - 1, pair {0, -1})
+    const int32_t* cball; int nb1;
     float* Out;            // (B, M, P)
     int M, K, P, B;
     // compact (distinct-neighbour) layout, csrc/compact.hip: per-position weights and the live column count
@@ -85,10 +89,17 @@ struct DirectArgs {
 
 template <int MODE, int NT>
 __device__ __forceinline__ void load_b(const DirectArgs& a, const float* xb, const float* yb, long rowP, int kb,
-                                       long pool_base, int np, RawB<NT>& f) {
+                                       long pool_base, int np, const int (&cb)[NT], RawB<NT>& f) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        if (MODE != B_DYPOOL) ldv<NT>(f.v[s], xb + (long)(kb + s) * rowP);
+        if (MODE != B_DYPOOL && MODE != B_DYPOOLC) ldv<NT>(f.v[s], xb + (long)(kb + s) * rowP);
+        if constexpr (MODE == B_DYPOOLC) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const float2 g = a.pk[(long)(kb + s) * a.nb1 + cb[t]];
+                f.v[s][t] = g.x; f.ar[s][t] = g.y;
+            }
+        }
         if (MODE >= B_DY) ldv<NT>(f.y[s], yb + (long)(kb + s) * rowP);
         if constexpr (MODE == B_DYPOOL && NT >= 2) {
             const float2 t = a.pk[pool_base + (long)(kb + s) * np];
@@ -117,6 +128,9 @@ __device__ __forceinline__ void compute_group(const RawB<NT>& f, const float4& a
             const int ak = __float_as_int(f.v[s][1]);
 #pragma unroll
             for (int t = 0; t < NT; ++t) bv[t] = (kk + t == ak) ? go : 0.f;
+        } else if constexpr (MODE == B_DYPOOLC) {        // kk = the lane's first column: non-zero only at the arg-max
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bv[t] = (__float_as_int(f.ar[s][t]) == kk + t) ? f.v[s][t] : 0.f;
         } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) bv[t] = f.v[s][t];
@@ -173,12 +187,20 @@ void direct_gemm_kernel(DirectArgs a) {
     for (int t = 0; t < NT; ++t) wv[t] = 1.f;
     if (a.w) ldv<NT>(wv, a.w + (long)b * a.P + p);
     const long rowP = a.P;
-    const float* xb = (MODE != B_DYPOOL) ? a.X + (long)b * a.K * rowP + p : nullptr;
+    const float* xb = (MODE != B_DYPOOL && MODE != B_DYPOOLC) ? a.X + (long)b * a.K * rowP + p : nullptr;
     const float* yb = (MODE >= B_DY) ? a.Y + (long)b * a.K * rowP + p : nullptr;
     const float* wa = a.A + (long)(m0 + l31) * a.K + 4 * h;
     const long wstep = 32L * a.K;
     int np = 1, kk = 0;
     long pool_base = 0;
+    int cb[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) cb[t] = 0;
+    if constexpr (MODE == B_DYPOOLC) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) cb[t] = a.cball[p + t];
+        kk = p;                  // compared against the absolute arg-max column
+    }
     if (MODE == B_DYPOOL) {
         np = a.P / a.ns;
         const int j = p / a.ns;
@@ -205,7 +227,7 @@ void direct_gemm_kernel(DirectArgs a) {
     auto load = [&](auto stc, int g) {
         constexpr int st = decltype(stc)::value;
         const int kb = 8 * g + 4 * h;
-        load_b<MODE, NT>(a, xb, yb, rowP, kb, pool_base, np, f[st]);
+        load_b<MODE, NT>(a, xb, yb, rowP, kb, pool_base, np, cb, f[st]);
         wa0[st] = *reinterpret_cast<const float4*>(wa + 8 * g);
         if constexpr (MT == 2) wa1[st] = *reinterpret_cast<const float4*>(wa + 8 * g + wstep);
         else wa1[st] = wa0[st];
@@ -402,6 +424,21 @@ int o3d_direct_dgrad(const float* dN, const float* pk, int ns,
     a.Out = dNprev; a.M = Cin; a.K = Cout; a.P = P; a.B = B; a.part = part;
     a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p;
     return dN ? launch_direct<B_DY, 1>(a, tile, st) : launch_direct<B_DYPOOL, 1>(a, tile, st);
+}
+
+// the same from the pooled tensors of the compact layout: pkc (Cout, nb1) pairs per (channel, ball), cball (P)
+int o3d_direct_dgrad_pooled_c(const float* pkc, const int32_t* cball, int nb1, const float* Y, const float* A1,
+                              const float* A2, const float* A3, const float* Wt, int Cin, int Cout, int P,
+                              const float* Yprev, const float* scale_p, const float* shift_p, const float* mean_p,
+                              float* dNprev, float* part, const float* w, const int32_t* meta, long start1, int tile,
+                              hipStream_t st) {
+    DirectArgs a = {};
+    a.w = w; a.meta = meta; a.start1 = start1;
+    a.A = Wt; a.Y = Y; a.c1 = A1; a.c2 = A2; a.c3 = A3; a.pk = reinterpret_cast<const float2*>(pkc); a.ns = 4;
+    a.cball = cball; a.nb1 = nb1;
+    a.Out = dNprev; a.M = Cin; a.K = Cout; a.P = P; a.B = 1; a.part = part;
+    a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p;
+    return launch_direct<B_DYPOOLC, 1>(a, tile, st);
 }
 
 // ---- 1-D conv stacks (the trackers' heads) on the flat (C, P) layout, P = B*N columns -------------------------

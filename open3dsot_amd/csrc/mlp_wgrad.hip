@@ -19,8 +19,10 @@ namespace {
 
 struct Wgrad2Args {
     const float* dN;       // (B,Cout,P) dense source or NULL
-    const float2* pk;      // pooled source (B,Cout,P/ns)
+    const float2* pk;      // pooled source (B,Cout,P/ns); compact pooled source (POOLED == 2): (Cout, nb1) pairs
+                           // {masked dOut, bits(arg-max column)} per (channel, ball)
     int ns;
+    const int32_t* cball; int nb1;   // POOLED == 2: ball of every column (padding columns: the dummy ball nb1 - 1)
     const float* Y;        // (B,Cout,P)
     const float* A1; const float* A2; const float* A3;
     const float* X;        // (B,Cin,P) raw output of the producer
@@ -34,7 +36,7 @@ struct Wgrad2Args {
                            // segment 0's (A1..A3 after Cout floats, in_scale/in_shift after Cin floats)
 };
 
-template <int TM, int TN, bool POOLED>
+template <int TM, int TN, int POOLED>
 __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
     constexpr int WM = TM / 64, WN = TN / 64, WK = 4 / (WM * WN);
     constexpr int CP = (TM + TN == 128) ? 64 : 32;      // positions per staged chunk
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
     const float x_floor = plain_x ? -INFINITY : 0.f;
     const int chunks_per_b = a.P / CP;
     const int r0 = tid / F, c4 = tid % F;
-    const int np = POOLED ? a.P / a.ns : 1;
+    const int np = POOLED == 1 ? a.P / a.ns : 1;
 
     // per-row constants of this thread's staging rows
     float ka1[PA], ka2[PA], ka3[PA], ksc[PB], ksh[PB];
@@ -109,6 +111,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
     }
 
     float4 rg[PA], ry[PA], rx[PB];
+    float4 rg2[POOLED == 2 ? PA : 1];      // compact pooled source: the second pair of (value, arg) per row
     float4 rw = make_float4(1.f, 1.f, 1.f, 1.f);
     int rk = 0;
     auto load_chunk = [&](int chl) {
@@ -116,11 +119,18 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
         const long b = chg / chunks_per_b;
         const int p = (int)(chg - b * chunks_per_b) * CP + 4 * c4;
         if (a.w) rw = *reinterpret_cast<const float4*>(&a.w[b * a.P + p]);
+        int4 cb = make_int4(0, 0, 0, 0);
+        if constexpr (POOLED == 2) { cb = *reinterpret_cast<const int4*>(&a.cball[p]); rk = p; }
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const long row = b * a.Cout + co0 + r0 + RPP * i;
             ry[i] = *reinterpret_cast<const float4*>(&a.Y[row * a.P + p]);
-            if (POOLED) {
+            if constexpr (POOLED == 2) {
+                const float2* pr = a.pk + row * a.nb1;
+                const float2 g0 = pr[cb.x], g1 = pr[cb.y], g2 = pr[cb.z], g3 = pr[cb.w];
+                rg[i] = make_float4(g0.x, g0.y, g1.x, g1.y);
+                rg2[i] = make_float4(g2.x, g2.y, g3.x, g3.y);
+            } else if (POOLED) {
                 const int j = p / a.ns;
                 const float2 t = a.pk[row * np + j];
                 rg[i].x = t.x; rg[i].y = t.y;
@@ -137,7 +147,12 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             float4 g;
-            if (POOLED) {
+            if constexpr (POOLED == 2) {       // rk = first column of the thread's four: non-zero only at the arg-max
+                g.x = (__float_as_int(rg[i].y) == rk + 0) ? rg[i].x : 0.f;
+                g.y = (__float_as_int(rg[i].w) == rk + 1) ? rg[i].z : 0.f;
+                g.z = (__float_as_int(rg2[i].y) == rk + 2) ? rg2[i].x : 0.f;
+                g.w = (__float_as_int(rg2[i].w) == rk + 3) ? rg2[i].z : 0.f;
+            } else if (POOLED) {
                 const int ak = __float_as_int(rg[i].y);
                 const float go = rg[i].x;
                 g.x = (rk + 0 == ak) ? go : 0.f; g.y = (rk + 1 == ak) ? go : 0.f;
@@ -213,14 +228,16 @@ template <int TM, int TN>
 int launch_wgrad2(const Wgrad2Args& a, hipStream_t s) {
     constexpr int CP = (TM + TN == 128) ? 64 : 32;
     const size_t lds = sizeof(float) * 2 * (TM + TN) * (CP + 4);
-    const void* fn = a.dN ? reinterpret_cast<const void*>(wgrad2_kernel<TM, TN, false>)
-                          : reinterpret_cast<const void*>(wgrad2_kernel<TM, TN, true>);
+    const void* fn = a.dN ? reinterpret_cast<const void*>(wgrad2_kernel<TM, TN, 0>)
+                   : a.cball ? reinterpret_cast<const void*>(wgrad2_kernel<TM, TN, 2>)
+                             : reinterpret_cast<const void*>(wgrad2_kernel<TM, TN, 1>);
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return O3D_ELAUNCH;
     const int ntile = (a.Cout / TM) * (a.Cin / TN);
-    if (a.dN) hipLaunchKernelGGL((wgrad2_kernel<TM, TN, false>), dim3(ntile * a.nslices), dim3(256), lds, s, a);
-    else      hipLaunchKernelGGL((wgrad2_kernel<TM, TN, true>), dim3(ntile * a.nslices), dim3(256), lds, s, a);
+    if (a.dN)         hipLaunchKernelGGL((wgrad2_kernel<TM, TN, 0>), dim3(ntile * a.nslices), dim3(256), lds, s, a);
+    else if (a.cball) hipLaunchKernelGGL((wgrad2_kernel<TM, TN, 2>), dim3(ntile * a.nslices), dim3(256), lds, s, a);
+    else              hipLaunchKernelGGL((wgrad2_kernel<TM, TN, 1>), dim3(ntile * a.nslices), dim3(256), lds, s, a);
     return o3d_launch_status();
 }
 
@@ -255,7 +272,7 @@ extern "C" long o3d_mlp_conv_wgrad2_scratch(int B, int Cin, int Cout, int P) {
 static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y, const float* A1, const float* A2,
                        const float* A3, const float* X, const float* in_scale, const float* in_shift, int B, int Cin,
                        int Cout, int P, const float* w, const int32_t* meta, long start1, float* scratch, float* dW,
-                       void* stream);
+                       void* stream, const int32_t* cball = nullptr, int nb1 = 0);
 
 extern "C" int o3d_mlp_conv_wgrad2(const float* dN, const float* pk, int ns, const float* Y, const float* A1,
                                    const float* A2, const float* A3, const float* X, const float* in_scale,
@@ -275,10 +292,21 @@ extern "C" int o3d_mlp_conv_wgrad2_c(const float* dN, const float* Y, const floa
                        scratch, dW, stream);
 }
 
+// compact layout with the pooled layer's gradient read from the pooled tensors (pkc (Cout, nb1), cball (ldp))
+extern "C" int o3d_mlp_conv_wgrad2_cp(const float* pkc, const int32_t* cball, int nb1, const float* Y, const float* A1,
+                                      const float* A2, const float* A3, const float* X, const float* in_scale,
+                                      const float* in_shift, int Cin, int Cout, long ldp, const float* w,
+                                      const int32_t* meta, long start1, float* scratch, float* dW, void* stream) {
+    if (!pkc || !cball || nb1 <= 0 || !w || !meta || ldp <= 0 || ldp > 0x7fffffff || start1 < 0 || start1 % 256 != 0)
+        return O3D_EINVAL;
+    return wgrad2_impl(nullptr, pkc, 4, Y, A1, A2, A3, X, in_scale, in_shift, 1, Cin, Cout, (int)ldp, w, meta, start1,
+                       scratch, dW, stream, cball, nb1);
+}
+
 static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y, const float* A1, const float* A2,
                        const float* A3, const float* X, const float* in_scale, const float* in_shift, int B, int Cin,
                        int Cout, int P, const float* w, const int32_t* meta, long start1, float* scratch, float* dW,
-                       void* stream) {
+                       void* stream, const int32_t* cball, int nb1) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || P <= 0 || P % 64 || !Y || !A1 || !A2 || !A3 ||
         !X || (in_scale == nullptr) != (in_shift == nullptr) || !scratch || !dW || (!dN && (!pk || ns < 4 || ns % 4)))
         return O3D_EINVAL;
@@ -292,7 +320,7 @@ static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y,
     a.chunks_per_block = (a.total_chunks + nsl - 1) / nsl;
     a.nslices = nsl;
     a.part = scratch;
-    a.w = w; a.meta = meta; a.start1 = start1;
+    a.w = w; a.meta = meta; a.start1 = start1; a.cball = cball; a.nb1 = nb1;
     hipStream_t s = o3d_stream(stream);
     int rc;
     if (TM == 128 && TN == 128) rc = launch_wgrad2<128, 128>(a, s);

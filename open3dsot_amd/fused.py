@@ -57,6 +57,11 @@ capi.register("o3d_pack_points", [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i
 capi.register("o3d_center_term", [_vp, _vp, _i, _i, _i, _vp, _vp])
 capi.register("o3d_pool_fwd_c", [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_bwd_c", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _l, _vp, _vp, _vp])
+capi.register("o3d_pool_bwd_pk", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_dgrad_cp", [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _l, _i, _vp, _vp, _vp,
+                                        _vp, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_wgrad2_cp", [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _l, _vp, _vp,
+                                         _vp])
 capi.register("o3d_group_reduce_c", [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp,
                                      _vp, _vp])
 capi.register("o3d_direct_tile", [ctypes.c_long, _i, _i])
@@ -626,11 +631,20 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                 else:
                     dst.copy_(dOuts[s_])
         part = torch.empty((nseg, POOL_BWD_SPLIT, 2, Cl), device=dev, dtype=f32)
-        dN = torch.empty((Cl, ldp), device=dev, dtype=f32)          # dense class-sum gradient of the pooled layer
         np1 = npoints[1] if nseg == 2 else 0
-        _call("pool_bwd", 0.0, lib.o3d_pool_bwd_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
-              means[-1].data_ptr(), B, Cl, npoints[0], np1, meta.data_ptr(), start1, ldp, dN.data_ptr(), part.data_ptr(),
-              st)
+        pkc = None
+        if _POOLED_PK["on"]:
+            # the dense gradient of the pooled layer (one non-zero per ball and channel) is never written: its two
+            # consumers gather {gradient, arg-max column} pairs per (channel, ball) through the column -> ball map
+            dN = None
+            pkc = torch.empty((Cl, nballs + 1, 2), device=dev, dtype=f32)
+            _call("pool_bwd", 0.0, lib.o3d_pool_bwd_pk, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
+                  means[-1].data_ptr(), B, Cl, npoints[0], np1, part.data_ptr(), pkc.data_ptr(), st)
+        else:
+            dN = torch.empty((Cl, ldp), device=dev, dtype=f32)          # dense class-sum gradient of the pooled layer
+            _call("pool_bwd", 0.0, lib.o3d_pool_bwd_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
+                  means[-1].data_ptr(), B, Cl, npoints[0], np1, meta.data_ptr(), start1, ldp, dN.data_ptr(),
+                  part.data_ptr(), st)
         dtile = 0
         main, side = torch.cuda.current_stream(), _side_stream(dev)
         keep = []        # buffers the side stream still reads: must outlive the join at the end
@@ -725,21 +739,33 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             flops = (2.0 * Cin * Cout, meta, ldp)      # executed FLOPs = per live column (count read back when profiling)
             dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
             wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, ldp),), device=dev, dtype=f32)
-            keep += [dN, wpart, coef]
+            keep += [dN, pkc, wpart, coef]
             side.wait_stream(main)
             with torch.cuda.stream(side):
-                _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
-                      Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Cin, Cout, ldp,
-                      cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(), dW.data_ptr(), side.cuda_stream)
+                if dN is None:
+                    _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_cp, pkc.data_ptr(), cball.data_ptr(), nballs + 1,
+                          Ys[l].data_ptr(), A[0], A[1], A[2], Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(),
+                          shifts[l - 1].data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(),
+                          dW.data_ptr(), side.cuda_stream)
+                else:
+                    _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
+                          Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Cin, Cout, ldp,
+                          cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(), dW.data_ptr(), side.cuda_stream)
             grads[3 * l] = dW
             Wt = Ws[l].t().contiguous()
             dNp = torch.empty((Cin, ldp), device=dev, dtype=f32)
             dtile = _direct_tile(lib, ldp, Cin)
             part = torch.empty((ldp // dtile, 2, Cin), device=dev, dtype=f32)
-            _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
-                  Wt.data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1, dtile, Ys[l - 1].data_ptr(),
-                  scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),
-                  part.data_ptr(), st)
+            if dN is None:
+                _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_cp, pkc.data_ptr(), cball.data_ptr(), nballs + 1,
+                      Ys[l].data_ptr(), A[0], A[1], A[2], Wt.data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1,
+                      dtile, Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(),
+                      means[l - 1].data_ptr(), dNp.data_ptr(), part.data_ptr(), st)
+            else:
+                _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
+                      Wt.data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1, dtile, Ys[l - 1].data_ptr(),
+                      scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),
+                      part.data_ptr(), st)
             dN = dNp
         main.wait_stream(side)       # join: every weight gradient is complete before autograd sees it
         del keep
@@ -761,6 +787,15 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
 # quadratic); the balanced walk (equal shares of the sorted entries per thread, one atomic per run of equal points)
 # takes 0.50 ms including the index build.  ON by default; O3D_REDUCE_GATHER=0 selects the atomic kernel.
 _REDUCE_GATHER = {"on": _os.environ.get("O3D_REDUCE_GATHER", "1") != "0"}
+
+
+# Pooled layer's gradient gathered from the pooled tensors instead of a dense (C, live columns) tensor (zero fill +
+# scatter + two reads); O3D_POOLED_PK=0 selects the dense path (A/B switch)
+_POOLED_PK = {"on": _os.environ.get("O3D_POOLED_PK", "1") != "0"}
+
+
+def set_pooled_pk(enabled):
+    _POOLED_PK["on"] = bool(enabled)
 
 
 def set_reduce_gather(enabled):

@@ -579,3 +579,40 @@ def test_fused_path_on_a_non_current_device():
     assert torch.cuda.current_device() == 0
     got = fused.sa_group_mlp_pool(grouper, mlp1, xyz.to(dev1), new_xyz.to(dev1), feats.to(dev1))
     assert got.device == dev1 and rel(got, want) < 1e-6
+
+
+@pytest.mark.parametrize("kind,B,full", [("sa1", 3, False), ("sa2", 3, False), ("sa3", 3, False), ("rpn", 3, False),
+                                         ("sa1", 48, True), ("sa3", 48, True)])
+def test_pooled_pairs_match_dense_pooled_gradient(kind, B, full):
+    """the pooled layer's gradient gathered from {gradient, arg-max column} pairs per (channel, ball)
+    (o3d_pool_bwd_pk + o3d_mlp_conv_dgrad_cp / o3d_mlp_conv_wgrad2_cp) against the dense (C, live columns) tensor
+    (zero fill + scatter, o3d_pool_bwd_c): the same terms in the same order -> bitwise equal gradients, through the
+    two-segment (template + search) call"""
+    import copy
+    from open3dsot_amd import fused
+    grouper, mlp, xyz_s, new_s, feats_s = make_case(kind, B=B, full=full)
+    N, npoint = xyz_s.shape[1], new_s.shape[1]
+    xyz_t = (xyz_s[:, :N // 2, :] * 0.9 + 0.05).contiguous()
+    new_t = xyz_t[:, :npoint // 2, :].contiguous()
+    feats_t = torch.randn(feats_s.shape[0], feats_s.shape[1], N // 2, device="cuda") if feats_s is not None else None
+    grads = []
+    was, was_rg = fused._POOLED_PK["on"], fused.reduce_gather_enabled()
+    fused.set_reduce_gather(False)          # (the LDS-atomic orders of the layer-0 reduce differ run to run either way)
+    try:
+        for pk in (False, True):
+            fused.set_pooled_pk(pk)
+            m = copy.deepcopy(mlp)
+            segs = [[t.clone().requires_grad_(True) if t is not None else None for t in sg]
+                    for sg in ((xyz_t, new_t, feats_t), (xyz_s, new_s, feats_s))]
+            outs = fused.sa_group_mlp_pool_pair(grouper, m, tuple(segs[0]), tuple(segs[1]))
+            gen = torch.Generator(device="cuda").manual_seed(4)
+            torch.autograd.backward(list(outs), [torch.randn(o.shape, device="cuda", generator=gen) for o in outs])
+            grads.append([(n1, p.grad) for n1, p in m.named_parameters()])
+    finally:
+        fused.set_pooled_pk(was)
+        fused.set_reduce_gather(was_rg)
+    for (n1, a), (_, b) in zip(*grads):
+        if n1.startswith("layer0"):        # behind the atomic layer-0 reduce: equal up to its summation order
+            assert l2rel(a, b) < 5e-5, (n1, l2rel(a, b))
+        else:
+            assert torch.equal(a, b), (n1, l2rel(a, b))
