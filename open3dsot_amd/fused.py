@@ -528,11 +528,11 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             if not unit:
                 centers = centers * cfg.inv_radius
         Z = torch.empty((C0, ldz), device=dev, dtype=f32)
-        if Cin0p == Cin0:
-            W0p = Ws[0]
-        else:       # zero-padded copy in a buffer kept on the module: one copy launch per step
-            W0p = _padded(cfg.bns[0], "_o3d_w0p", (C0, Cin0p), dev)
-            W0p[:, :Cin0].copy_(Ws[0])
+        # zero-padded / transposed weight copies come from the device's WeightPrep table (open3dsot_amd/fused_heads.py):
+        # inside a tracker forward they were all refreshed by ONE launch, otherwise `get` copies on the spot
+        from .fused_heads import prep_for
+        prep = prep_for(dev)
+        W0p = prep.get(params[0], C0, Cin0p)
         _call("conv_fwd_points", 2.0 * Cin0p * C0 * ldz, lib.o3d_mlp_conv_fwd, X0n.data_ptr(), W0p.data_ptr(),
               None, None, 1, Cin0p, C0, ldz, Z.data_ptr(), None, None, st)
         counts = [float(pm) for pm in Pmaxs]          # BatchNorm counts every slot (copies included)
@@ -590,6 +590,10 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         if need_bwd:
             ctx.cfg = cfg
             ctx.versions = _versions(params)
+            # weights as the backward's GEMMs want them: W_l^T for the data gradients, W0^T padded to 64 rows
+            ctx.Wts = [None] + [prep.get(params[3 * l], Ws[l].shape[1], Ws[l].shape[0], transpose=True) for l in range(1, L)]
+            want_in = any(ctx.needs_input_grad[2:2 + 4 * nseg])
+            ctx.W0t = prep.get(params[0], -(-Cin0 // 64) * 64, C0, transpose=True) if want_in else None
             ctx.geom = (B, ns, C, nseg, Ns, Npads, npoints, Pmaxs, starts, pt_bases, ball_bases, nballs_s)
             ctx.saved = (X0n, centers, ball_off, ball_cnt, gp, cball, cw, meta, Ws, gammas, Ys, means, invstds, scales,
                          shifts, out.detach(), argq, yarg)
@@ -720,8 +724,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                 if want_xyz or want_feats:
                     # dX = W0^T . S as a plain forward GEMM on the direct MFMA kernel: rows padded to a multiple of 64
                     Cinm = -(-Cin // 64) * 64
-                    W0t = _padded(cfg.bns[0], "_o3d_w0t", (Cinm, Cout), dev)                          # (Cinm, Cout), rows >= Cin zero
-                    W0t[:Cin].copy_(Ws[0].t())
+                    W0t = ctx.W0t                                                          # (Cinm, Cout), rows >= Cin zero
                     dX = torch.empty((Cinm, ldz), device=dev, dtype=f32)
                     _call("conv_dgrad_points", 2.0 * Cinm * Cout * ldz, lib.o3d_mlp_conv_fwd, S.data_ptr(), W0t.data_ptr(),
                           None, None, 1, Cout, Cinm, ldz, dX.data_ptr(), None, None, st)
@@ -752,7 +755,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                           Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Cin, Cout, ldp,
                           cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(), dW.data_ptr(), side.cuda_stream)
             grads[3 * l] = dW
-            Wt = Ws[l].t().contiguous()
+            Wt = ctx.Wts[l]
             dNp = torch.empty((Cin, ldp), device=dev, dtype=f32)
             dtile = _direct_tile(lib, ldp, Cin)
             part = torch.empty((ldp // dtile, 2, Cin), device=dev, dtype=f32)
@@ -789,9 +792,14 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
 _REDUCE_GATHER = {"on": _os.environ.get("O3D_REDUCE_GATHER", "1") != "0"}
 
 
-# Pooled layer's gradient gathered from the pooled tensors instead of a dense (C, live columns) tensor (zero fill +
-# scatter + two reads); O3D_POOLED_PK=0 selects the dense path (A/B switch)
-_POOLED_PK = {"on": _os.environ.get("O3D_POOLED_PK", "1") != "0"}
+# Pooled layer's gradient gathered from {gradient, arg-max column} pairs per (channel, ball) instead of a dense
+# (C, live columns) tensor (zero fill + scatter + two reads, ~1.5 GB of traffic per BAT step at batch 48).  Bitwise the
+# same gradients (tests/test_fused_gpu.py::test_pooled_pairs_match_dense_pooled_gradient), but measured on the MI355X
+# (BAT, batch 48, same run A/B) it LOSES: 7.73 vs 7.02 ms per step -- the pool backward drops from 0.29 to 0.11 ms, the
+# weight gradients pay +0.06 ms, and the five data-gradient launches of the pooled layers go from 1.13 to 1.96 ms: four
+# 8-byte gathers per k row and lane instead of one dwordx4 stream starve the barrier-free MFMA loop.  OFF by default
+# (O3D_POOLED_PK=1 enables it); a ball-aligned tile order would be needed to make the pooled read a broadcast.
+_POOLED_PK = {"on": _os.environ.get("O3D_POOLED_PK", "0") == "1"}
 
 
 def set_pooled_pk(enabled):
