@@ -449,6 +449,17 @@ int o3d_xcorr_reduce(const float* dN, const float* Y0, const float* A1, const fl
                      const float* sim, const float* W0, int ldw, int B, int M, int N, int C0, float* S, long lds,
                      float* dsim_part, float* dw_part, void* stream);
 
+/* ---- tracking inference: one set abstraction in ONE kernel ---------------------
+ * Eval mode (models/base_model.py:59-86 tracks frame by frame, batch 1, BatchNorm on running statistics): gather +
+ * centre subtraction + three 1x1 convolutions with BatchNorm + ReLU + max over nsample, activations in LDS.
+ * out (B, C2, np) from Z (C0, ldz) = W0 . [xyz ; feats] per point (o3d_pack_points + o3d_mlp_conv_fwd),
+ * idx (B, np, ns), centers (B*np, 3) or NULL, v_l (4, C_l) = o3d_bn_eval_consts of layer l.
+ * C0 % 8 == 0, C1 % 32 == 0, C2 % 32 == 0, ns a power of two <= 32, (B*np*ns) % 32 == 0; ld = point columns per
+ * cloud in Z, pt_base = first column of this set of clouds. */
+int o3d_sa_eval_fused(const float* Z, long ldz, const int32_t* idx, const float* centers, const float* W0, int ldw,
+                      const float* v0, const float* W1, const float* v1, const float* W2, const float* v2, int C0, int C1,
+                      int C2, int B, int np, int ns, int ld, long pt_base, float* out, void* stream);
+
 /* ---- tracker losses (next row of SURVEY.md section 8f: the loss as one launch) ----------------------
  * MatchingBaseModel.compute_loss (models/base_model.py:122-164) + the BoxCloud term (models/bat.py:57-65)
  * + the weighted total (models/bat.py:131-137, models/p2b.py:69-74) and the gradients of the total.

@@ -25,6 +25,7 @@ SOURCES = [
     ("pointwise.hip", []),
     ("heads.hip", []),
     ("xcorr.hip", []),
+    ("sa_eval.hip", []),
     ("loss.hip", []),
     ("boxcloud.hip", []),
     ("capi_misc.hip", []),

@@ -62,6 +62,7 @@ capi.register("o3d_mlp_conv_dgrad_cp", [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _
                                         _vp, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_wgrad2_cp", [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _l, _vp, _vp,
                                          _vp])
+capi.register("o3d_sa_eval_fused", [_vp, _l, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _l, _vp, _vp])
 capi.register("o3d_group_reduce_c", [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp,
                                      _vp, _vp])
 capi.register("o3d_direct_tile", [ctypes.c_long, _i, _i])
@@ -824,6 +825,87 @@ def _padded(owner, name, shape, dev):
     return buf
 
 
+# ---- tracking inference: one kernel per set abstraction (csrc/sa_eval.hip) --------------------------------------
+_EVAL_FUSED = {"on": _os.environ.get("O3D_EVAL_FUSED", "1") != "0"}
+
+
+def set_eval_fused(enabled):
+    _EVAL_FUSED["on"] = bool(enabled)
+
+
+def _eval_vec(lib, bn, gamma, beta, st):
+    """(4, C) eval-mode BatchNorm constants, cached on the module until one of its tensors changes"""
+    key = (bn.running_mean._version, bn.running_var._version, gamma._version, beta._version, bn.running_mean.data_ptr(),
+           gamma.data_ptr(), float(bn.eps))
+    hit = getattr(bn, "_o3d_eval_vec", None)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    vec = torch.empty((4, 1, bn.running_mean.numel()), device=bn.running_mean.device, dtype=torch.float32)
+    _eval_consts(lib, bn, gamma.detach(), beta.detach(), vec, 1, st)
+    object.__setattr__(bn, "_o3d_eval_vec", (key, vec))
+    return vec
+
+
+def _eval_fused_ok(mlp, layers, segs, nxyz):
+    if not _EVAL_FUSED["on"] or mlp.training or layers is None or len(layers) != 3:
+        return False
+    if torch.is_grad_enabled() and (any(t is not None and t.requires_grad for sg in segs for t in sg[:3]) or
+                                    any(p.requires_grad for p in mlp.parameters())):
+        return False
+    c = [conv.out_channels for conv, _ in layers]
+    for sg in segs:
+        B, npoint, ns = sg[3].shape
+        if ns > 32 or (ns & (ns - 1)) or (B * npoint * ns) % 32:
+            return False
+    return c[0] % 8 == 0 and c[1] % 32 == 0 and c[2] % 32 == 0
+
+
+def _run_eval(mlp, layers, segs, nxyz, inv_radius):
+    """eval-mode QueryAndGroup + SharedMLP + max for one or two sets of clouds: per-point layer-0 GEMM for all of them,
+    then ONE kernel per set (csrc/sa_eval.hip).  -> [pooled (B, C_last, npoint_s)]"""
+    lib = capi.load()
+    dev = segs[0][3].device
+    f32 = torch.float32
+    nseg = len(segs)
+    B, _, ns = segs[0][3].shape
+    C = segs[0][2].shape[1] if segs[0][2] is not None else 0
+    Ws = [conv.weight.detach().reshape(conv.out_channels, -1) for conv, _ in layers]
+    Cin0, C0 = nxyz + C, Ws[0].shape[0]
+    Ns = [sg[2].shape[2] if sg[2] is not None else sg[0].shape[1] for sg in segs]
+    Npads = [-(-n // TILE) * TILE for n in Ns]
+    pt_bases = [0, B * Npads[0]][:nseg]
+    ldz = sum(B * n for n in Npads)
+    Cin0p = -(-Cin0 // 16) * 16 if Cin0 > 16 else Cin0
+    with torch.cuda.device(dev):
+        st = _stream()
+        X0n = torch.empty((Cin0p, ldz), device=dev, dtype=f32)
+        xs = [sg[0].detach().contiguous() if nxyz else None for sg in segs]
+        fs = [sg[2].detach().contiguous() if C else None for sg in segs]
+        _call("pack_points", 0.0, lib.o3d_pack_points, _ptr(xs[0]), _ptr(fs[0]), Ns[0], Npads[0],
+              _ptr(xs[-1]) if nseg == 2 else None, _ptr(fs[-1]) if nseg == 2 else None, Ns[-1] if nseg == 2 else 0,
+              Npads[-1] if nseg == 2 else 0, B, nxyz, C, float(inv_radius), Cin0p, X0n.data_ptr(), st)
+        from .fused_heads import prep_for
+        W0p = prep_for(dev).get(layers[0][0].weight, C0, Cin0p)
+        Z = torch.empty((C0, ldz), device=dev, dtype=f32)
+        _call("conv_fwd_points", 2.0 * Cin0p * C0 * ldz, lib.o3d_mlp_conv_fwd, X0n.data_ptr(), W0p.data_ptr(), None, None, 1,
+              Cin0p, C0, ldz, Z.data_ptr(), None, None, st)
+        vecs = [_eval_vec(lib, bn, bn.weight, bn.bias, st) for _, bn in layers]
+        outs = []
+        for s_, sg in enumerate(segs):
+            npoint = sg[3].shape[1]
+            centers = None
+            if nxyz:
+                centers = sg[1].detach().reshape(-1, 3)
+                centers = (centers * inv_radius if inv_radius != 1.0 else centers).contiguous()
+            out = torch.empty((B, Ws[2].shape[0], npoint), device=dev, dtype=f32)
+            _call("sa_eval_fused", 0.0, lib.o3d_sa_eval_fused, Z.data_ptr(), ldz, sg[3].data_ptr(), _ptr(centers),
+                  Ws[0].data_ptr(), Cin0, vecs[0].data_ptr(), Ws[1].data_ptr(), vecs[1].data_ptr(), Ws[2].data_ptr(),
+                  vecs[2].data_ptr(), C0, Ws[1].shape[0], Ws[2].shape[0], B, npoint, ns, Npads[s_], pt_bases[s_],
+                  out.data_ptr(), st)
+            outs.append(out)
+    return outs
+
+
 def _compact_ok(layers, npoint, ns, B):
     if ns > 64 or B * npoint > 65536:
         return False
@@ -842,6 +924,8 @@ def _run(mlp, xyz, new_xyz, feats, idx, nxyz, inv_radius):
     for conv, bn in layers:
         params += [conv.weight, bn.weight, bn.bias]
     B, npoint, ns = idx.shape
+    if _eval_fused_ok(mlp, layers, [(xyz, new_xyz, feats, idx)], nxyz):
+        return _run_eval(mlp, layers, [(xyz, new_xyz, feats, idx)], nxyz, float(inv_radius))[0]
     if _COMPACT["on"] and _compact_ok(layers, npoint, ns, B):
         return FusedGroupedMLPCompact.apply(cfg, 1, xyz, new_xyz, feats, idx, *params)
     return FusedGroupedMLP.apply(xyz, new_xyz, feats, idx, cfg, *params)
@@ -873,9 +957,12 @@ def sa_group_mlp_pool_pair(grouper, mlp, a, b):
     if not (_shape_ok(np_a, ns) and _shape_ok(np_b, ns) and _compact_ok(layers, np_a, ns, B) and
             _compact_ok(layers, np_b, ns, B) and (B * np_a * ns) % 256 == 0):
         return None
+    inv_r = float(1.0 / grouper.radius if grouper.normalize_xyz else 1.0)
+    if _eval_fused_ok(mlp, layers, [(a[0], a[1], a[2], idx_a), (b[0], b[1], b[2], idx_b)], 3):
+        return tuple(_run_eval(mlp, layers, [(a[0], a[1], a[2], idx_a), (b[0], b[1], b[2], idx_b)], 3, inv_r))
     cfg = _Cfg()
     cfg.nxyz, cfg.training = 3, bool(mlp.training)
-    cfg.inv_radius = float(1.0 / grouper.radius if grouper.normalize_xyz else 1.0)
+    cfg.inv_radius = inv_r
     cfg.bns = [bn for _, bn in layers]
     params = []
     for conv, bn in layers:

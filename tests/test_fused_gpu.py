@@ -616,3 +616,57 @@ def test_pooled_pairs_match_dense_pooled_gradient(kind, B, full):
             assert l2rel(a, b) < 5e-5, (n1, l2rel(a, b))
         else:
             assert torch.equal(a, b), (n1, l2rel(a, b))
+
+
+@pytest.mark.parametrize("kind", ["sa1", "sa2", "sa3", "rpn"])
+def test_eval_fused_kernel_matches_layerwise_path(kind):
+    """tracking inference (eval mode, no autograd): the one-kernel set abstraction of csrc/sa_eval.hip against the
+    layer-by-layer kernels and the fp64 shadow; single call and the template + search pair"""
+    from open3dsot_amd import fused
+    grouper, mlp, xyz, new_xyz, feats = make_case(kind, train=False)
+    idx = grouper.query(xyz, new_xyz)
+    ref64, _, _ = shadow64(mlp, xyz, new_xyz, feats, idx, False)
+    N, npoint = xyz.shape[1], new_xyz.shape[1]
+    xyz_t = (xyz[:, :N // 2, :] * 0.9 + 0.05).contiguous()
+    new_t = xyz_t[:, :npoint // 2, :].contiguous()
+    feats_t = torch.randn(feats.shape[0], feats.shape[1], N // 2, device="cuda") if feats is not None else None
+    res = {}
+    was = fused._EVAL_FUSED["on"]
+    try:
+        for on in (False, True):
+            fused.set_eval_fused(on)
+            with torch.no_grad():
+                one = fused.sa_group_mlp_pool(grouper, mlp, xyz, new_xyz, feats)
+                pair = fused.sa_group_mlp_pool_pair(grouper, mlp, (xyz_t, new_t, feats_t), (xyz, new_xyz, feats))
+            res[on] = (one, pair)
+    finally:
+        fused.set_eval_fused(was)
+    assert rel(res[True][0], ref64) < 2e-5, rel(res[True][0], ref64)
+    assert rel(res[True][0], res[False][0]) < 1e-5
+    if res[False][1] is not None:
+        assert res[True][1] is not None
+        for a, b in zip(res[True][1], res[False][1]):
+            assert a.shape == b.shape and rel(a, b) < 1e-5, rel(a, b)
+        assert rel(res[True][1][1], ref64) < 2e-5
+
+
+def test_eval_fused_kernel_knn_groups():
+    """the BoxCloud xcorr grouping (k-NN lists of 4, no xyz channels: models/head/xcorr.py:89-100) through the same kernel"""
+    from open3dsot_amd import fused, nn_blocks, ops
+    torch.manual_seed(3)
+    B, M, N, k = 4, 64, 128, 4
+    bundle = torch.randn(B, 268, M, device="cuda")
+    idx = ops.knn_point(k, torch.rand(B, N, 9, device="cuda"), torch.rand(B, M, 9, device="cuda"))
+    mlp = nn_blocks.SharedMLP([268, 256, 256, 256], bn=True).cuda().eval()
+    with torch.no_grad():
+        for m in mlp.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5); m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2)
+        want, _, _ = shadow64(mlp, None, None, bundle, idx, False)
+        got = fused.group_mlp_pool(mlp, bundle, idx)
+        fused.set_eval_fused(False)
+        try:
+            layerwise = fused.group_mlp_pool(mlp, bundle, idx)
+        finally:
+            fused.set_eval_fused(True)
+    assert rel(got, want) < 2e-5 and rel(got, layerwise) < 1e-5

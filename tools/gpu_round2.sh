@@ -28,7 +28,7 @@ F=$(find $OUT/trace_eager -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && c
 G=$(find $OUT/trace_graph -name "*kernel_trace.csv" | head -1); [ -n "$G" ] && python tools/trace_steps.py "$G" 20 100 > $OUT/steady_state_per_step.txt
 mkdir -p $OUT/pmc; find $OUT/pmc_fetch $OUT/pmc_write -name "*counter_collection.csv" | while read f; do cp "$f" $OUT/pmc/$(echo $f | grep -o "pmc_[a-z]*")_$(basename $f); done
 python tools/pmc_summary.py $OUT/pmc $OUT/pmc_summary.csv
-python tools/hbm_traffic.py $OUT/pmc_summary.csv $OUT/hbm_traffic.json BAT 48
+python tools/hbm_traffic.py $OUT/pmc_summary.csv $OUT/hbm_traffic.json BAT 48 8   # 3 warm-up + 2 timed + 3 roofline-profile eager steps
 rm -rf $OUT/trace_eager $OUT/trace_graph $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc
 head -3 $OUT/steady_state_per_step.txt
 for f in bench bench_dense bench_p2b bench_p2b_b1 bench_m2track bench_nuscenes2048 bench_infer; do python - <<PY
