@@ -185,3 +185,18 @@ def test_two_rank_gloo_real_tracker(tmp_path):
     finally:
         from open3dsot_amd import sa_modules
         sa_modules.set_fused(True)
+
+
+def test_bench_refuses_to_report_fewer_gpus_than_asked():
+    """`python bench.py --gpus N` outside torchrun spawns N ranks itself; with fewer than N GPUs visible it must stop
+    with an error, never print a line for a smaller job (here: no GPU at all, or one)"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    n = 64                       # more than any node has
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0
+    assert "refusing" in (r.stderr + r.stdout)
+    assert '"n_gpus"' not in r.stdout
