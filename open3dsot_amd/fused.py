@@ -16,7 +16,6 @@ running_var, momentum 0.1); the NEXT kernel applies BN+ReLU while loading.  Save
 backward: Y_l and four per-channel vectors per layer, plus arg-max of the pool.
 """
 import ctypes
-import math
 
 import torch
 from torch import nn
@@ -813,16 +812,6 @@ def set_reduce_gather(enabled):
 
 def reduce_gather_enabled():
     return _REDUCE_GATHER["on"]
-
-
-def _padded(owner, name, shape, dev):
-    """zero-initialised scratch kept on `owner` (a module of the layer): callers overwrite the live part each
-    step and rely on the padding staying zero"""
-    buf = getattr(owner, name, None)
-    if buf is None or tuple(buf.shape) != tuple(shape) or buf.device != dev:
-        buf = torch.zeros(shape, device=dev, dtype=torch.float32)
-        object.__setattr__(owner, name, buf)
-    return buf
 
 
 # ---- tracking inference: one kernel per set abstraction (csrc/sa_eval.hip) --------------------------------------

@@ -38,16 +38,11 @@ def supported(mlp, t_feat, s_feat):
 _STATIC = {}
 
 
-def _static(dev, B, M, N):
-    """ball bookkeeping of the regular (every column live) layout: ball_off, ball_cnt, meta -- built once per shape"""
-    key = (str(dev), B, M, N)
+def _zero_row(dev, B, M):
+    """the similarity channel's slot in the per-point operand: a (B,1,M) block of zeros, built once per shape"""
+    key = (str(dev), B, M)
     if key not in _STATIC:
-        nballs = B * N
-        P = nballs * M
-        _STATIC[key] = (torch.arange(0, P + 1, M, dtype=torch.int32, device=dev),
-                        torch.full((nballs,), M, dtype=torch.int32, device=dev),
-                        torch.tensor([P, P, nballs, 0], dtype=torch.int32, device=dev),
-                        torch.zeros((B, 1, M), dtype=torch.float32, device=dev))
+        _STATIC[key] = torch.zeros((B, 1, M), dtype=torch.float32, device=dev)
     return _STATIC[key]
 
 
@@ -73,7 +68,7 @@ class FusedP2BXCorr(torch.autograd.Function):
         dev, f32 = sim.device, torch.float32
         st = _stream()
         prep = prep_for(dev)
-        ball_off, ball_cnt, meta, zero1 = _static(dev, B, M, N)
+        zero1 = _zero_row(dev, B, M)
         simf = sim.detach().contiguous()
         need_bwd = any(ctx.needs_input_grad)
         C0 = Ws[0].shape[0]
@@ -130,7 +125,7 @@ class FusedP2BXCorr(torch.autograd.Function):
             ctx.geom = (B, N, M, f, K0, K0p, tile)
             ctx.versions = [(p, p._version) for p in params]
             W0t = prep.get(params[0], K0p, C0, transpose=True)
-            ctx.saved = (X0, simf, Ys, vecs, Ws, Wts, W0t, gammas, meta, out.detach(), argq, yarg)
+            ctx.saved = (X0, simf, Ys, vecs, Ws, Wts, W0t, gammas, out.detach(), argq, yarg)
         return out.view(Cl, B, N).permute(1, 0, 2)
 
     @staticmethod
@@ -142,7 +137,7 @@ class FusedP2BXCorr(torch.autograd.Function):
         for p, v in ctx.versions:
             if p._version != v:
                 raise RuntimeError("a parameter of the fused xcorr MLP was modified in place between forward and backward")
-        X0, simf, Ys, vecs, Ws, Wts, W0t, gammas, meta, out, argq, yarg = ctx.saved
+        X0, simf, Ys, vecs, Ws, Wts, W0t, gammas, out, argq, yarg = ctx.saved
         L = len(Ws)
         P, Pm = B * N * M, B * M
         dev, f32 = dOut.device, torch.float32
