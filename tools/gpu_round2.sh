@@ -23,7 +23,12 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_e
 timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_graph -o bench -- python $REPO/bench.py --steps 40 --warmup 5 --no-cpu-baseline > $OUT/rocprof_graph.log 2>&1; echo "trace graph exit $?"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python $REPO/bench.py --steps 2 --warmup 3 --no-graph --no-cpu-baseline > $OUT/rocprof_fetch.log 2>&1; echo "pmc fetch exit $?"
 timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- python $REPO/bench.py --steps 2 --warmup 3 --no-graph --no-cpu-baseline > $OUT/rocprof_write.log 2>&1; echo "pmc write exit $?"
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq1 -o bench -- python $REPO/bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline > $OUT/rocprof_sq1.log 2>&1; echo "pmc sq1 exit $?"
+timeout 600 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $OUT/pmc_sq2 -o bench -- python $REPO/bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline > $OUT/rocprof_sq2.log 2>&1; echo "pmc sq2 exit $?"
 cd $REPO
+S1=$(find $OUT/pmc_sq1 -name "*counter_collection.csv" | head -1); S2=$(find $OUT/pmc_sq2 -name "*counter_collection.csv" | head -1)
+[ -n "$S1" ] && [ -n "$S2" ] && python tools/sq_summary.py "$S1" "$S2" $OUT/sq_counters.csv
+rm -rf $OUT/pmc_sq1 $OUT/pmc_sq2
 F=$(find $OUT/trace_eager -name "*kernel_stats.csv" | head -1); [ -n "$F" ] && cp "$F" $OUT/kernel_stats_eager.csv
 G=$(find $OUT/trace_graph -name "*kernel_trace.csv" | head -1); [ -n "$G" ] && python tools/trace_steps.py "$G" 20 100 > $OUT/steady_state_per_step.txt
 mkdir -p $OUT/pmc; find $OUT/pmc_fetch $OUT/pmc_write -name "*counter_collection.csv" | while read f; do cp "$f" $OUT/pmc/$(echo $f | grep -o "pmc_[a-z]*")_$(basename $f); done
