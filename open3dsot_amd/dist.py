@@ -128,8 +128,9 @@ class DataParallelStep:
         saved = [b.clone() for b in buffers]
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):      # one more eager pass on the capture stream's allocator
-            self._forward_backward(self._static)
+        with torch.cuda.stream(side):      # eager passes on the capture stream's allocator; two, so that whatever
+            self._forward_backward(self._static)      # the first one registered (weight-preparation jobs, cached
+            self._forward_backward(self._static)      # constants) is in its steady state when the capture begins
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         for b, v in zip(buffers, saved):

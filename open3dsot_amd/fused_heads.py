@@ -145,6 +145,11 @@ class WeightPrep:
         if not self.jobs:
             return
         if self.dirty or self.table is None:
+            if torch.cuda.is_current_stream_capturing():
+                # the job table is uploaded from the host, which a capturing stream cannot do: this forward copies per
+                # `get` instead (run one eager forward before capturing and the table is already in place)
+                self.fresh = set()
+                return
             rows = [[j.src_ptr, j.dst.data_ptr(), j.rows, j.cols, j.dst.shape[1], int(j.transpose)] for j in self.jobs.values()]
             self.table = torch.tensor(rows, dtype=torch.int64, device=self.dev)       # only while the job set changes
             self.dirty = False
