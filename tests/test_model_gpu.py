@@ -489,12 +489,14 @@ def test_graph_replay_gradients_equal_eager_gradients():
     loss_e.backward()
     assert abs(loss_g - float(loss_e)) <= 1e-5 * (1 + abs(float(loss_e))), (loss_g, float(loss_e))
     worst = 0.0
+    top = max(float(p.grad.abs().max()) for p in twin.parameters() if p.grad is not None)
     for k, p in twin.named_parameters():
         if p.grad is None:
             assert k not in grads_g
             continue
         scale = float(p.grad.abs().max())
-        if scale == 0.0:
+        if scale < 1e-4 * top:           # e.g. conv_final.bias: every consumer starts with a training-mode BatchNorm,
+            assert float(grads_g[k].abs().max()) < 1e-3 * top, k     # so its true gradient is zero (rounding noise)
             continue
         err = float((grads_g[k] - p.grad).abs().max()) / scale
         worst = max(worst, err)
