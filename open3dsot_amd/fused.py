@@ -107,6 +107,34 @@ def _eval_consts(lib, bn, gamma, beta, vec, nrep, st, conv_bias=None):
           gamma.data_ptr(), beta.data_ptr(), _ptr(conv_bias), float(bn.eps), bn.running_mean.numel(), nrep, vec.data_ptr(), st)
 
 
+# BatchNorm `num_batches_tracked` increments: inside a tracker forward (fused_heads.prep_scope) they are collected and
+# applied by ONE multi-tensor launch at the end of the forward instead of one launch per fused operator
+_COUNTERS = {"pending": None}
+
+
+def count_batches(bns, inc=1):
+    tensors = [bn.num_batches_tracked for bn in bns if bn.num_batches_tracked is not None]
+    if not tensors:
+        return
+    if _COUNTERS["pending"] is None:
+        torch._foreach_add_(tensors, inc)
+    else:
+        _COUNTERS["pending"].setdefault(inc, []).extend(tensors)
+
+
+def counters_begin():
+    if _COUNTERS["pending"] is not None:
+        return False
+    _COUNTERS["pending"] = {}
+    return True
+
+
+def counters_end():
+    pending, _COUNTERS["pending"] = _COUNTERS["pending"], None
+    for inc, tensors in (pending or {}).items():
+        torch._foreach_add_(tensors, inc)
+
+
 def _versions(params):
     """[(tensor, version)]: the fused functions keep detached views of the live parameter storage for their backward
     (no copy), so autograd's own in-place check does not see them -- `_check_versions` restores it"""
@@ -290,7 +318,7 @@ class FusedGroupedMLP(torch.autograd.Function):
             Ys.append(Y)
             means.append(vec[0]); invstds.append(vec[1]); scales.append(vec[2]); shifts.append(vec[3])
         if cfg.training:
-            torch._foreach_add_([bn.num_batches_tracked for bn in cfg.bns], 1)
+            count_batches(cfg.bns, 1)
         Cl = Ws[-1].shape[0]
         out = torch.empty((B, Cl, npoint), device=dev, dtype=torch.float32)
         arg = torch.empty((B, Cl, npoint), device=dev, dtype=torch.int32) if need_bwd else None
@@ -578,7 +606,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             Ys.append(Y)
             means.append(vec[0]); invstds.append(vec[1]); scales.append(vec[2]); shifts.append(vec[3])
         if cfg.training:
-            torch._foreach_add_([bn.num_batches_tracked for bn in cfg.bns], nseg)     # one launch for all layers
+            count_batches(cfg.bns, nseg)
         Cl = Ws[-1].shape[0]
         # pooled tensors: one (B, Cl, npoint_s) block per segment in one buffer
         out = torch.empty((nballs * Cl,), device=dev, dtype=f32)

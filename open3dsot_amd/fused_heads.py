@@ -23,7 +23,7 @@ import weakref
 import torch
 
 from . import capi
-from .fused import _call, _const_vec, _eval_consts, _ptr, _stream
+from .fused import _call, _const_vec, _eval_consts, _ptr, _stream, count_batches, counters_begin, counters_end
 
 _vp, _i, _l, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 capi.register("o3d_pack_rows", [_vp, _i, _i, _i, _i, _vp, _vp])
@@ -182,10 +182,13 @@ def prep_scope(dev):
         return
     prep.refresh()
     prep.active = True
+    own_counters = counters_begin()
     try:
         yield
     finally:
         prep.active = False
+        if own_counters:
+            counters_end()
 
 
 # ---- the stack ---------------------------------------------------------------------------------------------
@@ -284,7 +287,7 @@ class FlatChain(torch.autograd.Function):
             Ys.append(Y)
             Kp = Mp
         if cfg.training and L > 1:
-            torch._foreach_add_([bn.num_batches_tracked for bn in cfg.bns[:L - 1]], 1)
+            count_batches(cfg.bns[:L - 1], 1)
         Cl = params[4 * (L - 1)].shape[0]
         if need_bwd:
             ctx.cfg = cfg

@@ -13,7 +13,7 @@ import ctypes
 import torch
 
 from . import capi
-from .fused import _call, _check_versions, _const_vec, _eval_consts, _ptr, _stream, _versions, POOL_BWD_SPLIT, TILE
+from .fused import _call, _check_versions, _const_vec, _eval_consts, _ptr, _stream, _versions, count_batches, POOL_BWD_SPLIT, TILE
 
 _vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
 capi.register("o3d_bn_relu_apply", [_vp, _vp, _vp, _i, _l, _vp, _vp])
@@ -75,7 +75,7 @@ class FusedPointwiseChain(torch.autograd.Function):
             Ys.append(Y)
             means.append(vec[0]); invstds.append(vec[1]); scales.append(vec[2]); shifts.append(vec[3])
         if cfg.training:
-            torch._foreach_add_([bn.num_batches_tracked for bn in cfg.bns], 1)
+            count_batches(cfg.bns, 1)
         Cl = Ws[-1].shape[0]
         need_bwd = any(ctx.needs_input_grad)
         argq = yarg = None

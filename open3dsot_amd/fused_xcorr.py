@@ -14,7 +14,7 @@ import ctypes
 import torch
 
 from . import capi
-from .fused import _call, _const_vec, _eval_consts, _layers, _ptr, _stream
+from .fused import _call, _const_vec, _eval_consts, _layers, _ptr, _stream, count_batches
 from .fused_heads import _up, pack_rows, prep_for
 
 _vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
@@ -110,7 +110,7 @@ class FusedP2BXCorr(torch.autograd.Function):
             Ys.append(Y)
             vecs.append(vec)
         if cfg.training:
-            torch._foreach_add_([bn.num_batches_tracked for bn in cfg.bns], 1)
+            count_batches(cfg.bns, 1)
         Cl = Ws[-1].shape[0]
         # max over the template axis = over the M contiguous columns of a ball: the regular (slot) pooling kernel on the
         # flat layout (one "cloud" of B*N balls); the pooled tensor comes out flat (Cl, B*N), the layout the
