@@ -410,6 +410,16 @@ int o3d_row_sum(const float* G, int C, long P, float* out, void* stream);
 
 int o3d_pw_tile(long P, int M);
 
+/* A per-point stack whose input is [X ; a per-cloud CONSTANT block] (SegPointNet: the pooled feature broadcast to every
+ * point and concatenated, models/backbone/pointnet.py:188-190): the constant block contributes W_b . pooled[b] to every
+ * column of cloud b -- a per-cloud bias cbias (Cout, B), not 1024 more GEMM rows.
+ * o3d_pw_fwd_cloud: Y (Cout, B*N) = W_a (Cout, Cin) . X + cbias[:, cloud], statistics partials [P/128][2][Cout] of it.
+ * o3d_cloud_sum_dy: out (C, B) = per-cloud sums of dY = A1*dN + A2*Y + A3, the gradient of cbias. */
+int o3d_pw_fwd_cloud(const float* X, const float* W, const float* cbias, int B, int N, int Cin, int Cout, float* Y,
+                     float* part, const float* stat_c, void* stream);
+int o3d_cloud_sum_dy(const float* dN, const float* Y, const float* A1, const float* A2, const float* A3, int C, int B,
+                     int N, float* out, void* stream);
+
 /* Eval-mode BatchNorm constants in one launch: vec (4, nrep, C) = {mean, invstd, scale, shift} with
  * invstd = 1/sqrt(running_var + eps), scale = gamma*invstd, shift = beta - mean*scale (pytorch_utils.py:56-59 in
  * eval mode); conv_bias (C) or NULL is a bias of the convolution in front, folded into the mean. */

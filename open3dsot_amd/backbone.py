@@ -84,7 +84,24 @@ def _pointwise_chain(x, layers, pool=False):
     return h.amax(dim=2) if pool else h
 
 
-_FUSED_PW = {"on": True}
+def _cloud_chain(second, pooled, layers):
+    """(Conv1d -> BatchNorm1d -> ReLU)* on cat([second, pooled broadcast over the points]) (models/backbone/pointnet.py:
+    188-193); on the GPU the broadcast block becomes a per-cloud bias (fused_pointwise.chain_cloud)"""
+    if second.is_cuda and _FUSED_PW["on"] and _FUSED_PW["cloud_bias"]:
+        from . import fused_pointwise
+        pairs = [(conv, bn) for conv, bn, _ in layers]
+        if fused_pointwise.cloud_supported(second, pooled, pairs):
+            return fused_pointwise.chain_cloud(second.contiguous(), pooled, pairs)
+    x = torch.cat([second, pooled.unsqueeze(-1).expand(-1, -1, second.shape[2])], dim=1)
+    return _pointwise_chain(x, layers)
+
+
+_FUSED_PW = {"on": True, "cloud_bias": True}
+
+
+def set_cloud_bias(enabled):
+    """SegPointNet's pooled-feature block as a per-cloud bias (default) or as 1024 broadcast GEMM rows (A/B, tests)"""
+    _FUSED_PW["cloud_bias"] = bool(enabled)
 
 
 def set_fused_pointwise(enabled):
@@ -167,8 +184,7 @@ class SegPointNet(nn.Module):
             first = [tuple(m) for m in self.seq_per_point]
             second = _pointwise_chain(x, first[:2])
             pooled = _pointwise_chain(second, first[2:], pool=True).unsqueeze(-1)      # (B,C1,1)
-            x = torch.cat([second, pooled.expand(-1, -1, second.shape[2])], dim=1)
-            x = _pointwise_chain(x, [tuple(m) for m in self.seq_per_point2])
+            x = _cloud_chain(second, pooled.squeeze(-1), [tuple(m) for m in self.seq_per_point2])
             if self.output_size > 0:
                 x = nn_blocks.pointwise_conv1d(self.fc, x.contiguous())
         else:

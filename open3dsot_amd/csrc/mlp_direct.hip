@@ -85,6 +85,10 @@ struct DirectArgs {
     // EPI 2 (plain layer of a 1-D conv stack): out = acc + bias[m] + resid[m, p]   (either may be NULL)
     const float* bias;     // (M)
     const float* resid;    // (M, P), same layout as Out
+    // EPI 0: per-cloud bias cbias (M, cb_B): out[m, q] += cbias[m, q / cb_N] before the statistics -- a per-cloud
+    // CONSTANT input channel block (the pooled feature SegPointNet broadcasts to every point, models/backbone/
+    // pointnet.py:188-190) contributes W_b . pooled[b] to every column of cloud b: a bias, not 1024 GEMM rows
+    const float* cbias; int cb_N, cb_B;
 };
 
 template <int MODE, int NT>
@@ -302,6 +306,11 @@ void direct_gemm_kernel(DirectArgs a) {
 #pragma unroll
                 for (int t = 0; t < NT; ++t) v[t] = (v[t] + bm) + rs[t];
             } else {
+                if (a.cbias) {          // (a column tile never straddles clouds: cb_N % (32*NT) == 0)
+                    const float cbv = a.cbias[(long)m * a.cb_B + (int)(((long)b * a.P + p0) / a.cb_N)];
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) { v[t] += cbv; acc[i][t][r] = v[t]; }
+                }
 #pragma unroll
                 for (int t = 0; t < NT; ++t) sum = fmaf(wv[t], v[t], sum);
             }
@@ -487,4 +496,19 @@ extern "C" int o3d_pw_dgrad(const float* dN, const float* Y, const float* A1, co
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (Yprev) return Y ? launch_direct_small<B_DY, 1>(a, tile, st) : launch_direct_small<B_PLAIN, 1>(a, tile, st);
     return Y ? launch_direct_small<B_DY, 2>(a, tile, st) : launch_direct_small<B_PLAIN, 2>(a, tile, st);
+}
+
+// Layer 0 of a per-point stack whose input is [X (Cin rows) ; a per-cloud constant block]: Y (Cout, P) = W_a . X +
+// cbias[:, cloud of the column], cbias (Cout, B) = W_b . pooled^T computed by the caller; statistics partials
+// [P/tile][2][Cout] of the biased output.  P = B*N, N % 128 == 0, Cin % 16 == 0, Cout % 64 == 0.
+extern "C" int o3d_pw_fwd_cloud(const float* X, const float* W, const float* cbias, int B, int N, int Cin, int Cout,
+                                float* Y, float* part, const float* stat_c, void* stream) {
+    const long P = (long)B * N;
+    if (!X || !W || !cbias || !Y || B <= 0 || N <= 0 || N % 128 != 0 || P > 0x7fffffff || Cin <= 0 || Cin % 16 != 0 ||
+        Cout <= 0 || Cout % DT_M != 0)
+        return O3D_EINVAL;
+    DirectArgs a = {};
+    a.A = W; a.X = X; a.Out = Y; a.M = Cout; a.K = Cin; a.P = (int)P; a.B = 1; a.part = part; a.stat_c = stat_c; a.ns = 4;
+    a.cbias = cbias; a.cb_N = N; a.cb_B = B;
+    return launch_direct<B_PLAIN, 0>(a, 128, reinterpret_cast<hipStream_t>(stream));
 }

@@ -19,6 +19,8 @@ _vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
 capi.register("o3d_bn_relu_apply", [_vp, _vp, _vp, _i, _l, _vp, _vp])
 capi.register("o3d_act_bwd_partials", [_vp, _vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _vp])
 capi.register("o3d_gmax_fwd", [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp])
+capi.register("o3d_pw_fwd_cloud", [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
+capi.register("o3d_cloud_sum_dy", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp])
 
 
 class _Cfg:
@@ -32,11 +34,12 @@ def supported(x, layers):
 
 
 class FusedPointwiseChain(torch.autograd.Function):
-    """(x (B,Cin,N), cfg, W0,b0,g0,beta0, W1,...) -> act (B,C_L,N) | pooled (B,C_L)"""
+    """(x (B,Cin,N), cbias (C_0,B) | None, cfg, W0,b0,g0,beta0, W1,...) -> act (B,C_L,N) | pooled (B,C_L)
+    `cbias`: per-cloud bias added to layer 0's output before its BatchNorm (see `chain_cloud`)."""
 
     @staticmethod
     @capi.on_tensor_device
-    def forward(ctx, x, cfg, *params):
+    def forward(ctx, x, cbias, cfg, *params):
         lib = capi.load()
         L = len(params) // 4
         Ws = [params[4 * l].detach()[:, :, 0].contiguous() for l in range(L)]
@@ -57,9 +60,14 @@ class FusedPointwiseChain(torch.autograd.Function):
             part = torch.empty((ntiles, 2, Cout), device=dev, dtype=f32) if cfg.training else None
             stat_c = bn.running_mean if cfg.training else None
             src = X0 if l == 0 else Ys[-1]
-            _call("pw_conv_fwd", 2.0 * Cin * Cout * P, lib.o3d_mlp_conv_fwd, src.data_ptr(), Ws[l].data_ptr(),
-                  None if l == 0 else scales[-1].data_ptr(), None if l == 0 else shifts[-1].data_ptr(), 1, Cin, Cout, P,
-                  Y.data_ptr(), _ptr(part), _ptr(stat_c), st)
+            if l == 0 and cbias is not None:
+                cb = cbias.detach().contiguous()
+                _call("pw_conv_fwd", 2.0 * Cin * Cout * P, lib.o3d_pw_fwd_cloud, src.data_ptr(), Ws[0].data_ptr(), cb.data_ptr(),
+                      B, N, Cin, Cout, Y.data_ptr(), _ptr(part), _ptr(stat_c), st)
+            else:
+                _call("pw_conv_fwd", 2.0 * Cin * Cout * P, lib.o3d_mlp_conv_fwd, src.data_ptr(), Ws[l].data_ptr(),
+                      None if l == 0 else scales[-1].data_ptr(), None if l == 0 else shifts[-1].data_ptr(), 1, Cin, Cout, P,
+                      Y.data_ptr(), _ptr(part), _ptr(stat_c), st)
             vec = torch.empty((4, Cout), device=dev, dtype=f32)
             b = biases[l].detach() if biases[l] is not None else None
             if cfg.training:
@@ -95,6 +103,7 @@ class FusedPointwiseChain(torch.autograd.Function):
             ctx.versions = _versions(params)
             ctx.dims = (B, N, L)
             ctx.has_bias = [b is not None for b in biases]
+            ctx.has_cbias = cbias is not None
             ctx.saved = (X0, Ws, gammas, Ys, means, invstds, scales, shifts, out.detach() if cfg.mode != "act" else None,
                          argq, yarg)
         return out
@@ -127,7 +136,7 @@ class FusedPointwiseChain(torch.autograd.Function):
                   means[-1].data_ptr(), B, Cl, 1, 0, meta.data_ptr(), 0, P, dN.data_ptr(), part.data_ptr(), st)
             nparts = POOL_BWD_SPLIT
         grads = [None] * (4 * L)
-        dx = None
+        dx = dcb = None
         for l in range(L - 1, -1, -1):
             Cout, Cin = Ws[l].shape
             coef = torch.empty((5, Cout), device=dev, dtype=f32)
@@ -144,11 +153,16 @@ class FusedPointwiseChain(torch.autograd.Function):
             A = (coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr())
             dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
             flops = 2.0 * Cin * Cout * P
-            if l >= 1 and Cin % 64 == 0 and Cout % 64 == 0:
+            if l == 0 and ctx.has_cbias and ctx.needs_input_grad[1]:
+                dcb = torch.empty((Cout, B), device=dev, dtype=f32)       # gradient of the per-cloud bias
+                _call("cloud_sum", 0.0, lib.o3d_cloud_sum_dy, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1], A[2], Cout, B, N,
+                      dcb.data_ptr(), st)
+            if Cin % 64 == 0 and Cout % 64 == 0:
                 wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, P),), device=dev, dtype=f32)
+                xs = (X0.data_ptr(), None, None) if l == 0 else \
+                     (Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr())
                 _call("pw_conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2, dN.data_ptr(), None, 4, Ys[l].data_ptr(), A[0], A[1],
-                      A[2], Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), 1, Cin, Cout, P,
-                      wpart.data_ptr(), dW.data_ptr(), st)
+                      A[2], xs[0], xs[1], xs[2], 1, Cin, Cout, P, wpart.data_ptr(), dW.data_ptr(), st)
             else:
                 tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
                 nsl = max(1, min(P // 32 // 4, 768 // tiles))
@@ -173,7 +187,7 @@ class FusedPointwiseChain(torch.autograd.Function):
                 _call("pw_conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_plain, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1],
                       A[2], Ws[0].data_ptr(), 1, Cin, Cout, P, dX.data_ptr(), st)
                 dx = dX.permute(1, 0, 2)
-        return (dx, None, *grads)
+        return (dx, dcb, None, *grads)
 
 
 _META = {}
@@ -193,4 +207,30 @@ def chain(x, layers, mode):
     params = []
     for conv, bn in layers:
         params += [conv.weight, conv.bias, bn.weight, bn.bias]
-    return FusedPointwiseChain.apply(x, cfg, *params)
+    return FusedPointwiseChain.apply(x, None, cfg, *params)
+
+
+def cloud_supported(x, pooled, layers):
+    conv0 = layers[0][0]
+    B, C, N = x.shape
+    return supported(x, layers) and pooled.dim() == 2 and pooled.shape[0] == B and conv0.in_channels == C + pooled.shape[1] \
+        and C % 64 == 0 and conv0.out_channels % 64 == 0 and N % 128 == 0
+
+
+def chain_cloud(x, pooled, layers, mode="act"):
+    """chain(cat([x, pooled expanded over the N points]), layers): SegPointNet's second per-point stack
+    (models/backbone/pointnet.py:188-193).  The pooled feature is the same at every point of a cloud, so its 1024 input
+    channels of the first layer are NOT run through the GEMM at all 2048 points: W_b . pooled[b] is a per-cloud bias
+    (C_0, B) -- one small matmul -- added in the GEMM's epilogue before the BatchNorm statistics.  Exact; removes
+    1024/1088 of that layer's FLOPs (40 % of the whole M2-Track step).  Backward: the bias gradient is the per-cloud
+    column sum of dY, which autograd carries through the small matmul into W_b and the pooled feature."""
+    conv0, bn0 = layers[0]
+    C = x.shape[1]
+    w = conv0.weight                                  # (C_0, C + Cp, 1)
+    cbias = torch.mm(w[:, C:, 0], pooled.t())         # (C_0, B)
+    cfg = _Cfg()
+    cfg.mode, cfg.training, cfg.bns = mode, bool(bn0.training), [bn for _, bn in layers]
+    params = [w[:, :C], conv0.bias, bn0.weight, bn0.bias]
+    for conv, bn in layers[1:]:
+        params += [conv.weight, conv.bias, bn.weight, bn.bias]
+    return FusedPointwiseChain.apply(x, cbias, cfg, *params)

@@ -503,3 +503,57 @@ def test_graph_replay_gradients_equal_eager_gradients():
         worst = max(worst, err)
         assert err < 5e-3, (k, err)          # LDS-atomic summation order differs run to run; nothing else may
     print("graph replay vs eager: worst per-parameter max-norm gradient difference %.1e" % worst)
+
+
+@pytest.mark.parametrize("train", [True, False])
+def test_segpointnet_cloud_bias_matches_broadcast_concat(train):
+    """SegPointNet (models/backbone/pointnet.py:144-204): the pooled feature broadcast to every point and concatenated
+    (:188-190) as a per-cloud bias (fused_pointwise.chain_cloud) against the literal concatenation through the same
+    fused stack, and against the module evaluated in fp64 on torch ops: outputs, input gradient, every parameter
+    gradient, running statistics"""
+    import copy
+    from open3dsot_amd import backbone, nn_blocks
+    torch.manual_seed(21)
+    net = backbone.SegPointNet(input_channel=14, per_point_mlp1=[64, 64, 64, 128, 1024],
+                               per_point_mlp2=[512, 256, 128, 128], output_size=11).cuda().train(train)
+    g = torch.Generator().manual_seed(22)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.copy_(torch.empty(m.weight.shape).uniform_(0.5, 1.5, generator=g))
+                m.bias.copy_(torch.empty(m.bias.shape).normal_(0, 0.2, generator=g))
+                m.running_mean.copy_(torch.empty(m.bias.shape).normal_(0, 0.2, generator=g))
+                m.running_var.copy_(torch.empty(m.bias.shape).uniform_(0.5, 1.5, generator=g))
+    x = torch.randn(6, 14, 256, device="cuda")
+    ct = torch.randn(6, 11, 256, device="cuda")
+    runs = {}
+    for mode in ("cloud", "concat", "fp64"):
+        m = copy.deepcopy(net)
+        xi = x.clone().requires_grad_(True)
+        if mode == "fp64":
+            m, xi = m.double(), x.double().requires_grad_(True)
+            nn_blocks.set_flat_pointwise(False)          # the nn.Sequential path of the mirror, torch ops in fp64
+        backbone.set_cloud_bias(mode == "cloud")
+        try:
+            out = m(xi)
+            (out * ct.to(out.dtype)).sum().backward()
+        finally:
+            backbone.set_cloud_bias(True)
+            nn_blocks.set_flat_pointwise(True)
+        runs[mode] = (out.detach(), xi.grad, {k: p.grad for k, p in m.named_parameters()},
+                      {k: b for k, b in m.named_buffers() if b.dtype.is_floating_point})
+    for mode in ("cloud", "concat"):
+        out, dx, gp, bufs = runs[mode]
+        ref_out, ref_dx, ref_gp, ref_bufs = runs["fp64"]
+        assert rel(out, ref_out) < 2e-5, (mode, rel(out, ref_out))
+        assert float((dx.double() - ref_dx).norm() / ref_dx.norm()) < 5e-4, mode
+        for k, gq in ref_gp.items():
+            if gq is None or float(gq.abs().max()) < 1e-9 * float(ref_dx.abs().max()):
+                continue
+            err = float((gp[k].double() - gq).norm() / (gq.norm() + 1e-30))
+            if float(gq.norm()) < 1e-6 * float(ref_gp["fc.weight"].norm()):      # a bias in front of a training-mode BN
+                continue
+            assert err < 5e-4, (mode, k, err)
+        if train:
+            for k, b in ref_bufs.items():
+                assert rel(bufs[k], b) < 1e-5, (mode, k)
