@@ -545,15 +545,19 @@ def test_segpointnet_cloud_bias_matches_broadcast_concat(train):
     for mode in ("cloud", "concat"):
         out, dx, gp, bufs = runs[mode]
         ref_out, ref_dx, ref_gp, ref_bufs = runs["fp64"]
+        # gradients: nine ReLU layers and 6 x 1024 global arg-max decisions on 1 536 columns -- one routing flip against
+        # fp64 moves a gradient by ~1e-3; both fp32 paths are held to the same 3e-3
+        gtol = 3e-3 if train else 5e-4
         assert rel(out, ref_out) < 2e-5, (mode, rel(out, ref_out))
-        assert float((dx.double() - ref_dx).norm() / ref_dx.norm()) < 5e-4, mode
+        assert float((dx.double() - ref_dx).norm() / ref_dx.norm()) < gtol, mode
         for k, gq in ref_gp.items():
             if gq is None or float(gq.abs().max()) < 1e-9 * float(ref_dx.abs().max()):
                 continue
             err = float((gp[k].double() - gq).norm() / (gq.norm() + 1e-30))
             if float(gq.norm()) < 1e-6 * float(ref_gp["fc.weight"].norm()):      # a bias in front of a training-mode BN
                 continue
-            assert err < 5e-4, (mode, k, err)
+            assert err < gtol, (mode, k, err)
         if train:
             for k, b in ref_bufs.items():
                 assert rel(bufs[k], b) < 1e-5, (mode, k)
+    assert rel(runs["cloud"][0], runs["concat"][0]) < 1e-5          # the two formulations of the same layer
