@@ -561,4 +561,4 @@ def test_segpointnet_cloud_bias_matches_broadcast_concat(train):
         if train:
             for k, b in ref_bufs.items():
                 assert rel(bufs[k], b) < 1e-5, (mode, k)
-    assert rel(runs["cloud"][0], runs["concat"][0]) < 1e-5          # the two formulations of the same layer
+    assert rel(runs["cloud"][0], runs["concat"][0]) < 5e-5          # the two formulations of the same layer
