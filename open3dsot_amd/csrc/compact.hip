@@ -428,12 +428,16 @@ __global__ __launch_bounds__(BT) void reduce_c_kernel(const float* __restrict__ 
 //   csr_build_kernel   per cloud, once per SA call: the cloud's columns sorted by (column chunk, point, column) in
 //                      `perm` (counting sort in LDS, lists sorted -> fixed summation order) and the list starts
 //                      poff[cloud][chunk*ld + n] (relative to the cloud's first column), total at [nchunk*ld].
-//   reduce_gather_kernel  per (cloud, RG_CS channels): the chunk's dY staged in LDS with plain stores; thread n
+//   reduce_gather_kernel  per (cloud, CS channels): the chunk's dY staged in LDS with plain stores; thread n
 //                      gathers its own list, thread j sums its ball's contiguous range.
 // Behind O3D_REDUCE_GATHER=1 (open3dsot_amd/fused.py) until it has been through the GPU parity tests.
 // ---------------------------------------------------------------------------------------
 constexpr int RG_CH = 2048;     // columns per chunk (16-bit list entries: <= 65536)
-constexpr int RG_CS = 2;        // channels per workgroup
+// channels per workgroup: 2 or 4 (O3D_RG_CS; the chunk's index is re-read once per channel group)
+static int rg_cs() {
+    static const int v = [] { const char* e = getenv("O3D_RG_CS"); const int c = e ? atoi(e) : 2; return c == 4 ? 4 : 2; }();
+    return v;
+}
 
 __global__ __launch_bounds__(1024) void csr_build_kernel(const int32_t* __restrict__ gp,
                                                          const int32_t* __restrict__ ball_off,
@@ -486,6 +490,7 @@ __global__ __launch_bounds__(1024) void csr_build_kernel(const int32_t* __restri
     }
 }
 
+template <int CS>
 __global__ __launch_bounds__(256) void reduce_gather_kernel(const float* __restrict__ dN, const float* __restrict__ Y0,
                                                             long ldp, const float* __restrict__ A1,
                                                             const float* __restrict__ A2, const float* __restrict__ A3,
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(256) void reduce_gather_kernel(const float* __restr
                                                             SegParams sp0, SegParams sp1, int C0, long lds_row,
                                                             float* __restrict__ S, float* __restrict__ T, int nballs) {
     extern __shared__ float rg_sm[];        // dy[CS][CH], sacc[CS][ld], tacc[CS][npoint], list[CH] packed (point, column)
-    constexpr int CS = RG_CS, CH = RG_CH;
+    constexpr int CH = RG_CH;
     const int slabs = (C0 + CS - 1) / CS;
     const int cloud = blockIdx.x / slabs, c0 = (blockIdx.x - cloud * slabs) * CS;
     const int seg = cloud >= B ? 1 : 0, b = cloud - seg * B;
@@ -852,8 +857,8 @@ extern "C" long o3d_group_reduce_gather_scratch(int B, int nseg, int npoint0, in
     const int ldm = nseg == 2 && ld1 > ld0 ? ld1 : ld0, npm = nseg == 2 && npoint1 > npoint0 ? npoint1 : npoint0;
     const long nbin = (long)rg_nchunk(spanmax) * ldm;
     const size_t lds_csr = ((size_t)nbin + 1 + 1024) * 4;
-    const size_t lds_red = ((size_t)RG_CS * RG_CH + (size_t)RG_CS * (ldm + npm)) * 4 + (size_t)RG_CH * 4 + 8;
-    if (lds_csr > 128 * 1024 || lds_red > 64 * 1024) return -1;
+    const size_t lds_red = ((size_t)rg_cs() * RG_CH + (size_t)rg_cs() * (ldm + npm)) * 4 + (size_t)RG_CH * 4 + 8;
+    if (lds_csr > 128 * 1024 || lds_red > 80 * 1024) return -1;
     return (long)B * nseg * (nbin + 1);
 }
 
@@ -874,19 +879,25 @@ extern "C" int o3d_group_reduce_gather(const float* dN, const float* Y0, long ld
     const int nchunk = rg_nchunk(spanmax);
     const int stride = nchunk * ldm + 1;
     const size_t lds_csr = ((size_t)nchunk * ldm + 1 + 1024) * 4;
-    const size_t lds_red = ((size_t)RG_CS * RG_CH + (size_t)RG_CS * (ldm + npm)) * 4 + (size_t)RG_CH * 4 + 8;
+    const int cs = rg_cs();
+    const size_t lds_red = ((size_t)cs * RG_CH + (size_t)cs * (ldm + npm)) * 4 + (size_t)RG_CH * 4 + 8;
     if (lds_csr > 48 * 1024 &&
         hipFuncSetAttribute(reinterpret_cast<const void*>(csr_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_csr) != hipSuccess)
         return O3D_ELAUNCH;
+    const void* rgk = cs == 4 ? reinterpret_cast<const void*>(reduce_gather_kernel<4>)
+                              : reinterpret_cast<const void*>(reduce_gather_kernel<2>);
     if (lds_red > 48 * 1024 &&
-        hipFuncSetAttribute(reinterpret_cast<const void*>(reduce_gather_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_red) != hipSuccess)
+        hipFuncSetAttribute(rgk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_red) != hipSuccess)
         return O3D_ELAUNCH;
     hipLaunchKernelGGL(csr_build_kernel, dim3(B * nseg), dim3(1024), lds_csr, s, gp, ball_off, ball_cnt, B, sp0, sp1, nchunk,
                        stride, perm, poff);
-    const int slabs = (C0 + RG_CS - 1) / RG_CS;
-    hipLaunchKernelGGL(reduce_gather_kernel, dim3(B * nseg * slabs), dim3(256), lds_red, s, dN, Y0, ldp, A1, A2, A3, cw,
-                       ball_off, ball_cnt, perm, poff, stride, B, sp0, sp1, C0, lds_row, S, T, nballs);
+    const int slabs = (C0 + cs - 1) / cs;
+    if (cs == 4)
+        hipLaunchKernelGGL(reduce_gather_kernel<4>, dim3(B * nseg * slabs), dim3(256), lds_red, s, dN, Y0, ldp, A1, A2, A3, cw,
+                           ball_off, ball_cnt, perm, poff, stride, B, sp0, sp1, C0, lds_row, S, T, nballs);
+    else
+        hipLaunchKernelGGL(reduce_gather_kernel<2>, dim3(B * nseg * slabs), dim3(256), lds_red, s, dN, Y0, ldp, A1, A2, A3, cw,
+                           ball_off, ball_cnt, perm, poff, stride, B, sp0, sp1, C0, lds_row, S, T, nballs);
     return o3d_launch_status();
 }
