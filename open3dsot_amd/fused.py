@@ -187,6 +187,10 @@ def profile_step(step_fn, peak_tflops, repeats=3):
     flops = sum(v[1] for v in gemm.values())
     ms = sum(v[2] for v in gemm.values())
     ach = flops / (ms * 1e-3) / 1e12
+    # the set-abstraction / xcorr grouped MLPs alone (round 1's GEMM family, before the heads' launch-latency-bound
+    # 1-D conv stacks joined it): comparable across rounds
+    sa = {k: v for k, v in gemm.items() if not k.startswith("pw_")}
+    sa_ms, sa_fl = sum(v[2] for v in sa.values()), sum(v[1] for v in sa.values())
     per_kernel = {k: {"launches": v[0] // repeats, "ms_per_step": round(v[2] / repeats, 4),
                       "tflops": round(v[1] / (v[2] * 1e-3) / 1e12, 2) if v[2] > 0 and v[1] > 0 else None}
                   for k, v in sorted(agg.items())}
@@ -201,6 +205,10 @@ def profile_step(step_fn, peak_tflops, repeats=3):
             "launches_per_step": launches // repeats, "avg_launch_ms": round(ms / launches, 5),
             "gemm_ms_per_step": round(ms / repeats, 4), "gemm_gflop_per_step": round(flops / repeats / 1e9, 2),
             "fused_kernels_ms_per_step": round(sum(v[2] for v in agg.values()) / repeats, 4),
+            "grouped_mlp_only": {"launches_per_step": sum(v[0] for v in sa.values()) // repeats,
+                                 "ms_per_step": round(sa_ms / repeats, 4), "gflop_per_step": round(sa_fl / repeats / 1e9, 2),
+                                 "achieved": round(sa_fl / (sa_ms * 1e-3) / 1e12, 3) if sa_ms > 0 else None,
+                                 "frac": round(sa_fl / (sa_ms * 1e-3) / 1e12 / peak_tflops, 4) if sa_ms > 0 else None},
             "per_kernel": per_kernel}
 
 
