@@ -15,7 +15,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import fused_heads, fused_loss
+from . import fused_heads, fused_loss, optim
 from . import nn_blocks as pt_utils
 from .backbone import Pointnet_Backbone
 from .rpn import P2BVoteNetRPN
@@ -50,11 +50,9 @@ class MatchingBaseModel(nn.Module):
         if str(c.optimizer).lower() == "sgd":
             opt = torch.optim.SGD(self.parameters(), lr=c.lr, momentum=0.9, weight_decay=c.wd)
         else:
-            # same update rule as the reference's torch.optim.Adam; on the GPU as the single multi-tensor kernel
-            # (fused=True) instead of ~12 foreach launches per step
-            params = list(self.parameters())
-            opt = torch.optim.Adam(params, lr=c.lr, weight_decay=c.wd, betas=(0.5, 0.999), eps=1e-06,
-                                   fused=True if params and all(q.is_cuda for q in params) else None)
+            # same update rule as the reference's torch.optim.Adam; on the GPU one launch on flat buffers
+            # (open3dsot_amd/optim.py::FlatAdam) instead of ~12 foreach launches per step
+            opt = optim.make_adam(self.parameters(), c.lr, c.wd)
         sched = torch.optim.lr_scheduler.StepLR(opt, step_size=c.lr_decay_step, gamma=c.lr_decay_rate)
         return {"optimizer": opt, "lr_scheduler": sched}
 

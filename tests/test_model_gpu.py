@@ -562,3 +562,44 @@ def test_segpointnet_cloud_bias_matches_broadcast_concat(train):
             for k, b in ref_bufs.items():
                 assert rel(bufs[k], b) < 1e-5, (mode, k)
     assert rel(runs["cloud"][0], runs["concat"][0]) < 5e-5          # the two formulations of the same layer
+
+
+def test_flat_adam_matches_torch_adam():
+    """open3dsot_amd.optim.FlatAdam (one launch on flat buffers) against torch.optim.Adam with the reference's
+    hyper-parameters (models/base_model.py:32-33) over several steps with real gradients, lr schedule included;
+    state_dict layouts are interchangeable"""
+    import copy
+    from open3dsot_amd import optim, synth, trackers
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    a = trackers.BAT().to(dev).train()
+    b = copy.deepcopy(a)
+    conf = a.configure_optimizers()
+    oa, sa = conf["optimizer"], conf["lr_scheduler"]
+    assert isinstance(oa, optim.FlatAdam)
+    ob = torch.optim.Adam(b.parameters(), lr=1e-3, weight_decay=0, betas=(0.5, 0.999), eps=1e-6)
+    sb = torch.optim.lr_scheduler.StepLR(ob, step_size=12, gamma=0.2)
+    g = torch.Generator(device=dev).manual_seed(9)
+    for it in range(15):
+        grads = [torch.randn(p.shape, device=dev, generator=g) * (0.1 if it % 3 else 1e-4) for p in a.parameters()]
+        for (p, q, gr) in zip(a.parameters(), b.parameters(), grads):
+            p.grad, q.grad = gr.clone(), gr.clone()
+        oa.step(); ob.step(); sa.step(); sb.step()
+    for (k, p), q in zip(a.named_parameters(), b.parameters()):
+        assert rel(p, q) < 2e-6, (k, rel(p, q))
+    sda, sdb = oa.state_dict(), ob.state_dict()
+    assert sda["param_groups"][0]["lr"] == sdb["param_groups"][0]["lr"]
+    for i in sdb["state"]:
+        assert float(sda["state"][i]["step"]) == float(sdb["state"][i]["step"]) == 15
+        assert rel(sda["state"][i]["exp_avg"], sdb["state"][i]["exp_avg"]) < 2e-6
+        assert rel(sda["state"][i]["exp_avg_sq"], sdb["state"][i]["exp_avg_sq"]) < 2e-6
+    # torch's state loads into FlatAdam and the next step agrees again
+    oa.load_state_dict(copy.deepcopy(sdb))
+    for (p, q) in zip(a.parameters(), b.parameters()):
+        gr = torch.randn(p.shape, device=dev, generator=g)
+        p.grad, q.grad = gr.clone(), gr.clone()
+    oa.step(); ob.step()
+    for (k, p), q in zip(a.named_parameters(), b.parameters()):
+        assert rel(p, q) < 2e-6, (k, rel(p, q))
+    out = a(synth.to_torch(synth.make_batch(5, 2, 256, 512), dev))      # the re-pointed parameters still drive the model
+    assert torch.isfinite(out["estimation_boxes"]).all()
