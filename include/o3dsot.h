@@ -413,8 +413,8 @@ int o3d_pw_tile(long P, int M);
 /* torch.optim.Adam's update (models/base_model.py:32-33) for all parameters in one launch: parameters and moments in
  * flat buffers, gradients found through a DEVICE job table of njobs x 3 longs {gradient ptr, offset, n};
  * bc1 = 1 - beta1^t, bc2 = 1 - beta2^t.  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps), g += weight_decay*p first. */
-int o3d_adam_step(const long* jobs, int njobs, float* params, float* exp_avg, float* exp_avg_sq, float lr, float beta1,
-                  float beta2, float eps, float weight_decay, float bc1, float bc2, void* stream);
+int o3d_adam_step(const long* jobs, int njobs, float* params, float* exp_avg, float* exp_avg_sq, double lr,
+                  double beta1, double beta2, double eps, double weight_decay, double bc1, double bc2, void* stream);
 
 /* A per-point stack whose input is [X ; a per-cloud CONSTANT block] (SegPointNet: the pooled feature broadcast to every
  * point and concatenated, models/backbone/pointnet.py:188-190): the constant block contributes W_b . pooled[b] to every

@@ -145,8 +145,8 @@ extern "C" int o3d_row_sum(const float* G, int C, long P, float* out, void* stre
 namespace {
 __global__ __launch_bounds__(256) void adam_step_kernel(const long* __restrict__ jobs, float* __restrict__ P,
                                                         float* __restrict__ M, float* __restrict__ V, float lr_bc1,
-                                                        float beta1, float beta2, float eps, float wd,
-                                                        float inv_sqrt_bc2) {
+                                                        float beta1, float omb1, float beta2, float omb2, float eps,
+                                                        float wd, float inv_sqrt_bc2) {
     const long* j = jobs + 3L * blockIdx.x;
     const float* g = reinterpret_cast<const float*>(j[0]);
     const long off = j[1], n = j[2];
@@ -155,8 +155,8 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const long* __restrict__
         float p = P[k];
         float gi = g[i];
         if (wd != 0.f) gi = fmaf(wd, p, gi);
-        const float m = fmaf(beta1, M[k], (1.f - beta1) * gi);
-        const float v = fmaf(beta2, V[k], (1.f - beta2) * gi * gi);
+        const float m = fmaf(beta1, M[k], omb1 * gi);
+        const float v = fmaf(beta2, V[k], omb2 * gi * gi);
         M[k] = m; V[k] = v;
         P[k] = p - lr_bc1 * m / (sqrtf(v) * inv_sqrt_bc2 + eps);
     }
@@ -167,11 +167,13 @@ __global__ __launch_bounds__(256) void adam_step_kernel(const long* __restrict__
 // element count}; bias corrections bc1 = 1 - beta1^t, bc2 = 1 - beta2^t computed by the caller (t = step count).
 //   m = beta1*m + (1-beta1)*g;  v = beta2*v + (1-beta2)*g^2;  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps)
 // (g += weight_decay * p first when weight_decay != 0) -- torch.optim.Adam without amsgrad / maximize.
-extern "C" int o3d_adam_step(const long* jobs, int njobs, float* params, float* exp_avg, float* exp_avg_sq, float lr,
-                             float beta1, float beta2, float eps, float weight_decay, float bc1, float bc2,
+extern "C" int o3d_adam_step(const long* jobs, int njobs, float* params, float* exp_avg, float* exp_avg_sq, double lr,
+                             double beta1, double beta2, double eps, double weight_decay, double bc1, double bc2,
                              void* stream) {
-    if (!jobs || njobs <= 0 || !params || !exp_avg || !exp_avg_sq || bc1 <= 0.f || bc2 <= 0.f) return O3D_EINVAL;
+    // hyper-parameters in double like torch's Python scalars: 1 - 0.999f is 4.7e-5 away from 0.001
+    if (!jobs || njobs <= 0 || !params || !exp_avg || !exp_avg_sq || bc1 <= 0. || bc2 <= 0.) return O3D_EINVAL;
     hipLaunchKernelGGL(adam_step_kernel, dim3(njobs, 8), dim3(256), 0, o3d_stream(stream), jobs, params, exp_avg,
-                       exp_avg_sq, lr / bc1, beta1, beta2, eps, weight_decay, 1.0f / sqrtf(bc2));
+                       exp_avg_sq, (float)(lr / bc1), (float)beta1, (float)(1. - beta1), (float)beta2, (float)(1. - beta2),
+                       (float)eps, (float)weight_decay, (float)(1.0 / sqrt(bc2)));
     return o3d_launch_status();
 }

@@ -8,13 +8,14 @@ one ~10 us launch.  `state_dict()` has torch.optim.Adam's layout (`step`, `exp_a
 checkpoints are interchangeable with the reference's optimizer.
 """
 import ctypes
+import os
 
 import torch
 
 from . import capi
 
-_vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
-capi.register("o3d_adam_step", [_vp, _i, _vp, _vp, _vp, _f, _f, _f, _f, _f, _f, _f, _vp])
+_vp, _i, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_double
+capi.register("o3d_adam_step", [_vp, _i, _vp, _vp, _vp, _d, _d, _d, _d, _d, _d, _d, _vp])
 
 
 class FlatAdam(torch.optim.Optimizer):
@@ -99,10 +100,11 @@ def make_adam(params, lr, weight_decay, betas=(0.5, 0.999), eps=1e-6):
     params = list(params)
     if params and all(q.is_cuda and q.dtype == torch.float32 for q in params) and _ON["on"]:
         return FlatAdam(params, lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
-    return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, betas=betas, eps=eps)
+    return torch.optim.Adam(params, lr=lr, weight_decay=weight_decay, betas=betas, eps=eps,
+                            fused=True if params and all(q.is_cuda for q in params) else None)
 
 
-_ON = {"on": True}
+_ON = {"on": os.environ.get("O3D_FLAT_ADAM", "1") != "0"}      # A/B switch
 
 
 def set_flat_adam(enabled):
