@@ -54,6 +54,8 @@ def parse():
     ap.add_argument("--search-size", type=int, default=1024, help="search-cloud points (BASELINE config 5, BAT_CAR_NUSCENES: 2048)")
     ap.add_argument("--dense", action="store_true", help="worst-case clouds: every ball full of distinct neighbours "
                     "(live_fraction 1.0) instead of the KITTI-like crops")
+    ap.add_argument("--per-launch", default=None, metavar="FILE", help="write the per-launch roofline table of the GEMM "
+                    "launches (algorithmic FLOPs / bytes, HIP-event time, share of max(MFMA, HBM) roofline) to FILE")
     ap.add_argument("--composed", action="store_true", help="disable the fused kernels (debug A/B only)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one HIP graph")
     return ap.parse_args()
@@ -311,6 +313,20 @@ def run(args):
             roofline = fused.profile_step(eager_step, PEAK_FP32_MFMA_TFLOPS)
     except ImportError:
         roofline = None
+    if roofline is not None:
+        rows = roofline.pop("per_launch", None) or []
+        if rows:          # both rooflines per launch, summed: the time the step's GEMM launches would take AT the roofline
+            roof_ms, ms = sum(r["roof_ms"] for r in rows), sum(r["ms"] for r in rows)
+            roofline["per_launch_roofline"] = {"launches": len(rows), "ms": round(ms, 4), "roof_ms": round(roof_ms, 4),
+                                               "frac": round(roof_ms / ms, 4),
+                                               "hbm_bound_launches": sum(1 for r in rows if r["bound"] == "hbm")}
+        if args.per_launch and rank == 0:
+            with open(args.per_launch, "w") as fh:
+                fh.write("kernel i Cin Cout cols ms TFLOP/s GB/s bound roof_ms frac\n")
+                for r in rows:
+                    fh.write("%-18s %2d %4d %4d %8d %.4f %6.1f %6.0f %-4s %.4f %.3f\n" % (
+                        r["kernel"], r["i"], r["Cin"], r["Cout"], r["cols"], r["ms"], r["tflops"], r["gbs"], r["bound"],
+                        r["roof_ms"], r["frac"]))
     if roofline is not None and args.model != "M2TRACK" and args.search_size == 1024:
         # the reference gathers first (layer 0 on npoint*nsample positions): rate in those terms as well
         ref_gflop = 3.0 * mlp_flops_per_pair(args.model) * args.batch / 1e9

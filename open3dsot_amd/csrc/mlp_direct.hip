@@ -85,7 +85,7 @@ struct DirectArgs {
     // EPI 2 (plain layer of a 1-D conv stack): out = acc + bias[m] + resid[m, p]   (either may be NULL)
     const float* bias;     // (M)
     const float* resid;    // (M, P), same layout as Out
-    // EPI 0: per-cloud bias cbias (M, cb_B): out[m, q] += cbias[m, q / cb_N] before the statistics -- a per-cloud
+    // EPI 3 (= EPI 0 plus) per-cloud bias cbias (M, cb_B): out[m, q] += cbias[m, q / cb_N] before the statistics -- a per-cloud
     // CONSTANT input channel block (the pooled feature SegPointNet broadcasts to every point, models/backbone/
     // pointnet.py:188-190) contributes W_b . pooled[b] to every column of cloud b: a bias, not 1024 GEMM rows
     const float* cbias; int cb_N, cb_B;
@@ -156,6 +156,8 @@ __device__ __forceinline__ void compute_group(const RawB<NT>& f, const float4& a
 
 // EPI 0: forward (store raw output, statistics {sum y, sum (y-c)^2})
 // EPI 1: data gradient (mask by the producer's ReLU, store, statistics {sum g, sum g*(yprev-mean)})
+// EPI 3: EPI 0 with a per-cloud bias added before the store and the statistics (its own instantiation: as a run-time
+//        branch of EPI 0 it cost every forward launch a 64-bit division per row, 1600 register moves and 138 spills)
 // EPI 2: plain store + per-row bias + residual tensor, no statistics (last layer of a Conv1d stack,
 //        pytorch_utils.py:124-155 with bn=False / activation=None, and the input gradient of a stack)
 // NT = 4: 128 columns per wave (one dwordx4 B load per k row); NT = 2: 64 columns (dwordx2) -- twice the waves
@@ -224,7 +226,10 @@ void direct_gemm_kernel(DirectArgs a) {
     // of 64 cycles; with 2 waves per SIMD and 64-row tiles (MT = 2) one group ahead covers a ~2000-cycle miss, the
     // 32-row tiles of the heads' small launches (one wave per SIMD, 8 MFMAs = 512 cycles per group) were bound by
     // load latency x groups (measured: 15-20 us for a 256x256x6144 GEMM, 15 us even at K = 64): they run 3 ahead.
-    constexpr int R = MT == 1 ? 4 : 2;
+    #ifndef O3D_RING_MT2
+#define O3D_RING_MT2 2
+#endif
+    constexpr int R = MT == 1 ? 4 : O3D_RING_MT2;
     const int G = a.K / 8;       // multiple of R (K % 16 == 0; K % 32 == 0 for MT == 1)
     RawB<NT> f[R];
     float4 wa0[R], wa1[R];
@@ -273,80 +278,91 @@ void direct_gemm_kernel(DirectArgs a) {
         }
     }
 
-    // ---------------- epilogue: store, then the two statistics one at a time (32 live values each)
-    float red[32];
+    // ---------------- epilogue, one 32-row m-tile at a time: every load of the m-tile (the producer's raw output for
+    // the ReLU mask / the residual, the per-row constants as float4) is issued BEFORE the first dependent use --
+    // written row by row the compiler serialises load -> s_waitcnt vmcnt(0) -> store 32 times (stores count in vmcnt
+    // on gfx9), i.e. 32 exposed memory latencies per wave; then store + both statistics of a row in the same pass and
+    // ONE 32-value reduce-scatter per m-tile (16 rows x {sum, second statistic})
+    int cloud = 0;
+    if constexpr (EPI == 3) cloud = (int)(((long)b * a.P + p0) / a.cb_N);
+    const bool stats = EPI != 2 && a.part != nullptr;
 #pragma unroll
-    for (int r = 0; r < 32; ++r) red[r] = 0.f;
+    for (int i = 0; i < MT; ++i) {
+        float red[32];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+        for (int hb = 0; hb < 2; ++hb) {                       // 8 rows per batch: 16 at once spills the row addresses
+            const int mb = m0 + 32 * i + 16 * hb + 4 * h;      // rows mb + 8*q + j, q < 2, j < 4
+            const long ob = ((long)b * a.M + mb) * rowP + p;
+            float ex[8][NT];                                   // EPI 1: Yprev rows, EPI 2: residual rows
+            float4 k1[2], k2[2], k3[2];                        // per-row constants, 4 consecutive rows each
+            if constexpr (EPI == 1 || EPI == 2) {
+                const float* src = EPI == 1 ? a.Yprev : a.resid;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + 32 * i + acc_row(r, h);
-            const long o = ((long)b * a.M + m) * rowP + p;
-            float v[NT];
+                for (int r = 0; r < 8; ++r) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) v[t] = acc[i][t][r];
-            float sum = 0.f;
-            if (EPI == 1) {
-                float yp[NT];
-                ldv<NT>(yp, a.Yprev + o);
-                const float sc = a.scale_p[m], sf = a.shift_p[m];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    v[t] = fmaf(yp[t], sc, sf) > 0.f ? v[t] : 0.f;
-                    acc[i][t][r] = v[t];
-                    sum += v[t];
+                    for (int t = 0; t < NT; ++t) ex[r][t] = 0.f;
+                    if (EPI == 1 || src) ldv<NT>(ex[r], src + ob + (long)(8 * (r >> 2) + (r & 3)) * rowP);
                 }
-            } else if (EPI == 2) {
-                const float bm = a.bias ? a.bias[m] : 0.f;
-                float rs[NT];
+            }
 #pragma unroll
-                for (int t = 0; t < NT; ++t) rs[t] = 0.f;
-                if (a.resid) ldv<NT>(rs, a.resid + o);
-#pragma unroll
-                for (int t = 0; t < NT; ++t) v[t] = (v[t] + bm) + rs[t];
-            } else {
-                if (a.cbias) {          // (a column tile never straddles clouds: cb_N % (32*NT) == 0)
-                    const float cbv = a.cbias[(long)m * a.cb_B + (int)(((long)b * a.P + p0) / a.cb_N)];
-#pragma unroll
-                    for (int t = 0; t < NT; ++t) { v[t] += cbv; acc[i][t][r] = v[t]; }
+            for (int q = 0; q < 2; ++q) {
+                k1[q] = k2[q] = k3[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (EPI == 1) {
+                    k1[q] = *reinterpret_cast<const float4*>(a.scale_p + mb + 8 * q);
+                    k2[q] = *reinterpret_cast<const float4*>(a.shift_p + mb + 8 * q);
+                    k3[q] = *reinterpret_cast<const float4*>(a.mean_p + mb + 8 * q);
+                } else if constexpr (EPI == 2) {
+                    if (a.bias) k1[q] = *reinterpret_cast<const float4*>(a.bias + mb + 8 * q);
+                } else {
+                    if (a.stat_c) k1[q] = *reinterpret_cast<const float4*>(a.stat_c + mb + 8 * q);
+                    if constexpr (EPI == 3) {
+                        k2[q].x = a.cbias[(long)(mb + 8 * q + 0) * a.cb_B + cloud];
+                        k2[q].y = a.cbias[(long)(mb + 8 * q + 1) * a.cb_B + cloud];
+                        k2[q].z = a.cbias[(long)(mb + 8 * q + 2) * a.cb_B + cloud];
+                        k2[q].w = a.cbias[(long)(mb + 8 * q + 3) * a.cb_B + cloud];
+                    }
                 }
-#pragma unroll
-                for (int t = 0; t < NT; ++t) sum = fmaf(wv[t], v[t], sum);
             }
-            stv<NT>(a.Out + o, v);
-            red[i * 16 + r] = sum;
-        }
-    if (EPI == 2 || !a.part) return;
-    // lane l31 of half h ends up owning value index l31 -> (i = l31>>4, r = l31&15)
-    float* dst = a.part + (long)tile * 2 * a.M + m0 + 32 * (l31 >> 4) + acc_row(l31 & 15, h);
-    const bool owner = (l31 >> 4) < MT;
-    reduce_scatter32(red, l31);
-    if (owner) dst[0] = red[0];
 #pragma unroll
-    for (int r = 0; r < 32; ++r) red[r] = 0.f;
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int q = r8 >> 2, j = r8 & 3, r = 8 * hb + r8;      // accumulator register r <-> row 8*(r>>2) + (r&3)
+                const float c1 = j == 0 ? k1[q].x : j == 1 ? k1[q].y : j == 2 ? k1[q].z : k1[q].w;
+                const float c2 = j == 0 ? k2[q].x : j == 1 ? k2[q].y : j == 2 ? k2[q].z : k2[q].w;
+                const float c3 = j == 0 ? k3[q].x : j == 1 ? k3[q].y : j == 2 ? k3[q].z : k3[q].w;
+                float v[NT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i)
+                for (int t = 0; t < NT; ++t) v[t] = acc[i][t][r];
+                float s1 = 0.f, s2 = 0.f;
+                if constexpr (EPI == 1) {          // mask by the producer's ReLU; {sum g, sum g*(yprev-mean)}
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + 32 * i + acc_row(r, h);
-            float q = 0.f;
-            if (EPI == 0) {
-                const float c = a.stat_c ? a.stat_c[m] : 0.f;
+                    for (int t = 0; t < NT; ++t) {
+                        v[t] = fmaf(ex[r8][t], c1, c2) > 0.f ? v[t] : 0.f;
+                        s1 += v[t];
+                        s2 = fmaf(v[t], ex[r8][t] - c3, s2);
+                    }
+                } else if constexpr (EPI == 2) {
 #pragma unroll
-                for (int t = 0; t < NT; ++t) q += wv[t] * (acc[i][t][r] - c) * (acc[i][t][r] - c);
-            } else {      // masked entries are zero, so the mask needs no second evaluation
-                float yp[NT];
-                ldv<NT>(yp, a.Yprev + ((long)b * a.M + m) * rowP + p);
-                const float mu = a.mean_p[m];
+                    for (int t = 0; t < NT; ++t) v[t] = (v[t] + c1) + ex[r8][t];
+                } else {                           // {sum w*y, sum w*(y-c)^2}
 #pragma unroll
-                for (int t = 0; t < NT; ++t) q = fmaf(acc[i][t][r], yp[t] - mu, q);
+                    for (int t = 0; t < NT; ++t) {
+                        if constexpr (EPI == 3) v[t] += c2;
+                        s1 = fmaf(wv[t], v[t], s1);
+                        s2 += wv[t] * (v[t] - c1) * (v[t] - c1);
+                    }
+                }
+                stv<NT>(a.Out + ob + (long)(8 * q + j) * rowP, v);
+                red[r] = s1;
+                red[16 + r] = s2;
             }
-            red[i * 16 + r] = q;
         }
-    reduce_scatter32(red, l31);
-    if (owner) dst[a.M] = red[0];
+        if (stats) {       // lane l31 of half h ends up owning value index l31 -> (statistic l31>>4, row r = l31&15)
+            reduce_scatter32(red, l31);
+            a.part[(long)tile * 2 * a.M + (long)(l31 >> 4) * a.M + m0 + 32 * i + acc_row(l31 & 15, h)] = red[0];
+        }
+    }
 }
+
 
 // All M/64 row slabs of a position tile run as the waves of ONE workgroup: they read the same B rows,
 // so those come from HBM once and from L1/L2 for the other slabs (rocprofv3 FETCH_SIZE of the
@@ -510,5 +526,5 @@ extern "C" int o3d_pw_fwd_cloud(const float* X, const float* W, const float* cbi
     DirectArgs a = {};
     a.A = W; a.X = X; a.Out = Y; a.M = Cout; a.K = Cin; a.P = (int)P; a.B = 1; a.part = part; a.stat_c = stat_c; a.ns = 4;
     a.cbias = cbias; a.cb_N = N; a.cb_B = B;
-    return launch_direct<B_PLAIN, 0>(a, 128, reinterpret_cast<hipStream_t>(stream));
+    return launch_direct_nt<B_PLAIN, 3, 4>(a, reinterpret_cast<hipStream_t>(stream));
 }

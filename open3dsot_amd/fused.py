@@ -88,14 +88,15 @@ def _stream():
     return torch.cuda.current_stream().cuda_stream
 
 
-def _call(name, flops, fn, *args):
-    """Launch one C-ABI entry; when profiling, bracket it with HIP events on the launch stream."""
+def _call(name, flops, fn, *args, dims=None):
+    """Launch one C-ABI entry; when profiling, bracket it with HIP events on the launch stream.
+    dims = (Cin, Cout[, pooled]) of a GEMM launch: only used for the per-launch roofline table of `profile_step`."""
     if _PROF["on"]:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         rc = fn(*args)
         e1.record()
-        _PROF["events"].append((name, flops, e0, e1))
+        _PROF["events"].append((name, flops, e0, e1, dims))
     else:
         rc = fn(*args)
     capi.check(rc, name)
@@ -168,7 +169,9 @@ def profile_step(step_fn, peak_tflops, repeats=3):
         _PROF["on"] = False
     agg = {}
     live_cols = slot_cols = 0.0
-    for name, flops, e0, e1 in _PROF["events"]:
+    launches_tab = {}
+    seq = {}
+    for name, flops, e0, e1, dims in _PROF["events"]:
         if isinstance(flops, tuple):       # (per-column FLOPs, meta, slots): the live column count is data dependent
             live = float(flops[1].view(-1, 4)[:, 0].sum().item())      # live columns of every segment
             if name == "conv_fwd":
@@ -178,7 +181,14 @@ def profile_step(step_fn, peak_tflops, repeats=3):
         a = agg.setdefault(name, [0, 0.0, 0.0])
         a[0] += 1
         a[1] += flops
-        a[2] += e0.elapsed_time(e1)
+        ms_l = e0.elapsed_time(e1)
+        a[2] += ms_l
+        if dims is not None and flops > 0:          # per-launch roofline row, keyed by (kind, position in the step)
+            i = seq[name] = seq.get(name, -1) + 1
+            row = launches_tab.setdefault((name, i % max(1, _launches_per_repeat(_PROF["events"], name, repeats))),
+                                          [dims, flops, 0.0, 0])
+            row[2] += ms_l
+            row[3] += 1
     _PROF["events"] = []
     gemm = {k: v for k, v in agg.items() if k in GEMM_KERNELS}
     if not gemm:
@@ -209,7 +219,39 @@ def profile_step(step_fn, peak_tflops, repeats=3):
                                  "ms_per_step": round(sa_ms / repeats, 4), "gflop_per_step": round(sa_fl / repeats / 1e9, 2),
                                  "achieved": round(sa_fl / (sa_ms * 1e-3) / 1e12, 3) if sa_ms > 0 else None,
                                  "frac": round(sa_fl / (sa_ms * 1e-3) / 1e12 / peak_tflops, 4) if sa_ms > 0 else None},
-            "per_kernel": per_kernel}
+            "per_kernel": per_kernel, "per_launch": _per_launch_rows(launches_tab, peak_tflops)}
+
+
+def _launches_per_repeat(events, name, repeats):
+    return sum(1 for e in events if e[0] == name and e[4] is not None) // repeats
+
+
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def _per_launch_rows(tab, peak_tflops):
+    """one row per GEMM launch of a step: algorithmic FLOPs and bytes (fp32 operands read once, result written once),
+    the time both rooflines allow (max of FLOPs / MFMA peak and bytes / HBM peak) and the share of it achieved"""
+    rows = []
+    for (name, i), (dims, flops, ms, n) in sorted(tab.items()):
+        cin, cout = dims[0], dims[1]
+        pooled = len(dims) > 2 and dims[2]
+        cols = flops / (2.0 * cin * cout)
+        if "wgrad" in name:      # dY (+ the raw output its BatchNorm backward needs) and the layer input
+            nrows = (cout if pooled else 2 * cout) + cin
+        elif "dgrad" in name:    # the same two operands, the result and the producer's raw output for the ReLU mask
+            nrows = (cout if pooled else 2 * cout) + 2 * cin
+        else:                    # forward: input rows in, output rows out
+            nrows = cin + cout
+        byts = 4.0 * nrows * cols
+        ms1 = ms / n
+        t_mfma = flops / (peak_tflops * 1e12) * 1e3
+        t_hbm = byts / (HBM_PEAK_GBS * 1e9) * 1e3
+        rows.append({"kernel": name, "i": i, "Cin": cin, "Cout": cout, "cols": int(cols), "ms": round(ms1, 4),
+                     "tflops": round(flops / ms1 / 1e9, 1), "gbs": round(byts / ms1 / 1e6, 0),
+                     "bound": "mfma" if t_mfma >= t_hbm else "hbm", "roof_ms": round(max(t_mfma, t_hbm), 4),
+                     "frac": round(max(t_mfma, t_hbm) / ms1, 3)})
+    return rows
 
 
 # ---- module introspection --------------------------------------------------------------
@@ -597,7 +639,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             else:
                 _call("conv_fwd", (2.0 * Cin * Cout, meta, ldp), lib.o3d_mlp_conv_fwd_c, Ys[-1].data_ptr(), Ws[l].data_ptr(),
                       scales[-1].data_ptr(), shifts[-1].data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1,
-                      tile, Y.data_ptr(), _ptr(part), _ptr(statc), st)
+                      tile, Y.data_ptr(), _ptr(part), _ptr(statc), st, dims=(Cin, Cout))
             vec = torch.empty((4, nseg, Cout), device=dev, dtype=f32)      # mean, invstd, scale, shift per segment
             if cfg.training and nseg == 1:
                 _call("bn_finalize", 0.0, lib.o3d_bn_finalize_c, part.data_ptr(), Pmaxs[0] // tile, Cout, counts[0],
@@ -785,11 +827,12 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                     _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_cp, pkc.data_ptr(), cball.data_ptr(), nballs + 1,
                           Ys[l].data_ptr(), A[0], A[1], A[2], Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(),
                           shifts[l - 1].data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(),
-                          dW.data_ptr(), side.cuda_stream)
+                          dW.data_ptr(), side.cuda_stream, dims=(Cin, Cout, True))
                 else:
                     _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
                           Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Cin, Cout, ldp,
-                          cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(), dW.data_ptr(), side.cuda_stream)
+                          cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(), dW.data_ptr(), side.cuda_stream,
+                          dims=(Cin, Cout))
             grads[3 * l] = dW
             Wt = ctx.Wts[l]
             dNp = torch.empty((Cin, ldp), device=dev, dtype=f32)
@@ -799,12 +842,12 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                 _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_cp, pkc.data_ptr(), cball.data_ptr(), nballs + 1,
                       Ys[l].data_ptr(), A[0], A[1], A[2], Wt.data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1,
                       dtile, Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(),
-                      means[l - 1].data_ptr(), dNp.data_ptr(), part.data_ptr(), st)
+                      means[l - 1].data_ptr(), dNp.data_ptr(), part.data_ptr(), st, dims=(Cin, Cout, True))
             else:
                 _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
                       Wt.data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1, dtile, Ys[l - 1].data_ptr(),
                       scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),
-                      part.data_ptr(), st)
+                      part.data_ptr(), st, dims=(Cin, Cout))
             dN = dNp
         main.wait_stream(side)       # join: every weight gradient is complete before autograd sees it
         del keep

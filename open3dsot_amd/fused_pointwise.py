@@ -63,11 +63,11 @@ class FusedPointwiseChain(torch.autograd.Function):
             if l == 0 and cbias is not None:
                 cb = cbias.detach().contiguous()
                 _call("pw_conv_fwd", 2.0 * Cin * Cout * P, lib.o3d_pw_fwd_cloud, src.data_ptr(), Ws[0].data_ptr(), cb.data_ptr(),
-                      B, N, Cin, Cout, Y.data_ptr(), _ptr(part), _ptr(stat_c), st)
+                      B, N, Cin, Cout, Y.data_ptr(), _ptr(part), _ptr(stat_c), st, dims=(Cin, Cout))
             else:
                 _call("pw_conv_fwd", 2.0 * Cin * Cout * P, lib.o3d_mlp_conv_fwd, src.data_ptr(), Ws[l].data_ptr(),
                       None if l == 0 else scales[-1].data_ptr(), None if l == 0 else shifts[-1].data_ptr(), 1, Cin, Cout, P,
-                      Y.data_ptr(), _ptr(part), _ptr(stat_c), st)
+                      Y.data_ptr(), _ptr(part), _ptr(stat_c), st, dims=(Cin, Cout))
             vec = torch.empty((4, Cout), device=dev, dtype=f32)
             b = biases[l].detach() if biases[l] is not None else None
             if cfg.training:
@@ -162,7 +162,7 @@ class FusedPointwiseChain(torch.autograd.Function):
                 xs = (X0.data_ptr(), None, None) if l == 0 else \
                      (Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr())
                 _call("pw_conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2, dN.data_ptr(), None, 4, Ys[l].data_ptr(), A[0], A[1],
-                      A[2], xs[0], xs[1], xs[2], 1, Cin, Cout, P, wpart.data_ptr(), dW.data_ptr(), st)
+                      A[2], xs[0], xs[1], xs[2], 1, Cin, Cout, P, wpart.data_ptr(), dW.data_ptr(), st, dims=(Cin, Cout))
             else:
                 tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
                 nsl = max(1, min(P // 32 // 4, 768 // tiles))
@@ -171,7 +171,7 @@ class FusedPointwiseChain(torch.autograd.Function):
                      (Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr())
                 _call("pw_conv_wgrad", flops, lib.o3d_mlp_conv_wgrad, dN.data_ptr(), None, None, None, 4, Ys[l].data_ptr(),
                       A[0], A[1], A[2], xs[0], xs[1], xs[2], None, None, None, None, 0, 0, 0, 1.0, 1, Cin, Cout, P, nsl,
-                      wpart.data_ptr(), dW.data_ptr(), st)
+                      wpart.data_ptr(), dW.data_ptr(), st, dims=(Cin, Cout))
             grads[4 * l] = dW.unsqueeze(-1)
             if l >= 1:
                 Wt = Ws[l].t().contiguous()
@@ -180,12 +180,12 @@ class FusedPointwiseChain(torch.autograd.Function):
                 _call("pw_conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_wt, dN.data_ptr(), None, None, None, 4,
                       Ys[l].data_ptr(), A[0], A[1], A[2], Ws[l].data_ptr(), Wt.data_ptr(), None, 1, Cin, Cout, P,
                       Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(),
-                      dNp.data_ptr(), part.data_ptr(), st)
+                      dNp.data_ptr(), part.data_ptr(), st, dims=(Cin, Cout))
                 dN, nparts = dNp, ntiles
             elif ctx.needs_input_grad[0]:
                 dX = torch.empty((Cin, B, N), device=dev, dtype=f32)
                 _call("pw_conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_plain, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1],
-                      A[2], Ws[0].data_ptr(), 1, Cin, Cout, P, dX.data_ptr(), st)
+                      A[2], Ws[0].data_ptr(), 1, Cin, Cout, P, dX.data_ptr(), st, dims=(Cin, Cout))
                 dx = dX.permute(1, 0, 2)
         return (dx, dcb, None, *grads)
 

@@ -95,7 +95,7 @@ class FusedP2BXCorr(torch.autograd.Function):
             else:
                 _call("conv_fwd", 2.0 * Cin * Cout * P, lib.o3d_pw_fwd, Ys[-1].data_ptr(), Ws[l].data_ptr(),
                       vecs[-1][2].data_ptr(), vecs[-1][3].data_ptr(), None, None, Cin, Cout, P, Y.data_ptr(), _ptr(part),
-                      _ptr(statc), st)
+                      _ptr(statc), st, dims=(Cin, Cout))
                 if need_bwd:
                     Wts.append(prep.get(params[3 * l], Cin, Cout, transpose=True))
             vec = torch.empty((4, Cout), device=dev, dtype=f32)
@@ -198,7 +198,8 @@ class FusedP2BXCorr(torch.autograd.Function):
             scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, P),), device=dev, dtype=f32)
             _call("conv_wgrad", 2.0 * Cin * Cout * P, lib.o3d_mlp_conv_wgrad2, _ptr(dN), pk.data_ptr() if dN is None else None,
                   M if dN is None else 4, Ys[l].data_ptr(), A[0], A[1], A[2], Ys[l - 1].data_ptr(), vecs[l - 1][2].data_ptr(),
-                  vecs[l - 1][3].data_ptr(), 1, Cin, Cout, P, scratch.data_ptr(), dW.data_ptr(), st)
+                  vecs[l - 1][3].data_ptr(), 1, Cin, Cout, P, scratch.data_ptr(), dW.data_ptr(), st,
+                  dims=(Cin, Cout, dN is None))
             grads[3 * l] = dW
             dNp = torch.empty((Cin, P), device=dev, dtype=f32)
             vp = vecs[l - 1]
@@ -207,13 +208,13 @@ class FusedP2BXCorr(torch.autograd.Function):
                 _call("conv_dgrad", 2.0 * Cin * Cout * P, lib.o3d_mlp_conv_dgrad_wt, None, g.data_ptr(), out.data_ptr(),
                       argq.data_ptr(), M, Ys[l].data_ptr(), A[0], A[1], A[2], Ws[l].data_ptr(), Wts[l - 1].data_ptr(),
                       pk.data_ptr(), 1, Cin, Cout, P, Ys[l - 1].data_ptr(), vp[2].data_ptr(), vp[3].data_ptr(), vp[0].data_ptr(),
-                      dNp.data_ptr(), part.data_ptr(), st)
+                      dNp.data_ptr(), part.data_ptr(), st, dims=(Cin, Cout, True))
                 nparts = P // 128
             else:
                 part = torch.empty((P // tile, 2, Cin), device=dev, dtype=f32)
                 _call("conv_dgrad", 2.0 * Cin * Cout * P, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
                       Wts[l - 1].data_ptr(), Cin, Cout, P, Ys[l - 1].data_ptr(), vp[2].data_ptr(), vp[3].data_ptr(),
-                      vp[0].data_ptr(), None, dNp.data_ptr(), part.data_ptr(), st)
+                      vp[0].data_ptr(), None, dNp.data_ptr(), part.data_ptr(), st, dims=(Cin, Cout))
                 nparts = P // tile
             dN = dNp
         gw = []
