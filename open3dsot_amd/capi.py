@@ -13,6 +13,8 @@ import torch  # noqa: F401  (must be loaded before the HIP library, see above)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SO_PATH = os.path.join(_HERE, "_lib", "libo3dsot_hip.so")
+if os.environ.get("O3D_LIB_VARIANT"):      # A/B builds of tools/build_variant.sh (same ABI, different -D switches)
+    SO_PATH = os.path.join(_HERE, "_lib", "libo3dsot_hip.%s.so" % os.environ["O3D_LIB_VARIANT"])
 
 _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 

@@ -229,7 +229,11 @@ void direct_gemm_kernel(DirectArgs a) {
     #ifndef O3D_RING_MT2
 #define O3D_RING_MT2 2
 #endif
-    constexpr int R = MT == 1 ? 4 : O3D_RING_MT2;
+    // O3D_RING_FWD: build-time experiment switch (tools/build_variant.sh): ring depth of the forward (EPI 0) 64-row tiles
+#ifndef O3D_RING_FWD
+#define O3D_RING_FWD O3D_RING_MT2
+#endif
+    constexpr int R = MT == 1 ? 4 : (EPI == 0 ? O3D_RING_FWD : O3D_RING_MT2);
     const int G = a.K / 8;       // multiple of R (K % 16 == 0; K % 32 == 0 for MT == 1)
     RawB<NT> f[R];
     float4 wa0[R], wa1[R];
@@ -253,6 +257,27 @@ void direct_gemm_kernel(DirectArgs a) {
             compute_group<MODE, NT, MT>(f[1], wa0[1], wa1[1], kk, wv, acc);
             __builtin_amdgcn_sched_barrier(0);
         }
+    } else if constexpr (R == 3) {      // 2 groups ahead; G is not a multiple of 3: whole rounds, then 1 or 2 tail groups
+        const int last = G - 1;
+        const int G3 = G - G % 3;
+        load(std::integral_constant<int, 0>{}, 0);
+        load(std::integral_constant<int, 1>{}, 1 < last ? 1 : last);
+        for (int g = 0; g < G3; g += 3) {
+            load(std::integral_constant<int, 2>{}, g + 2 < last ? g + 2 : last);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group<MODE, NT, MT>(f[0], wa0[0], wa1[0], kk, wv, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            load(std::integral_constant<int, 0>{}, g + 3 < last ? g + 3 : last);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group<MODE, NT, MT>(f[1], wa0[1], wa1[1], kk, wv, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            load(std::integral_constant<int, 1>{}, g + 4 < last ? g + 4 : last);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group<MODE, NT, MT>(f[2], wa0[2], wa1[2], kk, wv, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (G3 < G) compute_group<MODE, NT, MT>(f[0], wa0[0], wa1[0], kk, wv, acc);          // group G3 (stage 0)
+        if (G3 + 1 < G) compute_group<MODE, NT, MT>(f[1], wa0[1], wa1[1], kk, wv, acc);      // group G3 + 1 (stage 1)
     } else {
         const int last = G - 1;
         load(std::integral_constant<int, 0>{}, 0);
@@ -286,6 +311,30 @@ void direct_gemm_kernel(DirectArgs a) {
     int cloud = 0;
     if constexpr (EPI == 3) cloud = (int)(((long)b * a.P + p0) / a.cb_N);
     const bool stats = EPI != 2 && a.part != nullptr;
+    // per-row constants that do not come with a tensor load (statistics shift, bias, cloud bias): all rows of the wave
+    // tile up front -- loaded per batch they put a wait (which on gfx9 also waits for the previous batch's stores)
+    // in front of every batch of stores
+    float4 kc1[MT][4], kc2[MT][4];
+    if constexpr (EPI != 1) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int mb = m0 + 32 * i + 4 * h + 8 * q;
+                kc1[i][q] = kc2[i][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (EPI == 2) {
+                    if (a.bias) kc1[i][q] = *reinterpret_cast<const float4*>(a.bias + mb);
+                } else {
+                    if (a.stat_c) kc1[i][q] = *reinterpret_cast<const float4*>(a.stat_c + mb);
+                    if constexpr (EPI == 3) {
+                        kc2[i][q].x = a.cbias[(long)(mb + 0) * a.cb_B + cloud];
+                        kc2[i][q].y = a.cbias[(long)(mb + 1) * a.cb_B + cloud];
+                        kc2[i][q].z = a.cbias[(long)(mb + 2) * a.cb_B + cloud];
+                        kc2[i][q].w = a.cbias[(long)(mb + 3) * a.cb_B + cloud];
+                    }
+                }
+            }
+    }
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
         float red[32];
@@ -306,21 +355,14 @@ void direct_gemm_kernel(DirectArgs a) {
             }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                k1[q] = k2[q] = k3[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                k3[q] = make_float4(0.f, 0.f, 0.f, 0.f);
                 if constexpr (EPI == 1) {
                     k1[q] = *reinterpret_cast<const float4*>(a.scale_p + mb + 8 * q);
                     k2[q] = *reinterpret_cast<const float4*>(a.shift_p + mb + 8 * q);
                     k3[q] = *reinterpret_cast<const float4*>(a.mean_p + mb + 8 * q);
-                } else if constexpr (EPI == 2) {
-                    if (a.bias) k1[q] = *reinterpret_cast<const float4*>(a.bias + mb + 8 * q);
                 } else {
-                    if (a.stat_c) k1[q] = *reinterpret_cast<const float4*>(a.stat_c + mb + 8 * q);
-                    if constexpr (EPI == 3) {
-                        k2[q].x = a.cbias[(long)(mb + 8 * q + 0) * a.cb_B + cloud];
-                        k2[q].y = a.cbias[(long)(mb + 8 * q + 1) * a.cb_B + cloud];
-                        k2[q].z = a.cbias[(long)(mb + 8 * q + 2) * a.cb_B + cloud];
-                        k2[q].w = a.cbias[(long)(mb + 8 * q + 3) * a.cb_B + cloud];
-                    }
+                    k1[q] = kc1[i][2 * hb + q];
+                    k2[q] = kc2[i][2 * hb + q];
                 }
             }
 #pragma unroll
