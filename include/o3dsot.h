@@ -60,6 +60,11 @@ int o3d_gather_points(const float* feats, const int32_t* idx, int B, int C, int 
 int o3d_gather_points_grad(const float* grad_out, const int32_t* idx, int B, int C, int N,
                            int npoint, float* grad_feats, void* stream);
 
+/* rows of a point-major tensor: src (B,N,D), idx (B,npoint) -> out (B,npoint,D), out[b,j,:] = src[b,idx[b,j],:].
+ * The ball centres of a set abstraction, new_xyz = gather_operation(xyz^T, fps_idx)^T (pointnet2_modules.py:52-62),
+ * without the two transposed copies. */
+int o3d_gather_rows(const float* src, const int32_t* idx, int B, int N, int D, int npoint, float* out, void* stream);
+
 /* ---- ball query -----------------------------------------------------------------------
  * replaces _ext.ball_query(new_xyz, xyz, radius, nsample) pointnet2_utils.py:268
  * new_xyz (B,npoint,3), xyz (B,N,3) -> idx (B,npoint,nsample) i32: first `nsample`

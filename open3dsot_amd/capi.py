@@ -25,6 +25,7 @@ SIGNATURES = {
     "o3d_furthest_point_sampling_pair": [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _vp],
     "o3d_gather_points": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "o3d_gather_points_grad": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "o3d_gather_rows": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "o3d_ball_query": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
     "o3d_group_points": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "o3d_group_points_grad": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],

@@ -245,6 +245,32 @@ extern "C" int o3d_group_points_grad(const float* grad_out, const int32_t* idx, 
     return o3d_launch_status();
 }
 
+// rows of a point-major tensor: out[b, j, :] = src[b, idx[b, j], :]  (src (B,N,D), idx (B,npoint), out (B,npoint,D)).
+// The sampled ball centres new_xyz = gather_operation(xyz^T, idx)^T (pointnet2_modules.py:52-62) without the two
+// transposed copies around the channel-major gather.
+namespace {
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                          int N, int D, int npoint, long total, float* __restrict__ out) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;      // (b, j, d), d fastest
+    if (t >= total) return;
+    const long bj = t / D;
+    const int d = (int)(t - bj * D);
+    const long b = bj / npoint;
+    out[t] = src[(b * N + idx[bj]) * D + d];
+}
+}  // namespace
+
+extern "C" int o3d_gather_rows(const float* src, const int32_t* idx, int B, int N, int D, int npoint, float* out,
+                               void* stream) {
+    if (B < 0 || N < 0 || D <= 0 || npoint < 0) return O3D_EINVAL;
+    const long total = (long)B * npoint * D;
+    if (total == 0) return O3D_OK;
+    if (!src || !idx || !out || N == 0) return O3D_EINVAL;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)o3d_cdiv(total, 256)), dim3(256), 0, o3d_stream(stream), src, idx,
+                       N, D, npoint, total, out);
+    return o3d_launch_status();
+}
+
 extern "C" int o3d_gather_points(const float* feats, const int32_t* idx, int B, int C, int N,
                                  int npoint, float* out, void* stream) {
     return o3d_group_points(feats, idx, B, C, N, npoint, 1, out, stream);

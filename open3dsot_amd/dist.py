@@ -145,8 +145,9 @@ class DataParallelStep:
 
     def step(self, batch):
         if self.graph is not None:
-            for k, v in batch.items():
-                self._static[k].copy_(v, non_blocking=True)
+            keys = [k for k in batch if batch[k] is not self._static[k]]
+            if keys:                      # one multi-tensor copy instead of a launch per input
+                torch._foreach_copy_([self._static[k] for k in keys], [batch[k] for k in keys], non_blocking=True)
             self.graph.replay()
             for p, g in zip(self.grads.params, self._static_grads):   # replay rewrote these buffers in place
                 p.grad = g

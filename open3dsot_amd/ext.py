@@ -84,6 +84,19 @@ def gather_points(features, idx):
     return out
 
 
+def gather_rows(src, idx):
+    """src (B,N,D) point-major, idx (B,npoint) -> (B,npoint,D): out[b,j] = src[b,idx[b,j]]"""
+    _chk_f(src, "src")
+    _chk_i(idx, "idx")
+    B, N, D = src.shape
+    npoint = idx.shape[1]
+    out = torch.empty((B, npoint, D), dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        capi.check(capi.load().o3d_gather_rows(src.data_ptr(), idx.data_ptr(), B, N, D, npoint, out.data_ptr(),
+                                               _stream()), "gather_rows")
+    return out
+
+
 def gather_points_grad(grad_out, idx, n):
     """grad_out (B,C,npoint), idx (B,npoint) -> (B,C,n)   [pointnet2_utils.py:98]"""
     _chk_f(grad_out, "grad_out")

@@ -55,6 +55,15 @@ class GatherOperation(Function):
 gather_operation = GatherOperation.apply
 
 
+def gather_xyz(xyz, idx):
+    """new_xyz (B,npoint,3) = gather_operation(xyz^T, idx)^T (pointnet2_modules.py:52-62).  One launch on the
+    point-major tensor when no gradient flows to the coordinates (they are inputs in every tracker); the reference's
+    composition otherwise."""
+    if xyz.requires_grad and torch.is_grad_enabled():
+        return gather_operation(xyz.transpose(1, 2).contiguous(), idx).transpose(1, 2).contiguous()
+    return _ext.gather_rows(xyz.contiguous(), idx)
+
+
 class ThreeNN(Function):
     """unknown (B,n,3), known (B,m,3) -> (dist (B,n,3) L2 distances, idx (B,n,3) i32)."""
 

@@ -28,6 +28,23 @@ _FUSED = {"enabled": True, "paired": os.environ.get("O3D_PAIRED", "1") != "0", "
 _STREAMS = {}
 
 
+_PREFIX_IDX = {}
+
+
+def _prefix_idx(B, npoint, dev):
+    """the reference's `torch.arange(npoint).repeat(B, 1)` sample indices (pointnet2_modules.py:59-60): a constant,
+    built once per (B, npoint, device) instead of two launches per call.  Shared: read-only for the callers."""
+    key = (B, npoint, str(dev))
+    t = _PREFIX_IDX.get(key)
+    if t is None:
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            return torch.arange(npoint, dtype=torch.int32, device=dev).repeat(B, 1)      # not cached: graph-pool memory
+        if len(_PREFIX_IDX) > 64:
+            _PREFIX_IDX.clear()
+        t = _PREFIX_IDX[key] = torch.arange(npoint, dtype=torch.int32, device=dev).repeat(B, 1)
+    return t
+
+
 def _fps_stream(dev):
     key = str(dev)
     if key not in _STREAMS:
@@ -86,10 +103,9 @@ class _PointnetSAModuleBase(nn.Module):
             raise ValueError("npoint (%d) exceeds the number of points (%d)" % (npoint, xyz.size(1)))
         if self.use_fps:
             sample_idxs = pointnet2_utils.furthest_point_sample(xyz, npoint)
-            new_xyz = pointnet2_utils.gather_operation(
-                xyz.transpose(1, 2).contiguous(), sample_idxs).transpose(1, 2).contiguous()
+            new_xyz = pointnet2_utils.gather_xyz(xyz, sample_idxs)
         else:
-            sample_idxs = torch.arange(npoint, dtype=torch.int32, device=xyz.device).repeat(xyz.size(0), 1)
+            sample_idxs = _prefix_idx(xyz.size(0), npoint, xyz.device)
             new_xyz = xyz[:, :npoint, :].contiguous()
         return sample_idxs, new_xyz
 
@@ -115,8 +131,8 @@ class _PointnetSAModuleBase(nn.Module):
                     new_b.record_stream(main)
                 elif self.use_fps:       # both farthest-point samplings in one launch (one wave per cloud each)
                     idx_a, idx_b = pointnet2_utils.furthest_point_sample_pair(xyz_a, npoint_a, xyz_b, npoint_b)
-                    new_a = pointnet2_utils.gather_operation(xyz_a.transpose(1, 2).contiguous(), idx_a).transpose(1, 2).contiguous()
-                    new_b = pointnet2_utils.gather_operation(xyz_b.transpose(1, 2).contiguous(), idx_b).transpose(1, 2).contiguous()
+                    new_a = pointnet2_utils.gather_xyz(xyz_a, idx_a)
+                    new_b = pointnet2_utils.gather_xyz(xyz_b, idx_b)
                 else:
                     idx_a, new_a = self._sample(xyz_a, npoint_a)
                     idx_b, new_b = self._sample(xyz_b, npoint_b)

@@ -27,6 +27,14 @@ def gather_points(features, idx):
     return torch.from_numpy(ops.gather_points(_np(features), _np(idx)))
 
 
+def gather_rows(src, idx):
+    """src (B,N,D), idx (B,npoint) -> (B,npoint,D): the channel-major gather of pointnet2_utils.py:68-103 on the
+    transposed tensor (pointnet2_modules.py:52-62 transposes around it)"""
+    a = _np(src)
+    out = ops.gather_points(a.transpose(0, 2, 1).copy(), _np(idx))
+    return torch.from_numpy(out.transpose(0, 2, 1).copy())
+
+
 def gather_points_grad(grad_out, idx, n):
     return torch.from_numpy(ops.gather_points_grad(_np(grad_out), _np(idx), int(n)))
 

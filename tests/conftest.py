@@ -31,7 +31,7 @@ def cpu_ext(monkeypatch):
     from oracle import ext_shim
     import open3dsot_amd.ext as ext
     from open3dsot_amd import sa_modules
-    for name in ("furthest_point_sampling", "gather_points", "gather_points_grad", "three_nn",
+    for name in ("furthest_point_sampling", "gather_points", "gather_points_grad", "gather_rows", "three_nn",
                  "three_interpolate", "three_interpolate_grad", "ball_query", "group_points",
                  "group_points_grad"):
         monkeypatch.setattr(ext, name, getattr(ext_shim, name))

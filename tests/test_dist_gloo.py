@@ -108,7 +108,7 @@ def _patch_ext_with_oracle():
     from oracle import ext_shim, ops as oops
     import open3dsot_amd.ext as ext
     from open3dsot_amd import sa_modules
-    for name in ("furthest_point_sampling", "gather_points", "gather_points_grad", "three_nn", "three_interpolate",
+    for name in ("furthest_point_sampling", "gather_points", "gather_points_grad", "gather_rows", "three_nn", "three_interpolate",
                  "three_interpolate_grad", "ball_query", "group_points", "group_points_grad"):
         setattr(ext, name, getattr(ext_shim, name))
     ext.knn = lambda q, r, k: torch.from_numpy(oops.knn(q.detach().numpy(), r.detach().numpy(), k))

@@ -194,3 +194,27 @@ def test_fps_pair_launch_is_bit_identical(Na, npa, Nb, npb):
     ia, ib = ext.furthest_point_sampling_pair(a, npa, b, npb)
     assert torch.equal(ia, ext.furthest_point_sampling(a, npa))
     assert torch.equal(ib, ext.furthest_point_sampling(b, npb))
+
+
+def test_gather_rows_is_the_references_centre_gather():
+    """o3d_gather_rows: new_xyz = gather_operation(xyz^T, idx)^T (pointnet2_modules.py:52-62) in one launch on the
+    point-major tensor -- exact against the oracle's channel-major gather, duplicates and the empty case included;
+    `ops.gather_xyz` takes the reference's composition when a gradient flows to the coordinates"""
+    from open3dsot_amd import ext, ops      # (not part of the reference's _ext surface: the package's own operator set)
+    rng = np.random.default_rng(77)
+    for B, N, npoint in ((48, 1024, 512), (3, 37, 37), (2, 9, 20), (1, 5, 1)):
+        xyz = cloud(B * 31 + N, B, N)
+        idx = rng.integers(0, N, (B, npoint)).astype(np.int32)
+        got = ext.gather_rows(dev(xyz), dev(idx)).cpu().numpy()
+        exp = O.gather_points(np.ascontiguousarray(xyz.transpose(0, 2, 1)), idx).transpose(0, 2, 1)
+        assert np.array_equal(got, exp)
+        assert np.array_equal(ops.gather_xyz(dev(xyz), dev(idx)).cpu().numpy(), exp)
+        x = dev(xyz).requires_grad_(True)
+        y = ops.gather_xyz(x, dev(idx))
+        assert np.array_equal(y.detach().cpu().numpy(), exp)
+        y.sum().backward()
+        cnt = np.zeros((B, N), f32)
+        for b in range(B):
+            np.add.at(cnt[b], idx[b], 1.0)
+        assert np.array_equal(x.grad.cpu().numpy(), np.repeat(cnt[:, :, None], 3, 2))
+    assert ext.gather_rows(dev(np.zeros((2, 4, 3), f32)), dev(np.zeros((2, 0), np.int32))).shape == (2, 0, 3)
