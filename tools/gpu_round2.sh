@@ -11,11 +11,11 @@ timeout 300 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke
 timeout 1500 python -m pytest tests -m gpu -q --timeout=900 -p no:cacheprovider --durations=10 > $OUT/pytest.log 2>&1
 echo "pytest exit $?" >> $OUT/pytest.log
 grep -E "passed|failed|^E  |exit|^FAILED" $OUT/pytest.log | cut -c1-250 | head -20
-timeout 900 python bench.py > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
-timeout 300 python bench.py --no-cpu-baseline --dense > $OUT/bench_dense.json 2>/dev/null; echo "dense exit $?"
-timeout 400 python bench.py --model P2B --cpu-budget 40 > $OUT/bench_p2b.json 2>/dev/null; echo "p2b exit $?"
+timeout 900 python bench.py --per-launch $OUT/per_launch_roofline_bat.txt > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
+timeout 300 python bench.py --no-cpu-baseline --dense --per-launch $OUT/per_launch_roofline_dense.txt > $OUT/bench_dense.json 2>/dev/null; echo "dense exit $?"
+timeout 400 python bench.py --model P2B --cpu-budget 40 --per-launch $OUT/per_launch_roofline_p2b.txt > $OUT/bench_p2b.json 2>/dev/null; echo "p2b exit $?"
 timeout 400 python bench.py --model P2B --batch 1 --cpu-budget 30 > $OUT/bench_p2b_b1.json 2>/dev/null; echo "p2b b1 exit $?"
-timeout 300 python bench.py --model M2TRACK > $OUT/bench_m2track.json 2>/dev/null; echo "m2track exit $?"
+timeout 300 python bench.py --model M2TRACK --per-launch $OUT/per_launch_roofline_m2track.txt > $OUT/bench_m2track.json 2>/dev/null; echo "m2track exit $?"
 timeout 300 python bench.py --no-cpu-baseline --search-size 2048 > $OUT/bench_nuscenes2048.json 2>/dev/null; echo "nuscenes exit $?"
 timeout 200 python bench.py --infer --steps 500 --warmup 20 > $OUT/bench_infer.json 2>/dev/null; echo "infer exit $?"
 cd /tmp
