@@ -99,6 +99,7 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(const int32_t* __rest
 // expand: Y0[c,q] = Z[c,gp[q]] - W0[c,0:3].centre[cball[q]], weighted statistics partials
 //   workgroup = 256 columns, 4 waves; wave w takes channels w, w+4, ...; lane = 4 columns
 // ---------------------------------------------------------------------------------------
+template <bool CENTERS>      // compile-time: a run-time `if (centers)` around a load makes the compiler drain vmcnt at the join
 __global__ __launch_bounds__(256) void expand_c_kernel(const float* __restrict__ Z, long ldz,
                                                        const int32_t* __restrict__ gp,
                                                        const int32_t* __restrict__ cball,
@@ -117,7 +118,7 @@ __global__ __launch_bounds__(256) void expand_c_kernel(const float* __restrict__
     const int4 id = *reinterpret_cast<const int4*>(&gp[q]);
     const float4 w = *reinterpret_cast<const float4*>(&cw[q]);
     float cx[4] = {0.f, 0.f, 0.f, 0.f}, cy[4] = {0.f, 0.f, 0.f, 0.f}, cz[4] = {0.f, 0.f, 0.f, 0.f};
-    if (centers) {
+    if constexpr (CENTERS) {
         const int4 bj = *reinterpret_cast<const int4*>(&cball[q]);
         const int bb[4] = {bj.x, bj.y, bj.z, bj.w};
 #pragma unroll
@@ -133,34 +134,36 @@ __global__ __launch_bounds__(256) void expand_c_kernel(const float* __restrict__
     const int cbeg = blockIdx.y * cper, cend = cbeg + cper < C0 ? cbeg + cper : C0;
     for (int g0 = cbeg + wave; g0 < cend; g0 += 4 * EG) {
         float4 y[EG];
+        float w0[EG], w1[EG], w2[EG], sc_[EG];
 #pragma unroll
         for (int g = 0; g < EG; ++g) {
             const int co = g0 + 4 * g < cend ? g0 + 4 * g : cend - 1;
             const float* z = Z + (long)co * ldz;
             y[g].x = z[id.x]; y[g].y = z[id.y]; y[g].z = z[id.z]; y[g].w = z[id.w];
+            // the per-channel constants with the gathers, not between the stores below: a load issued after a store
+            // makes the wait for it wait for the store as well (vmcnt counts both on gfx9) -- EG round trips per pass
+            w0[g] = w1[g] = w2[g] = 0.f;
+            if constexpr (CENTERS) { const float* wr = W0 + (long)co * ldw; w0[g] = wr[0]; w1[g] = wr[1]; w2[g] = wr[2]; }
+            sc_[g] = (part && stat_c) ? stat_c[co] : 0.f;
         }
         float s[EG], v[EG];
 #pragma unroll
         for (int g = 0; g < EG; ++g) {
             const int co = g0 + 4 * g;
             if (co >= cend) { s[g] = 0.f; v[g] = 0.f; continue; }
-            float w0 = 0.f, w1 = 0.f, w2 = 0.f;
-            if (centers) { const float* wr = W0 + (long)co * ldw; w0 = wr[0]; w1 = wr[1]; w2 = wr[2]; }
-            y[g].x -= fmaf(w2, cz[0], fmaf(w1, cy[0], w0 * cx[0]));
-            y[g].y -= fmaf(w2, cz[1], fmaf(w1, cy[1], w0 * cx[1]));
-            y[g].z -= fmaf(w2, cz[2], fmaf(w1, cy[2], w0 * cx[2]));
-            y[g].w -= fmaf(w2, cz[3], fmaf(w1, cy[3], w0 * cx[3]));
+            y[g].x -= fmaf(w2[g], cz[0], fmaf(w1[g], cy[0], w0[g] * cx[0]));
+            y[g].y -= fmaf(w2[g], cz[1], fmaf(w1[g], cy[1], w0[g] * cx[1]));
+            y[g].z -= fmaf(w2[g], cz[2], fmaf(w1[g], cy[2], w0[g] * cx[2]));
+            y[g].w -= fmaf(w2[g], cz[3], fmaf(w1[g], cy[3], w0[g] * cx[3]));
             *reinterpret_cast<float4*>(&Y0[(long)co * ldp + q]) = y[g];
-            const float c = (part && stat_c) ? stat_c[co] : 0.f;
+            const float c = sc_[g];
             s[g] = fmaf(w.x, y[g].x, fmaf(w.y, y[g].y, fmaf(w.z, y[g].z, w.w * y[g].w)));
             v[g] = w.x * (y[g].x - c) * (y[g].x - c) + w.y * (y[g].y - c) * (y[g].y - c) +
                    w.z * (y[g].z - c) * (y[g].z - c) + w.w * (y[g].w - c) * (y[g].w - c);
         }
         if (part) {
 #pragma unroll
-            for (int m = 1; m < 64; m <<= 1)
-#pragma unroll
-                for (int g = 0; g < EG; ++g) { s[g] += __shfl_xor(s[g], m, 64); v[g] += __shfl_xor(v[g], m, 64); }
+            for (int g = 0; g < EG; ++g) { s[g] = wave_sum(s[g]); v[g] = wave_sum(v[g]); }
             if (lane == 0)
 #pragma unroll
                 for (int g = 0; g < EG; ++g) {
@@ -191,6 +194,8 @@ __device__ __forceinline__ long pool_index(int c, int ball, int C, int seg1_ball
     return (s1 ? (long)seg1_ball * C : 0) + ((long)b * C + c) * np + j;
 }
 
+// (dpp_f / dpp_i of o3d_common.hpp) lane <- lane ^ 1, lane ^ 2 (quad permutes) and lane <- 7 - lane within each group of
+// 8 (row_half_mirror): after the three steps lane 0 of every 8-lane group has combined all 8 lanes.
 template <int POOL_CH>
 __global__ __launch_bounds__(256) void pool_c_kernel(const float* __restrict__ Y, long ldp,
                                                      const float* __restrict__ scale,
@@ -206,48 +211,70 @@ __global__ __launch_bounds__(256) void pool_c_kernel(const float* __restrict__ Y
     const int q0 = ball_off[ball], q1 = q0 + ball_cnt[ball];
     const int c0 = blockIdx.y * POOL_CH;
     if (ball >= seg1_ball) { scale += C; shift += C; }       // second segment: its own BatchNorm constants
-    // all loads of the workgroup's 8 channels first (4 per lane and channel cover a 32-column ball; clamped, not
-    // predicated), then the compares: the kernel is a latency chain otherwise (1.7 TB/s measured with one load in
-    // flight per lane)
+    // ALL loads of the workgroup's channels first -- the 4 columns per lane and channel that cover a 32-column ball
+    // (clamped, not predicated) and the per-channel constants -- then the compares, then ALL stores: written channel by
+    // channel the kernel is a chain of store -> load constants -> s_waitcnt vmcnt(0) round trips (stores count in vmcnt
+    // on gfx9, so every wait for the next channel's constants also waited for the previous channel's stores)
     constexpr int PU = 4;
-    float v[POOL_CH][PU];
+    float v[POOL_CH][PU], sc[POOL_CH], sf[POOL_CH];
 #pragma unroll
     for (int cc = 0; cc < POOL_CH; ++cc) {
-        const float* y = Y + (long)(c0 + cc < C ? c0 + cc : C - 1) * ldp;
+        const int c = c0 + cc < C ? c0 + cc : C - 1;
+        const float* y = Y + (long)c * ldp;
 #pragma unroll
         for (int i = 0; i < PU; ++i) {
             const int q = q0 + e + 8 * i;
             v[cc][i] = y[q < q1 ? q : q1 - 1];
         }
+        sc[cc] = scale[c];
+        sf[cc] = shift[c];
     }
+    float rbest[POOL_CH], ryb[POOL_CH];
+    int rbq[POOL_CH];
 #pragma unroll
     for (int cc = 0; cc < POOL_CH; ++cc) {
-        const int c = c0 + cc;
-        if (c >= C) break;
-        const float sc = scale[c], sf = shift[c];
         float best = -INFINITY, yb = 0.f;
         int bq = 0x7fffffff;
 #pragma unroll
         for (int i = 0; i < PU; ++i) {
             const int q = q0 + e + 8 * i;
-            const float n = fmaf(v[cc][i], sc, sf);
+            const float n = fmaf(v[cc][i], sc[cc], sf[cc]);
             if (q < q1 && n > best) { best = n; bq = q; yb = v[cc][i]; }
         }
-        const float* y = Y + (long)c * ldp;
-        for (int q = q0 + e + 8 * PU; q < q1; q += 8) {      // balls of more than 32 columns
-            const float w = y[q], n = fmaf(w, sc, sf);
-            if (n > best) { best = n; bq = q; yb = w; }
+        if (q1 - q0 > 8 * PU) {                               // balls of more than 32 columns (no tracker has them)
+            const float* y = Y + (long)(c0 + cc < C ? c0 + cc : C - 1) * ldp;
+            for (int q = q0 + e + 8 * PU; q < q1; q += 8) {
+                const float w = y[q], n = fmaf(w, sc[cc], sf[cc]);
+                if (n > best) { best = n; bq = q; yb = w; }
+            }
         }
-#pragma unroll
-        for (int off = 4; off >= 1; off >>= 1) {
-            const float ob = __shfl_xor(best, off, 64), oy = __shfl_xor(yb, off, 64);
-            const int oq = __shfl_xor(bq, off, 64);
+        // first maximum of the 8 lanes (largest value, smallest column on ties): xor 1, xor 2, mirror
+        {
+            const float ob = dpp_f<0xB1>(best), oy = dpp_f<0xB1>(yb);
+            const int oq = dpp_i<0xB1>(bq);
             if (ob > best || (ob == best && oq < bq)) { best = ob; bq = oq; yb = oy; }
         }
-        if (live && e == 0) {
-            const long o = pool_index(c, ball, C, seg1_ball, np0, np1);
-            out[o] = fmaxf(best, 0.f);
-            if (argq) { argq[o] = bq; yarg[o] = yb; }
+        {
+            const float ob = dpp_f<0x4E>(best), oy = dpp_f<0x4E>(yb);
+            const int oq = dpp_i<0x4E>(bq);
+            if (ob > best || (ob == best && oq < bq)) { best = ob; bq = oq; yb = oy; }
+        }
+        {
+            const float ob = dpp_f<0x141>(best), oy = dpp_f<0x141>(yb);
+            const int oq = dpp_i<0x141>(bq);
+            if (ob > best || (ob == best && oq < bq)) { best = ob; bq = oq; yb = oy; }
+        }
+        rbest[cc] = best; ryb[cc] = yb; rbq[cc] = bq;
+    }
+    if (live && e == 0) {
+#pragma unroll
+        for (int cc = 0; cc < POOL_CH; ++cc) {
+            const int c = c0 + cc;
+            if (c < C) {
+                const long o = pool_index(c, ball, C, seg1_ball, np0, np1);
+                out[o] = fmaxf(rbest[cc], 0.f);
+                if (argq) { argq[o] = rbq[cc]; yarg[o] = ryb[cc]; }
+            }
         }
     }
 }
@@ -528,26 +555,49 @@ __global__ __launch_bounds__(256) void reduce_gather_kernel(const float* __restr
     }
     for (int k = 0, lo = q0a; lo < q1; ++k, lo += CH) {
         const int hi = lo + CH < q1 ? lo + CH : q1;
-        __syncthreads();                    // previous chunk fully consumed (first pass: the zero fill)
-        for (int i = 4 * threadIdx.x; i < CH; i += 1024) {        // phase A: dY of the chunk, plain LDS stores
-            const int q = lo + i;
-            if (q >= hi) break;
-            const float4 w4 = *reinterpret_cast<const float4*>(&cw[q]);
+        // phase A: every global load of the chunk in flight before the first wait -- the chunk's slice of the sorted
+        // index (<= CH entries: 8 per thread, clamped) and the dN / Y0 rows of both column quads of the thread --
+        // then dY and the index into LDS with plain stores
+        const int l0 = po[k * ld], l1 = po[(k + 1) * ld];         // this chunk's slice of perm (sorted by point)
+        const int cnt = l1 - l0;
+        int ent[CH / 256];
+#pragma unroll
+        for (int u = 0; u < CH / 256; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            ent[u] = perm[cnt > 0 ? q0 + l0 + (i < cnt ? i : cnt - 1) : 0];
+        }
+        float4 d[CH / 1024][CS], y[CH / 1024][CS], w4[CH / 1024];
+#pragma unroll
+        for (int it = 0; it < CH / 1024; ++it) {
+            const int q = lo + 4 * threadIdx.x + 1024 * it;
+            const int qc = q < hi ? q : lo;                       // clamped, not predicated (lo < hi always)
+            w4[it] = *reinterpret_cast<const float4*>(&cw[qc]);
 #pragma unroll
             for (int c = 0; c < CS; ++c) {
-                const float4 d = *reinterpret_cast<const float4*>(&dN[(long)crow[c] * ldp + q]);
-                const float4 y = *reinterpret_cast<const float4*>(&Y0[(long)crow[c] * ldp + q]);
+                d[it][c] = *reinterpret_cast<const float4*>(&dN[(long)crow[c] * ldp + qc]);
+                y[it][c] = *reinterpret_cast<const float4*>(&Y0[(long)crow[c] * ldp + qc]);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);  // (keeps the machine scheduler from pulling the first quad's arithmetic, and
+                                            // with it a full wait, in front of the remaining loads)
+        __syncthreads();                    // previous chunk fully consumed (first pass: the zero fill)
+#pragma unroll
+        for (int it = 0; it < CH / 1024; ++it) {
+            // UNCONDITIONAL stores (columns at or beyond `hi` get the clamped column's values: no index entry and no
+            // ball range refers to them): under an `if` the compiler sinks the loads into the branch, behind the barrier
+            const int i = 4 * threadIdx.x + 1024 * it;
+#pragma unroll
+            for (int c = 0; c < CS; ++c) {
                 float4 o;
-                o.x = fmaf(a1[c], d.x, w4.x * fmaf(a2[c], y.x, a3[c]));
-                o.y = fmaf(a1[c], d.y, w4.y * fmaf(a2[c], y.y, a3[c]));
-                o.z = fmaf(a1[c], d.z, w4.z * fmaf(a2[c], y.z, a3[c]));
-                o.w = fmaf(a1[c], d.w, w4.w * fmaf(a2[c], y.w, a3[c]));
+                o.x = fmaf(a1[c], d[it][c].x, w4[it].x * fmaf(a2[c], y[it][c].x, a3[c]));
+                o.y = fmaf(a1[c], d[it][c].y, w4[it].y * fmaf(a2[c], y[it][c].y, a3[c]));
+                o.z = fmaf(a1[c], d[it][c].z, w4[it].z * fmaf(a2[c], y[it][c].z, a3[c]));
+                o.w = fmaf(a1[c], d[it][c].w, w4[it].w * fmaf(a2[c], y[it][c].w, a3[c]));
                 *reinterpret_cast<float4*>(&dy[c * CH + i]) = o;
             }
         }
-        const int l0 = po[k * ld], l1 = po[(k + 1) * ld];         // this chunk's slice of perm (sorted by point)
-        const int cnt = l1 - l0;
-        for (int i = threadIdx.x; i < cnt; i += 256) lst[i] = perm[q0 + l0 + i];
+#pragma unroll
+        for (int u = 0; u < CH / 256; ++u) lst[threadIdx.x + 256 * u] = ent[u];      // (entries >= cnt: never read)
         __syncthreads();
         // phase B, balanced: every thread takes an equal share of the chunk's entries (a point referenced by hundreds
         // of balls no longer serialises on one thread) and flushes a run of equal points with one LDS atomic
@@ -696,8 +746,12 @@ extern "C" int o3d_group_expand_c(const float* Z, long ldz, const int32_t* gp, c
     // 0.26, 2 ranges 0.20, 4 ranges 0.19; a range keeps >= 32 channels = one full pass of its 4 waves
     static const int ysplit_env = [] { const char* e = getenv("O3D_EXPAND_SPLIT"); return e ? atoi(e) : 0; }();
     const int ysplit = ysplit_env > 0 ? ysplit_env : (C0 >= 128 ? 4 : C0 >= 64 ? 2 : 1);
-    hipLaunchKernelGGL(expand_c_kernel, dim3((unsigned)(ldp / 256), ysplit), dim3(256), 0, o3d_stream(stream), Z, ldz, gp,
-                       cball, cw, centers, W0, ldw, C0, meta, start1, ldp, Y0, part, stat_c);
+    if (centers)
+        hipLaunchKernelGGL(expand_c_kernel<true>, dim3((unsigned)(ldp / 256), ysplit), dim3(256), 0, o3d_stream(stream), Z,
+                           ldz, gp, cball, cw, centers, W0, ldw, C0, meta, start1, ldp, Y0, part, stat_c);
+    else
+        hipLaunchKernelGGL(expand_c_kernel<false>, dim3((unsigned)(ldp / 256), ysplit), dim3(256), 0, o3d_stream(stream), Z,
+                           ldz, gp, cball, cw, centers, W0, ldw, C0, meta, start1, ldp, Y0, part, stat_c);
     return o3d_launch_status();
 }
 

@@ -22,3 +22,27 @@ __device__ __forceinline__ float o3d_sqdist3(float ax, float ay, float az, float
 }
 
 static inline int o3d_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---- cross-lane moves on the DPP path (no LDS round trip like ds_bpermute / __shfl_xor) ---------------------------
+// CTRL: 0xB1 quad_perm [1,0,3,2] (lane ^ 1), 0x4E quad_perm [2,3,0,1] (lane ^ 2), 0x141 row_half_mirror (lane -> 7 - lane
+// within 8), 0x140 row_mirror (lane -> 15 - lane within 16)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+
+// sum over the 64 lanes of a wave, the same value in every lane: four DPP steps inside each row of 16, then the four
+// row sums through v_readlane (fixed order: deterministic)
+__device__ __forceinline__ float wave_sum(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    v += dpp_f<0x140>(v);
+    const float r0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0));
+    const float r1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16));
+    const float r2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32));
+    const float r3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48));
+    return (r0 + r1) + (r2 + r3);
+}

@@ -12,6 +12,7 @@
 //             [slot][channel] so a lane's four k's are one ds_read_b128; BatchNorm + ReLU applied in the epilogue
 //   pool      max over the ball's nsample (<= 32, power of two) slots = xor-shuffles inside a 32-lane half wave
 // Duplicate slots (ball_query's padding) are simply computed: max ignores them and at batch 1 the work is nothing.
+#include <cstdint>
 #include "mlp_common.hpp"
 
 namespace {
@@ -42,27 +43,52 @@ __device__ __forceinline__ void sa_eval_layer(const SaEvalArgs& a, const float* 
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // the 16 rows of this lane: 32*mt + 8*q + 4*h + j -- their BatchNorm constants as four float4 each, loaded BEFORE the
+        // k loop (per row in the epilogue they were 16 load -> wait round trips per tile)
+        float4 sc4[4], sh4[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            sc4[q] = *reinterpret_cast<const float4*>(scale + mt * 32 + 8 * q + 4 * h);
+            sh4[q] = *reinterpret_cast<const float4*>(shift + mt * 32 + 8 * q + 4 * h);
+        }
         const float* wa = W + (long)(mt * 32 + l31) * K + 4 * h;
-        float4 an = *reinterpret_cast<const float4*>(wa);
-        for (int g = 0; g < G; ++g) {
-            const float4 av = an;
-            if (g + 1 < G) an = *reinterpret_cast<const float4*>(wa + 8 * (g + 1));
-            const float4 bv = *reinterpret_cast<const float4*>(ba + 8 * g);
-            acc = mfma32(av.x, bv.x, acc);
-            acc = mfma32(av.y, bv.y, acc);
-            acc = mfma32(av.z, bv.z, acc);
-            acc = mfma32(av.w, bv.w, acc);
+        // weights stream from L2 (~500 cycles) against 4 MFMAs (256 cycles) per group: three groups in flight
+        // (a ring with STATIC slots, unrolled by 4: rotating registers that are targets of loads still in flight makes
+        // the compiler wait for all of them)
+        float4 w[4];
+#pragma unroll
+        for (int u = 0; u < 3; ++u) w[u] = *reinterpret_cast<const float4*>(wa + 8 * (u < G ? u : G - 1));
+        for (int g = 0; g < G; g += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                w[(u + 3) & 3] = *reinterpret_cast<const float4*>(wa + 8 * (g + u + 3 < G ? g + u + 3 : G - 1));
+                if (g + u < G) {
+                    const float4 av = w[u];
+                    const float4 bv = *reinterpret_cast<const float4*>(ba + 8 * (g + u));
+                    acc = mfma32(av.x, bv.x, acc);
+                    acc = mfma32(av.y, bv.y, acc);
+                    acc = mfma32(av.z, bv.z, acc);
+                    acc = mfma32(av.w, bv.w, acc);
+                }
+            }
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int m = mt * 32 + acc_row(r, h);
-            float y = fmaxf(fmaf(acc[r], scale[m], shift[m]), 0.f);
-            if (POOL) {
-                for (int off = 1; off < a.ns; off <<= 1) y = fmaxf(y, __shfl_xor(y, off, 64));
+            const int q = r >> 2, j = r & 3;
+            const float scv = j == 0 ? sc4[q].x : j == 1 ? sc4[q].y : j == 2 ? sc4[q].z : sc4[q].w;
+            const float shv = j == 0 ? sh4[q].x : j == 1 ? sh4[q].y : j == 2 ? sh4[q].z : sh4[q].w;
+            float y = fmaxf(fmaf(acc[r], scv, shv), 0.f);
+            if (POOL) {       // max over the ball's ns (power of two <= 32) lanes: DPP inside a row of 16, one shuffle across
+                if (a.ns > 1) y = fmaxf(y, dpp_f<0xB1>(y));
+                if (a.ns > 2) y = fmaxf(y, dpp_f<0x4E>(y));
+                if (a.ns > 4) y = fmaxf(y, dpp_f<0x141>(y));
+                if (a.ns > 8) y = fmaxf(y, dpp_f<0x140>(y));
+                if (a.ns > 16) y = fmaxf(y, __shfl_xor(y, 16, 64));
                 if ((l31 & (a.ns - 1)) == 0) {
                     const long ball = (slot0 + l31) / a.ns;
-                    const int b = (int)(ball / a.np), j = (int)(ball - (long)b * a.np);
-                    a.out[((long)b * M + m) * a.np + j] = y;
+                    const int b = (int)(ball / a.np), jb = (int)(ball - (long)b * a.np);
+                    a.out[((long)b * M + m) * a.np + jb] = y;
                 }
             } else {
                 Aout[l31 * (M + 4) + m] = y;
@@ -115,7 +141,7 @@ extern "C" int o3d_sa_eval_fused(const float* Z, long ldz, const int32_t* idx, c
     const long slots = (long)B * np * ns;
     if (!Z || !idx || !v0 || !W1 || !v1 || !W2 || !v2 || !out || (centers && (!W0 || ldw < 3)) || C0 <= 0 || C0 % 8 ||
         C1 <= 0 || C1 % 32 || C2 <= 0 || C2 % 32 || B <= 0 || np <= 0 || ns < 1 || ns > 32 || (ns & (ns - 1)) || ld <= 0 ||
-        pt_base < 0 || slots % 32 != 0)
+        pt_base < 0 || slots % 32 != 0 || ((uintptr_t)v1 & 15) || ((uintptr_t)v2 & 15))      // (v1, v2: read as float4)
         return O3D_EINVAL;
     SaEvalArgs a = {Z, ldz, idx, centers, W0, ldw, v0, v1, v2, W1, W2, C0, C1, C2, B, np, ns, ld, pt_base, out};
     const size_t lds = sizeof(float) * 32 * ((size_t)C0 + 4 + (size_t)C1 + 4);

@@ -36,30 +36,33 @@ __global__ __launch_bounds__(256) void xcorr_expand_kernel(const float* __restri
     const int cbeg = blockIdx.y * cper, cend = cbeg + cper < C0 ? cbeg + cper : C0;
     for (int g0 = cbeg + wave; g0 < cend; g0 += 4 * EG) {
         float4 y[EG];
+        float wq[EG], cq[EG];
 #pragma unroll
         for (int g = 0; g < EG; ++g) {
             const int co = g0 + 4 * g < cend ? g0 + 4 * g : cend - 1;
             y[g] = *reinterpret_cast<const float4*>(zb + (long)co * ldz);
+            // per-channel constants with the row loads, not between the stores below (a load issued after a store makes
+            // the wait for it wait for the store as well: vmcnt counts both on gfx9)
+            wq[g] = W0[(long)co * ldw];
+            cq[g] = (part && stat_c) ? stat_c[co] : 0.f;
         }
         float s[EG], v[EG];
 #pragma unroll
         for (int g = 0; g < EG; ++g) {
             const int co = g0 + 4 * g;
             if (co >= cend) { s[g] = 0.f; v[g] = 0.f; continue; }
-            const float w = W0[(long)co * ldw];
+            const float w = wq[g];
             y[g].x = fmaf(w, s4.x, y[g].x); y[g].y = fmaf(w, s4.y, y[g].y);
             y[g].z = fmaf(w, s4.z, y[g].z); y[g].w = fmaf(w, s4.w, y[g].w);
             *reinterpret_cast<float4*>(&Y0[(long)co * P + q]) = y[g];
-            const float c = (part && stat_c) ? stat_c[co] : 0.f;
+            const float c = cq[g];
             s[g] = (y[g].x + y[g].y) + (y[g].z + y[g].w);
             v[g] = (y[g].x - c) * (y[g].x - c) + (y[g].y - c) * (y[g].y - c) + (y[g].z - c) * (y[g].z - c) +
                    (y[g].w - c) * (y[g].w - c);
         }
         if (part) {
 #pragma unroll
-            for (int m = 1; m < 64; m <<= 1)
-#pragma unroll
-                for (int g = 0; g < EG; ++g) { s[g] += __shfl_xor(s[g], m, 64); v[g] += __shfl_xor(v[g], m, 64); }
+            for (int g = 0; g < EG; ++g) { s[g] = wave_sum(s[g]); v[g] = wave_sum(v[g]); }
             // the four waves of the workgroup hold disjoint channels: one partial row per 256 columns
             if (lane == 0)
 #pragma unroll
