@@ -10,7 +10,8 @@
 //     round touches no memory except one uniform 12-byte LDS read of the new centre.
 //   * N <= 2048: ONE wave per cloud, no barrier anywhere in the round loop; the arg-max
 //     is a DPP row reduction (quad_perm / row_half_mirror / row_mirror) + 4 v_readlane.
-//     2048 < N <= 8192: 8 waves per cloud, two LDS hand-offs per round.
+//     2048 < N <= 8192: 8 waves per cloud, ONE LDS hand-off and one barrier per round (every wave publishes its
+//     maximum and its best key at that maximum).
 //     N > 8192: generic strided kernel with the min-distance array in caller scratch.
 //   * bit-identical indices: the upstream winner among equal maxima is decided by its
 //     thread-strided scan + tree reduction, i.e. by
@@ -18,6 +19,7 @@
 //     lowest rank wins (L = log2 bs).  The reduction here is two-phase: wave/block max of
 //     the distance, then max of ((0xFFFF - rank) << 16 | k) over the lanes that hold that
 //     maximum -- independent of how points are laid over lanes.
+#include <cstdlib>
 #include "o3d_common.hpp"
 
 namespace {
@@ -72,7 +74,7 @@ struct FpsSet1 {
 };
 
 // One workgroup (NW waves) per cloud, PPT points per lane in registers.  N <= 64*NW*PPT,
-// N < 65535.  LDS: N*3 floats (cloud copy) + 2*NW words (cross-wave exchange).
+// N < 65535.  LDS: N*3 floats (cloud copy) + 4*NW words (cross-wave exchange).
 template <int PPT, int NW, bool USE_DPP>
 __global__ __launch_bounds__(64 * NW) void fps_reg_kernel(const float* __restrict__ xyz, int N,
                                                           int npoint, int bs_log2, int cpb,
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(64 * NW) void fps_reg_kernel(const float* __restric
         xyz = s1.xyz; idx = s1.idx; N = s1.N; npoint = s1.npoint; bs_log2 = s1.bs_log2; cpb = s1.cpb;
     }
     float* s_xyz = smem;
-    unsigned* s_x = reinterpret_cast<unsigned*>(smem + (size_t)N * 3);  // [2][NW]
+    unsigned* s_x = reinterpret_cast<unsigned*>(smem + (size_t)N * 3);  // [2][2][NW]: {maximum, key} per wave, two rounds
     constexpr int T = 64 * NW;
     const int tid = threadIdx.x;
     const int wave = tid >> 6;
@@ -123,17 +125,9 @@ __global__ __launch_bounds__(64 * NW) void fps_reg_kernel(const float* __restric
             tmp[i] = d2;
             hb = fmaxf(hb, d2);
         }
-        // phase 1: maximum distance over the cloud (non-negative floats order like u32)
-        unsigned M = wave_max_u32<USE_DPP>(__float_as_uint(hb));
-        if (NW > 1) {
-            unsigned* ex = s_x + ((j & 1) ? NW : 0);
-            if ((tid & 63) == 0) ex[wave] = M;
-            __syncthreads();
-#pragma unroll
-            for (int w = 0; w < NW; ++w) { const unsigned t = ex[w]; M = M > t ? M : t; }
-            __syncthreads();
-        }
-        // phase 2: lowest upstream rank among the points at that distance
+        // phase 1: maximum distance over the WAVE's points (non-negative floats order like u32)
+        const unsigned M = wave_max_u32<USE_DPP>(__float_as_uint(hb));
+        // phase 2: lowest upstream rank among the wave's points at that distance
         unsigned c = 0u;
 #pragma unroll
         for (int i = 0; i < PPT; ++i) {
@@ -142,12 +136,21 @@ __global__ __launch_bounds__(64 * NW) void fps_reg_kernel(const float* __restric
         }
         unsigned L = wave_max_u32<USE_DPP>(c);
         if (NW > 1) {
-            unsigned* ex = s_x + ((j & 1) ? NW : 0);
-            if ((tid & 63) == 0) ex[wave] = L;
+            // ONE hand-off per round: every wave publishes (its maximum, its best key at that maximum); the cloud's
+            // winner is the best key among the waves that hold the overall maximum.  Double-buffered by the round's
+            // parity, so one barrier per round is enough: a wave can only overwrite a buffer two rounds later, i.e.
+            // after the barrier of the round in between, which every reader of the old contents has reached.
+            unsigned* exM = s_x + ((j & 1) ? 2 * NW : 0);
+            unsigned* exL = exM + NW;
+            if ((tid & 63) == 0) { exM[wave] = M; exL[wave] = L; }
             __syncthreads();
+            unsigned Mg = 0u, Lg = 0u;
 #pragma unroll
-            for (int w = 0; w < NW; ++w) { const unsigned t = ex[w]; L = L > t ? L : t; }
-            __syncthreads();
+            for (int w = 0; w < NW; ++w) {
+                const unsigned m = exM[w], l = exL[w];
+                if (m > Mg || (m == Mg && l > Lg)) { Mg = m; Lg = l; }
+            }
+            L = Lg;
         }
         old = (int)(L & 0xFFFFu);  // L == 0 (nothing selectable) -> index 0, as upstream
         if (tid == 0) out[j] = old;
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(1024) void fps_generic_kernel(const float* __restri
 template <int PPT, int NW, bool USE_DPP>
 int launch_reg(const float* xyz, int B, int N, int npoint, int bs_log2, int cpb, int32_t* idx,
                hipStream_t s) {
-    const size_t lds = (size_t)N * 3 * sizeof(float) + 2 * NW * sizeof(unsigned);
+    const size_t lds = (size_t)N * 3 * sizeof(float) + 4 * NW * sizeof(unsigned);
     hipLaunchKernelGGL((fps_reg_kernel<PPT, NW, USE_DPP>), dim3(B), dim3(64 * NW), lds, s, xyz, N,
                        npoint, bs_log2, cpb, idx, FpsSet1{});
     return o3d_launch_status();
@@ -219,17 +222,27 @@ static void fps_rank_params(int N, int& bs_log2, int& cpb) {
     cpb = (N + (1 << bs_log2) - 1) >> bs_log2;
 }
 
-// both sets in one launch of the one-wave-per-cloud kernel sized for the larger cloud
-template <int PPT>
+// waves per cloud for 256 < N <= 2048: 1 (no hand-off), or 4 with O3D_FPS_NW=4 (a quarter of the per-round distance
+// updates per wave, one LDS hand-off + barrier per round).  Measured on the MI355X, same-box A/B at 512 / 1024 points:
+// the 4-wave form is SLOWER (BAT step 6.45 vs 6.43 ms, batch-1 frame 1.021 vs 1.006 ms) -- the round is ~100 VALU
+// instructions shorter, the barrier and the LDS round trip cost more.  Kept as a switch.
+static int fps_nw() {
+    static const int v = [] { const char* e = getenv("O3D_FPS_NW"); return e && atoi(e) == 4 ? 4 : 1; }();
+    return v;
+}
+
+// both sets in one launch of the register kernel sized for the larger cloud
+template <int PPT, int NW>
 int launch_pair(const float* xyz0, int N0, int np0, int32_t* idx0, const float* xyz1, int N1, int np1,
                 int32_t* idx1, int B, hipStream_t s) {
     int l0, c0, l1, c1;
     fps_rank_params(N0, l0, c0);
     fps_rank_params(N1, l1, c1);
     const int Nmax = N0 > N1 ? N0 : N1;
-    const size_t lds = (size_t)Nmax * 3 * sizeof(float) + 2 * sizeof(unsigned);
+    const size_t lds = (size_t)Nmax * 3 * sizeof(float) + 4 * NW * sizeof(unsigned);
     const FpsSet1 s1 = {xyz1, idx1, N1, np1, l1, c1, B};
-    hipLaunchKernelGGL((fps_reg_kernel<PPT, 1, true>), dim3(2 * B), dim3(64), lds, s, xyz0, N0, np0, l0, c0, idx0, s1);
+    hipLaunchKernelGGL((fps_reg_kernel<PPT, NW, true>), dim3(2 * B), dim3(64 * NW), lds, s, xyz0, N0, np0, l0, c0, idx0,
+                       s1);
     return o3d_launch_status();
 }
 
@@ -243,6 +256,11 @@ int fps_dispatch(const float* xyz, int B, int N, int npoint, float* temp, int32_
     if (N <= 64) return launch_reg<1, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
     if (N <= 128) return launch_reg<2, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
     if (N <= 256) return launch_reg<4, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
+    if (fps_nw() == 4 && N <= 2048) {
+        if (N <= 512) return launch_reg<2, 4, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
+        if (N <= 1024) return launch_reg<4, 4, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
+        return launch_reg<8, 4, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
+    }
     if (N <= 512) return launch_reg<8, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
     if (N <= 1024) return launch_reg<16, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
     if (N <= 2048) return launch_reg<32, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
@@ -275,10 +293,15 @@ extern "C" int o3d_furthest_point_sampling_pair(const float* xyz0, int N0, int n
     if (B <= 0 || N0 <= 0 || N1 <= 0 || npoint0 <= 0 || npoint1 <= 0 || Nmax > 2048 || !xyz0 || !xyz1 || !idx0 || !idx1)
         return O3D_EINVAL;
     hipStream_t s = o3d_stream(stream);
-    if (Nmax <= 256) return launch_pair<4>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
-    if (Nmax <= 512) return launch_pair<8>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
-    if (Nmax <= 1024) return launch_pair<16>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
-    return launch_pair<32>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
+    if (Nmax <= 256) return launch_pair<4, 1>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
+    if (fps_nw() == 4) {
+        if (Nmax <= 512) return launch_pair<2, 4>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
+        if (Nmax <= 1024) return launch_pair<4, 4>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
+        return launch_pair<8, 4>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
+    }
+    if (Nmax <= 512) return launch_pair<8, 1>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
+    if (Nmax <= 1024) return launch_pair<16, 1>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
+    return launch_pair<32, 1>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
 }
 
 // Test hook: same op through the ds_bpermute (__shfl_xor) reduction instead of DPP.
