@@ -604,3 +604,31 @@ def test_flat_adam_matches_torch_adam():
         assert rel(p, q) < 2e-5, (k, rel(p, q))      # lerp vs b1*m+(1-b1)*g rounding
     out = a(synth.to_torch(synth.make_batch(5, 2, 256, 512), dev))      # the re-pointed parameters still drive the model
     assert torch.isfinite(out["estimation_boxes"]).all()
+
+
+def test_flat_adam_behind_the_flat_gradient_exchange():
+    """the multi-rank order of DataParallelStep.step on one GPU: backward assigns p.grad, `FlatGrads.gather` packs the
+    gradients into the exchange buffer (where the all-reduce would run), `bind_views` re-points every p.grad at its
+    slice, then FlatAdam steps -- its job table must follow the re-pointed gradients.  Against torch.optim.Adam fed
+    the same gradients, eager steps and a captured step."""
+    import copy
+    from open3dsot_amd import dist as D, optim, synth, trackers
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(8)
+    model = trackers.BAT().to(dev).train()
+    twin = copy.deepcopy(model)
+    step = D.DataParallelStep(model, world=1, graph=False)
+    assert isinstance(step.optimizer, optim.FlatAdam)
+    ob = torch.optim.Adam(twin.parameters(), lr=1e-3, weight_decay=0, betas=(0.5, 0.999), eps=1e-6)
+    for it in range(4):
+        batch = synth.to_torch(synth.make_batch(700 + 4 * it, 4, 256, 512), dev)
+        step._forward_backward(batch)
+        for p, q in zip(model.parameters(), twin.parameters()):
+            q.grad = p.grad.detach().clone()
+        step.grads.gather([p.grad for p in step.grads.params])        # what reduce_gradients does at world > 1 ...
+        step.grads.flat.div_(1)                                       # ... around the all-reduce
+        step.grads.bind_views()
+        step.optimizer.step()
+        ob.step()
+        for (k, p), q in zip(model.named_parameters(), twin.parameters()):
+            assert rel(p, q) < 2e-5, (it, k, rel(p, q))
