@@ -1,0 +1,148 @@
+"""The HIP product path pinned DIRECTLY on the reference's own model classes: tests/golden/ref_trackers.npz holds what
+models/bat.py::BAT and models/p2b.py::P2B produced (forward end points, loss, gradients, BatchNorm running statistics,
+eval forward, one Adam step) for closed-form weights and a synthetic batch (tests/golden/make_golden_trackers.py, run
+with the reference imported).  tests/test_golden_trackers.py checks the host mirror against it on the CPU with the
+oracle shim standing in for the library; here the SAME fixtures are compared with the GPU run -- fused kernels, C-ABI
+library, FlatAdam -- with no oracle in between."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+import det_init  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(ROOT, "tests", "golden", "ref_trackers.npz"))
+
+
+def rel(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def build(name, train):
+    from open3dsot_amd import sa_modules, synth, trackers
+    assert sa_modules.fused_enabled()
+    dev = torch.device("cuda", 0)
+    model = trackers.get_model(name)()
+    det_init.fill_state_dict(model)
+    model = model.to(dev).train(train)
+    batch = synth.to_torch(synth.make_batch(40, 2, 256, 512), dev)
+    captured = {}
+    fwd = model.forward
+
+    def rec(b):
+        r = fwd(b)
+        captured.update(r)
+        return r
+    model.forward = rec
+    return model, batch, captured
+
+
+@pytest.mark.parametrize("name", ["BAT", "P2B"])
+def test_gpu_training_step_matches_reference_class(gold, name):
+    model, batch, end = build(name, True)
+    loss, _ = model.training_loss(batch)
+    loss.backward()
+    torch.cuda.synchronize()
+    for k in [k for k in gold.files if k.startswith(name + ".train.") and k != name + ".train.loss"]:
+        want, got = gold[k], end[k.split(".train.")[1]].detach().cpu().numpy()
+        if want.dtype.kind in "iu":
+            assert np.array_equal(got, want), k                 # sampling / grouping indices: exact
+        else:
+            # 2e-4 holds for every end point on the CPU twin (same torch ops in the same order as the reference); the GPU
+            # kernels sum in another order and the fixture's batch is TWO pairs -- 128 to 512 samples per BatchNorm
+            # channel in the heads -- which amplifies that rounding: 2.1e-4 (BAT) / 6.8e-4 (P2B) on the objectness logits,
+            # below 2e-4 elsewhere.  The benchmarked batch holds 1e-4 (tests/test_model_gpu.py, batch 48).
+            loose = "score" in k or "estimation_cla" in k       # the objectness logits and their sigmoid
+            assert rel(got, want) < (1e-3 if loose else 2e-4), (k, rel(got, want))
+    want_loss = float(gold[name + ".train.loss"])
+    assert abs(float(loss.detach()) - want_loss) <= 1e-4 * (1 + abs(want_loss))
+    named = dict(model.named_parameters())
+    gnorm = float(gold[name + ".gradnorm"])
+    for k in [k for k in gold.files if k.startswith(name + ".grad.")]:
+        g = named[k.split(".grad.")[1]].grad.detach().cpu().numpy().ravel().astype(np.float64)
+        want = gold[k].ravel().astype(np.float64)
+        # A WIRING check, deliberately loose: at this batch of two pairs the fp32 gradient is ill-conditioned on every
+        # implementation -- measured against an fp64 evaluation of the same step (tools/exp/golden_grad_truth.py,
+        # profiles/r02_golden_batch2_fp64_diag.txt) the reference's own CPU gradients stored in the fixture are 10-40 %
+        # off on the first layers, torch's GPU fp32 run 12 % (BAT) / 35 % (P2B) on the whole gradient and this path
+        # 10 % / 30 %.  A mis-wired gradient is off by >= 100 %.  The rounding check is tests/test_model_gpu.py at the
+        # benchmarked batch (fp64 shadow, 48 pairs).
+        err = float(np.linalg.norm(g - want))
+        assert err <= 0.6 * np.linalg.norm(want) + 1e-5 * gnorm, (k, err, float(np.linalg.norm(want)))
+    norm = sum(float(p.grad.double().pow(2).sum()) for p in model.parameters() if p.grad is not None) ** 0.5
+    assert abs(norm / gnorm - 1) < 0.2
+    sd = model.state_dict()
+    for k in [k for k in gold.files if k.startswith(name + ".after.")]:
+        key = k.split(".after.")[1]
+        if "num_batches" in key:
+            assert int(sd[key]) == int(gold[k]), key
+        else:
+            assert rel(sd[key].cpu().numpy(), gold[k]) < 2e-4, (key, rel(sd[key].cpu().numpy(), gold[k]))
+
+
+@pytest.mark.parametrize("name", ["BAT", "P2B"])
+def test_gpu_eval_forward_matches_reference_class(gold, name):
+    """eval mode after the reference's one training step: the one-kernel set abstraction (csrc/sa_eval.hip) and the
+    eval-mode heads against the reference's eval forward"""
+    from open3dsot_amd import synth, trackers
+    dev = torch.device("cuda", 0)
+    model = trackers.get_model(name)()
+    det_init.fill_state_dict(model)
+    sd = model.state_dict()
+    for k in [k for k in gold.files if k.startswith(name + ".after.")]:
+        sd[k.split(".after.")[1]] = torch.from_numpy(gold[k])
+    model.load_state_dict(sd, strict=True)
+    model = model.to(dev).eval()
+    batch = synth.to_torch(synth.make_batch(40, 2, 256, 512), dev)
+    with torch.no_grad():
+        end = model(batch)
+    for k in [k for k in gold.files if k.startswith(name + ".eval.")]:
+        want, got = gold[k], end[k.split(".eval.")[1]].cpu().numpy()
+        if want.dtype.kind in "iu":
+            assert np.array_equal(got, want), k
+        else:
+            assert rel(got, want) < 2e-4, (k, rel(got, want))
+
+
+@pytest.mark.parametrize("name", ["BAT", "P2B"])
+def test_gpu_optimizer_step_matches_reference_class(gold, name):
+    """configure_optimizers on the GPU hands out FlatAdam: hyper-parameters and the first step against the reference's
+    torch.optim.Adam (models/base_model.py:28-36)"""
+    from open3dsot_amd import optim
+    model, batch, _ = build(name, True)
+    loss, _ = model.training_loss(batch)
+    loss.backward()
+    conf = model.configure_optimizers()
+    opt, sched = conf["optimizer"], conf["lr_scheduler"]
+    assert isinstance(opt, optim.FlatAdam)
+    grp = opt.param_groups[0]
+    got = [grp["lr"], grp["betas"][0], grp["betas"][1], grp["eps"], grp["weight_decay"], sched.step_size, sched.gamma]
+    assert np.allclose(got, gold[name + ".opt.hyper"], rtol=0, atol=1e-12), got
+    before = {k: v.detach().cpu().clone() for k, v in model.named_parameters()}
+    opt.step()
+    torch.cuda.synchronize()
+    named = dict(model.named_parameters())
+    for k in [k for k in gold.files if k.startswith(name + ".stepped.")]:
+        key = k.split(".stepped.")[1]
+        g_ref = gold["%s.grad.%s" % (name, key)]
+        if np.abs(g_ref).max() < 1e-5 * float(gold[name + ".gradnorm"]):
+            continue                        # gradient = rounding noise (bias in front of a BatchNorm): so is the step
+        mine = (named[key].detach().cpu() - before[key]).numpy().ravel()
+        ref = (torch.from_numpy(gold[k]) - before[key]).numpy().ravel()
+        assert np.abs(mine).max() <= grp["lr"] * 1.01 and np.abs(ref).max() <= grp["lr"] * 1.01, key
+        # Adam's first step is lr * g / (|g| + eps): its sign.  The GPU gradient is within ~5 % (L2) of the reference's
+        # (test above), so only elements well above that noise have a defined direction
+        firm = np.abs(g_ref.ravel()) > 0.15 * np.abs(g_ref).max()
+        assert np.mean(np.sign(mine[firm]) == np.sign(ref[firm])) > 0.99, key
+        big = np.abs(g_ref.ravel()) > 0.3 * np.abs(g_ref).max()
+        assert np.abs(mine[big] - ref[big]).max() < 0.05 * grp["lr"], key
