@@ -1,0 +1,39 @@
+"""M2-Track on the GPU (flat-GEMM per-point stacks on the library's kernels, restructuring 5) against the reference's
+own model: tests/golden/ref_m2track.npz holds what /root/reference/models/m2track.py produced (forward, compute_loss,
+BatchNorm running statistics; tests/golden/make_golden_m2track.py).  GPU twin of tests/test_golden_m2track.py."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gold():
+    return np.load(os.path.join(ROOT, "tests", "golden", "ref_m2track.npz"))
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_gpu_m2track_matches_reference(gold, mode):
+    from open3dsot_amd import m2track, nn_blocks
+    assert nn_blocks._FLAT["on"]
+    net = m2track.M2TRACK()
+    net.load_state_dict({k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("sd.")}, strict=True)
+    net = net.cuda().train(mode == "train")
+    b = {k[3:]: torch.from_numpy(gold[k]).cuda() for k in gold.files if k.startswith("in.")}
+    with torch.set_grad_enabled(mode == "train"):
+        out = net(b)
+        ld = net.compute_loss(b, out)
+    # the heads run BatchNorm1d over the fixture's batch of 8 clouds: a 1e-7 change of the pooled features (the GEMM
+    # kernels sum in their own order) moves a normalised value by 1e-4 -- the bound of the CPU twin's flat path
+    for k in out:
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), gold["%s.out.%s" % (mode, k)], err_msg=k, rtol=2e-3, atol=5e-4)
+    for k in ld:
+        assert abs(float(ld[k]) - float(gold["%s.loss.%s" % (mode, k)])) < 1e-3 * (1 + abs(float(ld[k]))), k
+    if mode == "train":
+        for k, v in net.state_dict().items():
+            if "running" in k:
+                np.testing.assert_allclose(v.cpu().numpy(), gold["train.sd_after." + k], rtol=1e-4, atol=1e-5, err_msg=k)
