@@ -415,6 +415,21 @@ int o3d_row_sum(const float* G, int C, long P, float* out, void* stream);
 
 int o3d_pw_tile(long P, int M);
 
+/* Data gradient + weight gradient of one aligned inner layer in ONE launch (csrc/mlp_wgrad.hip::fused_bwd_kernel):
+ * replaces the pair o3d_mlp_conv_wgrad2_c + o3d_mlp_conv_dgrad_c for Cin == 64, Cout in {64, 128} and a dense dN --
+ * dY and relu(bn(Yprev)) are staged once for both MFMA chains.  A1..A3 (nseg,Cout); in_scale / in_shift / in_mean
+ * (nseg,Cin): BatchNorm of the producer layer; Wt (Cin,Cout) = W^T; w / meta / start1: compact layout (or NULL, NULL, 0).
+ * scratch: o3d_mlp_conv_bwd_fused_scratch(...) floats.  part_s [2][rows][2][Cin], rows = o3d_mlp_conv_bwd_fused_rows(...)
+ * (-1: shape not supported): BatchNorm-backward partials {sum g, sum g*(yprev-mean)} of dNprev, segment 1's block after
+ * segment 0's -- finalize with o3d_bn_bwd_finalize (one segment) / o3d_bn_bwd_finalize_c2(part_s, rows, rows, ..., meta
+ * = NULL, tile = 1). */
+int o3d_mlp_conv_bwd_fused_rows(int Cin, int Cout, long P);
+long o3d_mlp_conv_bwd_fused_scratch(int Cin, int Cout, long P);
+int o3d_mlp_conv_bwd_fused_c(const float* dN, const float* Y, const float* A1, const float* A2, const float* A3,
+                             const float* X, const float* in_scale, const float* in_shift, const float* in_mean,
+                             const float* Wt, int Cin, int Cout, long ldp, const float* w, const int32_t* meta,
+                             long start1, float* scratch, float* dW, float* part_s, float* dNprev, void* stream);
+
 /* torch.optim.Adam's update (models/base_model.py:32-33) for all parameters in one launch: parameters and moments in
  * flat buffers, gradients found through a DEVICE job table of njobs x 3 longs {gradient ptr, offset, n};
  * bc1 = 1 - beta1^t, bc2 = 1 - beta2^t.  p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps), g += weight_decay*p first. */

@@ -33,6 +33,9 @@ capi.register("o3d_mlp_conv_dgrad_wt", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_wgrad2", [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_wgrad2_scratch", [_i, _i, _i, _i])
+capi.register("o3d_mlp_conv_bwd_fused_rows", [_i, _i, ctypes.c_long])
+capi.register("o3d_mlp_conv_bwd_fused_scratch", [_i, _i, ctypes.c_long])
+capi.register("o3d_mlp_conv_bwd_fused_c", [_vp] * 10 + [_i, _i, ctypes.c_long, _vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_dgrad_plain", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp])
 capi.register("o3d_bn_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_bn_relu_maxpool_fwd", [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
@@ -149,7 +152,7 @@ def _check_versions(saved, what):
                                "would silently yield wrong gradients)" % what)
 
 
-GEMM_KERNELS = ("conv_fwd", "conv_fwd_points", "conv_dgrad", "conv_dgrad_points", "conv_wgrad", "conv_wgrad_points",
+GEMM_KERNELS = ("conv_fwd", "conv_fwd_points", "conv_dgrad", "conv_dgrad_points", "conv_wgrad", "conv_wgrad_points", "conv_bwd_fused",
                 "pw_conv_fwd", "pw_conv_dgrad", "pw_conv_wgrad")
 
 
@@ -237,7 +240,9 @@ def _per_launch_rows(tab, peak_tflops):
         cin, cout = dims[0], dims[1]
         pooled = len(dims) > 2 and dims[2]
         cols = flops / (2.0 * cin * cout)
-        if "wgrad" in name:      # dY (+ the raw output its BatchNorm backward needs) and the layer input
+        if "bwd_fused" in name:  # dN, Y, the producer's raw output in; the data gradient out (the weight gradient is small)
+            nrows = 2 * cout + 2 * cin
+        elif "wgrad" in name:    # dY (+ the raw output its BatchNorm backward needs) and the layer input
             nrows = (cout if pooled else 2 * cout) + cin
         elif "dgrad" in name:    # the same two operands, the result and the producer's raw output for the ReLU mask
             nrows = (cout if pooled else 2 * cout) + 2 * cin
@@ -728,6 +733,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                   means[-1].data_ptr(), B, Cl, npoints[0], np1, meta.data_ptr(), start1, ldp, dN.data_ptr(),
                   part.data_ptr(), st)
         dtile = 0
+        part_rows = 0    # > 0: `part` comes from the fused data + weight gradient kernel (rows per segment block)
         main, side = torch.cuda.current_stream(), _side_stream(dev)
         keep = []        # buffers the side stream still reads: must outlive the join at the end
         seg_grads = [[None, None, None] for _ in range(nseg)]
@@ -741,6 +747,14 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                           gammas[l].data_ptr(), means[l].data_ptr(), invstds[l].data_ptr(), *cp, None, st)
                 else:
                     _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize_c2, part.data_ptr(), POOL_BWD_SPLIT, POOL_BWD_SPLIT,
+                          Cout, counts[0], counts[1], gammas[l].data_ptr(), means[l].data_ptr(), invstds[l].data_ptr(), *cp,
+                          None, 1, st)
+            elif part_rows:      # partials of the fused data + weight gradient kernel: part_rows rows per segment block, all live
+                if nseg == 1:
+                    _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize, part.data_ptr(), part_rows, Cout, counts[0],
+                          gammas[l].data_ptr(), means[l].data_ptr(), invstds[l].data_ptr(), *cp, None, st)
+                else:
+                    _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize_c2, part.data_ptr(), part_rows, part_rows,
                           Cout, counts[0], counts[1], gammas[l].data_ptr(), means[l].data_ptr(), invstds[l].data_ptr(), *cp,
                           None, 1, st)
             elif nseg == 1:
@@ -817,6 +831,23 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                             seg_grads[s_][1] = dnew_all[:, ball_bases[s_]:ball_bases[s_] + nballs_s[s_]].reshape(
                                 3, B, npoints[s_]).permute(1, 2, 0)
                 continue
+            rows_fb = lib.o3d_mlp_conv_bwd_fused_rows(Cin, Cout, ldp) if (_FUSED_BWD["on"] and dN is not None and
+                                                                          Cout <= _FUSED_BWD["max_cout"]) else -1
+            if rows_fb > 0:      # data + weight gradient in one launch (64-channel layers; csrc/mlp_wgrad.hip)
+                dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
+                wpart = torch.empty((lib.o3d_mlp_conv_bwd_fused_scratch(Cin, Cout, ldp),), device=dev, dtype=f32)
+                dNp = torch.empty((Cin, ldp), device=dev, dtype=f32)
+                part = torch.empty((2, rows_fb, 2, Cin), device=dev, dtype=f32)
+                _call("conv_bwd_fused", (4.0 * Cin * Cout, meta, ldp), lib.o3d_mlp_conv_bwd_fused_c, dN.data_ptr(),
+                      Ys[l].data_ptr(), A[0], A[1], A[2], Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(),
+                      shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), ctx.Wts[l].data_ptr(), Cin, Cout, ldp, cw.data_ptr(),
+                      meta.data_ptr(), start1, wpart.data_ptr(), dW.data_ptr(), part.data_ptr(), dNp.data_ptr(), st,
+                      dims=(Cin, Cout))
+                keep += [dN, wpart, coef]
+                grads[3 * l] = dW
+                dN, part_rows = dNp, rows_fb
+                continue
+            part_rows = 0
             flops = (2.0 * Cin * Cout, meta, ldp)      # executed FLOPs = per live column (count read back when profiling)
             dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
             wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, ldp),), device=dev, dtype=f32)
@@ -868,6 +899,10 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
 # step: a point referenced by hundreds of balls serialised on one thread, and the per-list insertion sort was
 # quadratic); the balanced walk (equal shares of the sorted entries per thread, one atomic per run of equal points)
 # takes 0.50 ms including the index build.  ON by default; O3D_REDUCE_GATHER=0 selects the atomic kernel.
+# data + weight gradient of the 64 -> 64 layers in one kernel (O3D_FUSED_BWD=0: the wgrad2 + direct-dgrad pair);
+# O3D_FUSED_BWD_MAX_COUT=128 also takes the 64 -> 128 layers (measured 4 % faster in isolation, not yet in the step)
+_FUSED_BWD = {"on": _os.environ.get("O3D_FUSED_BWD", "1") != "0",
+              "max_cout": int(_os.environ.get("O3D_FUSED_BWD_MAX_COUT", "64"))}
 _REDUCE_GATHER = {"on": _os.environ.get("O3D_REDUCE_GATHER", "1") != "0"}
 
 

@@ -12,7 +12,7 @@
 //       B fragments = dY[co][pos] read back from the staging buffer, one ds_read_b32 per MFMA
 //   BatchNorm-backward partials of the data gradient, {sum g, sum g*(yprev - mean)}: the second from
 //       sum g*Xt  (Xt is what the LDS holds):  sum g*(yprev-mean) = (sum g*Xt - beta*sum g) / sc,  beta = sh + sc*mean
-//       summed over the tile's 32 columns with DPP steps and accumulated in per-wave LDS slots
+//       accumulated per lane (its one column of every chunk) in 32 registers, folded over the lanes once at the end
 // Registers: ~225-240 VGPRs + 80 AGPRs -> ONE workgroup (4 waves) per CU; the whole next chunk (49-65 KB per CU) is in
 // flight while the current one is multiplied, which is more than latency x bandwidth needs (1 us x 5 TB/s = 5 MB < 12 MB).
 // Scope: Cin == 64, Cout in {64, 128}; dense dN; compact layout (w, meta, start1) or plain (all NULL / 0).
@@ -53,8 +53,6 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs a) {   // ~
     constexpr int NG = CP / WK / 8;                       // k groups of 8 positions per wave per chunk (weight gradient)
     constexpr int GD = TM / 8;                            // k groups of 8 output channels (data gradient)
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    __shared__ float sst[4 * 2 * 32 * 2];                 // [wave][statistic][row of the wave's ci tile][16-lane group]
-    for (int i = threadIdx.x; i < 4 * 2 * 32 * 2; i += 256) sst[i] = 0.f;      // (visible after the first barrier below)
     auto As = [&](int buf) -> float* { return smem + buf * ((TM + TN) * LD); };
     auto Bs = [&](int buf) -> float* { return smem + buf * ((TM + TN) * LD) + TM * LD; };
 
@@ -143,6 +141,10 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs a) {   // ~
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    float sacc[32];            // data-gradient statistics of this lane's column share: [statistic][r]
+#pragma unroll
+    for (int r = 0; r < 32; ++r) sacc[r] = 0.f;
+
     if (c_begin < c_end) {
         load_chunk(c_begin);
         store_chunk(0);
@@ -190,25 +192,16 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs a) {   // ~
                     d = mfma32(wt[g].w, b3, d);
                 }
                 const long q = (col0 / CP + ch) * CP + 32 * dpt + l31;      // this lane's column
-                // mask, store, and the two sums of every row over the tile's 32 columns: four DPP steps give each row of
-                // 16 lanes its sum, lanes 0 / 16 of the half-wave add it to the wave's private LDS slots (plain
-                // read-modify-write: one owner per slot) -- 32 live values per lane for a reduce-scatter do not fit
+                // mask, store, and this lane's share (its one column per chunk) of the two sums of every row: at one workgroup
+                // per CU the register file has room for 32 accumulators per lane; they are folded over the lanes once, at the end
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = acc_row(r, h);
                     const float xt = B_[(dci + row) * LD + 32 * dpt + l31];
                     const float gq = xt > 0.f ? d[r] : 0.f;
                     a.dX[(long)(dci + row) * a.P + q] = gq;
-                    float s1 = gq, s2 = gq * xt;
-                    s1 += dpp_f<0xB1>(s1); s2 += dpp_f<0xB1>(s2);
-                    s1 += dpp_f<0x4E>(s1); s2 += dpp_f<0x4E>(s2);
-                    s1 += dpp_f<0x141>(s1); s2 += dpp_f<0x141>(s2);
-                    s1 += dpp_f<0x140>(s1); s2 += dpp_f<0x140>(s2);
-                    if ((l31 & 15) == 0) {
-                        float* slot = sst + ((wave * 2 + 0) * 32 + row) * 2 + (l31 >> 4);
-                        slot[0] += s1;
-                        slot[2 * 32 * 1] += s2;          // statistic 1 sits one [32][2] block further
-                    }
+                    sacc[r] += gq;
+                    sacc[16 + r] = fmaf(gq, xt, sacc[16 + r]);
                 }
             }
             if (ch + 1 < c_end) store_chunk((t + 1) & 1);
@@ -226,20 +219,20 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs a) {   // ~
             for (int tn = 0; tn < 2; ++tn) dst[(long)co * TN + 32 * tn + l31] = acc[tm][tn][r];
         }
     // ---- BatchNorm-backward partials of the data gradient: row (slice*NPT + dpt) of this slice's segment block, zeros in
-    // the other segment's block.  Thread (wave, lane < 32) finishes row `lane` of the wave's ci tile.
-    __syncthreads();
-    if (dactive && lane < 32) {
-        const int ci = dci + lane;
-        const float* b0 = sst + ((wave * 2 + 0) * 32 + lane) * 2;
-        const float* b1 = sst + ((wave * 2 + 1) * 32 + lane) * 2;
-        const float s1 = b0[0] + b0[1], s2x = b1[0] + b1[1];                        // sum g, sum g*Xt
+    // the other segment's block.  After the reduce-scatter lane l31 of half h owns (statistic l31>>4, row acc_row(l31&15, h)).
+    if (dactive) {
+        reduce_scatter32(sacc, l31);
+        const int ci = dci + acc_row(l31 & 15, h);
+        const int which = l31 >> 4;
+        const float other = __shfl_xor(sacc[0], 16, 64);      // the other statistic of the same row sits 16 lanes away
+        const float s1 = which ? other : sacc[0], s2x = which ? sacc[0] : other;    // sum g, sum g*Xt
         const float sc = in_scale[ci], beta = fmaf(sc, in_mean[ci], in_shift[ci]);
         const float s2 = sc != 0.f ? (s2x - beta * s1) / sc : 0.f;                  // sum g*(yprev - mean)
         const long rows = (long)a.nslices * NPT, row = (long)slice * NPT + dpt;
         float* mine = a.part_s + ((long)seg * rows + row) * 2 * TN;
         float* theirs = a.part_s + ((long)(1 - seg) * rows + row) * 2 * TN;
-        mine[ci] = s1; mine[TN + ci] = s2;
-        theirs[ci] = 0.f; theirs[TN + ci] = 0.f;
+        mine[which * TN + ci] = which ? s2 : s1;
+        theirs[which * TN + ci] = 0.f;
     }
 }
 
