@@ -13,13 +13,14 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-SO = os.path.join(HERE, "_fused_bwd.so")
+V3 = "--v3" in sys.argv                     # the unverified 64-positions-per-chunk variant (tools/exp/fused_bwd_v3.hip)
+SO = os.path.join(HERE, "_fused_bwd_v3.so" if V3 else "_fused_bwd.so")
 sys.path.insert(0, ROOT)
 
 
 def build():
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
-           "-I", os.path.join(ROOT, "open3dsot_amd", "csrc"), os.path.join(HERE, "fused_bwd.hip"), "-o", SO]
+           "-I", os.path.join(ROOT, "open3dsot_amd", "csrc"), os.path.join(HERE, "fused_bwd_v3.hip" if V3 else "fused_bwd.hip"), "-o", SO]
     subprocess.check_call(cmd)
     print("built", SO)
 
@@ -72,7 +73,7 @@ def main(big):
             st64[s_, 1] = (gq * (X[:, sl].double() - mu[s_].double()[:, None])).sum(1)
         # ---- experimental kernel
         nsl = exp.o3d_exp_bwd_fused_slices(Cout, ldp)
-        WK, NPT = 4 // (Cout // 64), (2 if Cout == 64 else 1)
+        WK, NPT = 4 // (Cout // 64), (2 if (Cout == 64 or V3) else 1)
         part_w = torch.full((nsl * WK, Cout, Cin), float("nan"), device=dev)
         part_s = torch.full((2, nsl * NPT, 2, Cin), float("nan"), device=dev)
         dX = torch.zeros(Cin, ldp, device=dev)
