@@ -13,14 +13,16 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-V3 = "--v3" in sys.argv                     # the unverified 64-positions-per-chunk variant (tools/exp/fused_bwd_v3.hip)
-SO = os.path.join(HERE, "_fused_bwd_v3.so" if V3 else "_fused_bwd.so")
+V4 = "--v4" in sys.argv                     # unverified: v3 + Cin = 128 (tools/exp/fused_bwd_v4.hip)
+V3 = "--v3" in sys.argv or V4               # unverified: 64 positions per chunk for Cout = 128 as well (fused_bwd_v3.hip)
+SRC = "fused_bwd_v4.hip" if V4 else "fused_bwd_v3.hip" if V3 else "fused_bwd.hip"
+SO = os.path.join(HERE, "_" + SRC.replace(".hip", ".so"))
 sys.path.insert(0, ROOT)
 
 
 def build():
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-munsafe-fp-atomics",
-           "-I", os.path.join(ROOT, "open3dsot_amd", "csrc"), os.path.join(HERE, "fused_bwd_v3.hip" if V3 else "fused_bwd.hip"), "-o", SO]
+           "-I", os.path.join(ROOT, "open3dsot_amd", "csrc"), os.path.join(HERE, SRC), "-o", SO]
     subprocess.check_call(cmd)
     print("built", SO)
 
@@ -32,15 +34,21 @@ def main(big):
     exp = ctypes.CDLL(SO)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
     exp.o3d_exp_bwd_fused.argtypes = [vp] * 10 + [i32, i32, i64, vp, vp, i64, i32, vp, vp, vp, vp]
-    exp.o3d_exp_bwd_fused_slices.argtypes = [i32, i64]
+    if V4:
+        exp.o3d_exp_bwd_fused_slices_v4.argtypes = [i32, i32, i64]
+    else:
+        exp.o3d_exp_bwd_fused_slices.argtypes = [i32, i64]
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev).manual_seed(3)
     st = torch.cuda.current_stream().cuda_stream
-    Cin = 64
-    cases = [(64, 256 * 40, 256 * 13, 256 * 17), (128, 256 * 40, 256 * 13, 256 * 17), (64, 256 * 8, 256 * 3, 256 * 1)]
+    cases = [(64, 64, 256 * 40, 256 * 13, 256 * 17), (64, 128, 256 * 40, 256 * 13, 256 * 17), (64, 64, 256 * 8, 256 * 3, 256 * 1)]
+    if V4:
+        cases += [(128, 128, 256 * 40, 256 * 13, 256 * 17)]
     if big:
-        cases += [(64, 256 * 4608, 256 * 500, 256 * 1000), (128, 256 * 4608, 256 * 500, 256 * 1000)]
-    for Cout, ldp, live0, live1 in cases:
+        cases += [(64, 64, 256 * 4608, 256 * 500, 256 * 1000), (64, 128, 256 * 4608, 256 * 500, 256 * 1000)]
+        if V4:      # SA2 layer 1 at the benchmarked batch: 201 472 live columns of 589 824
+            cases += [(128, 128, 256 * 2304, 256 * 262, 256 * 525)]
+    for Cin, Cout, ldp, live0, live1 in cases:
         start1 = (ldp // 512) * 256
         rnd = lambda *s: torch.randn(*s, device=dev, generator=g)
         dN, Y, X = rnd(Cout, ldp), rnd(Cout, ldp), rnd(Cin, ldp)
@@ -72,8 +80,9 @@ def main(big):
             st64[s_, 0] = gq.sum(1)
             st64[s_, 1] = (gq * (X[:, sl].double() - mu[s_].double()[:, None])).sum(1)
         # ---- experimental kernel
-        nsl = exp.o3d_exp_bwd_fused_slices(Cout, ldp)
-        WK, NPT = 4 // (Cout // 64), (2 if (Cout == 64 or V3) else 1)
+        nsl = exp.o3d_exp_bwd_fused_slices_v4(Cin, Cout, ldp) if V4 else exp.o3d_exp_bwd_fused_slices(Cout, ldp)
+        WK = 4 // ((Cout // 64) * (Cin // 64))
+        NPT = (2 if Cin == 64 else 1) if V4 else (2 if (Cout == 64 or V3) else 1)
         part_w = torch.full((nsl * WK, Cout, Cin), float("nan"), device=dev)
         part_s = torch.full((2, nsl * NPT, 2, Cin), float("nan"), device=dev)
         dX = torch.zeros(Cin, ldp, device=dev)
@@ -86,7 +95,7 @@ def main(big):
         live = torch.zeros(ldp, dtype=torch.bool, device=dev)
         for b0, n in segs:
             live[b0:b0 + n] = True
-        print("Cout %3d ldp %8d live %d+%d nslices %d rc %d" % (Cout, ldp, live0, live1, nsl, rc))
+        print("Cin %3d Cout %3d ldp %8d live %d+%d nslices %d rc %d" % (Cin, Cout, ldp, live0, live1, nsl, rc))
         print("   fused   : dW %.2e   dX %.2e   sum g %.2e   sum g(y-mean) %.2e" % (
             rel(part_w.sum(0), dW64), rel(dX[:, live], dX64[:, live]), rel(part_s.sum(1)[:, 0], st64[:, 0]),
             rel(part_s.sum(1)[:, 1], st64[:, 1])))
