@@ -109,3 +109,30 @@ def test_entry_points_reject_bad_arguments_before_touching_the_device():
     assert lib.o3d_pool_fwd_c(None, 256, None, None, None, None, 1, 8, 8, 0, None, None, None, None) == EINVAL
     assert lib.o3d_center_term(None, None, 8, 8, 3, None, None) == EINVAL
     assert lib.o3d_bn_finalize_c2(None, 1, 1, 8, 1.0, 1.0, *([None] * 5), 0.1, 1e-5, *([None] * 5), 128, None) == EINVAL
+
+
+def test_fused_backward_entry_validates_shapes_without_a_device():
+    """o3d_mlp_conv_bwd_fused_*: the supported shapes (Cin 64, Cout 64 / 128, columns a multiple of 64) are decided on the
+    host -- rows / scratch report -1 elsewhere and the launch entry refuses NULL operands and odd shapes before any HIP call;
+    the gather / optimizer entries added in round 2 likewise"""
+    from open3dsot_amd import capi, fused, optim  # noqa: F401  (they register argtypes)
+    lib = capi.load()
+    assert lib.o3d_mlp_conv_bwd_fused_rows(64, 64, 1179648) == 512            # 256 workgroups x two 32-position tiles
+    assert lib.o3d_mlp_conv_bwd_fused_rows(64, 128, 1179648) == 256
+    assert lib.o3d_mlp_conv_bwd_fused_rows(64, 64, 2048) == 16                # 32 chunks: 8 workgroups of 4 chunks
+    assert lib.o3d_mlp_conv_bwd_fused_scratch(64, 64, 1179648) == 256 * 4 * 64 * 64
+    assert lib.o3d_mlp_conv_bwd_fused_scratch(64, 128, 1179648) == 256 * 2 * 128 * 64
+    for cin, cout, p_ in ((128, 128, 4096), (64, 256, 4096), (32, 64, 4096), (64, 64, 100), (64, 64, 0)):
+        assert lib.o3d_mlp_conv_bwd_fused_rows(cin, cout, p_) == -1
+        assert lib.o3d_mlp_conv_bwd_fused_scratch(cin, cout, p_) == -1
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    EINVAL = lib.o3d_mlp_conv_bwd_fused_c(*([None] * 10), 64, 64, 4096, None, None, 0, None, None, None, None, None)
+    assert EINVAL != 0
+    assert lib.o3d_mlp_conv_bwd_fused_c(*([p] * 10), 128, 128, 4096, p, p, 0, p, p, p, p, None) == EINVAL      # Cin 128
+    assert lib.o3d_mlp_conv_bwd_fused_c(*([p] * 10), 64, 64, 4096, p, None, 0, p, p, p, p, None) == EINVAL      # w without meta
+    assert lib.o3d_mlp_conv_bwd_fused_c(*([p] * 10), 64, 64, 4096, p, p, 100, p, p, p, p, None) == EINVAL       # start1 % 256
+    assert lib.o3d_gather_rows(None, None, 2, 8, 3, 4, None, None) == EINVAL
+    assert lib.o3d_gather_rows(None, None, 2, 8, 3, 0, None, None) == 0                                         # nothing to gather
+    assert lib.o3d_adam_step(None, 0, None, None, None, 1e-3, 0.5, 0.999, 1e-6, 0.0, 0.5, 1e-3, None) == EINVAL
+    assert lib.o3d_adam_step(p, 1, p, p, p, 1e-3, 0.5, 0.999, 1e-6, 0.0, 0.0, 1e-3, None) == EINVAL             # bc1 = 0: step 0
