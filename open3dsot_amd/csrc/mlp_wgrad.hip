@@ -455,7 +455,21 @@ __global__ __launch_bounds__(256) void fused_bwd_kernel(FusedBwdArgs a) {   // ~
         const float other = __shfl_xor(sacc[0], 16, 64);      // the other statistic of the same row sits 16 lanes away
         const float s1 = which ? other : sacc[0], s2x = which ? sacc[0] : other;    // sum g, sum g*Xt
         const float sc = in_scale[ci], beta = fmaf(sc, in_mean[ci], in_shift[ci]);
-        const float s2 = sc != 0.f ? (s2x - beta * s1) / sc : 0.f;                  // sum g*(yprev - mean)
+        float s2 = sc != 0.f ? (s2x - beta * s1) / sc : 0.f;                        // sum g*(yprev - mean)
+        if (sc == 0.f && which) {
+            // gamma == 0 (zero-initialised / pruned channel): relu(bn(yprev)) is the constant beta, the sum cannot be
+            // recovered from the staged value.  Rare, so the owning lane simply re-reads its row: the masked gradient this
+            // wave stored above and the producer's raw output, over this wave's 32-position tile of every chunk of the slice
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const float mu = in_mean[ci];
+            float t2 = 0.f;
+            for (int ch = c_begin; ch < c_end; ++ch) {
+                const long qb = (col0 / CP + ch) * CP + 32 * dpt;
+                for (int j = 0; j < 32; ++j)
+                    t2 = fmaf(a.dX[(long)ci * a.P + qb + j], a.X[(long)ci * a.P + qb + j] - mu, t2);
+            }
+            s2 = t2;
+        }
         const long rows = (long)a.nslices * NPT, row = (long)slice * NPT + dpt;
         float* mine = a.part_s + ((long)seg * rows + row) * 2 * TN;
         float* theirs = a.part_s + ((long)(1 - seg) * rows + row) * 2 * TN;

@@ -15,6 +15,7 @@ import os
 
 import torch
 import torch.distributed as dist
+from torch.autograd.graph import increment_version
 
 
 def env_rank():
@@ -105,6 +106,7 @@ class DataParallelStep:
         self._static_loss = None
         self._static_grads = None      # the gradient tensors the captured backward writes (graph pool)
         self._eager_steps = 0
+        self._buffers = [b for b in model.buffers()]
 
     def reduce_gradients(self):
         """p.grad as produced by backward -> mean over ranks, left in p.grad"""
@@ -149,6 +151,9 @@ class DataParallelStep:
             if keys:                      # one multi-tensor copy instead of a launch per input
                 torch._foreach_copy_([self._static[k] for k in keys], [batch[k] for k in keys], non_blocking=True)
             self.graph.replay()
+            # the replayed finalize kernels rewrote the BatchNorm running statistics through raw pointers: bump their
+            # version counters (host only) so version-keyed caches -- eval-mode constants -- see a training step
+            increment_version(self._buffers)
             for p, g in zip(self.grads.params, self._static_grads):   # replay rewrote these buffers in place
                 p.grad = g
             loss = self._static_loss.clone()      # the graph rewrites its own buffer at the next replay

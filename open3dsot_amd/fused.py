@@ -19,6 +19,7 @@ import ctypes
 
 import torch
 from torch import nn
+from torch.autograd.graph import increment_version as _increment_version
 
 from . import capi
 from .ops import QueryAndGroup
@@ -116,7 +117,19 @@ def _eval_consts(lib, bn, gamma, beta, vec, nrep, st, conv_bias=None):
 _COUNTERS = {"pending": None}
 
 
+def touch(tensors):
+    """bump the autograd version counters of tensors a raw-pointer kernel has just written (running statistics in the
+    finalize kernels, parameters in FlatAdam): everything keyed on `_version` -- the eval-mode constant cache below,
+    the forward/backward parameter guards -- then sees those writes like any in-place torch op (host only, no launch)"""
+    tensors = [t for t in tensors if t is not None]
+    if tensors:
+        _increment_version(tensors)
+
+
 def count_batches(bns, inc=1):
+    """a training forward through `bns` has happened: its finalize kernels wrote the running statistics through raw
+    pointers (version counters bumped here) and `num_batches_tracked` is due `inc` increments"""
+    touch([t for bn in bns for t in (bn.running_mean, bn.running_var)])
     tensors = [bn.num_batches_tracked for bn in bns if bn.num_batches_tracked is not None]
     if not tensors:
         return

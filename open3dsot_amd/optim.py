@@ -11,6 +11,7 @@ import ctypes
 import os
 
 import torch
+from torch.autograd.graph import increment_version
 
 from . import capi
 
@@ -48,6 +49,13 @@ class FlatAdam(torch.optim.Optimizer):
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         lib = capi.load()
+        base = self._flat.data_ptr()
+        for p, (off, _) in self._offsets.items():
+            # every parameter must still be a view of the flat buffer: a second optimizer built on the same model,
+            # module.to(dtype) or any `p.data = ...` re-homes it and this update would silently go nowhere
+            if p.data_ptr() != base + 4 * off:
+                raise RuntimeError("FlatAdam: a parameter no longer lives in this optimizer's flat buffer (re-homed by "
+                                   "another FlatAdam, module.to(...) or a p.data assignment); rebuild the optimizer")
         self._step += 1
         t = float(self._step)
         for gi, group in enumerate(self.param_groups):
@@ -73,6 +81,9 @@ class FlatAdam(torch.optim.Optimizer):
                                              float(group["eps"]), float(group["weight_decay"]), 1.0 - b1 ** t,
                                              1.0 - b2 ** t, torch.cuda.current_stream(dev).cuda_stream), "adam_step")
             self._keep = grads                      # the launch reads them: alive until the next step
+            # the kernel wrote the parameters through the flat buffer: bump their version counters like an in-place
+            # torch op would, so the forward/backward guards of the fused operators and the eval-constant cache see it
+            increment_version(live)
         return loss
 
     def load_state_dict(self, state_dict):
@@ -81,14 +92,17 @@ class FlatAdam(torch.optim.Optimizer):
             step = None
             for p, (off, n) in self._offsets.items():
                 st = self.state.get(p)
-                if not st:
+                if not st:          # e.g. a torch.optim.Adam checkpoint taken before its first step: fresh moments
+                    self._m[off:off + n].zero_()
+                    self._v[off:off + n].zero_()
+                    self.state[p] = {"step": self._step, "exp_avg": self._m[off:off + n].view_as(p),
+                                     "exp_avg_sq": self._v[off:off + n].view_as(p)}
                     continue
                 self._m[off:off + n].view_as(p).copy_(st["exp_avg"])
                 self._v[off:off + n].view_as(p).copy_(st["exp_avg_sq"])
                 step = float(st["step"]) if step is None else step
                 st["exp_avg"], st["exp_avg_sq"] = self._m[off:off + n].view_as(p), self._v[off:off + n].view_as(p)
-            if step is not None:
-                self._step.fill_(step)
+            self._step.fill_(step if step is not None else 0.0)
             for st in self.state.values():
                 st["step"] = self._step
         self._key = self._table = None

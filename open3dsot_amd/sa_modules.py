@@ -33,14 +33,14 @@ _PREFIX_IDX = {}
 
 def _prefix_idx(B, npoint, dev):
     """the reference's `torch.arange(npoint).repeat(B, 1)` sample indices (pointnet2_modules.py:59-60): a constant,
-    built once per (B, npoint, device) instead of two launches per call.  Shared: read-only for the callers."""
+    built once per (B, npoint, device) instead of two launches per call.  Shared and kept for the life of the process:
+    READ-ONLY for the callers (tests/test_fused_gpu.py::test_prefix_indices_are_shared_and_intact)."""
     key = (B, npoint, str(dev))
     t = _PREFIX_IDX.get(key)
     if t is None:
         if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
             return torch.arange(npoint, dtype=torch.int32, device=dev).repeat(B, 1)      # not cached: graph-pool memory
-        if len(_PREFIX_IDX) > 64:
-            _PREFIX_IDX.clear()
+        # never evicted (an entry is B * npoint int32): a captured HIP graph may hold the tensor's address
         t = _PREFIX_IDX[key] = torch.arange(npoint, dtype=torch.int32, device=dev).repeat(B, 1)
     return t
 

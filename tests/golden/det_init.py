@@ -32,3 +32,34 @@ def fill_state_dict(module):
         new[key] = v.to(t.dtype).reshape(t.shape)
     module.load_state_dict(new, strict=True)
     return module
+
+
+def fill_state_dict_random(module, seed=0):
+    """Storage-free like `fill_state_dict`, but non-degenerate: every tensor is drawn from a numpy PCG64 stream seeded by
+    (crc32(key), seed) -- He-normal conv weights, BatchNorm gamma in [0.7, 1.3], small biases / running means, running
+    variances in [0.6, 1.4].  The cos/sin waves above are periodic along the input channels, which makes the heads'
+    BatchNorm batch variances tiny for many channels (1/sigma then amplifies fp32 rounding); these are not."""
+    import numpy as np
+    sd = module.state_dict()
+    new = {}
+    for key in sorted(sd):
+        t = sd[key]
+        if not t.dtype.is_floating_point:
+            new[key] = torch.zeros_like(t)
+            continue
+        rng = np.random.default_rng([zlib.crc32(key.encode()), seed])
+        shape = tuple(t.shape)
+        if key.endswith("running_var"):
+            v = rng.uniform(0.6, 1.4, shape)
+        elif key.endswith("running_mean"):
+            v = rng.normal(0.0, 0.1, shape)
+        elif key.endswith("bn.weight") or key.endswith("bn.bn.weight"):
+            v = rng.uniform(0.7, 1.3, shape)
+        elif key.endswith("bias"):
+            v = rng.normal(0.0, 0.05, shape)
+        else:
+            fan_in = max(1, t.numel() // t.shape[0])
+            v = rng.normal(0.0, (2.0 / fan_in) ** 0.5, shape)
+        new[key] = torch.from_numpy(np.asarray(v)).to(t.dtype)
+    module.load_state_dict(new, strict=True)
+    return module

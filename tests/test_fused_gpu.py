@@ -32,10 +32,12 @@ def assert_grad_close(a, b, what, l2tol=5e-4, maxtol=1e-2):
     assert l2rel(a, b) < l2tol and rel(a, b) < maxtol, (what, l2rel(a, b), rel(a, b))
 
 
-def shadow64(mlp, xyz, new_xyz, feats, idx, train, inv_radius=1.0):
+def shadow64(mlp, xyz, new_xyz, feats, idx, train, inv_radius=1.0, ties=None):
     """fp64 restatement of QueryAndGroup -> SharedMLP -> max over nsample on torch ops
     (pointnet2_utils.py:299-339, pytorch_utils.py:12-37, pointnet2_modules.py:69-73).
-    -> (out, leaves: dict name -> fp64 leaf, buffers: dict name -> fp64 running stat)"""
+    -> (out, leaves: dict name -> fp64 leaf, buffers: dict name -> fp64 running stat)
+    ties: a list -> receives the per-ball near-tie margin (B, npoint) in fp32 ulps (tests/flip_proof.py): the minimum over
+    every ReLU unit of the ball (all layers, channels, slots) and over the max-pool candidates"""
     B, npoint, ns = idx.shape
     flat = idx.long().reshape(B, 1, npoint * ns)
     leaves, bufs = {}, {}
@@ -61,7 +63,13 @@ def shadow64(mlp, xyz, new_xyz, feats, idx, train, inv_radius=1.0):
         x = F.batch_norm(x, rm, rv, leaf(name + ".bn.bn.weight", bn.weight), leaf(name + ".bn.bn.bias", bn.bias),
                          train, bn.momentum, bn.eps)
         bufs[name + ".bn.bn.running_mean"], bufs[name + ".bn.bn.running_var"] = rm, rv
+        if ties is not None:
+            import flip_proof
+            m = flip_proof.relu_margin_ulps(x.detach(), 1).amin(dim=-1)
+            ties[:] = [m if not ties else torch.minimum(ties[0], m)]
         x = F.relu(x)
+    if ties is not None:
+        ties[:] = [torch.minimum(ties[0], flip_proof.pool_margin_ulps(x.detach(), 1))]
     return x.max(dim=-1)[0], leaves, bufs
 
 
@@ -234,12 +242,16 @@ def _paired_case(kind, train, B=3, full=False):
     mlp_ref = copy.deepcopy(mlp)
     mlp_ref0 = copy.deepcopy(mlp)
     want_xyz = kind == "sa2"
-    segs, refs, outs64 = [], [], []
+    segs, refs, outs64, idxs, margins = [], [], [], [], []
+    prove = full and train          # stage 1 / stage 2 of tests/flip_proof.py
     for xyz, new_xyz, feats in ((xyz_t, new_t, feats_t), (xyz_s, new_s, feats_s)):
         segs.append([t.clone().requires_grad_(True) if t is not None and (t is feats or want_xyz) else t
                      for t in (xyz, new_xyz, feats)])
         idx = grouper.query(xyz, new_xyz)
-        o64, l64, b64 = shadow64(mlp_ref, xyz, new_xyz, feats, idx, train)
+        ties = [] if prove else None
+        o64, l64, b64 = shadow64(mlp_ref, xyz, new_xyz, feats, idx, train, ties=ties)
+        idxs.append(idx)
+        margins.append(ties[0] if prove else None)
         outs64.append(o64)
         refs.append(l64)
         if train:      # the second call starts from the running statistics the first one left
@@ -264,7 +276,7 @@ def _paired_case(kind, train, B=3, full=False):
     gos = [torch.randn(o.shape, device="cuda", generator=gen) for o in outs]
     torch.autograd.backward(list(outs), gos)
     for o64, go in zip(outs64, gos):
-        o64.backward(go.double())
+        o64.backward(go.double(), retain_graph=prove)
     tol = 5e-4 if train else 6e-3      # eval: nothing damps an argmax flip, and two clouds contribute flips
     yard = {}
     if full:
@@ -301,6 +313,187 @@ def _paired_case(kind, train, B=3, full=False):
               {k: ("%.1e" % v[0], "%.1e" % v[1]) for k, v in report.items()})
     for got, want, what, l2tol, maxtol in checks:
         assert_grad_close(got, want, what, l2tol=l2tol, maxtol=maxtol)
+    if prove:
+        _prove_flips("paired %s B=%d" % (kind, B), mlp_ref0, segs, refs, outs64, idxs, margins, gos,
+                     lambda m, sg: fused.sa_group_mlp_pool_pair(grouper, m, tuple(sg[0]), tuple(sg[1])))
+
+
+@pytest.mark.parametrize("kind", ["rpn", "xcorr"])
+def test_full_size_batch48_single_segment_flip_proof(kind):
+    """The two grouped MLPs of the step that are not a template/search pair, at the benchmarked 48 pairs: the RPN's vote
+    aggregation (64 balls x 16 of 128 votes, every input gradient live: rpn.py:55-60) and BoxAwareXCorr's k-NN group
+    (128 x 4 of 64 template points, xcorr.py:89-100).  Forward 2e-5 against fp64; gradients by tests/flip_proof.py."""
+    import copy
+    from open3dsot_amd import fused, nn_blocks
+    B = 48
+    if kind == "rpn":
+        grouper, mlp, xyz, new_xyz, feats = make_case("rpn", B=B, train=True)
+        seg = [t.clone().requires_grad_(True) for t in (xyz, new_xyz, feats)]
+        idx = grouper.query(xyz, new_xyz)
+        run = lambda m, sg: [fused.sa_group_mlp_pool(grouper, m, *sg[0])]
+    else:
+        torch.manual_seed(4)
+        M, N, k, f = 64, 128, 4, 256
+        bundle = torch.randn(B, 3 + 9 + f, M, device="cuda")
+        idx = torch.randint(0, M, (B, N, k), device="cuda", dtype=torch.int32)
+        mlp = nn_blocks.SharedMLP([3 + 9 + f, 256, 256, 256], bn=True).cuda().train()
+        xyz = new_xyz = None
+        feats = bundle
+        seg = [None, None, bundle.clone().requires_grad_(True)]
+        run = lambda m, sg: [fused.group_mlp_pool(m, sg[0][2], idx)]
+    mlp0 = copy.deepcopy(mlp)
+    ties = []
+    o64, l64, b64 = shadow64(copy.deepcopy(mlp), xyz, new_xyz, feats, idx, True, ties=ties)
+    out = run(mlp, [seg])[0]
+    assert rel(out, o64) < 2e-5, rel(out, o64)
+    for n1, b1 in mlp.named_buffers():
+        if b1.dtype.is_floating_point:
+            assert rel(b1, b64[n1]) < 1e-5, n1
+    go = torch.randn(out.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    out.backward(go)
+    o64.backward(go.double(), retain_graph=True)
+    for n1, p1 in mlp.named_parameters():        # loose first (flips included), then the proof
+        assert l2rel(p1.grad, l64[n1].grad) < 3e-3, (n1, l2rel(p1.grad, l64[n1].grad))
+    _prove_flips("%s B=%d" % (kind, B), mlp0, [seg], [l64], [o64], [idx], [ties[0]], [go], run)
+
+
+def _prove_flips(tag, mlp0, segs, refs, outs64, idxs, margins, gos, run):
+    """tests/flip_proof.py on a paired full-size case: (1) every input-gradient outlier sits on a point of a ball with an
+    fp64 near-tie; (2) with the cotangent zeroed on those balls, every gradient meets the TIGHT bound"""
+    import copy
+    import flip_proof as fp
+    from open3dsot_amd import fused
+    flagged = [m < fp.TIE_ULPS for m in margins]                       # (B, npoint) per segment
+    for si, (sg, l64, idx, fl, m) in enumerate(zip(segs, refs, idxs, flagged, margins)):
+        B, npoint, ns = idx.shape
+        N = sg[0].shape[1] if sg[0] is not None else sg[2].shape[2]
+        # a point is flagged when any flagged ball lists it; its margin = the smallest margin of the balls listing it
+        pmargin = torch.full((B, N), float("inf"), device=idx.device, dtype=torch.float64)
+        pmargin.scatter_reduce_(1, idx.long().reshape(B, -1), m[:, :, None].expand(B, npoint, ns).reshape(B, -1), "amin")
+        pflag = pmargin < fp.TIE_ULPS
+        for nm, a, cols, flg, mar in (("xyz", sg[0], (0, 1), pflag, pmargin), ("new_xyz", sg[1], (0, 1), fl, m),
+                                      ("feats", sg[2], (0, 2), pflag, pmargin)):
+            if a is not None and a.requires_grad:
+                out, emap = fp.outlier_columns(a.grad, l64[nm].grad, cols)
+                fp.check_outliers_flagged("%s seg %d d%s" % (tag, si, nm), out, emap, flg, mar)
+    # stage 2: both evaluations again with the cotangent zeroed on the flagged balls
+    mlp2 = copy.deepcopy(mlp0)
+    segs2 = [[t.detach().clone().requires_grad_(t.requires_grad) if t is not None else None for t in sg] for sg in segs]
+    gos2 = [go * (~fl)[:, None, :].to(go.dtype) for go, fl in zip(gos, flagged)]
+    for l64 in refs:
+        for t in l64.values():
+            t.grad = None
+    outs2 = run(mlp2, segs2)
+    torch.autograd.backward(list(outs2), gos2)
+    for o64, go in zip(outs64, gos2):
+        o64.backward(go.double())
+    pairs = [(n1, p1.grad, sum(l64[n1].grad for l64 in refs)) for n1, p1 in mlp2.named_parameters()]
+    for si, (sg, l64) in enumerate(zip(segs2, refs)):
+        for nm, a in zip(("xyz", "new_xyz", "feats"), sg):
+            if a is not None and a.requires_grad:
+                pairs.append(("%d.%s" % (si, nm), a.grad, l64[nm].grad))
+    fp.record("%s: flagged balls %s of %s" % (tag, [int(f.sum()) for f in flagged], [f.numel() for f in flagged]))
+    fp.check_tight(tag, pairs)
+
+
+@pytest.mark.parametrize("mode", ["single", "paired", "eval"])
+def test_fused_sa_normalize_xyz(mode):
+    """QueryAndGroup(normalize_xyz=True) (pointnet2_utils.py:321-322: grouped_xyz /= radius): the scaling branch of the
+    fused path (per-point operand and ball centres scaled by 1/radius, xyz gradients scaled back) against the fp64
+    shadow and the composed torch chain -- one call, the paired template/search launch, and the one-kernel eval path"""
+    import copy
+    from open3dsot_amd import fused, ops
+    train = mode != "eval"
+    _, mlp, xyz, new_xyz, feats = make_case("sa2", train=train)
+    grouper = ops.QueryAndGroup(0.5, 32, use_xyz=True, normalize_xyz=True)
+    inv_r = 1.0 / 0.5
+    mlp_ref, mlp32 = copy.deepcopy(mlp), copy.deepcopy(mlp)
+    segs = [(xyz, new_xyz, feats)]
+    if mode == "paired":
+        N, npoint = xyz.shape[1], new_xyz.shape[1]
+        xt = (xyz[:, :N // 2, :] * 0.9 + 0.05).contiguous()
+        segs = [(xt, xt[:, :npoint // 2, :].contiguous(), torch.randn(feats.shape[0], feats.shape[1], N // 2, device="cuda")),
+                (xyz, new_xyz, feats)]
+    leaves = [[t.clone().requires_grad_(train) for t in sg] for sg in segs]
+    outs64, refs = [], []
+    for sg in segs:
+        idx = grouper.query(sg[0], sg[1])
+        o64, l64, b64 = shadow64(mlp_ref, *sg, idx, train, inv_radius=inv_r)
+        outs64.append(o64)
+        refs.append(l64)
+        if train:
+            with torch.no_grad():
+                for n1, b1 in mlp_ref.named_buffers():
+                    if n1 in b64:
+                        b1.copy_(b64[n1])
+    if mode == "paired":
+        outs = fused.sa_group_mlp_pool_pair(grouper, mlp, tuple(leaves[0]), tuple(leaves[1]))
+    else:
+        outs = [fused.sa_group_mlp_pool(grouper, mlp, *leaves[0])]
+    with torch.no_grad():
+        ref32 = [composed(grouper, mlp32, *sg) for sg in segs]
+    for o, o32, o64 in zip(outs, ref32, outs64):
+        assert rel(o, o32) < 1e-4 and rel(o, o64) < 2e-5, (rel(o, o32), rel(o, o64))
+    if not train:
+        return
+    gen = torch.Generator(device="cuda").manual_seed(2)
+    gos = [torch.randn(o.shape, device="cuda", generator=gen) for o in outs]
+    torch.autograd.backward(list(outs), gos)
+    for o64, go in zip(outs64, gos):
+        o64.backward(go.double())
+    for n1, p1 in mlp.named_parameters():
+        assert_grad_close(p1.grad, sum(l64[n1].grad for l64 in refs), n1)
+    for sg, l64 in zip(leaves, refs):
+        for nm, a in zip(("xyz", "new_xyz", "feats"), sg):
+            assert_grad_close(a.grad, l64[nm].grad, nm)
+    for n1, b1 in mlp.named_buffers():
+        if b1.dtype.is_floating_point:
+            assert rel(b1, b64[n1]) < 1e-5, n1
+
+
+def test_prefix_indices_are_shared_and_intact():
+    """the arange(npoint) sample indices of the non-FPS levels (pointnet2_modules.py:56) are one cached tensor per
+    (B, npoint, device), never evicted (a captured graph may hold its address) and never written by the module"""
+    from open3dsot_amd import sa_modules
+    dev = torch.device("cuda", 0)
+    a = sa_modules._prefix_idx(3, 16, dev)
+    for i in range(80):                       # more keys than the old eviction threshold
+        sa_modules._prefix_idx(2, 100 + i, dev)
+    b = sa_modules._prefix_idx(3, 16, dev)
+    assert a.data_ptr() == b.data_ptr()
+    grouper, mlp, xyz, new_xyz, feats = make_case("sa2")
+    mod = sa_modules.PointnetSAModule(mlp=[128, 128, 128, 256], radius=0.5, nsample=32).cuda()
+    _, _, idx = mod(xyz, feats, 128, True)
+    want = torch.arange(128, dtype=torch.int32, device=dev).repeat(xyz.shape[0], 1)
+    assert torch.equal(idx, want) and torch.equal(sa_modules._prefix_idx(xyz.shape[0], 128, dev), want)
+
+
+def test_fused_bwd_with_zero_gamma():
+    """a zero BatchNorm scale in the PRODUCER layer (zero-initialised / pruned channel): the fused data + weight gradient
+    kernel cannot recover sum g*(y - mean) from relu(bn(y)) = const there and re-reads the row instead
+    (csrc/mlp_wgrad.hip) -- dgamma of that channel must equal the fp64 value, as with the unfused kernel pair"""
+    import copy
+    from open3dsot_amd import fused
+    grouper, mlp, xyz, new_xyz, feats = make_case("sa1", B=4, train=True)
+    bns = [m for m in mlp.modules() if isinstance(m, torch.nn.BatchNorm2d)]
+    with torch.no_grad():
+        bns[0].weight[3] = 0.0            # beta > 0: the channel passes the ReLU as a constant
+        bns[0].bias[3] = 0.4
+        bns[0].weight[7] = 0.0            # beta < 0: masked everywhere
+        bns[0].bias[7] = -0.4
+    idx = grouper.query(xyz, new_xyz)
+    o64, l64, _ = shadow64(copy.deepcopy(mlp), xyz, new_xyz, feats, idx, True)
+    out = fused.sa_group_mlp_pool(grouper, mlp, xyz, new_xyz, feats)
+    go = torch.randn(out.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    out.backward(go)
+    o64.backward(go.double())
+    for n1, p1 in mlp.named_parameters():
+        assert_grad_close(p1.grad, l64[n1].grad, n1)
+    name0 = [n for n, _ in mlp.named_parameters() if n.endswith("bn.bn.weight")][0]
+    g, g64 = dict(mlp.named_parameters())[name0].grad, l64[name0].grad
+    for c in (3, 7):
+        assert abs(float(g[c]) - float(g64[c])) <= 1e-4 * float(g64.abs().max()), (c, float(g[c]), float(g64[c]))
+    assert float(g64[3].abs()) > 1e-3 * float(g64.abs().max())       # the case is not vacuous
 
 
 def test_paired_backbone_matches_sequential():

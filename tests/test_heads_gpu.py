@@ -92,7 +92,14 @@ def test_flat_chain_vs_fp64(name, train, B, N):
     from open3dsot_amd import fused_heads, nn_blocks
     src_C, widths, residual = CASES[name]
     seq = build_seq(widths, sum(src_C), 3).train(train)
+    seq0 = copy.deepcopy(seq)
     ref = copy.deepcopy(seq).double()
+    zs = []       # per hidden layer: (B, N) margin of the fp64 BatchNorm output to zero, in fp32 ulps of the layer's rms
+    if B * N > 1024:
+        import flip_proof
+        for m in ref.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.register_forward_hook(lambda mod, inp, outp: zs.append(flip_proof.relu_margin_ulps(outp.detach(), 1)))
     g = torch.Generator(device="cuda").manual_seed(5)
     parts = []
     for C in src_C:     # xyz arrives as a transposed (B,N,3) tensor, features as (B,C,N)
@@ -107,27 +114,42 @@ def test_flat_chain_vs_fp64(name, train, B, N):
     assert out.shape == ref_out.shape
     assert rel(out, ref_out) < 2e-5, rel(out, ref_out)
     ct = torch.randn(out.shape, device="cuda", generator=g)
-    (out * ct).sum().backward()
-    (ref_out * ct.double()).sum().backward()
-    # ReLU masks are discrete: a pre-activation within fp32 rounding of zero (|z| < ~3e-7: about one in 3e6
-    # activations, i.e. ~0.5 per 256-channel layer at 6144 columns) is routed differently than in fp64, which changes
-    # that ONE column's gradient by O(1) and every parameter gradient by ~1/sqrt(columns) (measured on the MI355X,
-    # profiles/r02_relu_flip_diag.txt: one such column at (48,128), none at (4,64); everything else agrees to 5e-7).
-    # So at the large size: inputs must agree to 1e-3 of the rms on all but 0.1 % of the elements, parameters to
-    # 3e-3 L2; at the small size the tight bounds apply.
     big = B * N > 1024
-    for a, b in zip(parts, parts64):
-        if big:
-            err = (a.grad.double() - b.grad).abs()
-            assert float((err > 1e-3 * b.grad.pow(2).mean().sqrt()).double().mean()) < 1e-3, "input"
-            assert float(err.median() / b.grad.abs().max()) < 1e-5, "input (median)"
-        else:
+    (out * ct).sum().backward()
+    (ref_out * ct.double()).sum().backward(retain_graph=big)
+    # ReLU masks are discrete: a pre-activation within fp32 rounding of zero is routed differently than in fp64, which
+    # changes that ONE column's gradient by O(1) and every parameter gradient by ~1/sqrt(columns).  At the small size no
+    # unit is that close and the tight bounds apply directly.  At the benchmarked size (48 x 128 columns) the test PROVES
+    # the reading instead of tolerating it (tests/flip_proof.py): stage 1 -- every column whose input gradient is off by
+    # more than 1e-4 of the rms has an fp64 pre-activation within TIE_ULPS fp32 ulps of zero; stage 2 -- with the
+    # cotangent zeroed on the flagged columns in both evaluations, every gradient meets the tight bounds.
+    if not big:
+        for a, b in zip(parts, parts64):
             assert l2rel(a.grad, b.grad) < 5e-4 and rel(a.grad, b.grad) < 1e-2, ("input", l2rel(a.grad, b.grad))
-    for (n1, p), (_, q) in zip(seq.named_parameters(), ref.named_parameters()):
-        assert p.grad is not None, n1
-        assert p.grad.shape == p.shape
-        assert l2rel(p.grad, q.grad) < (3e-3 if big else 5e-4) and rel(p.grad, q.grad) < (3e-2 if big else 1e-2), \
-            (n1, l2rel(p.grad, q.grad), rel(p.grad, q.grad))
+        for (n1, p), (_, q) in zip(seq.named_parameters(), ref.named_parameters()):
+            assert p.grad is not None and p.grad.shape == p.shape, n1
+            assert l2rel(p.grad, q.grad) < 5e-4 and rel(p.grad, q.grad) < 1e-2, (n1, l2rel(p.grad, q.grad), rel(p.grad, q.grad))
+    else:
+        import flip_proof as fp
+        tag = "flat chain %s %s (%d,%d)" % (name, "train" if train else "eval", B, N)
+        margin = torch.stack(zs).amin(dim=0)                       # (B, N): min over the hidden layers' ReLU units, in ulps
+        flagged = margin < fp.TIE_ULPS
+        for i, (a, b) in enumerate(zip(parts, parts64)):
+            outl, emap = fp.outlier_columns(a.grad, b.grad, (0, 2))
+            fp.check_outliers_flagged("%s d(source %d)" % (tag, i), outl, emap, flagged, margin)
+        for (n1, p), (_, q) in zip(seq.named_parameters(), ref.named_parameters()):     # loose: includes the flips
+            assert p.grad is not None and p.grad.shape == p.shape, n1
+            assert l2rel(p.grad, q.grad) < 3e-3, (n1, l2rel(p.grad, q.grad))
+        seq2 = copy.deepcopy(seq0)
+        parts2 = [t.detach().clone().requires_grad_(True) for t in parts]
+        ct2 = ct * (~flagged)[:, None, :].to(ct.dtype)
+        for t in parts64 + list(ref.parameters()):
+            t.grad = None
+        (nn_blocks.seq_apply(seq2, parts2, residual) * ct2).sum().backward()
+        (ref_out * ct2.double()).sum().backward()
+        pairs = [("source %d" % i, a.grad, b.grad) for i, (a, b) in enumerate(zip(parts2, parts64))]
+        pairs += [(n1, p.grad, q.grad) for (n1, p), (_, q) in zip(seq2.named_parameters(), ref.named_parameters())]
+        fp.check_tight(tag, pairs)
     if train:
         for (n1, b1), (_, b2) in zip(seq.named_buffers(), ref.named_buffers()):
             if b1.dtype.is_floating_point:

@@ -632,3 +632,82 @@ def test_flat_adam_behind_the_flat_gradient_exchange():
         ob.step()
         for (k, p), q in zip(model.named_parameters(), twin.parameters()):
             assert rel(p, q) < 2e-5, (it, k, rel(p, q))
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_train_eval_train_eval_uses_fresh_batchnorm_constants(graph):
+    """the reference's fit loop validates every epoch (train -> eval -> train -> eval).  The one-kernel eval path caches
+    its BatchNorm constants on the module keyed on version counters; the training kernels and FlatAdam write through raw
+    pointers, so they bump those counters explicitly (fused.touch / increment_version) -- also behind a replayed HIP
+    graph.  The second eval must equal the layer-wise eval path (which computes its constants afresh) and must differ
+    from the first eval."""
+    from open3dsot_amd import dist as D, fused, optim, synth
+    dev = torch.device("cuda", 0)
+    model = make_model("BAT", 12)
+    step = D.DataParallelStep(model, world=1, graph=graph, graph_warmup=1)
+    assert isinstance(step.optimizer, optim.FlatAdam)
+    val = synth.to_torch(synth.make_batch(31, 2, 512, 1024), dev)
+
+    def evaluate():
+        model.eval()
+        with torch.no_grad():
+            out = {k: v.clone() for k, v in model(val).items() if v.dtype.is_floating_point}
+        model.train()
+        return out
+    first = evaluate()
+    for it in range(4):
+        step.step(synth.to_torch(synth.make_batch(40 + 4 * it, 4, 512, 1024), dev))
+    assert (step.graph is not None) == graph, step.graph_error
+    second = evaluate()
+    fused.set_eval_fused(False)
+    try:
+        want = evaluate()
+    finally:
+        fused.set_eval_fused(True)
+    for k in want:
+        assert rel(second[k], want[k]) < 1e-4, (k, rel(second[k], want[k]))
+    assert rel(second["estimation_boxes"], first["estimation_boxes"]) > 1e-3      # four Adam steps moved the model
+
+
+def test_flat_adam_step_between_forward_and_backward_is_refused():
+    """FlatAdam updates the parameters through a raw-pointer kernel; it bumps their version counters so the fused
+    operators' saved-parameter guard fires exactly as for torch optimizers"""
+    from open3dsot_amd import optim, synth
+    dev = torch.device("cuda", 0)
+    model = make_model("BAT", 5)
+    opt = model.configure_optimizers()["optimizer"]
+    assert isinstance(opt, optim.FlatAdam)
+    batch = synth.to_torch(synth.make_batch(3, 2, 256, 512), dev)
+    loss, _ = model.training_loss(batch)
+    loss.backward()
+    v0 = [p._version for p in model.parameters()]
+    opt.step()
+    assert all(p._version > v for p, v in zip(model.parameters(), v0))
+    loss, _ = model.training_loss(batch)
+    opt.step()                      # a second update before the backward of the new forward
+    with pytest.raises(RuntimeError, match="modified in place|modified by an inplace"):
+        loss.backward()
+
+
+def test_flat_adam_detects_rehomed_parameters_and_fresh_torch_state():
+    """a second FlatAdam on the same model re-homes the parameters: the first one must refuse to step instead of
+    updating memory the model no longer reads; loading a torch.optim.Adam state taken before its first step resets the
+    moments"""
+    from open3dsot_amd import optim
+    dev = torch.device("cuda", 0)
+    lin = torch.nn.Linear(8, 4).to(dev)
+    a = optim.FlatAdam(lin.parameters(), lr=1e-2)
+    for p in lin.parameters():
+        p.grad = torch.ones_like(p)
+    a.step()
+    m_before = a._m.clone()
+    assert float(m_before.abs().max()) > 0
+    fresh = torch.optim.Adam([torch.nn.Parameter(p.detach().clone()) for p in lin.parameters()], lr=1e-2)
+    a.load_state_dict(fresh.state_dict())            # empty state: moments and step start over
+    assert float(a._m.abs().max()) == 0 and float(a._v.abs().max()) == 0 and float(a._step) == 0
+    a.step()
+    assert float(a._step) == 1
+    b = optim.FlatAdam(lin.parameters(), lr=1e-2)    # re-homes the parameters into b's buffer
+    with pytest.raises(RuntimeError, match="no longer lives"):
+        a.step()
+    b.step()
