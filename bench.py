@@ -47,7 +47,11 @@ def parse():
     ap.add_argument("--model", default="BAT", choices=["BAT", "P2B", "M2TRACK"])
     ap.add_argument("--pool", type=int, default=4, help="distinct resident synthetic batches cycled through")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=60.0, help="seconds of host time the CPU baseline may take")
+    ap.add_argument("--cpu-budget", type=float, default=150.0, help="seconds of host time the CPU baseline may take")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the short driver-visible lines of the other BASELINE "
+                    "configs (P2B batch 48 / batch 1, M2-Track, tracking inference) appended to the main line as `secondary`")
+    ap.add_argument("--secondary-steps", type=int, default=20)
+    ap.add_argument("--secondary-only", action="store_true", help=argparse.SUPPRESS)     # the child process of `secondary`
     ap.add_argument("--infer", action="store_true", help="tracking-inference latency instead of the training step: eval-mode "
                     "forward of one frame (SURVEY.md section 8f-4, models/base_model.py:59-86), one HIP graph replay per frame")
     ap.add_argument("--infer-batch", type=int, default=1, help="frames per forward in --infer mode (the reference tracks at 1)")
@@ -100,12 +104,55 @@ def _cpu_step_fn(model_name, sd):
     return step
 
 
-def cpu_baseline(model_name, sd, batch_size, budget_s=60.0):
-    """Oracle restatement (oracle/torch_ref.py) of the same training step on the host cores.  More threads than the
-    problem has parallel work THRASH (round 1's 128-thread figure was 4x slower than 8 threads), so the thread count
-    is swept: a batch-8 probe per candidate, then the two best candidates are timed on the bench batch itself
-    (B = 48; 1 warm-up + 3 timed iterations each, the better one is `value`) and the best one
-    on B = 1 (3 warm-up + 10 timed); everything bounded by `budget_s`."""
+def _cpu_worker(rank, model_name, sd, batch_size, threads, iters, barrier, out):
+    """one replica of the process-parallel CPU figure: `threads` cores, its own batches, 1 warm-up + `iters` timed"""
+    torch.set_num_threads(threads)
+    step = _cpu_step_fn(model_name, sd)
+    step(synth.to_torch(synth.make_batch(7000 + 1000 * rank, batch_size)))
+    batches = [synth.to_torch(synth.make_batch(7100 + 1000 * rank + it * batch_size, batch_size)) for it in range(iters)]
+    barrier.wait()
+    t0 = time.perf_counter()
+    for b in batches:
+        step(b)
+    out.put((rank, time.perf_counter() - t0))
+
+
+def cpu_process_parallel(model_name, sd, batch_size, threads, cores, iters=2, timeout_s=120.0):
+    """the same-host figure that uses ALL physical cores: cores // threads independent replicas of the port (one process
+    each, `threads` intra-op threads, its own batch-`batch_size` stream: what a CPU data-parallel run of the reference
+    would be), started together behind a barrier; value = all pairs / the slowest replica's time"""
+    import torch.multiprocessing as mp
+    nproc = max(1, cores // threads)
+    ctx = mp.get_context("spawn")
+    barrier, out = ctx.Barrier(nproc), ctx.Queue()
+    procs = [ctx.Process(target=_cpu_worker, args=(r, model_name, sd, batch_size, threads, iters, barrier, out), daemon=True)
+             for r in range(nproc)]
+    for pr in procs:
+        pr.start()
+    times, deadline = [], time.perf_counter() + timeout_s
+    while len(times) < nproc:
+        try:
+            times.append(out.get(timeout=1.0)[1])
+        except Exception:      # nothing yet: a replica that died (or the deadline) ends the measurement without a figure
+            if time.perf_counter() > deadline or any(pr.exitcode not in (None, 0) for pr in procs):
+                for pr in procs:
+                    if pr.is_alive():
+                        pr.terminate()
+                return None
+    for pr in procs:
+        pr.join(timeout=10)
+    return {"value": round(nproc * iters * batch_size / max(times), 3), "unit": "pairs/s", "processes": nproc,
+            "threads_per_process": threads, "cores": nproc * threads, "iterations_per_process": iters,
+            "sample": "%d processes x %d threads, each %d timed batch-%d steps after 1 warm-up, started behind a barrier; "
+                      "all pairs / slowest process" % (nproc, threads, iters, batch_size)}
+
+
+def cpu_baseline(model_name, sd, batch_size, budget_s=150.0):
+    """Oracle restatement (oracle/torch_ref.py) of the same training step on the host cores (kind "port": the reference
+    has no CPU path).  More threads than the problem has parallel work THRASH (round 1's 128-thread figure was 4x slower
+    than 8 threads), so the thread count is swept on a batch-8 probe first; the best count then runs the bench batch
+    itself -- SURVEY.md section 8d: 3 warm-up (2 when the budget is short) + >= 10 timed iterations, median -- and batch 1
+    (3 + 10); last, the process-parallel figure over all physical cores (cpu_process_parallel)."""
     try:
         import psutil
         cores = psutil.cpu_count(logical=False) or os.cpu_count() or 1
@@ -115,11 +162,11 @@ def cpu_baseline(model_name, sd, batch_size, budget_s=60.0):
     step = _cpu_step_fn(model_name, sd)
     probe = [synth.to_torch(synth.make_batch(5000 + 8 * i, 8)) for i in range(2)]
     sweep = {}
-    for n in sorted({c for c in (4, 8, 16, 32, 64, cores) if c <= cores}):
+    for n in sorted({c for c in (4, 8, 16, 32) if c <= cores} | ({cores} if cores <= 16 else set())):
         torch.set_num_threads(n)
         step(probe[0])                                   # warm-up at this thread count
         sweep[n] = round(8 / min(step(probe[1]), step(probe[0])), 2)
-        if time.perf_counter() - t_begin > 0.25 * budget_s:
+        if time.perf_counter() - t_begin > 0.12 * budget_s:
             break
 
     def sample(bs, warm, iters, until):
@@ -128,24 +175,26 @@ def cpu_baseline(model_name, sd, batch_size, budget_s=60.0):
             dt = step(synth.to_torch(synth.make_batch(6000 + it * bs, bs)))
             if it >= warm:
                 times.append(dt)
-            if len(times) >= 2 and time.perf_counter() > until:
+            if len(times) >= 3 and time.perf_counter() > until:
                 break
         return bs / sorted(times)[len(times) // 2], len(times)
 
-    full = {}
-    cands = sorted(sweep, key=sweep.get, reverse=True)[:2]
-    for i, n in enumerate(cands):
-        torch.set_num_threads(n)
-        full[n] = sample(batch_size, 1, 3, t_begin + budget_s * (0.55 if i == 0 else 0.85))
-    best = max(full, key=lambda n: full[n][0])
+    best = max(sweep, key=sweep.get)
     torch.set_num_threads(best)
-    v1, n1 = sample(1, 3, 10, t_begin + budget_s)
-    return {"value": round(full[best][0], 3), "unit": "pairs/s", "cores": best, "kind": "port",
-            "batch1_value": round(v1, 3), "host_physical_cores": cores, "thread_sweep_batch8_pairs_per_s": sweep,
-            "batch%d_pairs_per_s_by_threads" % batch_size: {n: round(v[0], 3) for n, v in full.items()},
-            "sample": "%s fwd+bwd+Adam on oracle/torch_ref.py (C index ops + PyTorch fp32 CPU convs); threads swept on a "
-                      "batch-8 probe, the two best timed on batch %d (median of %d iterations after 1 warm-up), best = %d "
-                      "threads; batch 1: median of %d after 3 warm-up" % (model_name, batch_size, full[best][1], best, n1)}
+    vfull, nfull = sample(batch_size, 2, 10, t_begin + 0.75 * budget_s)
+    v1, n1 = sample(1, 3, 10, t_begin + 0.8 * budget_s)
+    par = None
+    if cores >= 2 * best and time.perf_counter() - t_begin < 0.85 * budget_s:
+        par = cpu_process_parallel(model_name, sd, batch_size, best, cores)
+    res = {"value": round(vfull, 3), "unit": "pairs/s", "cores": best, "kind": "port",
+           "batch1_value": round(v1, 3), "host_physical_cores": cores, "thread_sweep_batch8_pairs_per_s": sweep,
+           "timed_iterations": nfull,
+           "sample": "%s fwd+bwd+Adam on oracle/torch_ref.py (C index ops + PyTorch fp32 CPU convs); threads swept on a "
+                     "batch-8 probe, the best (%d threads) timed on batch %d: median of %d iterations after 2 warm-up; "
+                     "batch 1: median of %d after 3 warm-up" % (model_name, best, batch_size, nfull, n1)}
+    if par is not None:
+        res["all_cores"] = par
+    return res
 
 
 def _spawned_rank(rank, args, port):
@@ -188,10 +237,9 @@ def run_infer(args):
     B = args.infer_batch
     frames = [synth.to_torch(synth.make_batch(100 + i * B, B), dev) for i in range(max(2, args.pool))]
 
-    def fwd(b):
-        with torch.no_grad():
-            out = model(b)
-            return out["estimation_boxes"], out["estimation_cla"]
+    def fwd(b):      # the network half of evaluate_one_sample (models/base_model.py:44-57): forward + the best proposal's
+        with torch.no_grad():      # (x, y, z, theta), selected on the device (no (64,5) copy to the host)
+            return model.evaluate_one_sample(b)
 
     for i in range(max(args.warmup, 3)):
         fwd(frames[i % len(frames)])
@@ -218,7 +266,7 @@ def run_infer(args):
         static[k].copy_(v)
     g.replay()
     torch.cuda.synchronize()
-    same = all(torch.allclose(a, b, rtol=1e-5, atol=1e-6) for a, b in zip(out, ref))
+    same = all(torch.allclose(a.float(), b.float(), rtol=1e-5, atol=1e-6) for a, b in zip(out, ref))
     for i in range(args.warmup):
         g.replay()
     torch.cuda.synchronize()
@@ -229,19 +277,26 @@ def run_infer(args):
         g.replay()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
-    print(json.dumps({
+    return {
         "metric": "tracked frames/sec (eval forward, %s KITTI-Car 512/1024 pts, batch %d)" % (model.__class__.__name__, B),
         "value": round(B / ms * 1e3, 1), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic KITTI-Car-like pairs (open3dsot_amd/synth.py), random-init weights, BatchNorm on running statistics",
         "config": {"workload": "%s_Car.yaml tracking inference, template 512 / search 1024 pts, batch %d, eval forward only, "
                                "fp32" % (model.__class__.__name__, B), "hip_graph": True, "eager_ms_per_frame": round(eager_ms, 4),
-                   "graph_replay_matches_eager": bool(same)}}))
+                   "best_proposal_on_device": True, "graph_replay_matches_eager": bool(same)}}
 
 
 def run(args):
+    if args.secondary_only:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs a GPU")
+        torch.cuda.set_device(0)
+        print(json.dumps(secondary_lines(args)))
+        return
     if args.infer:
-        return run_infer(args)
+        print(json.dumps(run_infer(args)))
+        return
     rank, local_rank, world = D.init_distributed()
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d but WORLD_SIZE is %d: launch with torch.distributed.run "
@@ -249,11 +304,68 @@ def run(args):
                          (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library is the only compute path (no CPU fallback)")
+    line = measure(args, rank, local_rank, world, full=True)
+    if rank == 0:
+        default_cfg = (args.model == "BAT" and not args.dense and args.search_size == 1024 and world == 1 and
+                       not args.composed and not args.no_graph)
+        if default_cfg and not args.no_secondary:
+            # in a child process: a fault in one of the short side runs must not take the main line down
+            import subprocess
+            try:
+                cp = subprocess.run([sys.executable, os.path.abspath(__file__), "--secondary-only", "--secondary-steps",
+                                     str(args.secondary_steps), "--pool", str(args.pool)], capture_output=True, text=True,
+                                    timeout=420)
+                rows = [ln for ln in cp.stdout.splitlines() if ln.startswith("{")]
+                line["secondary"] = json.loads(rows[-1]) if rows else {"error": "exit %d: %s" % (cp.returncode, cp.stderr[-300:])}
+            except Exception as e:
+                line["secondary"] = {"error": "%s: %s" % (type(e).__name__, e)}
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def secondary_lines(args):
+    """Short driver-visible lines of the other BASELINE configs (the driver runs ONE command): P2B at batch 48 and at
+    batch 1 (config 1's shape on the GPU), M2-Track (config 4), BAT at the NuScenes shapes (config 5: search 2048, and the
+    YAML's per-GPU batch 100 at search 1024), the worst-case dense clouds, and the tracking-inference latency (section
+    8f-4).  Each: `--secondary-steps` timed steps after the graph warm-up, same code path as the main line."""
+    import copy
+    out = {}
+
+    def one(tag, **over):
+        a = copy.copy(args)
+        a.steps, a.warmup, a.no_cpu_baseline, a.per_launch = args.secondary_steps, 5, True, None
+        for k, v in over.items():
+            setattr(a, k, v)
+        try:
+            if over.get("infer"):
+                a.steps, a.warmup = 200, 20
+                r = run_infer(a)
+            else:
+                r = measure(a, 0, 0, 1, full=False)
+            out[tag] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
+                        "workload": r["config"]["workload"]}
+        except Exception as e:  # a secondary line must never take the main line down
+            out[tag] = {"error": "%s: %s" % (type(e).__name__, e)}
+        torch.cuda.empty_cache()
+    one("p2b_batch48", model="P2B")
+    one("p2b_batch1", model="P2B", batch=1)
+    one("m2track_batch48", model="M2TRACK")
+    one("bat_nuscenes_search2048_batch48", search_size=2048)
+    one("bat_nuscenes_yaml_batch100", batch=100)
+    one("bat_dense_worst_case", dense=True)
+    one("bat_infer_batch1", infer=True)
+    one("p2b_infer_batch1", infer=True, model="P2B")
+    return out
+
+
+def measure(args, rank, local_rank, world, full=True):
+    """one timed run of the training step described by `args`; -> the JSON line as a dict (rank 0; {} elsewhere).
+    full=False: no roofline instrumentation and no CPU baseline (the `secondary` lines)."""
     dev = torch.device("cuda", local_rank)
     from open3dsot_amd import capi, sa_modules
     capi.load()
-    if args.composed:
-        sa_modules.set_fused(False)
+    sa_modules.set_fused(not args.composed)
 
     torch.manual_seed(1234)
     if args.model == "M2TRACK":      # BASELINE config 4 (parity case; no pointnet2 operator on this path)
@@ -306,7 +418,7 @@ def run(args):
     roofline = None
     try:
         from open3dsot_amd import fused
-        if sa_modules.fused_enabled() and hasattr(fused, "profile_step"):
+        if full and sa_modules.fused_enabled() and hasattr(fused, "profile_step"):
             def eager_step():      # event-bracketed launches cannot be replayed from a graph
                 trainer._forward_backward(pool[0])
                 trainer.reduce_gradients(); trainer.optimizer.step()
@@ -320,6 +432,13 @@ def run(args):
             roofline["per_launch_roofline"] = {"launches": len(rows), "ms": round(ms, 4), "roof_ms": round(roof_ms, 4),
                                                "frac": round(roof_ms / ms, 4),
                                                "hbm_bound_launches": sum(1 for r in rows if r["bound"] == "hbm")}
+            for fam, pick in (("grouped_mlp", lambda k: not k.startswith("pw_") and not k.endswith("_points")),
+                              ("per_point_layer0", lambda k: k.endswith("_points")), ("heads", lambda k: k.startswith("pw_"))):
+                sel = [r for r in rows if pick(r["kernel"])]
+                if sel:
+                    roofline["per_launch_roofline"][fam] = {
+                        "launches": len(sel), "ms": round(sum(r["ms"] for r in sel), 4),
+                        "frac": round(sum(r["roof_ms"] for r in sel) / sum(r["ms"] for r in sel), 4)}
         if args.per_launch and rank == 0:
             with open(args.per_launch, "w") as fh:
                 fh.write("kernel i Cin Cout cols ms TFLOP/s GB/s bound roof_ms frac\n")
@@ -335,7 +454,13 @@ def run(args):
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")   # rocprofv3 --pmc passes (tools/gpu_prof.sh)
         if os.path.exists(tfile):
             t = json.load(open(tfile))
-            if t.get("workload_batch") == args.batch and t.get("model") == args.model:
+            from open3dsot_amd import build as _build
+            if t.get("kernel_source_sha256") != _build.source_hash():
+                # the counters were taken on other kernels than the ones that just ran: no number rather than a stale one
+                roofline["traffic_note"] = ("profiles/hbm_traffic.json was recorded for kernel sources %s, this library is "
+                                            "built from %s: not reported" % (str(t.get("kernel_source_sha256"))[:12],
+                                                                            _build.source_hash()[:12]))
+            elif t.get("workload_batch") == args.batch and t.get("model") == args.model:
                 roofline["traffic"] = t["gemm_family_hbm_bytes_per_launch"]
                 roofline["traffic_source"] = t["source"]
                 # the same launches against the other roof.  FETCH_SIZE / WRITE_SIZE count the L2's memory-side (fabric)
@@ -344,7 +469,7 @@ def run(args):
                 gbs = roofline["traffic"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9
                 roofline["fabric_gbs"] = round(gbs, 1)
                 roofline["fabric_frac_of_hbm_peak"] = round(gbs / PEAK_HBM_GBS, 4)
-    if roofline is None:  # no instrumented kernels yet: whole-step algorithmic rate (labelled as such)
+    if roofline is None and full:  # no instrumented kernels yet: whole-step algorithmic rate (labelled as such)
         flops = 3.0 * mlp_flops_per_pair(args.model) * args.batch
         ach = flops / (elapsed / args.steps) / 1e12
         roofline = {"bound": "mfma", "achieved": round(ach, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -373,11 +498,11 @@ def run(args):
                        "hip_graph": trainer.graph is not None},
             "roofline": roofline,
         }
-        if not args.no_cpu_baseline and world == 1 and args.search_size == 1024:
+        if full and not args.no_cpu_baseline and world == 1 and args.search_size == 1024:
             line["cpu_baseline"] = cpu_baseline(args.model, sd_cpu, args.batch, args.cpu_budget)
-        print(json.dumps(line))
-    if world > 1:
-        dist.destroy_process_group()
+        line["config"]["rccl_world_size"] = dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1
+        return line
+    return {}
 
 
 if __name__ == "__main__":

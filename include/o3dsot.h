@@ -436,6 +436,12 @@ int o3d_mlp_conv_bwd_fused_c(const float* dN, const float* Y, const float* A1, c
 int o3d_adam_step(const long* jobs, int njobs, float* params, float* exp_avg, float* exp_avg_sq, double lr,
                   double beta1, double beta2, double eps, double weight_decay, double bc1, double bc2, void* stream);
 
+/* Best proposal of a tracked frame: replaces the host-side selection of MatchingBaseModel.evaluate_one_sample
+ * (models/base_model.py:44-57: `estimation_box.cpu().numpy()`, `[:, 4].argmax()`, `[best, 0:4]`) -- SURVEY.md section
+ * 8f-4 lists that device->host copy as part of the per-frame latency path.  boxes (B, P, 5) contiguous;
+ * out (B, 4) = boxes[b, argmax_p boxes[b, p, 4], 0:4] with numpy's tie rule (first maximum); out_idx (B) int32 or NULL. */
+int o3d_best_proposal(const float* boxes, int B, int P, float* out, int32_t* out_idx, void* stream);
+
 /* A per-point stack whose input is [X ; a per-cloud CONSTANT block] (SegPointNet: the pooled feature broadcast to every
  * point and concatenated, models/backbone/pointnet.py:188-190): the constant block contributes W_b . pooled[b] to every
  * column of cloud b -- a per-cloud bias cbias (Cout, B), not 1024 more GEMM rows.

@@ -34,6 +34,19 @@ COMMON = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-munsafe-fp-at
           "-Wall", "-Wno-unused-function"]
 
 
+def source_hash():
+    """sha256 over the kernel sources (csrc/*.hip, *.hpp, include/o3dsot.h): stamps measurement artefacts
+    (profiles/hbm_traffic.json) so that bench.py can refuse counters taken on other kernels"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp", ".h")))
+    files.append(os.path.join(HERE, "..", "include", "o3dsot.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def _stale(target, deps):
     if not os.path.exists(target):
         return True

@@ -177,3 +177,39 @@ extern "C" int o3d_adam_step(const long* jobs, int njobs, float* params, float* 
                        (float)eps, (float)weight_decay, (float)(1.0 / sqrt(bc2)));
     return o3d_launch_status();
 }
+
+
+// ---- best proposal of a tracked frame (models/base_model.py:44-57) ----------------------------------------------------
+// The reference ships the (P, 5) proposals of a frame to the host and takes `estimation_box_cpu[:, 4].argmax()` there
+// (numpy: the FIRST maximum), then keeps columns 0..3.  Here one wave per frame does the same on the device: lanes stride
+// over the proposals keeping (score, index) with "greater, or equal and lower index" as the order, a butterfly folds the
+// 64 lanes, lane 0 writes the four box values and the index.  A NaN score is never greater, like numpy's argmax only when
+// no NaN is present -- the trackers' heads emit finite values (checked by the tests).
+namespace {
+__global__ __launch_bounds__(64) void best_proposal_kernel(const float* __restrict__ boxes, int P, float* __restrict__ out,
+                                                           int32_t* __restrict__ out_idx) {
+    const float* bx = boxes + (long)blockIdx.x * P * 5;
+    const int lane = threadIdx.x;
+    float best = -__builtin_inff();
+    int bi = 0x7fffffff;
+    for (int j = lane; j < P; j += 64) {
+        const float s = bx[5 * j + 4];
+        if (s > best || (s == best && j < bi) || bi == 0x7fffffff) { best = s; bi = j; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float os = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || os > best || (os == best && oi < bi))) { best = os; bi = oi; }
+    }
+    if (lane < 4) out[4 * blockIdx.x + lane] = bx[5 * bi + lane];
+    if (lane == 0 && out_idx) out_idx[blockIdx.x] = bi;
+}
+}  // namespace
+
+// boxes (B, P, 5) contiguous -> out (B, 4) = boxes[b, argmax_p boxes[b, p, 4], 0:4], out_idx (B) int32 (may be NULL)
+extern "C" int o3d_best_proposal(const float* boxes, int B, int P, float* out, int32_t* out_idx, void* stream) {
+    if (!boxes || !out || B <= 0 || P <= 0) return O3D_EINVAL;
+    hipLaunchKernelGGL(best_proposal_kernel, dim3(B), dim3(64), 0, o3d_stream(stream), boxes, P, out, out_idx);
+    return o3d_launch_status();
+}

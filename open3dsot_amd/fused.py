@@ -253,7 +253,9 @@ def _per_launch_rows(tab, peak_tflops):
         cin, cout = dims[0], dims[1]
         pooled = len(dims) > 2 and dims[2]
         cols = flops / (2.0 * cin * cout)
-        if "bwd_fused" in name:  # dN, Y, the producer's raw output in; the data gradient out (the weight gradient is small)
+        if name == "conv_dgrad_points":      # a plain GEMM W0^T . S: S in, the point gradient out
+            nrows = cin + cout
+        elif "bwd_fused" in name:  # dN, Y, the producer's raw output in; the data gradient out (the weight gradient is small)
             nrows = 2 * cout + 2 * cin
         elif "wgrad" in name:    # dY (+ the raw output its BatchNorm backward needs) and the layer input
             nrows = (cout if pooled else 2 * cout) + cin
@@ -630,7 +632,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         prep = prep_for(dev)
         W0p = prep.get(params[0], C0, Cin0p)
         _call("conv_fwd_points", 2.0 * Cin0p * C0 * ldz, lib.o3d_mlp_conv_fwd, X0n.data_ptr(), W0p.data_ptr(),
-              None, None, 1, Cin0p, C0, ldz, Z.data_ptr(), None, None, st)
+              None, None, 1, Cin0p, C0, ldz, Z.data_ptr(), None, None, st, dims=(Cin0p, C0))
         counts = [float(pm) for pm in Pmaxs]          # BatchNorm counts every slot (copies included)
         Ys, means, invstds, scales, shifts = [], [], [], [], []
         if cfg.training:       # shift of the second moment: the running means before this call, one row per segment
@@ -809,7 +811,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                         dWm = torch.empty((Cout, Cinm), device=dev, dtype=f32)
                         _call("conv_wgrad_points", 2.0 * Cinm * Cout * ldz, lib.o3d_mlp_conv_wgrad2, S.data_ptr(), None, 4,
                               S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(), None, None, 1,
-                              Cinm, Cout, ldz, wpart.data_ptr(), dWm.data_ptr(), side.cuda_stream)
+                              Cinm, Cout, ldz, wpart.data_ptr(), dWm.data_ptr(), side.cuda_stream, dims=(Cinm, Cout, True))
                     else:
                         tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
                         total_chunks = ldz // 32
@@ -832,7 +834,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                     W0t = ctx.W0t                                                          # (Cinm, Cout), rows >= Cin zero
                     dX = torch.empty((Cinm, ldz), device=dev, dtype=f32)
                     _call("conv_dgrad_points", 2.0 * Cinm * Cout * ldz, lib.o3d_mlp_conv_fwd, S.data_ptr(), W0t.data_ptr(),
-                          None, None, 1, Cout, Cinm, ldz, dX.data_ptr(), None, None, st)
+                          None, None, 1, Cout, Cinm, ldz, dX.data_ptr(), None, None, st, dims=(Cout, Cinm))
                     dnew_all = ((-cfg.inv_radius) * Ws[0][:, :3]).t() @ T if want_xyz else None       # (3, balls)
                     for s_ in range(nseg):
                         view = dX[:Cin, pt_bases[s_]:pt_bases[s_] + B * Npads[s_]].view(Cin, B, Npads[s_])

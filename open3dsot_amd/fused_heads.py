@@ -265,7 +265,7 @@ class FlatChain(torch.autograd.Function):
                     nparts = P // lib.o3d_pw_tile(P, Mp)
                     part = torch.empty((nparts, 2, Mp), device=dev, dtype=f32)
                     _call("pw_conv_fwd", 2.0 * Kp * Mp * P, lib.o3d_pw_fwd, src.data_ptr(), Wp.data_ptr(), sc, sh, None, None,
-                          Kp, Mp, P, Y.data_ptr(), part.data_ptr(), bn.running_mean.data_ptr(), st)
+                          Kp, Mp, P, Y.data_ptr(), part.data_ptr(), bn.running_mean.data_ptr(), st, dims=(Kp, Mp))
                     fold = torch.empty((64, Mp), device=dev, dtype=f32)
                     _call("bn_finalize", 0.0, lib.o3d_bn_finalize, part.data_ptr(), nparts, Mp, float(P),
                           bn.running_mean.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(),
@@ -273,7 +273,7 @@ class FlatChain(torch.autograd.Function):
                           vec[2].data_ptr(), vec[3].data_ptr(), fold.data_ptr(), st)
                 else:
                     _call("pw_conv_fwd", 2.0 * Kp * Mp * P, lib.o3d_pw_fwd, src.data_ptr(), Wp.data_ptr(), sc, sh, None, None,
-                          Kp, Mp, P, Y.data_ptr(), None, None, st)
+                          Kp, Mp, P, Y.data_ptr(), None, None, st, dims=(Kp, Mp))
                     _eval_consts(lib, bn, gamma, beta, vec, 1, st)
                 vecs.append(vec)
             else:
@@ -283,7 +283,7 @@ class FlatChain(torch.autograd.Function):
                 if bp is None and not cfg.residual:       # plain store without statistics
                     bp = _const_vec(dev, Mp, 0.0)
                 _call("pw_conv_fwd", 2.0 * Kp * Mp * P, lib.o3d_pw_fwd, src.data_ptr(), Wp.data_ptr(), sc, sh, _ptr(bp),
-                      X0.data_ptr() if cfg.residual else None, Kp, Mp, P, Y.data_ptr(), None, None, st)
+                      X0.data_ptr() if cfg.residual else None, Kp, Mp, P, Y.data_ptr(), None, None, st, dims=(Kp, Mp))
             Ys.append(Y)
             Kp = Mp
         if cfg.training and L > 1:
@@ -336,7 +336,7 @@ class FlatChain(torch.autograd.Function):
                 scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Kp, Cout_p, P),), device=dev, dtype=f32)
                 _call("pw_conv_wgrad", 2.0 * Kp * Cout_p * P, lib.o3d_mlp_conv_wgrad2, dN.data_ptr(), None, 4, Y.data_ptr(),
                       A[0], A[1], A[2], Xs.data_ptr(), sc, sh, 1, Kp, Cout_p, P, scratch.data_ptr(), dW.data_ptr(),
-                      side.cuda_stream)
+                      side.cuda_stream, dims=(Kp, Cout_p, Y is dN))
                 Wl = Ws[l]
                 Cout, Cin = Wl.shape[0], Wl.shape[1]
                 out = (dW if (Cout, Cin) == (Cout_p, Kp) else dW[:Cout, :Cin]).reshape(Wl.shape)
@@ -363,12 +363,12 @@ class FlatChain(torch.autograd.Function):
             v = vecs[l - 1]
             _call("pw_conv_dgrad", 2.0 * Cp * Mp * P, lib.o3d_pw_dgrad, G.data_ptr(), None, None, None, None,
                   Wts[l].data_ptr(), Cp, Mp, P, Ys[l - 1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(), v[0].data_ptr(), None,
-                  dN.data_ptr(), part.data_ptr(), st)
+                  dN.data_ptr(), part.data_ptr(), st, dims=(Cp, Mp, True))
         elif want_x:
             dX0 = torch.empty((K0p, P), device=dev, dtype=f32)
             _call("pw_conv_dgrad", 2.0 * K0p * Mp * P, lib.o3d_pw_dgrad, G.data_ptr(), None, None, None, None,
                   Wts[0].data_ptr(), K0p, Mp, P, None, None, None, None, G.data_ptr() if cfg.residual else None,
-                  dX0.data_ptr(), None, st)
+                  dX0.data_ptr(), None, st, dims=(K0p, Mp, True))
         # ---- hidden layers: conv -> BatchNorm -> ReLU
         for l in range(L - 2, -1, -1):
             Cp = Ys[l].shape[0]
@@ -392,13 +392,13 @@ class FlatChain(torch.autograd.Function):
                 vp = vecs[l - 1]
                 _call("pw_conv_dgrad", 2.0 * Cq * Cp * P, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
                       Wts[l].data_ptr(), Cq, Cp, P, Ys[l - 1].data_ptr(), vp[2].data_ptr(), vp[3].data_ptr(), vp[0].data_ptr(),
-                      None, dNp.data_ptr(), part_next.data_ptr(), st)
+                      None, dNp.data_ptr(), part_next.data_ptr(), st, dims=(Cq, Cp))
                 dN, part, nparts = dNp, part_next, nparts_next
             elif want_x:
                 dX0 = torch.empty((K0p, P), device=dev, dtype=f32)
                 _call("pw_conv_dgrad", 2.0 * K0p * Cp * P, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1], A[2],
                       Wts[0].data_ptr(), K0p, Cp, P, None, None, None, None, G.data_ptr() if cfg.residual else None,
-                      dX0.data_ptr(), None, st)
+                      dX0.data_ptr(), None, st, dims=(K0p, Cp))
         if side is not main:
             main.wait_stream(side)       # join: every weight gradient is complete before autograd hands it on
         del keep

@@ -15,7 +15,9 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from . import fused_heads, fused_loss, optim
+import ctypes
+
+from . import capi, fused_heads, fused_loss, optim
 from . import nn_blocks as pt_utils
 from .backbone import Pointnet_Backbone
 from .rpn import P2BVoteNetRPN
@@ -40,6 +42,26 @@ def make_config(base, **overrides):
     return SimpleNamespace(**cfg)
 
 
+capi.register("o3d_best_proposal", [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_void_p])
+
+
+def best_proposal(boxes):
+    """boxes (B,P,5) -> (boxes[b, argmax_p boxes[b,p,4], 0:4] (B,4), argmax (B,) int32)   [models/base_model.py:47-52]"""
+    if not boxes.is_cuda:            # the CPU mirror used by the tests: the reference's own numpy formulation
+        idx = boxes[:, :, 4].detach().cpu().numpy().argmax(axis=1)
+        idx_t = torch.from_numpy(idx.astype("int32"))
+        return boxes[torch.arange(boxes.shape[0]), idx_t.long(), :4], idx_t
+    b = boxes.detach().contiguous().float()
+    B, P, _ = b.shape
+    out = torch.empty((B, 4), device=b.device, dtype=torch.float32)
+    idx = torch.empty((B,), device=b.device, dtype=torch.int32)
+    with torch.cuda.device(b.device):
+        capi.check(capi.load().o3d_best_proposal(b.data_ptr(), B, P, out.data_ptr(), idx.data_ptr(),
+                                                 torch.cuda.current_stream().cuda_stream), "best_proposal")
+    return out, idx
+
+
 class MatchingBaseModel(nn.Module):
     def __init__(self, config=None, **kwargs):
         super().__init__()
@@ -55,6 +77,15 @@ class MatchingBaseModel(nn.Module):
             opt = optim.make_adam(self.parameters(), c.lr, c.wd)
         sched = torch.optim.lr_scheduler.StepLR(opt, step_size=c.lr_decay_step, gamma=c.lr_decay_rate)
         return {"optimizer": opt, "lr_scheduler": sched}
+
+    def evaluate_one_sample(self, data_dict):
+        """The network half of MatchingBaseModel.evaluate_one_sample (models/base_model.py:44-57) without its host round
+        trip: forward, then the proposal with the highest objectness (column 4; numpy's argmax: the first maximum) and
+        its (x, y, z, theta) picked ON THE DEVICE (csrc/heads.hip::best_proposal_kernel) -- the reference copies the
+        (64, 5) proposals to the host for that.  -> (best (B,4) float32, index (B,) int32), device tensors; feeding
+        `getOffsetBB` (datasets/points_utils.py, host geometry on Box objects) is the caller's business."""
+        end_points = self(data_dict)
+        return best_proposal(end_points["estimation_boxes"])
 
     def compute_loss(self, data, output):
         """Siamese matching losses  [models/base_model.py:122-164]."""

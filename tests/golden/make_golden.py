@@ -94,7 +94,9 @@ def main():
     fix["search_points"] = batch["search_points"]
 
     # ---- BoxAwareXCorr + P2B_XCorr ------------------------------------------------------
-    B, f, M, N = 2, 256, 16, 32
+    # the trackers' own shapes (64 template / 128 search seeds) and four pairs: a BatchNorm channel of `fea_layer` sees 512
+    # samples (round 2's 2 x 32 made the train-mode output ill-conditioned: 1e-2 on the GPU)
+    B, f, M, N = 4, 256, 64, 128
     t_feat = torch.randn(B, f, M, generator=g)
     s_feat = torch.randn(B, f, N, generator=g)
     t_xyz = torch.randn(B, M, 3, generator=g)
@@ -123,11 +125,12 @@ def main():
         fix["p2b_xcorr.%s.out" % mode] = m2(t_feat, s_feat, t_xyz).detach().numpy()
 
     # ---- RPN -----------------------------------------------------------------------------
-    N = 64
-    xyz = torch.from_numpy(batch["search_points"][:, :N, :]).clone() * 0.3
-    feat = torch.randn(2, 256, N, generator=g)
+    N = 128
+    batch4 = synth.make_batch(10, 4, template_size=128, search_size=256)
+    xyz = torch.from_numpy(batch4["search_points"][:, :N, :]).clone() * 0.3
+    feat = torch.randn(4, 256, N, generator=g)
     fix["rpn.in.xyz"], fix["rpn.in.feat"] = xyz.numpy(), feat.numpy()
-    rpn = ref_rpn.P2BVoteNetRPN(256, vote_channel=256, num_proposal=16, normalize_xyz=False)
+    rpn = ref_rpn.P2BVoteNetRPN(256, vote_channel=256, num_proposal=64, normalize_xyz=False)
     randomize_bn(rpn, g)
     # make the vote offsets small so the vote ball queries are non-trivial
     with torch.no_grad():

@@ -19,10 +19,8 @@ equals the fp32 run's) with the pure data-movement operators (gather / group and
 ops, which keep the dtype.  The script asserts that the two runs agree to 1e-4 on every end point (no discrete
 decision flipped between them).
 """
-import importlib.util
 import os
 import sys
-import types
 
 import numpy as np
 import torch
@@ -33,7 +31,6 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 torch.Tensor.cuda = lambda self, *a, **k: self
 from oracle import ext_shim  # noqa: E402
-from oracle import ops as oracle_ops  # noqa: E402
 
 shim = ext_shim.install()
 sys.path.insert(0, REF)
@@ -75,62 +72,10 @@ def use_ops(table):
         setattr(shim, k, fn)
 
 
-def stub(name, **attrs):
-    m = types.ModuleType(name)
-    m.__dict__.update(attrs)
-    sys.modules[name] = m
-    return m
+import ref_stubs  # noqa: E402
+from ref_stubs import EasyDict  # noqa: E402
 
-
-def load(name, rel):
-    spec = importlib.util.spec_from_file_location(name, os.path.join(REF, rel))
-    mod = importlib.util.module_from_spec(spec)
-    sys.modules[name] = mod
-    spec.loader.exec_module(mod)
-    return mod
-
-
-class _Dummy:
-    def __init__(self, *a, **k):
-        pass
-
-
-class EasyDict(dict):
-    __getattr__ = dict.__getitem__
-    __setattr__ = dict.__setitem__
-
-
-class _Experiment:
-    def add_scalars(self, *a, **k):
-        pass
-
-
-class LightningModule(torch.nn.Module):
-    global_step = 0
-
-    def save_hyperparameters(self, *a, **k):
-        pass
-
-    def log(self, *a, **k):
-        pass
-
-    @property
-    def logger(self):
-        return types.SimpleNamespace(experiment=_Experiment())
-
-
-stub("pytorch_lightning", LightningModule=LightningModule)
-stub("easydict", EasyDict=EasyDict)
-stub("nuscenes"); stub("nuscenes.utils", geometry_utils=None); stub("nuscenes.utils.geometry_utils")
-stub("pyquaternion", Quaternion=_Dummy)
-stub("datasets", points_utils=None); stub("datasets.points_utils"); stub("datasets.data_classes", PointCloud=_Dummy, Box=_Dummy)
-stub("utils"); stub("utils.metrics", TorchSuccess=_Dummy, TorchPrecision=_Dummy, estimateOverlap=None, estimateAccuracy=None)
-pkg = stub("models"); stub("models.backbone"); stub("models.head")
-load("models.backbone.pointnet", "models/backbone/pointnet.py")
-load("models.head.xcorr", "models/head/xcorr.py")
-load("models.head.rpn", "models/head/rpn.py")
-pkg.base_model = load("models.base_model", "models/base_model.py")
-ref = {"BAT": load("models.bat", "models/bat.py").BAT, "P2B": load("models.p2b", "models/p2b.py").P2B}
+ref = ref_stubs.load_trackers(REF)
 cfgs = {"BAT": trackers.BAT_CAR, "P2B": trackers.P2B_CAR}
 
 # conv weights whose gradients are stored (one per block of the step); every 1-D parameter is stored as well

@@ -50,7 +50,7 @@ def test_torch_ref_xcorr_and_rpn(golden, mode):
     np.testing.assert_allclose(out.detach().numpy(), golden["p2b_xcorr.%s.out" % mode], **TOL)
     st = torch_ref.State(sd_from(golden, "rpn.sd.", "rpn."), mode == "train")
     boxes, cla, vote_xyz, centers = torch_ref.rpn(st, torch.from_numpy(golden["rpn.in.xyz"]),
-                                                  torch.from_numpy(golden["rpn.in.feat"]), 16)
+                                                  torch.from_numpy(golden["rpn.in.feat"]), 64)
     for nm, t in (("boxes", boxes), ("cla", cla), ("vote_xyz", vote_xyz), ("centers", centers)):
         np.testing.assert_allclose(t.detach().numpy(), golden["rpn.%s.%s" % (mode, nm)], **TOL)
 
@@ -88,7 +88,7 @@ def test_host_mirror_heads(golden, cpu_ext, mode):
     m.train(mode == "train")
     out = m(gi["t_feat"], gi["s_feat"], gi["t_xyz"])
     np.testing.assert_allclose(out.detach().numpy(), golden["p2b_xcorr.%s.out" % mode], **TOL)
-    m = P2BVoteNetRPN(256, vote_channel=256, num_proposal=16)
+    m = P2BVoteNetRPN(256, vote_channel=256, num_proposal=64)
     m.load_state_dict(sd_from(golden, "rpn.sd."), strict=True)
     m.train(mode == "train")
     outs = m(torch.from_numpy(golden["rpn.in.xyz"]), torch.from_numpy(golden["rpn.in.feat"]))

@@ -62,13 +62,11 @@ def test_gpu_heads_match_reference_modules(golden, mode):
         m.load_state_dict(sd_from(golden, "p2b_xcorr.sd."), strict=True)
         m = m.cuda().train(mode == "train")
         out = m(gi["t_feat"], gi["s_feat"], gi["t_xyz"])
-        # train mode: `fea_layer`'s BatchNorm normalises 2 x 128 samples per channel of a max-pooled feature whose batch
-        # variance is tiny for many channels with the fixture's closed-form weights: 1/sigma amplifies the 1e-6 rounding
-        # difference of the stage in front of it (pinned at 2e-5 against fp64 by tests/test_heads_gpu.py::
-        # test_p2b_xcorr_fused_vs_fp64) to 6e-3 here; eval mode (running statistics) holds 1e-4
-        tol = dict(rtol=1e-2, atol=1e-2) if mode == "train" else TOL
+        # (round 3: the fixture holds four pairs at the trackers' own 64 / 128 seed counts -- round 2's 2 x 32 columns made
+        # `fea_layer`'s train-mode BatchNorm ill-conditioned and this check had to be 1e-2; 2e-4 absolute in train mode now)
+        tol = dict(rtol=1e-4, atol=2e-4) if mode == "train" else TOL
         np.testing.assert_allclose(out.detach().cpu().numpy(), golden["p2b_xcorr.%s.out" % mode], **tol)
-        m = P2BVoteNetRPN(256, vote_channel=256, num_proposal=16)
+        m = P2BVoteNetRPN(256, vote_channel=256, num_proposal=64)
         m.load_state_dict(sd_from(golden, "rpn.sd."), strict=True)
         m = m.cuda().train(mode == "train")
         outs = m(dev(golden["rpn.in.xyz"]), dev(golden["rpn.in.feat"]))

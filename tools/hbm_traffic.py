@@ -29,7 +29,11 @@ for r in csv.DictReader(open(src)):
     m = re.search(r"(\w*kernel\w*(<[^>]*>)?)", k)
     short = m.group(1) if m else k[:60]
     per[short] = {"dispatches": n, "read_bytes": int(rd), "write_bytes": int(wr)}
-json.dump({"model": model, "workload_batch": batch,
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from open3dsot_amd import build as _build  # noqa: E402
+
+json.dump({"model": model, "workload_batch": batch, "kernel_source_sha256": _build.source_hash(),
            "gemm_family_hbm_bytes_per_launch": int(tot_bytes / max(launches, 1)),
            "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/gpu_round2.sh): the L2's "
                      "memory-side (fabric) request bytes, Infinity-Cache hits INCLUDED (an upper bound of HBM bytes); "
