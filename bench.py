@@ -396,15 +396,18 @@ def measure(args, rank, local_rank, world, full=True):
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
     tw = time.perf_counter()
-    for i in range(max(args.warmup, 4 if not args.no_graph else 0)):   # graph capture happens in here
-        trainer.step(pool[i % len(pool)])
+    # (next_batch: the loop knows which resident batch comes next, like a data loader with one batch of look-ahead; its
+    # farthest-point sampling -- a function of the input clouds only -- then runs beside the current step)
+    nwarm = max(args.warmup, 4 if not args.no_graph else 0)
+    for i in range(nwarm):   # graph capture happens in here
+        trainer.step(pool[i % len(pool)], next_batch=pool[(i + 1) % len(pool)] if i + 1 < nwarm else pool[0])
     torch.cuda.synchronize()
     log("warm-up: %.2f s; hip graph: %s %s" % (time.perf_counter() - tw, trainer.graph is not None,
                                               trainer.graph_error or ""))
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        trainer.step(pool[i % len(pool)])
+        trainer.step(pool[i % len(pool)], next_batch=pool[(i + 1) % len(pool)])
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0

@@ -47,15 +47,17 @@ class Pointnet_Backbone(nn.Module):
         return l_xyz[-1], l_features[-1], idx0
 
 
-def _backbone_forward_pair(self, pc_a, numpoints_a, pc_b, numpoints_b):
+def _backbone_forward_pair(self, pc_a, numpoints_a, pc_b, numpoints_b, sample_idxs=None):
     """self(pc_a, numpoints_a), self(pc_b, numpoints_b) with every level's two module calls issued as one
-    (sa_modules.forward_pair): same numbers as the two calls in that order."""
+    (sa_modules.forward_pair): same numbers as the two calls in that order.  sample_idxs = (idx_a, idx_b): level 0's
+    farthest-point-sampling indices when they were computed ahead of the step (`sampling_indices`)."""
     xyz_a, feat_a = self._break_up_pc(pc_a)
     xyz_b, feat_b = self._break_up_pc(pc_b)
     la, lb = ([xyz_a], [feat_a]), ([xyz_b], [feat_b])
     idx0 = [None, None]
     for i, sa in enumerate(self.SA_modules):
-        ra, rb = sa.forward_pair(la[0][i], la[1][i], numpoints_a[i], lb[0][i], lb[1][i], numpoints_b[i])
+        ra, rb = sa.forward_pair(la[0][i], la[1][i], numpoints_a[i], lb[0][i], lb[1][i], numpoints_b[i],
+                                 sample_idxs if i == 0 else None)
         for k, (lst, r) in enumerate(((la, ra), (lb, rb))):
             lst[0].append(r[0])
             lst[1].append(r[1])
@@ -67,6 +69,18 @@ def _backbone_forward_pair(self, pc_a, numpoints_a, pc_b, numpoints_b):
 
 
 Pointnet_Backbone.forward_pair = _backbone_forward_pair
+
+
+def sampling_indices(self, pc_a, npoint_a, pc_b, npoint_b):
+    """level 0's sampling indices of both clouds -- the part of the backbone that depends on the input clouds only
+    (pointnet2_modules.py:52-56) -- or None when level 0 does not sample with FPS.  One launch for both clouds."""
+    if not self.SA_modules[0].use_fps:
+        return None
+    from . import ops
+    return ops.furthest_point_sample_pair(pc_a[..., 0:3].contiguous(), npoint_a, pc_b[..., 0:3].contiguous(), npoint_b)
+
+
+Pointnet_Backbone.sampling_indices = sampling_indices
 
 
 def _pointwise_chain(x, layers, pool=False):

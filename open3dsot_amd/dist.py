@@ -107,6 +107,12 @@ class DataParallelStep:
         self._static_grads = None      # the gradient tensors the captured backward writes (graph pool)
         self._eager_steps = 0
         self._buffers = [b for b in model.buffers()]
+        # sampling prefetch: the farthest-point-sampling indices of batch t+1 are computed on a second
+        # stream while the graph of step t replays -- 766 strictly serial rounds on 96 of 1024 SIMDs otherwise head every
+        # step with the rest of the chip idle.  O3D_FPS_PREFETCH=0 keeps the sampling inside the captured step.
+        self._sampling = getattr(model, "sampling_inputs", None) if os.environ.get("O3D_FPS_PREFETCH", "1") != "0" else None
+        self._side = None
+        self._prefetched = None        # (batch object, {key: tensor}, event)
 
     def reduce_gradients(self):
         """flat exchange buffer (packed by `_forward_backward`) -> mean over ranks, p.grad = its views.  One collective on
@@ -132,6 +138,10 @@ class DataParallelStep:
 
     def _capture(self, batch):
         self._static = {k: v.clone() for k, v in batch.items()}
+        if self._sampling is not None:
+            # the sampling indices become INPUTS of the captured step (static buffers): the graph holds no FPS launch
+            with torch.no_grad():
+                self._static.update({k: v.clone() for k, v in self._sampling(self._static).items()})
         # the allocator warm-up pass below is NOT a training step: the BatchNorm running statistics and
         # num_batches_tracked it touches are put back, so a graph run sees exactly one update per step()
         buffers = list(self.model.buffers())
@@ -153,11 +163,43 @@ class DataParallelStep:
         self._static_grads = [p.grad for p in self.grads.params]
         self.graph = g
 
-    def step(self, batch):
+    def _sampling_for(self, batch):
+        """sampling inputs of `batch`: the prefetched ones when `batch` is the very object announced as `next_batch`
+        of the previous step (the main stream then waits for the side stream's event), else computed here and now"""
+        main = torch.cuda.current_stream()
+        if self._prefetched is not None and self._prefetched[0] is batch:
+            _, extra, ev = self._prefetched
+            main.wait_event(ev)
+            for t in extra.values():
+                t.record_stream(main)          # allocated on the side stream, read by the copy below on this one
+        else:
+            with torch.no_grad():
+                extra = self._sampling(batch)
+        self._prefetched = None
+        return extra
+
+    def _prefetch(self, next_batch):
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        with torch.cuda.stream(self._side), torch.no_grad():
+            extra = self._sampling(next_batch)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._prefetched = (next_batch, extra, ev)
+
+    def step(self, batch, next_batch=None):
+        """one training step on `batch`.  next_batch: the batch the NEXT call will be given (the very same dict object),
+        when the caller knows it -- its input-only preprocessing (farthest-point sampling) then runs beside this step"""
         if self.graph is not None:
-            keys = [k for k in batch if batch[k] is not self._static[k]]
+            src = batch
+            if self._sampling is not None and any(k not in batch for k in self._static):
+                src = dict(batch)
+                src.update(self._sampling_for(batch))
+            keys = [k for k in src if src[k] is not self._static[k]]
             if keys:                      # one multi-tensor copy instead of a launch per input
-                torch._foreach_copy_([self._static[k] for k in keys], [batch[k] for k in keys], non_blocking=True)
+                torch._foreach_copy_([self._static[k] for k in keys], [src[k] for k in keys], non_blocking=True)
+            if next_batch is not None and self._sampling is not None and len(self._static) > len(next_batch):
+                self._prefetch(next_batch)        # enqueued before the replay: it starts with the step
             self.graph.replay()
             # the replayed finalize kernels rewrote the BatchNorm running statistics through raw pointers: bump their
             # version counters (host only) so version-keyed caches -- eval-mode constants -- see a training step
@@ -176,7 +218,7 @@ class DataParallelStep:
                     self.graph = None
                     torch.cuda.synchronize()
             if self.graph is not None:
-                return self.step(batch)
+                return self.step(batch, next_batch)
             loss = self._forward_backward(batch)
             self._eager_steps += 1
         self.reduce_gradients()

@@ -84,10 +84,15 @@ class _PointnetSAModuleBase(nn.Module):
         x = F.max_pool2d(x, kernel_size=[1, x.size(3)])  # (B, mlp[-1], npoint, 1)
         return x.squeeze(-1)
 
-    def forward(self, xyz, features, npoint, return_idx=False):
-        """xyz (B,N,3), features (B,C,N) | None -> new_xyz (B,npoint,3), (B,sum(mlp[-1]),npoint)"""
+    def forward(self, xyz, features, npoint, return_idx=False, sample_idxs=None):
+        """xyz (B,N,3), features (B,C,N) | None -> new_xyz (B,npoint,3), (B,sum(mlp[-1]),npoint).
+        sample_idxs: (B,npoint) int32 sampling indices computed earlier by the same operator (they depend on the input
+        cloud only: a data-pipeline stage may run the farthest-point sampling ahead of the step)"""
         self.npoint = npoint
-        sample_idxs, new_xyz = self._sample(xyz, npoint)
+        if sample_idxs is not None:
+            new_xyz = pointnet2_utils.gather_xyz(xyz, sample_idxs)
+        else:
+            sample_idxs, new_xyz = self._sample(xyz, npoint)
         outs = [self._group_mlp_pool(i, xyz, new_xyz, features) for i in range(len(self.groupers))]
         feats = torch.cat(outs, dim=1) if len(outs) > 1 else outs[0]
         if return_idx:
@@ -109,15 +114,20 @@ class _PointnetSAModuleBase(nn.Module):
             new_xyz = xyz[:, :npoint, :].contiguous()
         return sample_idxs, new_xyz
 
-    def forward_pair(self, xyz_a, features_a, npoint_a, xyz_b, features_b, npoint_b):
+    def forward_pair(self, xyz_a, features_a, npoint_a, xyz_b, features_b, npoint_b, sample_idxs=None):
         """forward(xyz_a, ...) followed by forward(xyz_b, ...) -- the template and the search cloud through the
         shared module (models/bat.py:89-90) -- as one set of launches on the fused path: the weights are
         read once, the BatchNorm batch statistics stay separate and the running statistics see a's update
-        before b's.  Returns ((new_xyz, feats, sample_idxs)_a, (...)_b)."""
+        before b's.  Returns ((new_xyz, feats, sample_idxs)_a, (...)_b).
+        sample_idxs = (idx_a, idx_b): sampling indices computed ahead of the step (see `forward`)."""
         if (_FUSED["enabled"] and _FUSED["paired"] and xyz_a.is_cuda and len(self.groupers) == 1):
             from . import fused
             if fused.supports(self.groupers[0], self.mlps[0], features_a):
-                if self.use_fps and _FUSED["fps_streams"]:
+                if sample_idxs is not None:
+                    idx_a, idx_b = sample_idxs
+                    new_a = pointnet2_utils.gather_xyz(xyz_a, idx_a)
+                    new_b = pointnet2_utils.gather_xyz(xyz_b, idx_b)
+                elif self.use_fps and _FUSED["fps_streams"]:
                     # the two farthest-point samplings are one workgroup per cloud each (48 of 256 CUs busy): b's on a
                     # second stream beside a's.  OFF by default (O3D_FPS_STREAMS=1): measured on the MI355X the fork /
                     # join inside the HIP graph costs more than the 0.09 ms overlap gains (8.54 vs 8.22 ms per step)
@@ -141,7 +151,8 @@ class _PointnetSAModuleBase(nn.Module):
                 if outs is not None:
                     self.npoint = npoint_b
                     return (new_a, outs[0], idx_a), (new_b, outs[1], idx_b)
-        return self.forward(xyz_a, features_a, npoint_a, True), self.forward(xyz_b, features_b, npoint_b, True)
+        ia, ib = sample_idxs if sample_idxs is not None else (None, None)
+        return self.forward(xyz_a, features_a, npoint_a, True, ia), self.forward(xyz_b, features_b, npoint_b, True, ib)
 
 
 class PointnetSAModuleMSG(_PointnetSAModuleBase):

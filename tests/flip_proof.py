@@ -7,7 +7,7 @@ tests therefore proceed in two stages:
 
   (1) from the fp64 evaluation, flag every unit that is a NEAR-TIE: |BatchNorm output before the ReLU| < TIE_ULPS ulp(fp32)
       of the layer's rms, or (pool) best - second best < TIE_ULPS ulp of the pooled layer's rms.  Every column (point,
-      ball) whose gradient error exceeds 1e-4 of the gradient's rms must contain a flagged unit -- an unflagged outlier is
+      ball) whose gradient error exceeds OUTLIER (1e-3) of the gradient's rms must contain a flagged unit -- an unflagged outlier is
       a bug, not a flip, and fails the test;
   (2) the cotangent is zeroed on the flagged columns in BOTH evaluations and the backward passes are repeated: with the
       provable ties out of the picture the TIGHT bound (5e-4 relative L2, 1e-2 of the maximum) must hold for every input
@@ -22,7 +22,11 @@ import torch
 
 ULP = 2.0 ** -23
 TIE_ULPS = 64.0        # fp32 rounding of a K<=260-term dot product + BatchNorm affine: a few tens of ulps of the rms
-OUTLIER = 1e-4         # a column is an outlier when its gradient error exceeds this share of the gradient's rms
+# A column is an outlier when its worst gradient error exceeds this share of the gradient's rms.  Measured on the
+# MI355X (gpurun_out/r3a, round 3): plain fp32 rounding reaches 1e-4 .. 5e-4 of the rms on the worst of a column's 128-259
+# channels (K-term dot products with cancellation); a routing flip moves its column by >= 1e-2.  1e-3 separates the two;
+# stage 2 then bounds everything that is not flagged by the tight L2 criterion anyway.
+OUTLIER = 1e-3
 
 
 def rms(t):

@@ -99,7 +99,9 @@ def test_flat_chain_vs_fp64(name, train, B, N):
         import flip_proof
         for m in ref.modules():
             if isinstance(m, torch.nn.BatchNorm1d):
-                m.register_forward_hook(lambda mod, inp, outp: zs.append(flip_proof.relu_margin_ulps(outp.detach(), 1)))
+                # (the fp64 module runs the flat torch path: BatchNorm1d sees (1, C, B*N), column b*N + n)
+                m.register_forward_hook(lambda mod, inp, outp: zs.append(
+                    flip_proof.relu_margin_ulps(outp.detach(), 1).reshape(B, N)))
     g = torch.Generator(device="cuda").manual_seed(5)
     parts = []
     for C in src_C:     # xyz arrives as a transposed (B,N,3) tensor, features as (B,C,N)

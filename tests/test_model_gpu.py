@@ -815,3 +815,42 @@ def test_bat_nuscenes_yaml_batch100():
     for k in ref_ld:
         assert abs(ld[k] - ref_ld[k]) <= 1e-4 * (1 + abs(ref_ld[k])), k
     assert all(torch.isfinite(v).all() for v in g.values())
+
+
+def test_sampling_prefetch_feeds_the_same_indices_as_the_inline_step():
+    """DataParallelStep.step(batch, next_batch=...): the farthest-point sampling of the NEXT batch runs on a second
+    stream beside the replayed graph of this step and enters the next replay as an input.  The indices the captured step
+    consumes must be bit-identical to the operator's own output for that batch (pointnet2_utils.py:37-58), and the
+    losses must follow the trajectory of a trainer that samples inside its step."""
+    import copy
+    from open3dsot_amd import dist as D, ext, synth
+    dev = torch.device("cuda", 0)
+    model_a = make_model("BAT", 9)
+    model_b = copy.deepcopy(model_a)
+    pool = [synth.to_torch(synth.make_batch(300 + 4 * i, 4, 512, 1024), dev) for i in range(3)]
+    ta = D.DataParallelStep(model_a, world=1, graph=True, graph_warmup=1)
+    tb = D.DataParallelStep(model_b, world=1, graph=True, graph_warmup=1)
+    ta._sampling = None                                         # A: sampling inside the captured step (round 2's form)
+    assert tb._sampling is not None
+    la, lb = [], []
+    for i in range(7):
+        cur, nxt = pool[i % 3], pool[(i + 1) % 3]
+        la.append(float(ta.step(cur)))
+        lb.append(float(tb.step(cur, next_batch=nxt)))
+        if tb.graph is not None:
+            torch.cuda.synchronize()
+            want = ext.furthest_point_sampling(cur["search_points"].contiguous(), 512)
+            assert torch.equal(tb._static["fps_idx_s"], want), i
+            want_t = ext.furthest_point_sampling(cur["template_points"].contiguous(), 256)
+            assert torch.equal(tb._static["fps_idx_t"], want_t), i
+            if i >= 2:
+                assert tb._prefetched is not None and tb._prefetched[0] is nxt
+    assert ta.graph is not None and tb.graph is not None, (ta.graph_error, tb.graph_error)
+    assert "fps_idx_s" not in ta._static
+    for a, b in zip(la, lb):                                     # same trajectory (scatter sums are not bitwise reproducible)
+        assert abs(a - b) <= 2e-3 * (1 + abs(a)), (la, lb)
+    # a batch that was NOT announced: sampled on the spot, same result
+    other = synth.to_torch(synth.make_batch(900, 4, 512, 1024), dev)
+    tb.step(other)
+    torch.cuda.synchronize()
+    assert torch.equal(tb._static["fps_idx_s"], ext.furthest_point_sampling(other["search_points"].contiguous(), 512))
