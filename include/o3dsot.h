@@ -260,6 +260,13 @@ int o3d_compact_build(const int32_t* idx, int B, int npoint, int ns, int ld, int
                       int ball_base, int dummy_ball, int32_t* ball_cnt, int32_t* ball_off, int32_t* gp,
                       int32_t* cball, float* cw, int32_t* meta, void* stream);
 
+/* o3d_compact_build for the two segments of a paired call (template + search cloud through one shared module,
+ * models/bat.py:89-90) in three launches instead of six: segment 0 at column / point / ball base 0, segment 1 at
+ * col_base1 / pt_base1 / ball base B*npoint0; ball_cnt, ball_off: B*(npoint0+npoint1) (+1) entries, meta: 8 ints. */
+int o3d_compact_build2(const int32_t* idx0, int npoint0, int ld0, const int32_t* idx1, int npoint1, int ld1, int B,
+                       int ns, int col_base1, int pt_base1, int dummy_ball, int32_t* ball_cnt, int32_t* ball_off,
+                       int32_t* gp, int32_t* cball, float* cw, int32_t* meta, void* stream);
+
 /* Y0[c,q] = Z[c,gp[q]] - W0[c,0:3].centers[cball[q]] (QueryAndGroup + layer 0 after the per-point GEMM
  * Z = W0.[xyz;feats], pointnet2_utils.py:299-339); centers (balls+1, 3) or NULL; weighted statistics
  * partials part [ldp/256][2][C0] or NULL (stat_c: C0 floats per segment). */
@@ -429,6 +436,18 @@ int o3d_mlp_conv_bwd_fused_c(const float* dN, const float* Y, const float* A1, c
                              const float* X, const float* in_scale, const float* in_shift, const float* in_mean,
                              const float* Wt, int Cin, int Cout, long ldp, const float* w, const int32_t* meta,
                              long start1, float* scratch, float* dW, float* part_s, float* dNprev, void* stream);
+
+/* Several independent weight gradients of the flat (C, P) layout in one launch (+ one reduction launch): the 1-D conv
+ * stacks of the heads (models/head/rpn.py:16-39, models/head/xcorr.py:14-17, models/bat.py:22-26).  Job i computes what
+ * o3d_mlp_conv_wgrad2(dN, NULL, 4, Y, A1, A2, A3, X, in_scale, in_shift, 1, Cin, Cout, P, scratch, dW, stream) computes
+ * (same tile plan and summation order); njobs <= 4; scratch: o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, P) floats each. */
+typedef struct {
+    const float* dN; const float* Y; const float* A1; const float* A2; const float* A3;
+    const float* X; const float* in_scale; const float* in_shift;
+    int Cin, Cout; long P;
+    float* scratch; float* dW;
+} o3d_wgrad_job;
+int o3d_mlp_conv_wgrad2_group(const o3d_wgrad_job* jobs, int njobs, void* stream);
 
 /* torch.optim.Adam's update (models/base_model.py:32-33) for all parameters in one launch: parameters and moments in
  * flat buffers, gradients found through a DEVICE job table of njobs x 3 longs {gradient ptr, offset, n};

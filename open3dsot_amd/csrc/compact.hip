@@ -734,6 +734,101 @@ extern "C" int o3d_compact_build(const int32_t* idx, int B, int npoint, int ns, 
     return o3d_launch_status();
 }
 
+// Both segments of a paired call (template + search cloud through one shared module) in THREE launches instead of six:
+// every kernel covers segment 0's workgroups first, then segment 1's.  Arguments per segment as o3d_compact_build.
+namespace {
+struct CompactSeg {
+    const int32_t* idx; long nslots; int npoint, ld, col_base, pt_base, ball_base, nballs;
+    int32_t* ball_cnt; int32_t* ball_off; int32_t* meta;
+};
+
+__global__ __launch_bounds__(256) void compact_count2_kernel(CompactSeg s0, CompactSeg s1, int ns, int blocks0) {
+    const bool second = (int)blockIdx.x >= blocks0;
+    const CompactSeg& sg = second ? s1 : s0;
+    const long s = (long)(blockIdx.x - (second ? blocks0 : 0)) * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int v = s < sg.nslots ? sg.idx[s] : -1;
+    const int base = lane & ~(ns - 1), k = lane - base;
+    const int first = __shfl(v, base, 64);
+    const unsigned long long m = __ballot(v != first);
+    const unsigned long long seg = ns == 64 ? ~0ull : (((1ull << ns) - 1) << base);
+    const unsigned long long other = m & seg;
+    if (k == 0 && s < sg.nslots) sg.ball_cnt[s / ns] = other ? (63 - __clzll((long long)other)) - base + 1 : 1;
+}
+
+__global__ __launch_bounds__(1024) void compact_scan2_kernel(CompactSeg s0, CompactSeg s1) {
+    const CompactSeg& sg = blockIdx.x ? s1 : s0;
+    const int n = sg.nballs;
+    __shared__ int sh[1024];
+    const int per = (n + 1023) / 1024;
+    const int i0 = threadIdx.x * per;
+    int local = 0;
+    for (int i = i0; i < i0 + per && i < n; ++i) local += sg.ball_cnt[i];
+    sh[threadIdx.x] = local;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const int v = (int)threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+        __syncthreads();
+        sh[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = sg.col_base + sh[threadIdx.x] - local;
+    for (int i = i0; i < i0 + per && i < n; ++i) {
+        sg.ball_off[i] = run;
+        run += sg.ball_cnt[i];
+    }
+    if (threadIdx.x == 1023) {
+        const int tot = sh[1023];
+        sg.meta[0] = (tot + 255) & ~255;
+        sg.meta[1] = tot;
+        sg.meta[2] = n;
+        sg.meta[3] = 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void compact_fill2_kernel(CompactSeg s0, CompactSeg s1, int ns, int blocks0, int dummy_ball,
+                                                            int32_t* __restrict__ gp, int32_t* __restrict__ cball,
+                                                            float* __restrict__ cw) {
+    const bool second = (int)blockIdx.x >= blocks0 + 1;
+    const CompactSeg& sg = second ? s1 : s0;
+    const int blk = blockIdx.x - (second ? blocks0 + 1 : 0);
+    const int nblk = (int)(sg.nslots / 256);
+    if (blk == nblk) {       // padding columns [Ptot, Ptot_pad) of this segment
+        const int q = sg.meta[1] + threadIdx.x;
+        if (q < sg.meta[0]) { gp[sg.col_base + q] = 0; cball[sg.col_base + q] = dummy_ball; cw[sg.col_base + q] = 0.f; }
+        return;
+    }
+    const long s = (long)blk * 256 + threadIdx.x;
+    if (s >= sg.nslots) return;
+    const int ball = (int)(s / ns), k = (int)(s - (long)ball * ns);
+    const int cnt = sg.ball_cnt[ball];
+    if (k >= cnt) return;
+    const int q = sg.ball_off[ball] + k;                  // ball_off already includes col_base
+    gp[q] = sg.pt_base + (ball / sg.npoint) * sg.ld + sg.idx[s];
+    cball[q] = sg.ball_base + ball;
+    cw[q] = k == 0 ? (float)(1 + ns - cnt) : 1.f;
+}
+}  // namespace
+
+extern "C" int o3d_compact_build2(const int32_t* idx0, int npoint0, int ld0, const int32_t* idx1, int npoint1, int ld1,
+                                  int B, int ns, int col_base1, int pt_base1, int dummy_ball, int32_t* ball_cnt,
+                                  int32_t* ball_off, int32_t* gp, int32_t* cball, float* cw, int32_t* meta, void* stream) {
+    const long nb0 = (long)B * npoint0, nb1 = (long)B * npoint1;
+    if (!idx0 || !idx1 || !ball_cnt || !ball_off || !gp || !cball || !cw || !meta || B <= 0 || npoint0 <= 0 ||
+        npoint1 <= 0 || ns < 1 || ns > 64 || !pow2(ns) || nb0 > 65536 || nb1 > 65536 || (nb0 * ns) % 256 != 0 ||
+        (nb1 * ns) % 256 != 0 || ld0 <= 0 || ld1 <= 0 || col_base1 < 0 || col_base1 % 256 != 0 || pt_base1 < 0)
+        return O3D_EINVAL;
+    CompactSeg s0 = {idx0, nb0 * ns, npoint0, ld0, 0, 0, 0, (int)nb0, ball_cnt, ball_off, meta};
+    CompactSeg s1 = {idx1, nb1 * ns, npoint1, ld1, col_base1, pt_base1, (int)nb0, (int)nb1, ball_cnt + nb0, ball_off + nb0,
+                     meta + 4};
+    hipStream_t s = o3d_stream(stream);
+    const int b0 = (int)(s0.nslots / 256), b1 = (int)(s1.nslots / 256);
+    hipLaunchKernelGGL(compact_count2_kernel, dim3(b0 + b1), dim3(256), 0, s, s0, s1, ns, b0);
+    hipLaunchKernelGGL(compact_scan2_kernel, dim3(2), dim3(1024), 0, s, s0, s1);
+    hipLaunchKernelGGL(compact_fill2_kernel, dim3(b0 + b1 + 2), dim3(256), 0, s, s0, s1, ns, b0, dummy_ball, gp, cball, cw);
+    return o3d_launch_status();
+}
+
 // Y0 (C0, ldp) from Z (C0, ldz); centers ((nballs+1), 3) or NULL; part [ldp/256][2][C0] or NULL
 extern "C" int o3d_group_expand_c(const float* Z, long ldz, const int32_t* gp, const int32_t* cball,
                                   const float* cw, const float* centers, const float* W0, int ldw, int C0,

@@ -37,7 +37,7 @@ struct Wgrad2Args {
 };
 
 template <int TM, int TN, int POOLED>
-__global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
+__device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, const int bid, float* smem) {
     constexpr int WM = TM / 64, WN = TN / 64, WK = 4 / (WM * WN);
     constexpr int CP = (TM + TN == 128) ? 64 : 32;      // positions per staged chunk
     constexpr int LD = CP + 4;                          // [row][pos] stride: conflict-free ds_read_b128
@@ -45,7 +45,6 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
     constexpr int RPP = 256 / F;                        // rows staged per pass
     constexpr int PA = TM / RPP, PB = TN / RPP;         // passes
     constexpr int NG = CP / WK / 8;                     // k groups of 8 per wave per chunk
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     auto As = [&](int buf) -> float* { return smem + buf * ((TM + TN) * LD); };
     auto Bs = [&](int buf) -> float* { return smem + buf * ((TM + TN) * LD) + TM * LD; };
 
@@ -56,12 +55,12 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
     const int tiles_ci = a.Cin / TN, ntile = tiles_ci * (a.Cout / TM);
     int tile_id, slice;
     if ((a.nslices & 7) == 0) {      // keep the tiles of one position slice on one XCD (shared L2)
-        const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
+        const int xcd = bid & 7, local = bid >> 3;
         tile_id = local % ntile;
         slice = (local / ntile) * 8 + xcd;
     } else {
-        tile_id = blockIdx.x % ntile;
-        slice = blockIdx.x / ntile;
+        tile_id = bid % ntile;
+        slice = bid / ntile;
     }
     const int ci0 = (tile_id % tiles_ci) * TN, co0 = (tile_id / tiles_ci) * TM;
     int c_begin, c_end;
@@ -222,6 +221,74 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
 #pragma unroll
             for (int tn = 0; tn < 2; ++tn) dst[(long)co * a.Cin + ci0 + wn0 + 32 * tn + l31] = acc[tm][tn][r];
         }
+}
+
+template <int TM, int TN, int POOLED>
+__global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    wgrad2_body<TM, TN, POOLED>(a, blockIdx.x, smem);
+}
+
+// Several independent weight gradients (dense dN, flat layout) in ONE launch: the weight gradients of a 1-D conv stack
+// (models/head/rpn.py:16-39 ...) depend only on operands the data-gradient chain has already produced, and each of them is
+// a sub-round launch (192 workgroups of 4 short chunks for a 256 x 256 x 6144 problem: 22 us for 6 us of matrix work, plus
+// its slice reduction).  Grouped, their workgroups fill the chip together and overlap each other's staging latencies.
+constexpr int WG_MAXJOBS = 4;
+struct Wgrad2Group {
+    Wgrad2Args job[WG_MAXJOBS];
+    int first[WG_MAXJOBS + 1];     // first workgroup of every job
+    int kind[WG_MAXJOBS];          // 0: <128,128>  1: <128,64>  2: <64,128>  3: <64,64>
+    int njobs;
+};
+
+__global__ __launch_bounds__(256) void wgrad2_group_kernel(Wgrad2Group g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    int j = 0;
+    while (j + 1 < g.njobs && (int)blockIdx.x >= g.first[j + 1]) ++j;
+    const int bid = blockIdx.x - g.first[j];
+    switch (g.kind[j]) {
+        case 0: wgrad2_body<128, 128, 0>(g.job[j], bid, smem); break;
+        case 1: wgrad2_body<128, 64, 0>(g.job[j], bid, smem); break;
+        case 2: wgrad2_body<64, 128, 0>(g.job[j], bid, smem); break;
+        default: wgrad2_body<64, 64, 0>(g.job[j], bid, smem); break;
+    }
+}
+
+struct ReduceGroup {
+    const float* part[WG_MAXJOBS]; float* out[WG_MAXJOBS];
+    long n[WG_MAXJOBS]; int nslices[WG_MAXJOBS]; int first[WG_MAXJOBS + 1]; int njobs;
+};
+
+// the slice reductions of a group in one launch: wgrad_reduce1_kernel's arithmetic (mlp.hip), same fixed order
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(ReduceGroup r) {
+    __shared__ float sh[8][32];
+    int j = 0;
+    while (j + 1 < r.njobs && (int)blockIdx.x >= r.first[j + 1]) ++j;
+    const float* __restrict__ part = r.part[j];
+    const long n = r.n[j];
+    const int nslices = r.nslices[j];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const long i = (long)(blockIdx.x - r.first[j]) * 32 + col;
+    const int per = (nslices + 7) / 8, z0 = grp * per;
+    int z1 = z0 + per;
+    if (z1 > nslices) z1 = nslices;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (i < n) {
+        int z = z0;
+        for (; z + 3 < z1; z += 4) {
+            s0 += part[(long)z * n + i]; s1 += part[(long)(z + 1) * n + i];
+            s2 += part[(long)(z + 2) * n + i]; s3 += part[(long)(z + 3) * n + i];
+        }
+        for (; z < z1; ++z) s0 += part[(long)z * n + i];
+    }
+    sh[grp][col] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (grp == 0 && i < n) {
+        float t = 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) t += sh[g][col];
+        r.out[j][i] = t;
+    }
 }
 
 template <int TM, int TN>
@@ -578,6 +645,53 @@ static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y,
     if (rc != O3D_OK) return rc;
     const long n = (long)Cout * Cin;
     o3d_wgrad_reduce(scratch, nsl * WK, n, scratch + (long)nsl * WK * n, dW, s);
+    return o3d_launch_status();
+}
+
+
+// Up to WG_MAXJOBS independent weight gradients of the flat (C, P) layout in one launch + one reduction launch: job i is
+// o3d_mlp_conv_wgrad2(dN, NULL, 4, Y, A1, A2, A3, X, in_scale, in_shift, 1, Cin, Cout, P, scratch, dW) (dense dN; Y == dN
+// with A = (1, 0, 0) for a plain layer), scratch sized by o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, P).  Same numbers as
+// the single launches (same tile plan, same slice order).
+extern "C" int o3d_mlp_conv_wgrad2_group(const o3d_wgrad_job* jobs, int njobs, void* stream) {
+    if (!jobs || njobs < 1 || njobs > WG_MAXJOBS) return O3D_EINVAL;
+    Wgrad2Group g = {};
+    ReduceGroup r = {};
+    g.njobs = r.njobs = njobs;
+    size_t lds = 0;
+    int nblk = 0, rblk = 0;
+    for (int i = 0; i < njobs; ++i) {
+        const o3d_wgrad_job& q = jobs[i];
+        if (!q.dN || !q.Y || !q.A1 || !q.A2 || !q.A3 || !q.X || (q.in_scale == nullptr) != (q.in_shift == nullptr) ||
+            !q.scratch || !q.dW || q.Cin <= 0 || q.Cout <= 0 || q.Cin % 64 || q.Cout % 64 || q.P <= 0 || q.P % 64 ||
+            q.P > 0x7fffffff)
+            return O3D_EINVAL;
+        int TM, TN, WK, CP, nsl;
+        wgrad2_plan(q.Cin, q.Cout, 1, (int)q.P, TM, TN, WK, CP, nsl);
+        Wgrad2Args& a = g.job[i];
+        a.dN = q.dN; a.ns = 4; a.Y = q.Y; a.A1 = q.A1; a.A2 = q.A2; a.A3 = q.A3; a.X = q.X;
+        a.in_scale = q.in_scale; a.in_shift = q.in_shift; a.B = 1; a.Cin = q.Cin; a.Cout = q.Cout; a.P = (int)q.P;
+        a.total_chunks = (int)(q.P / CP);
+        a.chunks_per_block = (a.total_chunks + nsl - 1) / nsl;
+        a.nslices = nsl;
+        a.part = q.scratch;
+        g.kind[i] = TM == 128 ? (TN == 128 ? 0 : 1) : (TN == 128 ? 2 : 3);
+        g.first[i] = nblk;
+        nblk += (q.Cout / TM) * (q.Cin / TN) * nsl;
+        const size_t l = sizeof(float) * 2 * (TM + TN) * (CP + 4);
+        lds = l > lds ? l : lds;
+        r.part[i] = q.scratch; r.out[i] = q.dW; r.n[i] = (long)q.Cout * q.Cin; r.nslices[i] = nsl * WK;
+        r.first[i] = rblk;
+        rblk += o3d_cdiv(r.n[i], 32);
+    }
+    g.first[njobs] = nblk;
+    r.first[njobs] = rblk;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad2_group_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
+    if (!attr_ok || lds > 80 * 1024) return O3D_ELAUNCH;
+    hipStream_t s = o3d_stream(stream);
+    hipLaunchKernelGGL(wgrad2_group_kernel, dim3(nblk), dim3(256), lds, s, g);
+    hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3(rblk), dim3(256), 0, s, r);
     return o3d_launch_status();
 }
 

@@ -49,6 +49,7 @@ capi.register("o3d_mlp_conv_wgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
 
 _l = ctypes.c_long
 capi.register("o3d_compact_build", [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_compact_build2", [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_group_expand_c", [_vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _l, _vp, _vp, _vp, _vp])
 POOL_BWD_SPLIT = 8      # O3D_POOL_BWD_SPLIT of include/o3dsot.h
 capi.register("o3d_bn_finalize_c2", [_vp, _i, _i, _i, _d, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp])
@@ -521,6 +522,7 @@ class FusedGroupedMLP(torch.autograd.Function):
 
 import os as _os
 _COMPACT = {"on": True}
+_COMPACT2 = {"on": _os.environ.get("O3D_COMPACT2", "1") != "0"}      # paired compaction in 3 launches (A/B switch)
 _SIDE = {}
 _USE_SIDE = {"on": _os.environ.get("O3D_SIDE_STREAM", "0") == "1"}
 
@@ -602,11 +604,16 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         cball = torch.empty((ldp,), device=dev, dtype=i32)
         cw = torch.empty((ldp,), device=dev, dtype=f32)
         meta = torch.empty((nseg, 4), device=dev, dtype=i32)
-        for s_, sg in enumerate(segs):
-            _call("compact_build", 0.0, lib.o3d_compact_build, sg[3].data_ptr(), B, npoints[s_], ns, Npads[s_], starts[s_],
-                  pt_bases[s_], ball_bases[s_], nballs, ball_cnt[ball_bases[s_]:].data_ptr(),
-                  ball_off[ball_bases[s_]:].data_ptr(), gp.data_ptr(), cball.data_ptr(), cw.data_ptr(),
-                  meta[s_].data_ptr(), st)
+        if nseg == 2 and _COMPACT2["on"]:      # both segments: three launches instead of six
+            _call("compact_build", 0.0, lib.o3d_compact_build2, segs[0][3].data_ptr(), npoints[0], Npads[0],
+                  segs[1][3].data_ptr(), npoints[1], Npads[1], B, ns, starts[1], pt_bases[1], nballs, ball_cnt.data_ptr(),
+                  ball_off.data_ptr(), gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), meta.data_ptr(), st)
+        else:
+            for s_, sg in enumerate(segs):
+                _call("compact_build", 0.0, lib.o3d_compact_build, sg[3].data_ptr(), B, npoints[s_], ns, Npads[s_],
+                      starts[s_], pt_bases[s_], ball_bases[s_], nballs, ball_cnt[ball_bases[s_]:].data_ptr(),
+                      ball_off[ball_bases[s_]:].data_ptr(), gp.data_ptr(), cball.data_ptr(), cw.data_ptr(),
+                      meta[s_].data_ptr(), st)
         # ---- layer 0 on the points: Z = W0 . [xyz * inv_radius ; feats], flat (C0, ldz)
         padded = any(n != npd for n, npd in zip(Ns, Npads))
         # rows padded to a multiple of 16 (zero rows, zero weight columns): the per-point GEMM then runs on the

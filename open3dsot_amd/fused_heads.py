@@ -32,6 +32,17 @@ capi.register("o3d_row_sum", [_vp, _i, _l, _vp, _vp])
 capi.register("o3d_pw_tile", [_l, _i])
 capi.register("o3d_pw_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp])
 capi.register("o3d_pw_dgrad", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_wgrad2_group", [_vp, _i, _vp])
+
+
+class _WgradJob(ctypes.Structure):        # o3d_wgrad_job of include/o3dsot.h
+    _fields_ = [("dN", _vp), ("Y", _vp), ("A1", _vp), ("A2", _vp), ("A3", _vp), ("X", _vp), ("in_scale", _vp),
+                ("in_shift", _vp), ("Cin", _i), ("Cout", _i), ("P", _l), ("scratch", _vp), ("dW", _vp)]
+
+
+# the weight gradients of a stack as ONE grouped launch (+ one reduction launch) at the end of its backward instead of a
+# launch + reduction per layer (csrc/mlp_wgrad.hip::wgrad2_group_kernel); O3D_WGRAD_GROUP=0: one launch per layer
+_GROUP = {"on": __import__("os").environ.get("O3D_WGRAD_GROUP", "1") != "0"}
 
 import os as _os
 
@@ -324,11 +335,22 @@ class FlatChain(torch.autograd.Function):
         side = _side_stream(dev) if _SIDE["on"] else main
         keep = []            # buffers the side stream reads or writes: alive until the join below
 
+        jobs = []            # grouped weight gradients: launched together behind the data-gradient chain
+
         def wgrad(l, dN, Y, A, Cout_p, coef=None):
             Xs = X0 if l == 0 else Ys[l - 1]
             Kp = Xs.shape[0]
             sc = None if l == 0 else vecs[l - 1][2].data_ptr()
             sh = None if l == 0 else vecs[l - 1][3].data_ptr()
+            if _GROUP["on"] and side is main:
+                dW = torch.empty((Cout_p, Kp), device=dev, dtype=f32)
+                scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Kp, Cout_p, P),), device=dev, dtype=f32)
+                jobs.append((2.0 * Kp * Cout_p * P, (dN.data_ptr(), Y.data_ptr(), A[0], A[1], A[2], Xs.data_ptr(), sc, sh, Kp,
+                                                     Cout_p, P, scratch.data_ptr(), dW.data_ptr())))
+                keep.extend((dN, Y, scratch, dW, coef))
+                Wl = Ws[l]
+                Cout, Cin = Wl.shape[0], Wl.shape[1]
+                return (dW if (Cout, Cin) == (Cout_p, Kp) else dW[:Cout, :Cin]).reshape(Wl.shape)
             if side is not main:
                 side.wait_stream(main)           # dN and the BatchNorm-backward constants of this layer are ready
             with torch.cuda.stream(side):
@@ -399,6 +421,11 @@ class FlatChain(torch.autograd.Function):
                 _call("pw_conv_dgrad", 2.0 * K0p * Cp * P, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1], A[2],
                       Wts[0].data_ptr(), K0p, Cp, P, None, None, None, None, G.data_ptr() if cfg.residual else None,
                       dX0.data_ptr(), None, st, dims=(K0p, Cp))
+        for j0 in range(0, len(jobs), 4):
+            chunk = jobs[j0:j0 + 4]
+            arr = (_WgradJob * len(chunk))(*[_WgradJob(*j[1]) for j in chunk])
+            _call("pw_conv_wgrad", sum(j[0] for j in chunk), lib.o3d_mlp_conv_wgrad2_group, ctypes.addressof(arr),
+                  len(chunk), st)
         if side is not main:
             main.wait_stream(side)       # join: every weight gradient is complete before autograd hands it on
         del keep

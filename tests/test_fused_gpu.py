@@ -753,6 +753,47 @@ def test_compact_build(lib, ns):
     assert abs(float(cw_c[:tot].sum()) - Pmax) < 0.5      # the weights account for every slot
 
 
+@pytest.mark.parametrize("ns", [16, 32])
+def test_compact_build2_equals_two_single_builds(lib, ns):
+    """o3d_compact_build2 (both segments of a paired call in three launches) writes exactly what two o3d_compact_build
+    calls write: counts, offsets, per-column source point / ball / weight, the live counts of both segments"""
+    g = torch.Generator().manual_seed(100 + ns)
+    B, np0, np1, N0, N1 = 4, 32, 64, 100, 200
+    ld0, ld1 = 128, 256
+
+    def make(npoint, N):
+        idx = torch.zeros(B, npoint, ns, dtype=torch.int32)
+        for b in range(B):
+            for j in range(npoint):
+                cnt = int(torch.randint(1, ns + 1, (1,), generator=g))
+                hits = torch.randperm(N, generator=g)[:cnt].sort()[0].int()
+                idx[b, j, :cnt] = hits
+                idx[b, j, cnt:] = hits[0]
+        return idx.cuda()
+    i0, i1 = make(np0, N0), make(np1, N1)
+    nb0, nb1 = B * np0, B * np1
+    nballs, P0, P1 = nb0 + nb1, nb0 * ns, nb1 * ns
+    i32 = dict(device="cuda", dtype=torch.int32)
+
+    def bufs():
+        return (torch.full((nballs,), -1, **i32), torch.full((nballs + 1,), -1, **i32), torch.full((P0 + P1,), -1, **i32),
+                torch.full((P0 + P1,), -1, **i32), torch.full((P0 + P1,), -1.0, device="cuda"), torch.full((2, 4), -1, **i32))
+    a = bufs()
+    assert lib.o3d_compact_build(i0.data_ptr(), B, np0, ns, ld0, 0, 0, 0, nballs, a[0].data_ptr(), a[1].data_ptr(),
+                                 a[2].data_ptr(), a[3].data_ptr(), a[4].data_ptr(), a[5][0].data_ptr(), st()) == 0
+    assert lib.o3d_compact_build(i1.data_ptr(), B, np1, ns, ld1, P0, B * ld0, nb0, nballs, a[0][nb0:].data_ptr(),
+                                 a[1][nb0:].data_ptr(), a[2].data_ptr(), a[3].data_ptr(), a[4].data_ptr(),
+                                 a[5][1].data_ptr(), st()) == 0
+    b = bufs()
+    assert lib.o3d_compact_build2(i0.data_ptr(), np0, ld0, i1.data_ptr(), np1, ld1, B, ns, P0, B * ld0, nballs,
+                                  b[0].data_ptr(), b[1].data_ptr(), b[2].data_ptr(), b[3].data_ptr(), b[4].data_ptr(),
+                                  b[5].data_ptr(), st()) == 0
+    torch.cuda.synchronize()
+    for x, y, nm in zip(a, b, ("ball_cnt", "ball_off", "gp", "cball", "cw", "meta")):
+        assert torch.equal(x, y), nm
+    assert int(b[5][1, 1]) > 0 and int(b[5][0, 1]) > 0
+
+
 def test_in_place_weight_update_between_forward_and_backward_is_refused():
     """the fused functions keep views of the live parameter storage for backward: an in-place update in between must
     raise (as autograd's version counter does for saved tensors) instead of yielding wrong gradients"""
