@@ -398,8 +398,13 @@ def measure(args, rank, local_rank, world, full=True):
     tw = time.perf_counter()
     # (next_batch: the loop knows which resident batch comes next, like a data loader with one batch of look-ahead; its
     # farthest-point sampling -- a function of the input clouds only -- then runs beside the current step)
-    nwarm = max(args.warmup, 4 if not args.no_graph else 0)
+    nwarm = max(args.warmup, 8 if not args.no_graph else 0)
+    flat = False
     for i in range(nwarm):   # graph capture happens in here
+        if trainer.graph is not None and not flat:
+            # the resident batches in the layout of the captured step's static inputs: one device copy per step instead
+            # of one copy node per field (what a loader that fills one staging buffer per batch gives)
+            pool, flat = [trainer.make_batch(b) for b in pool], True
         trainer.step(pool[i % len(pool)], next_batch=pool[(i + 1) % len(pool)] if i + 1 < nwarm else pool[0])
     torch.cuda.synchronize()
     log("warm-up: %.2f s; hip graph: %s %s" % (time.perf_counter() - tw, trainer.graph is not None,

@@ -273,6 +273,9 @@ __global__ __launch_bounds__(BM * 2) void conv_fwd_kernel(FwdArgs a) {
 // BatchNorm statistics finalize: partials -> mean / invstd / scale / shift (+ running stats)
 // ======================================================================================
 // finalize kernels: FIN_CH channels x FIN_SL partial-list slices per 256-thread workgroup
+#ifndef O3D_FIN_FASTMATH
+#define O3D_FIN_FASTMATH 0
+#endif
 constexpr int FIN_CH = 4, FIN_SL = 64;      // measured: 2x128 and 8x32 are both slower (0.24 / 0.36 vs 0.17 ms per step)
 
 struct BnFinArgs {
@@ -337,10 +340,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
         if (seg) __syncthreads();
         fin_fold(s, q, sh);
         if (fin) {
+#if O3D_FIN_FASTMATH      // experiment (tools/build_variant.sh): no fp64 division / square root (software sequences of ~40 instructions)
+            const double ic = 1.0 / count;      // hoisted by the compiler: `count` is a kernel argument
+            const double mean = s * ic;
+            double var = q * ic - (mean - cs) * (mean - cs);
+            if (var < 0.0) var = 0.0;
+            const double v = var + (double)a.eps;
+            double rd = (double)rsqrtf((float)v);
+            rd = rd * (1.5 - 0.5 * v * rd * rd);          // one Newton step in fp64: ~1e-14 relative
+            const float invstd = (float)rd;
+#else
             const double mean = s / count;
             double var = q / count - (mean - cs) * (mean - cs);
             if (var < 0.0) var = 0.0;
             const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
+#endif
             a.mean[off + c] = (float)mean;
             a.invstd[off + c] = invstd;
             const float sc = g * invstd;

@@ -44,6 +44,38 @@ def shard_indices(step, rank, world, per_rank_batch):
     return first, per_rank_batch
 
 
+class FlatBatch(dict):
+    """A batch whose tensors are views of ONE flat device buffer (fields 256-byte aligned).  A captured step reads its
+    inputs from static buffers; handing it a new batch is then one device copy of `flat` instead of one copy node per
+    field (nine 5 us nodes per BAT step).  `extra`: {name: (shape, dtype)} of fields computed later on the device (the
+    prefetched sampling indices) that travel in the same buffer."""
+
+    def __init__(self, batch, extra=None):
+        super().__init__()
+        fields = [(k, tuple(v.shape), v.dtype) for k, v in batch.items()]
+        fields += [(k, tuple(shape), dtype) for k, (shape, dtype) in (extra or {}).items()]
+        dev = next(iter(batch.values())).device
+        offs, off = [], 0
+        for k, shape, dtype in fields:
+            n = 1
+            for d in shape:
+                n *= d
+            offs.append(off)
+            off += -(-n * torch.empty((), dtype=dtype).element_size() // 256) * 256
+        self.flat = torch.zeros(off, dtype=torch.uint8, device=dev)
+        self.layout = tuple(fields)
+        self.extra_keys = tuple((extra or {}).keys())
+        self.extra_valid = False
+        for (k, shape, dtype), o in zip(fields, offs):
+            n = 1
+            for d in shape:
+                n *= d
+            nbytes = n * torch.empty((), dtype=dtype).element_size()
+            self[k] = self.flat[o:o + nbytes].view(dtype).view(shape)
+        for k, v in batch.items():
+            self[k].copy_(v)
+
+
 class FlatGrads:
     """One contiguous fp32 buffer for the gradient exchange.  Autograd is left to ASSIGN each p.grad
     (p.grad is None before backward: AccumulateGrad then keeps the produced tensor, no `grad += new`
@@ -127,6 +159,8 @@ class DataParallelStep:
             self.grads.bind_views()
 
     def _forward_backward(self, batch):
+        if isinstance(batch, FlatBatch) and batch is not self._static and batch.extra_keys:
+            batch = {k: v for k, v in batch.items() if k not in batch.extra_keys}   # an eager step samples for itself
         self.grads.clear()
         loss, _ = self.model.training_loss(batch)
         loss.backward()
@@ -137,11 +171,15 @@ class DataParallelStep:
         return loss.detach()
 
     def _capture(self, batch):
-        self._static = {k: v.clone() for k, v in batch.items()}
+        extra = {}
         if self._sampling is not None:
             # the sampling indices become INPUTS of the captured step (static buffers): the graph holds no FPS launch
             with torch.no_grad():
-                self._static.update({k: v.clone() for k, v in self._sampling(self._static).items()})
+                extra = self._sampling({k: v for k, v in batch.items() if k not in getattr(batch, "extra_keys", ())})
+        src = {k: v for k, v in batch.items() if k not in extra}
+        self._static = FlatBatch(src, {k: (v.shape, v.dtype) for k, v in extra.items()})
+        for k, v in extra.items():
+            self._static[k].copy_(v)
         # the allocator warm-up pass below is NOT a training step: the BatchNorm running statistics and
         # num_batches_tracked it touches are put back, so a graph run sees exactly one update per step()
         buffers = list(self.model.buffers())
@@ -174,31 +212,56 @@ class DataParallelStep:
                 t.record_stream(main)          # allocated on the side stream, read by the copy below on this one
         else:
             with torch.no_grad():
-                extra = self._sampling(batch)
+                extra = self._sampling({k: v for k, v in batch.items() if k not in getattr(batch, "extra_keys", ())})
         self._prefetched = None
         return extra
 
     def _prefetch(self, next_batch):
         if self._side is None:
             self._side = torch.cuda.Stream()
+        own = getattr(next_batch, "extra_keys", ()) if next_batch is not self._static else ()
+        # behind everything the main stream has been given so far (the input copy of THIS step; not its graph, which is
+        # replayed after this call): nothing on the main stream still reads the buffers written here
+        self._side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._side), torch.no_grad():
-            extra = self._sampling(next_batch)
+            extra = self._sampling({k: v for k, v in next_batch.items() if k not in own})
+            if own:                    # a FlatBatch with room for them: they travel with its one flat copy
+                for k in own:
+                    next_batch[k].copy_(extra[k])
+                extra = {k: next_batch[k] for k in own}
             ev = torch.cuda.Event()
             ev.record(self._side)
         self._prefetched = (next_batch, extra, ev)
+
+    def make_batch(self, batch):
+        """batch (dict of device tensors) -> a FlatBatch laid out like the captured step's static inputs (one device copy
+        per step instead of one per field); before the capture, or for another layout, the dict itself"""
+        if self._static is None:
+            return batch
+        fb = FlatBatch({k: v for k, v in batch.items() if k not in self._static.extra_keys},
+                       {k: (self._static[k].shape, self._static[k].dtype) for k in self._static.extra_keys})
+        return fb if fb.layout == self._static.layout else batch
 
     def step(self, batch, next_batch=None):
         """one training step on `batch`.  next_batch: the batch the NEXT call will be given (the very same dict object),
         when the caller knows it -- its input-only preprocessing (farthest-point sampling) then runs beside this step"""
         if self.graph is not None:
             src = batch
-            if self._sampling is not None and any(k not in batch for k in self._static):
-                src = dict(batch)
-                src.update(self._sampling_for(batch))
-            keys = [k for k in src if src[k] is not self._static[k]]
-            if keys:                      # one multi-tensor copy instead of a launch per input
-                torch._foreach_copy_([self._static[k] for k in keys], [src[k] for k in keys], non_blocking=True)
-            if next_batch is not None and self._sampling is not None and len(self._static) > len(next_batch):
+            flat = isinstance(batch, FlatBatch) and batch.layout == self._static.layout
+            if self._sampling is not None and self._static.extra_keys:
+                extra = self._sampling_for(batch)
+                if not (flat and all(extra[k] is batch[k] for k in extra)):
+                    flat = False
+                    src = dict(batch)
+                    src.update(extra)
+            if flat:
+                if batch is not self._static:
+                    self._static.flat.copy_(batch.flat, non_blocking=True)       # every input field in one device copy
+            else:
+                keys = [k for k in src if src[k] is not self._static[k]]
+                if keys:
+                    torch._foreach_copy_([self._static[k] for k in keys], [src[k] for k in keys], non_blocking=True)
+            if next_batch is not None and self._sampling is not None and self._static.extra_keys:
                 self._prefetch(next_batch)        # enqueued before the replay: it starts with the step
             self.graph.replay()
             # the replayed finalize kernels rewrote the BatchNorm running statistics through raw pointers: bump their

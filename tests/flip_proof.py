@@ -58,13 +58,13 @@ def maxrel(a, b):
     return float((a - b).abs().max() / (b.abs().max() + 1e-300))
 
 
-def outlier_columns(got, want, column_dims):
+def outlier_columns(got, want, column_dims, outlier=None):
     """per-column error of a gradient: got/want (.., columns.., ..), reduce over every dim NOT in column_dims ->
-    bool tensor over the column dims: error > OUTLIER * rms(want), plus the error map itself"""
+    bool tensor over the column dims: error > outlier (default OUTLIER) * rms(want), plus the error map itself"""
     err = (got.detach().double() - want.detach().double()).abs()
     other = [d for d in range(err.dim()) if d not in column_dims]
     e = err.amax(dim=other) if other else err
-    return e > OUTLIER * rms(want), e / max(rms(want), 1e-300)
+    return e > (outlier or OUTLIER) * rms(want), e / max(rms(want), 1e-300)
 
 
 _LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "flip_proof.txt")
@@ -80,12 +80,12 @@ def record(line):
         pass
 
 
-def check_outliers_flagged(what, outliers, errmap, flagged, margin_ulps):
+def check_outliers_flagged(what, outliers, errmap, flagged, margin_ulps, outlier=None):
     """stage 1: every outlier column is flagged.  Logs each outlier with its margin."""
     bad = outliers & ~flagged
     n_out, n_flag = int(outliers.sum()), int(flagged.sum())
     record("%s: %d columns, %d flagged near-ties (< %.0f ulp), %d outliers (> %.0e rms), %d outliers NOT flagged" % (
-        what, outliers.numel(), n_flag, TIE_ULPS, n_out, OUTLIER, int(bad.sum())))
+        what, outliers.numel(), n_flag, TIE_ULPS, n_out, outlier or OUTLIER, int(bad.sum())))
     for pos in outliers.nonzero()[:32].tolist():
         record("    outlier column %s: error %.3e of rms, fp64 margin %.2f ulp" % (
             tuple(pos), float(errmap[tuple(pos)]), float(margin_ulps[tuple(pos)])))

@@ -828,8 +828,11 @@ def test_sampling_prefetch_feeds_the_same_indices_as_the_inline_step():
     model_a = make_model("BAT", 9)
     model_b = copy.deepcopy(model_a)
     pool = [synth.to_torch(synth.make_batch(300 + 4 * i, 4, 512, 1024), dev) for i in range(3)]
-    ta = D.DataParallelStep(model_a, world=1, graph=True, graph_warmup=1)
-    tb = D.DataParallelStep(model_b, world=1, graph=True, graph_warmup=1)
+    # (learning rate 0: every step's loss is then a function of the batch alone, so the two trainers are comparable step
+    # by step -- with Adam the first updates are +-lr whatever the gradient's size, and the run-to-run rounding noise of
+    # the scatter sums on near-zero gradients sends two identical trainers apart by percents within three steps)
+    ta = D.DataParallelStep(model_a, optimizer=torch.optim.SGD(model_a.parameters(), lr=0.0), world=1, graph=True, graph_warmup=1)
+    tb = D.DataParallelStep(model_b, optimizer=torch.optim.SGD(model_b.parameters(), lr=0.0), world=1, graph=True, graph_warmup=1)
     ta._sampling = None                                         # A: sampling inside the captured step (round 2's form)
     assert tb._sampling is not None
     la, lb = [], []
@@ -847,10 +850,40 @@ def test_sampling_prefetch_feeds_the_same_indices_as_the_inline_step():
                 assert tb._prefetched is not None and tb._prefetched[0] is nxt
     assert ta.graph is not None and tb.graph is not None, (ta.graph_error, tb.graph_error)
     assert "fps_idx_s" not in ta._static
-    for a, b in zip(la, lb):                                     # same trajectory (scatter sums are not bitwise reproducible)
-        assert abs(a - b) <= 2e-3 * (1 + abs(a)), (la, lb)
+    for a, b in zip(la, lb):                                     # same losses (scatter sums are not bitwise reproducible)
+        assert abs(a - b) <= 1e-5 * (1 + abs(a)), (la, lb)
+    assert abs(la[0] - la[3]) <= 1e-5 * (1 + abs(la[0])) and abs(la[0] - la[1]) > 1e-4      # batch 0 again / another batch
     # a batch that was NOT announced: sampled on the spot, same result
     other = synth.to_torch(synth.make_batch(900, 4, 512, 1024), dev)
     tb.step(other)
     torch.cuda.synchronize()
     assert torch.equal(tb._static["fps_idx_s"], ext.furthest_point_sampling(other["search_points"].contiguous(), 512))
+
+
+def test_flat_batch_single_copy_step_equals_per_field_step():
+    """DataParallelStep.make_batch: the inputs of a captured step as views of one flat buffer (one device copy per step);
+    same losses as the per-field copies, prefetched sampling indices travelling inside the flat buffer"""
+    import copy
+    from open3dsot_amd import dist as D, ext, synth
+    dev = torch.device("cuda", 0)
+    model_a = make_model("BAT", 10)
+    model_b = copy.deepcopy(model_a)
+    raw = [synth.to_torch(synth.make_batch(500 + 4 * i, 4, 512, 1024), dev) for i in range(3)]
+    ta = D.DataParallelStep(model_a, optimizer=torch.optim.SGD(model_a.parameters(), lr=0.0), world=1, graph=True, graph_warmup=1)
+    tb = D.DataParallelStep(model_b, optimizer=torch.optim.SGD(model_b.parameters(), lr=0.0), world=1, graph=True, graph_warmup=1)
+    for i in range(2):
+        ta.step(raw[i]); tb.step(raw[i])
+    assert ta.graph is not None and tb.graph is not None
+    pool = [tb.make_batch(b) for b in raw]
+    assert all(isinstance(b, D.FlatBatch) and b.layout == tb._static.layout for b in pool)
+    for i in range(6):
+        la = float(ta.step(raw[i % 3]))
+        lb = float(tb.step(pool[i % 3], next_batch=pool[(i + 1) % 3]))
+        assert abs(la - lb) <= 1e-5 * (1 + abs(la)), (i, la, lb)
+        torch.cuda.synchronize()
+        assert torch.equal(tb._static["fps_idx_s"], ext.furthest_point_sampling(raw[i % 3]["search_points"].contiguous(), 512))
+        assert torch.equal(tb._static["search_points"], raw[i % 3]["search_points"])
+    # an eager step on a FlatBatch ignores its (possibly stale) index fields
+    pool[0]["fps_idx_s"].zero_()
+    l_eager = float(tb._forward_backward(pool[0]))
+    assert abs(l_eager - float(ta.step(raw[0]))) <= 1e-5 * (1 + abs(l_eager))

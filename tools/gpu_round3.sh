@@ -33,8 +33,12 @@ if has bench; then
   timeout 1200 python bench.py --per-launch $OUT/per_launch_roofline_bat.txt > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
   tail -3 $OUT/bench.err | cut -c1-300
 fi
+if has qbench; then
+  timeout 600 python bench.py --no-cpu-baseline --no-secondary --per-launch $OUT/per_launch_roofline_bat.txt > $OUT/bench.json 2> $OUT/bench.err; echo "qbench exit $?"
+  tail -2 $OUT/bench.err | cut -c1-300
+fi
 for p in $PARTS; do case "$p" in ab:*)
-  bash tools/ab.sh "${p#ab:}" 3 > $OUT/ab_$(echo "${p#ab:}" | tr -c 'A-Za-z0-9_=' '_').txt 2>&1; cat $OUT/ab_*.txt | tail -4 ;;
+  bash tools/ab.sh "${p#ab:}" 2 > $OUT/ab_$(echo "${p#ab:}" | tr -c 'A-Za-z0-9_=' '_').txt 2>&1; cat $OUT/ab_$(echo "${p#ab:}" | tr -c 'A-Za-z0-9_=' '_').txt | tail -3 ;;
 esac; done
 if has trace; then
   cd /tmp
