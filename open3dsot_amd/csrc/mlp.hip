@@ -273,8 +273,11 @@ __global__ __launch_bounds__(BM * 2) void conv_fwd_kernel(FwdArgs a) {
 // BatchNorm statistics finalize: partials -> mean / invstd / scale / shift (+ running stats)
 // ======================================================================================
 // finalize kernels: FIN_CH channels x FIN_SL partial-list slices per 256-thread workgroup
+// (round 3 also tried folding the FIN_SL slices with fp64 butterflies instead of the serial LDS walk and fetching the
+// per-channel constants up front: +0.08 ms per step on the same box -- 16 ds_bpermute round trips per lane cost more than
+// 128 pipelined LDS reads by four lanes.  Not kept.)
 #ifndef O3D_FIN_FASTMATH
-#define O3D_FIN_FASTMATH 0
+#define O3D_FIN_FASTMATH 1
 #endif
 constexpr int FIN_CH = 4, FIN_SL = 64;      // measured: 2x128 and 8x32 are both slower (0.24 / 0.36 vs 0.17 ms per step)
 
@@ -293,40 +296,17 @@ struct BnFinArgs {
     int nparts1; double count1;
 };
 
-// sum over the FIN_SL slices of a workgroup: lanes hold (slice sl = tid / FIN_CH, channel cl = tid % FIN_CH), so the 16
-// slices of a wave fold with four butterfly steps (lane ^ 4, 8, 16, 32) and the four waves through 4 LDS entries -- a
-// serial walk over 64 LDS entries by one thread per channel was ~1 us of the kernel's ~7; fixed order: deterministic
-__device__ __forceinline__ void fin_fold(double& s, double& q, double (&sh)[2][4][FIN_CH]) {
-#pragma unroll
-    for (int off = FIN_CH; off < 64; off <<= 1) { s += __shfl_xor(s, off, 64); q += __shfl_xor(q, off, 64); }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane < FIN_CH) { sh[0][wave][lane] = s; sh[1][wave][lane] = q; }
-    __syncthreads();
-    if (threadIdx.x < FIN_CH) {
-        s = (sh[0][0][threadIdx.x] + sh[0][1][threadIdx.x]) + (sh[0][2][threadIdx.x] + sh[0][3][threadIdx.x]);
-        q = (sh[1][0][threadIdx.x] + sh[1][1][threadIdx.x]) + (sh[1][2][threadIdx.x] + sh[1][3][threadIdx.x]);
-    }
-}
-
 __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
     // FIN_CH channels x FIN_SL tile-slices per workgroup: the partial list (up to 13 824 tiles) is a
     // latency-bound strided read, so it is spread over many lanes with 8 loads in flight each
-    __shared__ double sh[2][4][FIN_CH];
+    __shared__ double sh[2][FIN_SL][FIN_CH + 1];
     const int cl = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
     const int c = blockIdx.x * FIN_CH + cl;
     const int nseg = a.nparts1 > 0 ? 2 : 1;
-    const bool fin = sl == 0 && c < a.C;         // the thread that finalises channel c: its constants are fetched up front,
-    float g = 1.f, bt = 0.f, rm = 0.f, rv = 0.f; // beside the partial list (they used to start a second latency chain)
-    if (fin) {
-        if (a.gamma) g = a.gamma[c];
-        if (a.beta) bt = a.beta[c];
-        if (a.running_mean && a.momentum >= 0.f) { rm = a.running_mean[c]; rv = a.running_var[c]; }
-    }
     for (int seg = 0; seg < nseg; ++seg) {
         const float* part = a.part + (seg ? (long)a.nparts * 2 * a.C : 0);
         const double count = seg ? a.count1 : a.count;
         const int off = seg * a.C;
-        const double cs = (fin && a.stat_c) ? (double)a.stat_c[off + c] : 0.0;
         double s = 0.0, q = 0.0;
         int nparts = seg ? a.nparts1 : a.nparts;
         if (a.meta) { const int live = a.meta[4 * seg] / a.tile; nparts = live < nparts ? live : nparts; }
@@ -338,16 +318,24 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
             }
         }
         if (seg) __syncthreads();
-        fin_fold(s, q, sh);
-        if (fin) {
-#if O3D_FIN_FASTMATH      // experiment (tools/build_variant.sh): no fp64 division / square root (software sequences of ~40 instructions)
-            const double ic = 1.0 / count;      // hoisted by the compiler: `count` is a kernel argument
+        sh[0][sl][cl] = s;
+        sh[1][sl][cl] = q;
+        __syncthreads();
+        if (sl == 0 && c < a.C) {
+            s = 0.0; q = 0.0;
+            for (int i = 0; i < FIN_SL; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
+            const double cs = a.stat_c ? (double)a.stat_c[off + c] : 0.0;
+#if O3D_FIN_FASTMATH
+            // no fp64 division / square root (software sequences of ~40 instructions each, on one lane per channel: measured
+            // -0.05 ms per BAT step over the 24 forward finalizes, same-box A/B): v_rsq_f32 + one fp64 Newton step
+            // (relative error ~1e-14), the reciprocal of the count taken once
+            const double ic = 1.0 / count;
             const double mean = s * ic;
             double var = q * ic - (mean - cs) * (mean - cs);
             if (var < 0.0) var = 0.0;
             const double v = var + (double)a.eps;
             double rd = (double)rsqrtf((float)v);
-            rd = rd * (1.5 - 0.5 * v * rd * rd);          // one Newton step in fp64: ~1e-14 relative
+            rd = rd * (1.5 - 0.5 * v * rd * rd);
             const float invstd = (float)rd;
 #else
             const double mean = s / count;
@@ -355,6 +343,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
             if (var < 0.0) var = 0.0;
             const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
 #endif
+            const float g = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
             a.mean[off + c] = (float)mean;
             a.invstd[off + c] = invstd;
             const float sc = g * invstd;
@@ -362,12 +351,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
             a.shift[off + c] = bt - (float)mean * sc;
             if (a.running_mean && a.momentum >= 0.f) {
                 const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-                rm = (1.f - a.momentum) * rm + a.momentum * (float)mean;
-                rv = (1.f - a.momentum) * rv + a.momentum * (float)unbiased;
+                a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
+                a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
             }
         }
     }
-    if (fin && a.running_mean && a.momentum >= 0.f) { a.running_mean[c] = rm; a.running_var[c] = rv; }
 }
 
 // Stage 1 of a long partial list: out[g][i] = sum over parts t = g, g+G, g+2G, ... of part[t][i],
@@ -517,19 +505,15 @@ struct BnBwdFinArgs {
 };
 
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFinArgs a) {
-    __shared__ double sh[2][4][FIN_CH];
+    __shared__ double sh[2][FIN_SL][FIN_CH + 1];
     const int cl = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
     const int c = blockIdx.x * FIN_CH + cl;
     const int nseg = a.nparts1 > 0 ? 2 : 1;
-    const bool fin = sl == 0 && c < a.C;
-    const double g = (fin && a.gamma) ? (double)a.gamma[c] : 1.0;      // fetched beside the partial list
     double dg = 0.0, db = 0.0;
     for (int seg = 0; seg < nseg; ++seg) {
         const float* part = a.part + (seg ? (long)a.nparts * 2 * a.C : 0);
         const double count = seg ? a.count1 : a.count;
         const int off = seg * a.C;
-        double is = 0.0, mu = 0.0;
-        if (fin) { is = (double)a.invstd[off + c]; mu = (double)a.mean[off + c]; }
         double s = 0.0, q = 0.0;
         int nparts = seg ? a.nparts1 : a.nparts;
         if (a.meta) { const int live = a.meta[4 * seg] / a.tile; nparts = live < nparts ? live : nparts; }
@@ -541,17 +525,29 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFinArgs a) {
             }
         }
         if (seg) __syncthreads();
-        fin_fold(s, q, sh);
-        if (fin) {
+        sh[0][sl][cl] = s;
+        sh[1][sl][cl] = q;
+        __syncthreads();
+        if (sl == 0 && c < a.C) {
+            s = 0.0; q = 0.0;
+            for (int i = 0; i < FIN_SL; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
+            const double g = a.gamma ? (double)a.gamma[c] : 1.0;
+            const double is = (double)a.invstd[off + c], mu = (double)a.mean[off + c];
             db += s;
             dg += q * is;
             const double a1 = g * is;
+#if O3D_FIN_FASTMATH
+            const double ic = 1.0 / count;
+            const double a2 = -a1 * is * is * q * ic;
+            const double a3 = -a1 * s * ic - a2 * mu;
+#else
             const double a2 = -a1 * is * is * q / count;
             const double a3 = -a1 * s / count - a2 * mu;
+#endif
             a.A1[off + c] = (float)a1; a.A2[off + c] = (float)a2; a.A3[off + c] = (float)a3;
         }
     }
-    if (fin) {
+    if (sl == 0 && c < a.C) {
         a.dbeta[c] = (float)db;
         a.dgamma[c] = (float)dg;
     }

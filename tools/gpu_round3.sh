@@ -1,5 +1,5 @@
 #!/bin/bash
-# Round 3's GPU call.  usage: gpu_round3.sh <tag> [parts]   parts = any of: smoke tests ref bench trace pmc sq ab:<env> k:<pytest -k expr>
+# Round 3's GPU call.  usage: gpu_round3.sh <tag> [parts]   parts = any of: smoke tests ref bench qbench trace pmc sq ab:<env> k:<name+name+...>
 # (default: smoke tests ref bench trace).  Everything lands in gpurun_out/<tag>/.
 TAG=${1:-r3}; shift
 PARTS="${*:-smoke tests ref bench trace}"
@@ -14,7 +14,7 @@ if has smoke; then
   timeout 400 python __graft_entry__.py --smoke > $OUT/smoke.log 2>&1; echo "smoke exit $?" | tee -a $OUT/smoke.log
 fi
 for p in $PARTS; do case "$p" in k:*)
-  timeout 1500 python -m pytest tests -m gpu -q --timeout=900 -p no:cacheprovider -x -k "${p#k:}" > $OUT/pytest_k.log 2>&1
+  timeout 1500 python -m pytest tests -m gpu -q --timeout=900 -p no:cacheprovider -x -k "$(echo "${p#k:}" | sed 's/+/ or /g')" > $OUT/pytest_k.log 2>&1
   echo "pytest -k exit $?" >> $OUT/pytest_k.log
   grep -E "passed|failed|^E  |exit|^FAILED|Error" $OUT/pytest_k.log | cut -c1-600 | head -60 ;;
 esac; done
