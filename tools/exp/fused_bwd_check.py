@@ -13,9 +13,8 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(os.path.dirname(HERE))
-V4 = "--v4" in sys.argv                     # unverified: v3 + Cin = 128 (tools/exp/fused_bwd_v4.hip)
-V3 = "--v3" in sys.argv or V4               # unverified: 64 positions per chunk for Cout = 128 as well (fused_bwd_v3.hip)
-SRC = "fused_bwd_v4.hip" if V4 else "fused_bwd_v3.hip" if V3 else "fused_bwd.hip"
+V4 = False          # (round 2's never-run v3 / v4 variants were deleted in round 3)
+SRC = "fused_bwd.hip"
 SO = os.path.join(HERE, "_" + SRC.replace(".hip", ".so"))
 sys.path.insert(0, ROOT)
 
