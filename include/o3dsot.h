@@ -437,6 +437,34 @@ int o3d_mlp_conv_bwd_fused_c(const float* dN, const float* Y, const float* A1, c
                              const float* Wt, int Cin, int Cout, long ldp, const float* w, const int32_t* meta,
                              long start1, float* scratch, float* dW, float* part_s, float* dNprev, void* stream);
 
+/* Two independent 1-D conv launches over the same number of columns as ONE launch (blockIdx.z selects): the stacks of
+ * the RPN that read the same seeds -- FC_layer_cla and vote_layer, models/head/rpn.py:16-28,44-54 -- advance layer by layer
+ * side by side.  Fields = the arguments of o3d_pw_fwd / o3d_pw_dgrad.  When the two problems do not take the same kernel
+ * instantiation the entry issues the two single launches instead; the numbers are the same either way. */
+typedef struct {      /* the arguments of o3d_bn_finalize (no fold scratch: partial lists of <= a few hundred rows) */
+    const float* part; int nparts, C; double count; const float* stat_c; const float* gamma; const float* beta;
+    float* running_mean; float* running_var; float momentum, eps; float* mean; float* invstd; float* scale; float* shift;
+} o3d_bn_fin_args;
+typedef struct {      /* the arguments of o3d_bn_bwd_finalize */
+    const float* part; int nparts, C; double count; const float* gamma; const float* mean; const float* invstd;
+    float* dgamma; float* dbeta; float* A1; float* A2; float* A3;
+} o3d_bn_bwd_fin_args;
+int o3d_bn_finalize_pair(const o3d_bn_fin_args* a, const o3d_bn_fin_args* b, void* stream);
+int o3d_bn_bwd_finalize_pair(const o3d_bn_bwd_fin_args* a, const o3d_bn_bwd_fin_args* b, void* stream);
+typedef struct {
+    const float* X; const float* W; const float* in_scale; const float* in_shift; const float* bias; const float* resid;
+    int Cin, Cout; long P;
+    float* Y; float* part; const float* stat_c;
+} o3d_pw_fwd_args;
+typedef struct {
+    const float* dN; const float* Y; const float* A1; const float* A2; const float* A3; const float* Wt;
+    int Cin, Cout; long P;
+    const float* Yprev; const float* scale_p; const float* shift_p; const float* mean_p; const float* resid;
+    float* dNprev; float* part;
+} o3d_pw_dgrad_args;
+int o3d_pw_fwd_pair(const o3d_pw_fwd_args* a, const o3d_pw_fwd_args* b, void* stream);
+int o3d_pw_dgrad_pair(const o3d_pw_dgrad_args* a, const o3d_pw_dgrad_args* b, void* stream);
+
 /* Several independent weight gradients of the flat (C, P) layout in one launch (+ one reduction launch): the 1-D conv
  * stacks of the heads (models/head/rpn.py:16-39, models/head/xcorr.py:14-17, models/bat.py:22-26).  Job i computes what
  * o3d_mlp_conv_wgrad2(dN, NULL, 4, Y, A1, A2, A3, X, in_scale, in_shift, 1, Cin, Cout, P, scratch, dW, stream) computes

@@ -296,12 +296,12 @@ struct BnFinArgs {
     int nparts1; double count1;
 };
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
+__device__ __forceinline__ void bn_finalize_body(const BnFinArgs& a, const int bx) {
     // FIN_CH channels x FIN_SL tile-slices per workgroup: the partial list (up to 13 824 tiles) is a
     // latency-bound strided read, so it is spread over many lanes with 8 loads in flight each
     __shared__ double sh[2][FIN_SL][FIN_CH + 1];
     const int cl = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
-    const int c = blockIdx.x * FIN_CH + cl;
+    const int c = bx * FIN_CH + cl;
     const int nseg = a.nparts1 > 0 ? 2 : 1;
     for (int seg = 0; seg < nseg; ++seg) {
         const float* part = a.part + (seg ? (long)a.nparts * 2 * a.C : 0);
@@ -356,6 +356,14 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) {
             }
         }
     }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(BnFinArgs a) { bn_finalize_body(a, blockIdx.x); }
+
+// two independent finalizes (two BatchNorm layers of two conv stacks advancing side by side) in one launch
+__global__ __launch_bounds__(256) void bn_finalize_pair_kernel(BnFinArgs a0, BnFinArgs a1) {
+    if (blockIdx.y == 0) { if ((int)blockIdx.x * FIN_CH < a0.C) bn_finalize_body(a0, blockIdx.x); }
+    else if ((int)blockIdx.x * FIN_CH < a1.C) bn_finalize_body(a1, blockIdx.x);
 }
 
 // Stage 1 of a long partial list: out[g][i] = sum over parts t = g, g+G, g+2G, ... of part[t][i],
@@ -504,10 +512,10 @@ struct BnBwdFinArgs {
     int nparts1; double count1;
 };
 
-__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFinArgs a) {
+__device__ __forceinline__ void bn_bwd_finalize_body(const BnBwdFinArgs& a, const int bx) {
     __shared__ double sh[2][FIN_SL][FIN_CH + 1];
     const int cl = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
-    const int c = blockIdx.x * FIN_CH + cl;
+    const int c = bx * FIN_CH + cl;
     const int nseg = a.nparts1 > 0 ? 2 : 1;
     double dg = 0.0, db = 0.0;
     for (int seg = 0; seg < nseg; ++seg) {
@@ -551,6 +559,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFinArgs a) {
         a.dbeta[c] = (float)db;
         a.dgamma[c] = (float)dg;
     }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(BnBwdFinArgs a) { bn_bwd_finalize_body(a, blockIdx.x); }
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_pair_kernel(BnBwdFinArgs a0, BnBwdFinArgs a1) {
+    if (blockIdx.y == 0) { if ((int)blockIdx.x * FIN_CH < a0.C) bn_bwd_finalize_body(a0, blockIdx.x); }
+    else if ((int)blockIdx.x * FIN_CH < a1.C) bn_bwd_finalize_body(a1, blockIdx.x);
 }
 
 // ======================================================================================
@@ -1162,6 +1177,39 @@ extern "C" int o3d_bn_finalize(const float* part, int nparts, int C, double coun
     BnFinArgs a = {part, nparts, C, nullptr, 1, count, stat_c, gamma, beta, running_mean, running_var, momentum, eps,
                    mean, invstd, scale, shift};
     return launch(bn_finalize_kernel, dim3(o3d_cdiv(C, FIN_CH)), dim3(256), 0, o3d_stream(stream), a);
+}
+
+// o3d_bn_finalize for two independent layers in one launch (short partial lists: no fold stage)
+extern "C" int o3d_bn_finalize_pair(const o3d_bn_fin_args* pa, const o3d_bn_fin_args* pb, void* stream) {
+    if (!pa || !pb) return O3D_EINVAL;
+    BnFinArgs v[2];
+    const o3d_bn_fin_args* q[2] = {pa, pb};
+    for (int i = 0; i < 2; ++i) {
+        const o3d_bn_fin_args& x = *q[i];
+        if (!x.part || x.nparts <= 0 || x.C <= 0 || !x.mean || !x.invstd || !x.scale || !x.shift) return O3D_EINVAL;
+        v[i] = BnFinArgs{x.part, x.nparts, x.C, nullptr, 1, x.count, x.stat_c, x.gamma, x.beta, x.running_mean, x.running_var,
+                         x.momentum, x.eps, x.mean, x.invstd, x.scale, x.shift};
+    }
+    const int cmax = pa->C > pb->C ? pa->C : pb->C;
+    hipLaunchKernelGGL(bn_finalize_pair_kernel, dim3(o3d_cdiv(cmax, FIN_CH), 2), dim3(256), 0, o3d_stream(stream), v[0], v[1]);
+    return o3d_launch_status();
+}
+
+extern "C" int o3d_bn_bwd_finalize_pair(const o3d_bn_bwd_fin_args* pa, const o3d_bn_bwd_fin_args* pb, void* stream) {
+    if (!pa || !pb) return O3D_EINVAL;
+    BnBwdFinArgs v[2];
+    const o3d_bn_bwd_fin_args* q[2] = {pa, pb};
+    for (int i = 0; i < 2; ++i) {
+        const o3d_bn_bwd_fin_args& x = *q[i];
+        if (!x.part || x.nparts <= 0 || x.C <= 0 || !x.mean || !x.invstd || !x.dgamma || !x.dbeta || !x.A1 || !x.A2 || !x.A3)
+            return O3D_EINVAL;
+        v[i] = BnBwdFinArgs{x.part, x.nparts, x.C, x.count, nullptr, 1, x.gamma, x.mean, x.invstd, x.dgamma, x.dbeta, x.A1, x.A2,
+                            x.A3};
+    }
+    const int cmax = pa->C > pb->C ? pa->C : pb->C;
+    hipLaunchKernelGGL(bn_bwd_finalize_pair_kernel, dim3(o3d_cdiv(cmax, FIN_CH), 2), dim3(256), 0, o3d_stream(stream), v[0],
+                       v[1]);
+    return o3d_launch_status();
 }
 
 extern "C" int o3d_bn_relu_maxpool_fwd(const float* Y, const float* scale, const float* shift, int B,

@@ -165,14 +165,13 @@ __device__ __forceinline__ void compute_group(const RawB<NT>& f, const float4& a
 // MT = 2: 64 output rows per wave; MT = 1: 32 rows -- half the MFMA chain per wave for the launch-latency-bound
 // problems of the heads (256 x 256 x 6144: 96 column tiles; a 64x64 wave tile is a 512-MFMA = 14 us serial chain).
 template <int WAVES, int MODE, int EPI, int NT, int MT = 2>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ? 2 : 4)))
-void direct_gemm_kernel(DirectArgs a) {
+__device__ __forceinline__ void direct_gemm_body(DirectArgs& a, const int bx, const int by) {
     constexpr int POS = 32 * NT;
     constexpr int DT_MW = 32 * MT;      // output rows per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int l31 = lane & 31, h = lane >> 5;
     const int tiles_per_b = a.P / POS;
-    const int tile = blockIdx.x;
+    const int tile = bx;
     const int b = tile / tiles_per_b, p0 = (tile - b * tiles_per_b) * POS;
     if (a.meta) {                                             // compact layout: dead tile?  which segment?
         const long c0 = (long)tile * POS;
@@ -186,7 +185,7 @@ void direct_gemm_kernel(DirectArgs a) {
             if (a.scale_p) { a.scale_p += a.M; a.shift_p += a.M; a.mean_p += a.M; }
         }
     }
-    const int m0 = (blockIdx.y * WAVES + wave) * DT_MW;
+    const int m0 = (by * WAVES + wave) * DT_MW;
     const int p = p0 + NT * l31;
     float wv[NT];
 #pragma unroll
@@ -406,6 +405,26 @@ void direct_gemm_kernel(DirectArgs a) {
 }
 
 
+template <int WAVES, int MODE, int EPI, int NT, int MT = 2>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ? 2 : 4)))
+void direct_gemm_kernel(DirectArgs a) {
+    direct_gemm_body<WAVES, MODE, EPI, NT, MT>(a, blockIdx.x, blockIdx.y);
+}
+
+// Two independent GEMMs of the same shape class (same columns, same operand / epilogue mode, same wave tile) in one
+// launch, blockIdx.z selects: the 1-D conv stacks of the RPN that read the same seeds (FC_layer_cla and vote_layer,
+// models/head/rpn.py:16-28,44-54) are serial chains of sub-round launches -- side by side their workgroups fill the chip
+// together.  Rows beyond a problem's own M return at once.
+template <int WAVES, int MODE, int EPI, int NT, int MT>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ? 2 : 4)))
+void direct_gemm_pair_kernel(DirectArgs a0, DirectArgs a1) {
+    if (blockIdx.z == 0) {
+        if ((int)blockIdx.y * WAVES * 32 * MT < a0.M) direct_gemm_body<WAVES, MODE, EPI, NT, MT>(a0, blockIdx.x, blockIdx.y);
+    } else {
+        if ((int)blockIdx.y * WAVES * 32 * MT < a1.M) direct_gemm_body<WAVES, MODE, EPI, NT, MT>(a1, blockIdx.x, blockIdx.y);
+    }
+}
+
 // All M/64 row slabs of a position tile run as the waves of ONE workgroup: they read the same B rows,
 // so those come from HBM once and from L1/L2 for the other slabs (rocprofv3 FETCH_SIZE of the
 // two-workgroup variant showed every slab re-reading HBM: 604 MB instead of 350 MB per launch).
@@ -447,8 +466,17 @@ int launch_direct_small(const DirectArgs& a, int tile, hipStream_t st) {
     return tile == 64 ? launch_direct_nt<MODE, EPI, 2>(a, st) : launch_direct_nt<MODE, EPI, 4>(a, st);
 }
 
+// 32-row wave tiles for the set-abstraction launches whose WORST-CASE column count is small (the vote aggregation:
+// 49 152 slots of which ~15 % are live -- 116 workgroups of four 64-row waves, i.e. 464 waves of a 512-MFMA chain on 1 024
+// SIMDs): twice the waves of half the chain.  O3D_SA_MT1_MAX = largest B*P taking them (0: never).
+static long sa_mt1_max() {
+    static const long v = [] { const char* e = getenv("O3D_SA_MT1_MAX"); return e ? atol(e) : 0L; }();
+    return v;
+}
+
 template <int MODE, int EPI>
 int launch_direct(const DirectArgs& a, int tile, hipStream_t st) {
+    if (tile == 64 && a.K % 32 == 0 && (long)a.B * a.P <= sa_mt1_max()) return launch_direct_nt<MODE, EPI, 2, 1>(a, st);
     return tile == 64 ? launch_direct_nt<MODE, EPI, 2>(a, st) : launch_direct_nt<MODE, EPI, 4>(a, st);
 }
 
@@ -554,6 +582,105 @@ extern "C" int o3d_pw_dgrad(const float* dN, const float* Y, const float* A1, co
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (Yprev) return Y ? launch_direct_small<B_DY, 1>(a, tile, st) : launch_direct_small<B_PLAIN, 1>(a, tile, st);
     return Y ? launch_direct_small<B_DY, 2>(a, tile, st) : launch_direct_small<B_PLAIN, 2>(a, tile, st);
+}
+
+// ---- pairs ---------------------------------------------------------------------------------------------------------------
+namespace {
+template <int MODE, int EPI, int NT, int MT>
+int launch_pair_nt(const DirectArgs& a, const DirectArgs& b, hipStream_t st) {
+    const int tiles = a.P / (32 * NT);
+    const int sa = a.M / (32 * MT), sb = b.M / (32 * MT);
+    const int smax = sa > sb ? sa : sb;
+    if (sa % 4 == 0 && sb % 4 == 0)
+        hipLaunchKernelGGL((direct_gemm_pair_kernel<4, MODE, EPI, NT, MT>), dim3(tiles, smax / 4, 2), dim3(256), 0, st, a, b);
+    else if (sa % 2 == 0 && sb % 2 == 0)
+        hipLaunchKernelGGL((direct_gemm_pair_kernel<2, MODE, EPI, NT, MT>), dim3(tiles, smax / 2, 2), dim3(128), 0, st, a, b);
+    else
+        hipLaunchKernelGGL((direct_gemm_pair_kernel<1, MODE, EPI, NT, MT>), dim3(tiles, smax, 2), dim3(64), 0, st, a, b);
+    return o3d_launch_status();
+}
+
+// the wave tile launch_direct_small picks: 0 = <1,1>, 1 = <2,1>, 2 = <2,2>, 3 = <4,2>
+static int small_class(const DirectArgs& a, int tile) {
+    if (a.K % 32 == 0) {
+        if (tile == 32) return 0;
+        if (tile == 64 && (long)a.M * a.P <= pw_small_max()) return 1;
+    }
+    return tile == 64 ? 2 : 3;
+}
+
+template <int MODE, int EPI>
+int launch_pair(const DirectArgs& a, const DirectArgs& b, int cls, hipStream_t st) {
+    switch (cls) {
+        case 0: return launch_pair_nt<MODE, EPI, 1, 1>(a, b, st);
+        case 1: return launch_pair_nt<MODE, EPI, 2, 1>(a, b, st);
+        case 2: return launch_pair_nt<MODE, EPI, 2, 2>(a, b, st);
+        default: return launch_pair_nt<MODE, EPI, 4, 2>(a, b, st);
+    }
+}
+
+static bool pw_fwd_args_ok(const o3d_pw_fwd_args& q) {
+    return q.X && q.W && q.Y && q.P > 0 && q.P <= 0x7fffffff && q.P % 64 == 0 && q.Cin > 0 && q.Cin % 16 == 0 && q.Cout > 0 &&
+           q.Cout % DT_M == 0 && (q.in_scale == nullptr) == (q.in_shift == nullptr) && !(q.part && (q.bias || q.resid));
+}
+static DirectArgs pw_fwd_direct(const o3d_pw_fwd_args& q) {
+    DirectArgs a = {};
+    a.A = q.W; a.X = q.X; a.c1 = q.in_scale; a.c2 = q.in_shift; a.Out = q.Y; a.M = q.Cout; a.K = q.Cin; a.P = (int)q.P; a.B = 1;
+    a.part = q.part; a.stat_c = q.stat_c; a.ns = 4; a.bias = q.bias; a.resid = q.resid;
+    return a;
+}
+static bool pw_dgrad_args_ok(const o3d_pw_dgrad_args& q) {
+    return q.dN && q.Wt && q.dNprev && q.P > 0 && q.P <= 0x7fffffff && q.P % 64 == 0 && q.Cin > 0 && q.Cin % DT_M == 0 &&
+           q.Cout > 0 && q.Cout % 16 == 0 && !(q.Y && (!q.A1 || !q.A2 || !q.A3)) &&
+           !(q.Yprev && (!q.scale_p || !q.shift_p || !q.mean_p || !q.part || q.resid)) && !(!q.Yprev && q.part);
+}
+static DirectArgs pw_dgrad_direct(const o3d_pw_dgrad_args& q) {
+    DirectArgs a = {};
+    a.A = q.Wt; a.X = q.dN; a.Y = q.Y; a.c1 = q.A1; a.c2 = q.A2; a.c3 = q.A3; a.ns = 4;
+    a.Out = q.dNprev; a.M = q.Cin; a.K = q.Cout; a.P = (int)q.P; a.B = 1; a.part = q.part;
+    a.Yprev = q.Yprev; a.scale_p = q.scale_p; a.shift_p = q.shift_p; a.mean_p = q.mean_p; a.resid = q.resid;
+    return a;
+}
+}  // namespace
+
+// o3d_pw_fwd for two independent problems over the same number of columns: ONE launch when both take the same kernel
+// instantiation (operand mode, epilogue, wave tile), else the two single launches -- the result is the same either way.
+extern "C" int o3d_pw_fwd_pair(const o3d_pw_fwd_args* pa, const o3d_pw_fwd_args* pb, void* stream) {
+    if (!pa || !pb || !pw_fwd_args_ok(*pa) || !pw_fwd_args_ok(*pb)) return O3D_EINVAL;
+    const o3d_pw_fwd_args &x = *pa, &y = *pb;
+    const int ta = pw_tile(x.P, x.Cout), tb = pw_tile(y.P, y.Cout);
+    if ((ta == 128 && x.P % 128) || (tb == 128 && y.P % 128)) return O3D_EINVAL;
+    DirectArgs a = pw_fwd_direct(x), b = pw_fwd_direct(y);
+    const bool epi2a = !(x.part || (!x.bias && !x.resid)), epi2b = !(y.part || (!y.bias && !y.resid));
+    const int ca = small_class(a, ta), cb = small_class(b, tb);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (x.P != y.P || ta != tb || ca != cb || epi2a != epi2b || (x.in_scale == nullptr) != (y.in_scale == nullptr)) {
+        const int rc = o3d_pw_fwd(x.X, x.W, x.in_scale, x.in_shift, x.bias, x.resid, x.Cin, x.Cout, x.P, x.Y, x.part, x.stat_c, stream);
+        if (rc != O3D_OK) return rc;
+        return o3d_pw_fwd(y.X, y.W, y.in_scale, y.in_shift, y.bias, y.resid, y.Cin, y.Cout, y.P, y.Y, y.part, y.stat_c, stream);
+    }
+    if (!epi2a) return x.in_scale ? launch_pair<B_XFORM, 0>(a, b, ca, st) : launch_pair<B_PLAIN, 0>(a, b, ca, st);
+    return x.in_scale ? launch_pair<B_XFORM, 2>(a, b, ca, st) : launch_pair<B_PLAIN, 2>(a, b, ca, st);
+}
+
+// o3d_pw_dgrad for two independent problems, likewise
+extern "C" int o3d_pw_dgrad_pair(const o3d_pw_dgrad_args* pa, const o3d_pw_dgrad_args* pb, void* stream) {
+    if (!pa || !pb || !pw_dgrad_args_ok(*pa) || !pw_dgrad_args_ok(*pb)) return O3D_EINVAL;
+    const o3d_pw_dgrad_args &x = *pa, &y = *pb;
+    const int ta = pw_tile(x.P, x.Cin), tb = pw_tile(y.P, y.Cin);
+    if ((ta == 128 && x.P % 128) || (tb == 128 && y.P % 128)) return O3D_EINVAL;
+    DirectArgs a = pw_dgrad_direct(x), b = pw_dgrad_direct(y);
+    const int ca = small_class(a, ta), cb = small_class(b, tb);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (x.P != y.P || ta != tb || ca != cb || (x.Yprev == nullptr) != (y.Yprev == nullptr) || (x.Y == nullptr) != (y.Y == nullptr)) {
+        const int rc = o3d_pw_dgrad(x.dN, x.Y, x.A1, x.A2, x.A3, x.Wt, x.Cin, x.Cout, x.P, x.Yprev, x.scale_p, x.shift_p, x.mean_p,
+                                    x.resid, x.dNprev, x.part, stream);
+        if (rc != O3D_OK) return rc;
+        return o3d_pw_dgrad(y.dN, y.Y, y.A1, y.A2, y.A3, y.Wt, y.Cin, y.Cout, y.P, y.Yprev, y.scale_p, y.shift_p, y.mean_p, y.resid,
+                            y.dNprev, y.part, stream);
+    }
+    if (x.Yprev) return x.Y ? launch_pair<B_DY, 1>(a, b, ca, st) : launch_pair<B_PLAIN, 1>(a, b, ca, st);
+    return x.Y ? launch_pair<B_DY, 2>(a, b, ca, st) : launch_pair<B_PLAIN, 2>(a, b, ca, st);
 }
 
 // Layer 0 of a per-point stack whose input is [X (Cin rows) ; a per-cloud constant block]: Y (Cout, P) = W_a . X +

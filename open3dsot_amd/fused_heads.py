@@ -235,6 +235,287 @@ def chain_supported(sources, units):
     return True
 
 
+# ---- launch plumbing: a stack's forward / backward is a GENERATOR of launches --------------------------------------------
+# (name, flops, C entry, argument list, dims).  Driven alone, every launch is issued as it comes; two stacks driven side
+# by side (`run_chain_pair`: FC_layer_cla and vote_layer read the same seeds, models/head/rpn.py:44-54) advance in
+# lockstep and a pair of launches of the same kind goes out as ONE launch (csrc/mlp_direct.hip::direct_gemm_pair_kernel,
+# csrc/mlp.hip::bn_*finalize_pair_kernel) -- the serial chain of ~15 us sub-round launches is then half as long.
+class _PwFwdArgs(ctypes.Structure):       # o3d_pw_fwd_args
+    _fields_ = [("X", _vp), ("W", _vp), ("in_scale", _vp), ("in_shift", _vp), ("bias", _vp), ("resid", _vp), ("Cin", _i),
+                ("Cout", _i), ("P", _l), ("Y", _vp), ("part", _vp), ("stat_c", _vp)]
+
+
+class _PwDgradArgs(ctypes.Structure):     # o3d_pw_dgrad_args
+    _fields_ = [("dN", _vp), ("Y", _vp), ("A1", _vp), ("A2", _vp), ("A3", _vp), ("Wt", _vp), ("Cin", _i), ("Cout", _i),
+                ("P", _l), ("Yprev", _vp), ("scale_p", _vp), ("shift_p", _vp), ("mean_p", _vp), ("resid", _vp),
+                ("dNprev", _vp), ("part", _vp)]
+
+
+class _BnFinArgs(ctypes.Structure):       # o3d_bn_fin_args
+    _fields_ = [("part", _vp), ("nparts", _i), ("C", _i), ("count", _d), ("stat_c", _vp), ("gamma", _vp), ("beta", _vp),
+                ("running_mean", _vp), ("running_var", _vp), ("momentum", _f), ("eps", _f), ("mean", _vp), ("invstd", _vp),
+                ("scale", _vp), ("shift", _vp)]
+
+
+class _BnBwdFinArgs(ctypes.Structure):    # o3d_bn_bwd_fin_args
+    _fields_ = [("part", _vp), ("nparts", _i), ("C", _i), ("count", _d), ("gamma", _vp), ("mean", _vp), ("invstd", _vp),
+                ("dgamma", _vp), ("dbeta", _vp), ("A1", _vp), ("A2", _vp), ("A3", _vp)]
+
+
+for _n in ("o3d_pw_fwd_pair", "o3d_pw_dgrad_pair", "o3d_bn_finalize_pair", "o3d_bn_bwd_finalize_pair"):
+    capi.register(_n, [_vp, _vp, _vp])
+# single entry -> (pair entry, argument struct, trailing arguments of the single call that the struct does not carry)
+_PAIRABLE = {"o3d_pw_fwd": ("o3d_pw_fwd_pair", _PwFwdArgs, 1), "o3d_pw_dgrad": ("o3d_pw_dgrad_pair", _PwDgradArgs, 1),
+             "o3d_bn_finalize": ("o3d_bn_finalize_pair", _BnFinArgs, 2),
+             "o3d_bn_bwd_finalize": ("o3d_bn_bwd_finalize_pair", _BnBwdFinArgs, 2)}
+_PAIRS = {"on": _os.environ.get("O3D_HEAD_PAIRS", "1") != "0"}        # A/B switch
+
+
+def _drive(gens):
+    """run the launch generators to completion -> their return values; two generators advance in lockstep and matching
+    pairable launches are merged"""
+    lib = capi.load()
+    n = len(gens)
+    pend, done, res = [None] * n, [False] * n, [None] * n
+
+    def advance(k):
+        try:
+            pend[k] = next(gens[k])
+        except StopIteration as e:
+            pend[k], done[k], res[k] = None, True, e.value
+
+    def single(k):
+        name, flops, entry, args, dims = pend[k]
+        _call(name, flops, getattr(lib, entry), *args, dims=dims)
+        advance(k)
+    for k in range(n):
+        advance(k)
+    while not all(done):
+        live = [k for k in range(n) if not done[k]]
+        if len(live) == 2 and pend[0][2] == pend[1][2] and pend[0][2] in _PAIRABLE and pend[0][3][-1] == pend[1][3][-1]:
+            pair_entry, struct, tail = _PAIRABLE[pend[0][2]]
+            sa, sb = struct(*pend[0][3][:-tail]), struct(*pend[1][3][:-tail])
+            _call(pend[0][0], pend[0][1] + pend[1][1], getattr(lib, pair_entry), ctypes.addressof(sa), ctypes.addressof(sb),
+                  pend[0][3][-1])
+            advance(0)
+            advance(1)
+        elif len(live) == 2:
+            # not aligned: issue the launch that has no partner (a pack, a row sum ...) or, failing that, the first one
+            k = next((k for k in live if pend[k][2] not in _PAIRABLE), live[0])
+            single(k)
+        else:
+            single(live[0])
+    return res
+
+
+class _State:
+    pass
+
+
+def _chain_forward(cfg, tensors, need_bwd):
+    """generator: launches of one stack's forward; returns (output view (B,Cout,N), state for the backward | None)"""
+    lib = capi.load()
+    srcs, params = tensors[:cfg.nsrc], tensors[cfg.nsrc:]
+    L = len(params) // 4
+    B, _, N = srcs[0].shape
+    P = B * N
+    dev, f32 = srcs[0].device, torch.float32
+    st = _stream()
+    prep = prep_for(dev)
+    K0 = sum(t.shape[1] for t in srcs)
+    K0p = _up(K0, 64)
+    X0 = _as_flat(srcs[0].detach()) if (cfg.nsrc == 1 and K0 == K0p) else None
+    if X0 is None:
+        X0 = pack_rows([t.detach() for t in srcs], K0p)
+    Ys, vecs, Wts = [], [], []
+    Kp = K0p
+    for l in range(L):
+        W, bias, gamma, beta = params[4 * l:4 * l + 4]
+        Cout = W.shape[0]
+        Mp = _up(Cout, 64)
+        Wp = prep.get(W, Mp, Kp)
+        if need_bwd:
+            Wts.append(prep.get(W, Kp, Mp, transpose=True))
+        src = X0 if l == 0 else Ys[-1]
+        sc = None if l == 0 else vecs[-1][2].data_ptr()
+        sh = None if l == 0 else vecs[-1][3].data_ptr()
+        Y = torch.empty((Mp, P), device=dev, dtype=f32)
+        if l < L - 1:
+            bn = cfg.bns[l]
+            vec = torch.empty((4, Mp), device=dev, dtype=f32)            # mean, invstd, scale, shift
+            if cfg.training:
+                nparts = P // lib.o3d_pw_tile(P, Mp)
+                part = torch.empty((nparts, 2, Mp), device=dev, dtype=f32)
+                yield ("pw_conv_fwd", 2.0 * Kp * Mp * P, "o3d_pw_fwd", [src.data_ptr(), Wp.data_ptr(), sc, sh, None, None, Kp, Mp,
+                                                                       P, Y.data_ptr(), part.data_ptr(),
+                                                                       bn.running_mean.data_ptr(), st], (Kp, Mp))
+                fold = torch.empty((64, Mp), device=dev, dtype=f32)
+                yield ("bn_finalize", 0.0, "o3d_bn_finalize", [part.data_ptr(), nparts, Mp, float(P), bn.running_mean.data_ptr(),
+                                                               gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(),
+                                                               bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
+                                                               vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
+                                                               vec[3].data_ptr(), fold.data_ptr(), st], None)
+            else:
+                yield ("pw_conv_fwd", 2.0 * Kp * Mp * P, "o3d_pw_fwd", [src.data_ptr(), Wp.data_ptr(), sc, sh, None, None, Kp, Mp,
+                                                                       P, Y.data_ptr(), None, None, st], (Kp, Mp))
+                _eval_consts(lib, bn, gamma, beta, vec, 1, st)
+            vecs.append(vec)
+        else:
+            bp = prep.get(bias, 1, Mp) if bias is not None else None
+            if cfg.residual and Mp != K0p:
+                raise ValueError("residual stack: padded output rows %d != padded input rows %d" % (Mp, K0p))
+            if bp is None and not cfg.residual:       # plain store without statistics
+                bp = _const_vec(dev, Mp, 0.0)
+            yield ("pw_conv_fwd", 2.0 * Kp * Mp * P, "o3d_pw_fwd", [src.data_ptr(), Wp.data_ptr(), sc, sh, _ptr(bp),
+                                                                   X0.data_ptr() if cfg.residual else None, Kp, Mp, P,
+                                                                   Y.data_ptr(), None, None, st], (Kp, Mp))
+        Ys.append(Y)
+        Kp = Mp
+    if cfg.training and L > 1:
+        count_batches(cfg.bns[:L - 1], 1)
+    Cl = params[4 * (L - 1)].shape[0]
+    state = None
+    if need_bwd:
+        state = _State()
+        state.cfg = cfg
+        state.geom = (B, N, L, K0, K0p, [t.shape[1] for t in srcs])
+        state.versions = [(p, p._version) for p in params if p is not None]
+        state.saved = (X0, Ys, vecs, Wts, [params[4 * l + 2] for l in range(L)], [params[4 * l] for l in range(L)])
+    return Ys[-1][:Cl].view(Cl, B, N).permute(1, 0, 2), state
+
+
+def _chain_backward(state, dOut, needs):
+    """generator: launches of one stack's backward; `needs` = needs_input_grad of (sources..., 4 parameters per layer);
+    returns the list of gradients in that order"""
+    lib = capi.load()
+    cfg = state.cfg
+    B, N, L, K0, K0p, src_C = state.geom
+    for p, v in state.versions:
+        if p._version != v:
+            raise RuntimeError("a parameter of a fused conv stack was modified in place between forward and backward")
+    X0, Ys, vecs, Wts, gammas, Ws = state.saved
+    P = B * N
+    dev, f32 = dOut.device, torch.float32
+    st = _stream()
+    nparts = 0
+    Cl = Ws[-1].shape[0]
+    Mp = Ys[-1].shape[0]
+    G = _as_flat(dOut) if Cl == Mp else None
+    if G is None:
+        G = pack_rows([dOut], Mp)
+    grads = [None] * (4 * L)
+    want_x = any(needs[:cfg.nsrc])
+    one, zero = _const_vec(dev, Mp, 1.0), _const_vec(dev, Mp, 0.0)
+    dX0 = None
+
+    main = torch.cuda.current_stream()
+    side = _side_stream(dev) if _SIDE["on"] else main
+    keep = []            # buffers the side stream reads or writes: alive until the join below
+    jobs = []            # grouped weight gradients: launched together behind the data-gradient chain
+
+    def wgrad(l, dN, Y, A, Cout_p, coef=None):
+        Xs = X0 if l == 0 else Ys[l - 1]
+        Kp = Xs.shape[0]
+        sc = None if l == 0 else vecs[l - 1][2].data_ptr()
+        sh = None if l == 0 else vecs[l - 1][3].data_ptr()
+        Wl = Ws[l]
+        Cout, Cin = Wl.shape[0], Wl.shape[1]
+        if _GROUP["on"] and side is main:
+            dW = torch.empty((Cout_p, Kp), device=dev, dtype=f32)
+            scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Kp, Cout_p, P),), device=dev, dtype=f32)
+            jobs.append((2.0 * Kp * Cout_p * P, (dN.data_ptr(), Y.data_ptr(), A[0], A[1], A[2], Xs.data_ptr(), sc, sh, Kp,
+                                                 Cout_p, P, scratch.data_ptr(), dW.data_ptr())))
+            keep.extend((dN, Y, scratch, dW, coef))
+            return (dW if (Cout, Cin) == (Cout_p, Kp) else dW[:Cout, :Cin]).reshape(Wl.shape)
+        if side is not main:
+            side.wait_stream(main)           # dN and the BatchNorm-backward constants of this layer are ready
+        with torch.cuda.stream(side):
+            dW = torch.empty((Cout_p, Kp), device=dev, dtype=f32)
+            scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Kp, Cout_p, P),), device=dev, dtype=f32)
+            _call("pw_conv_wgrad", 2.0 * Kp * Cout_p * P, lib.o3d_mlp_conv_wgrad2, dN.data_ptr(), None, 4, Y.data_ptr(),
+                  A[0], A[1], A[2], Xs.data_ptr(), sc, sh, 1, Kp, Cout_p, P, scratch.data_ptr(), dW.data_ptr(),
+                  side.cuda_stream, dims=(Kp, Cout_p, Y is dN))
+            out = (dW if (Cout, Cin) == (Cout_p, Kp) else dW[:Cout, :Cin]).reshape(Wl.shape)
+        keep.extend((dN, Y, scratch, dW, coef, out))
+        return out
+
+    # ---- last layer: plain conv (+ bias, + residual)
+    l = L - 1
+    if needs[cfg.nsrc + 4 * l + 1]:
+        if side is not main:
+            side.wait_stream(main)
+        with torch.cuda.stream(side):
+            db = torch.empty((Mp,), device=dev, dtype=f32)
+            _call("row_sum", 0.0, lib.o3d_row_sum, G.data_ptr(), Mp, P, db.data_ptr(), side.cuda_stream)
+        keep.extend((G, db))
+        grads[4 * l + 1] = db[:Cl]
+    grads[4 * l] = wgrad(l, G, G, (one.data_ptr(), zero.data_ptr(), zero.data_ptr()), Mp)
+    dN, part = None, None
+    if L > 1:
+        Cp = Ys[l - 1].shape[0]
+        dN = torch.empty((Cp, P), device=dev, dtype=f32)
+        nparts = P // lib.o3d_pw_tile(P, Cp)
+        part = torch.empty((nparts, 2, Cp), device=dev, dtype=f32)
+        v = vecs[l - 1]
+        yield ("pw_conv_dgrad", 2.0 * Cp * Mp * P, "o3d_pw_dgrad", [G.data_ptr(), None, None, None, None, Wts[l].data_ptr(), Cp,
+                                                                   Mp, P, Ys[l - 1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(),
+                                                                   v[0].data_ptr(), None, dN.data_ptr(), part.data_ptr(), st],
+               (Cp, Mp, True))
+    elif want_x:
+        dX0 = torch.empty((K0p, P), device=dev, dtype=f32)
+        yield ("pw_conv_dgrad", 2.0 * K0p * Mp * P, "o3d_pw_dgrad", [G.data_ptr(), None, None, None, None, Wts[0].data_ptr(), K0p,
+                                                                    Mp, P, None, None, None, None,
+                                                                    G.data_ptr() if cfg.residual else None, dX0.data_ptr(), None,
+                                                                    st], (K0p, Mp, True))
+    # ---- hidden layers: conv -> BatchNorm -> ReLU
+    for l in range(L - 2, -1, -1):
+        Cp = Ys[l].shape[0]
+        v = vecs[l]
+        coef = torch.empty((5, Cp), device=dev, dtype=f32)          # dgamma dbeta A1 A2 A3
+        fold = torch.empty((64, Cp), device=dev, dtype=f32)
+        yield ("bn_bwd_finalize", 0.0, "o3d_bn_bwd_finalize", [part.data_ptr(), nparts, Cp, float(P), gammas[l].data_ptr(),
+                                                               v[0].data_ptr(), v[1].data_ptr(), coef[0].data_ptr(),
+                                                               coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(),
+                                                               coef[4].data_ptr(), fold.data_ptr(), st], None)
+        if not cfg.training:
+            coef[3].zero_()
+            coef[4].zero_()
+        grads[4 * l + 2], grads[4 * l + 3] = coef[0], coef[1]
+        A = (coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr())
+        grads[4 * l] = wgrad(l, dN, Ys[l], A, Cp, coef)
+        if l > 0:
+            Cq = Ys[l - 1].shape[0]
+            dNp = torch.empty((Cq, P), device=dev, dtype=f32)
+            nparts_next = P // lib.o3d_pw_tile(P, Cq)
+            part_next = torch.empty((nparts_next, 2, Cq), device=dev, dtype=f32)
+            vp = vecs[l - 1]
+            yield ("pw_conv_dgrad", 2.0 * Cq * Cp * P, "o3d_pw_dgrad", [dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
+                                                                       Wts[l].data_ptr(), Cq, Cp, P, Ys[l - 1].data_ptr(),
+                                                                       vp[2].data_ptr(), vp[3].data_ptr(), vp[0].data_ptr(), None,
+                                                                       dNp.data_ptr(), part_next.data_ptr(), st], (Cq, Cp))
+            keep.append(dN)
+            dN, part, nparts = dNp, part_next, nparts_next
+        elif want_x:
+            dX0 = torch.empty((K0p, P), device=dev, dtype=f32)
+            yield ("pw_conv_dgrad", 2.0 * K0p * Cp * P, "o3d_pw_dgrad", [dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1], A[2],
+                                                                        Wts[0].data_ptr(), K0p, Cp, P, None, None, None, None,
+                                                                        G.data_ptr() if cfg.residual else None, dX0.data_ptr(),
+                                                                        None, st], (K0p, Cp))
+    for j0 in range(0, len(jobs), 4):
+        chunk = jobs[j0:j0 + 4]
+        arr = (_WgradJob * len(chunk))(*[_WgradJob(*j[1]) for j in chunk])
+        _call("pw_conv_wgrad", sum(j[0] for j in chunk), lib.o3d_mlp_conv_wgrad2_group, ctypes.addressof(arr),
+              len(chunk), st)
+    if side is not main:
+        main.wait_stream(side)       # join: every weight gradient is complete before autograd hands it on
+    del keep
+    gsrc, off = [], 0
+    for i, C in enumerate(src_C):
+        gsrc.append(dX0[off:off + C].view(C, B, N).permute(1, 0, 2) if (dX0 is not None and needs[i]) else None)
+        off += C
+    return gsrc + grads
+
+
 class FlatChain(torch.autograd.Function):
     """apply(cfg, src_0..src_{nsrc-1}, [W, bias | None, gamma | None, beta | None] per layer) -> (B, Cout, N) view of the
     flat (Cout_pad, B*N) output.  Hidden layers: conv -> BatchNorm -> ReLU; last layer: conv + bias (+ residual)."""
@@ -242,204 +523,52 @@ class FlatChain(torch.autograd.Function):
     @staticmethod
     @capi.on_tensor_device
     def forward(ctx, cfg, *tensors):
-        lib = capi.load()
-        srcs, params = tensors[:cfg.nsrc], tensors[cfg.nsrc:]
-        L = len(params) // 4
-        B, _, N = srcs[0].shape
-        P = B * N
-        dev, f32 = srcs[0].device, torch.float32
-        st = _stream()
-        prep = prep_for(dev)
-        K0 = sum(t.shape[1] for t in srcs)
-        K0p = _up(K0, 64)
-        X0 = _as_flat(srcs[0].detach()) if (cfg.nsrc == 1 and K0 == K0p) else None
-        if X0 is None:
-            X0 = pack_rows([t.detach() for t in srcs], K0p)
-        need_bwd = any(ctx.needs_input_grad)
-        Ys, vecs, Wts = [], [], []
-        Kp = K0p
-        for l in range(L):
-            W, bias, gamma, beta = params[4 * l:4 * l + 4]
-            Cout = W.shape[0]
-            Mp = _up(Cout, 64)
-            Wp = prep.get(W, Mp, Kp)
-            if need_bwd:
-                Wts.append(prep.get(W, Kp, Mp, transpose=True))
-            src = X0 if l == 0 else Ys[-1]
-            sc = None if l == 0 else vecs[-1][2].data_ptr()
-            sh = None if l == 0 else vecs[-1][3].data_ptr()
-            Y = torch.empty((Mp, P), device=dev, dtype=f32)
-            if l < L - 1:
-                bn = cfg.bns[l]
-                vec = torch.empty((4, Mp), device=dev, dtype=f32)            # mean, invstd, scale, shift
-                if cfg.training:
-                    nparts = P // lib.o3d_pw_tile(P, Mp)
-                    part = torch.empty((nparts, 2, Mp), device=dev, dtype=f32)
-                    _call("pw_conv_fwd", 2.0 * Kp * Mp * P, lib.o3d_pw_fwd, src.data_ptr(), Wp.data_ptr(), sc, sh, None, None,
-                          Kp, Mp, P, Y.data_ptr(), part.data_ptr(), bn.running_mean.data_ptr(), st, dims=(Kp, Mp))
-                    fold = torch.empty((64, Mp), device=dev, dtype=f32)
-                    _call("bn_finalize", 0.0, lib.o3d_bn_finalize, part.data_ptr(), nparts, Mp, float(P),
-                          bn.running_mean.data_ptr(), gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(),
-                          bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps), vec[0].data_ptr(), vec[1].data_ptr(),
-                          vec[2].data_ptr(), vec[3].data_ptr(), fold.data_ptr(), st)
-                else:
-                    _call("pw_conv_fwd", 2.0 * Kp * Mp * P, lib.o3d_pw_fwd, src.data_ptr(), Wp.data_ptr(), sc, sh, None, None,
-                          Kp, Mp, P, Y.data_ptr(), None, None, st, dims=(Kp, Mp))
-                    _eval_consts(lib, bn, gamma, beta, vec, 1, st)
-                vecs.append(vec)
-            else:
-                bp = prep.get(bias, 1, Mp) if bias is not None else None
-                if cfg.residual and Mp != K0p:
-                    raise ValueError("residual stack: padded output rows %d != padded input rows %d" % (Mp, K0p))
-                if bp is None and not cfg.residual:       # plain store without statistics
-                    bp = _const_vec(dev, Mp, 0.0)
-                _call("pw_conv_fwd", 2.0 * Kp * Mp * P, lib.o3d_pw_fwd, src.data_ptr(), Wp.data_ptr(), sc, sh, _ptr(bp),
-                      X0.data_ptr() if cfg.residual else None, Kp, Mp, P, Y.data_ptr(), None, None, st, dims=(Kp, Mp))
-            Ys.append(Y)
-            Kp = Mp
-        if cfg.training and L > 1:
-            count_batches(cfg.bns[:L - 1], 1)
-        Cl = params[4 * (L - 1)].shape[0]
-        if need_bwd:
-            ctx.cfg = cfg
-            ctx.geom = (B, N, L, K0, K0p, [t.shape[1] for t in srcs])
-            ctx.versions = [(p, p._version) for p in params if p is not None]
-            ctx.saved = (X0, Ys, vecs, Wts, [params[4 * l + 2] for l in range(L)], [params[4 * l] for l in range(L)])
-        return Ys[-1][:Cl].view(Cl, B, N).permute(1, 0, 2)
+        out, ctx.state = _drive([_chain_forward(cfg, tensors, any(ctx.needs_input_grad))])[0]
+        return out
 
     @staticmethod
     @capi.on_tensor_device
     def backward(ctx, dOut):
-        lib = capi.load()
-        cfg = ctx.cfg
-        B, N, L, K0, K0p, src_C = ctx.geom
-        for p, v in ctx.versions:
-            if p._version != v:
-                raise RuntimeError("a parameter of a fused conv stack was modified in place between forward and backward")
-        X0, Ys, vecs, Wts, gammas, Ws = ctx.saved
-        P = B * N
-        dev, f32 = dOut.device, torch.float32
-        st = _stream()
-        nparts = 0
-        Cl = Ws[-1].shape[0]
-        Mp = Ys[-1].shape[0]
-        G = _as_flat(dOut) if Cl == Mp else None
-        if G is None:
-            G = pack_rows([dOut], Mp)
-        grads = [None] * (4 * L)
-        want_x = any(ctx.needs_input_grad[1:1 + cfg.nsrc])
-        one, zero = _const_vec(dev, Mp, 1.0), _const_vec(dev, Mp, 0.0)
-        dX0 = None
-
-        main = torch.cuda.current_stream()
-        side = _side_stream(dev) if _SIDE["on"] else main
-        keep = []            # buffers the side stream reads or writes: alive until the join below
-
-        jobs = []            # grouped weight gradients: launched together behind the data-gradient chain
-
-        def wgrad(l, dN, Y, A, Cout_p, coef=None):
-            Xs = X0 if l == 0 else Ys[l - 1]
-            Kp = Xs.shape[0]
-            sc = None if l == 0 else vecs[l - 1][2].data_ptr()
-            sh = None if l == 0 else vecs[l - 1][3].data_ptr()
-            if _GROUP["on"] and side is main:
-                dW = torch.empty((Cout_p, Kp), device=dev, dtype=f32)
-                scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Kp, Cout_p, P),), device=dev, dtype=f32)
-                jobs.append((2.0 * Kp * Cout_p * P, (dN.data_ptr(), Y.data_ptr(), A[0], A[1], A[2], Xs.data_ptr(), sc, sh, Kp,
-                                                     Cout_p, P, scratch.data_ptr(), dW.data_ptr())))
-                keep.extend((dN, Y, scratch, dW, coef))
-                Wl = Ws[l]
-                Cout, Cin = Wl.shape[0], Wl.shape[1]
-                return (dW if (Cout, Cin) == (Cout_p, Kp) else dW[:Cout, :Cin]).reshape(Wl.shape)
-            if side is not main:
-                side.wait_stream(main)           # dN and the BatchNorm-backward constants of this layer are ready
-            with torch.cuda.stream(side):
-                dW = torch.empty((Cout_p, Kp), device=dev, dtype=f32)
-                scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Kp, Cout_p, P),), device=dev, dtype=f32)
-                _call("pw_conv_wgrad", 2.0 * Kp * Cout_p * P, lib.o3d_mlp_conv_wgrad2, dN.data_ptr(), None, 4, Y.data_ptr(),
-                      A[0], A[1], A[2], Xs.data_ptr(), sc, sh, 1, Kp, Cout_p, P, scratch.data_ptr(), dW.data_ptr(),
-                      side.cuda_stream, dims=(Kp, Cout_p, Y is dN))
-                Wl = Ws[l]
-                Cout, Cin = Wl.shape[0], Wl.shape[1]
-                out = (dW if (Cout, Cin) == (Cout_p, Kp) else dW[:Cout, :Cin]).reshape(Wl.shape)
-            keep.extend((dN, Y, scratch, dW, coef, out))
-            return out
-
-        # ---- last layer: plain conv (+ bias, + residual)
-        l = L - 1
-        if ctx.needs_input_grad[1 + cfg.nsrc + 4 * l + 1]:
-            if side is not main:
-                side.wait_stream(main)
-            with torch.cuda.stream(side):
-                db = torch.empty((Mp,), device=dev, dtype=f32)
-                _call("row_sum", 0.0, lib.o3d_row_sum, G.data_ptr(), Mp, P, db.data_ptr(), side.cuda_stream)
-            keep.extend((G, db))
-            grads[4 * l + 1] = db[:Cl]
-        grads[4 * l] = wgrad(l, G, G, (one.data_ptr(), zero.data_ptr(), zero.data_ptr()), Mp)
-        dN, part = None, None
-        if L > 1:
-            Cp = Ys[l - 1].shape[0]
-            dN = torch.empty((Cp, P), device=dev, dtype=f32)
-            nparts = P // lib.o3d_pw_tile(P, Cp)
-            part = torch.empty((nparts, 2, Cp), device=dev, dtype=f32)
-            v = vecs[l - 1]
-            _call("pw_conv_dgrad", 2.0 * Cp * Mp * P, lib.o3d_pw_dgrad, G.data_ptr(), None, None, None, None,
-                  Wts[l].data_ptr(), Cp, Mp, P, Ys[l - 1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(), v[0].data_ptr(), None,
-                  dN.data_ptr(), part.data_ptr(), st, dims=(Cp, Mp, True))
-        elif want_x:
-            dX0 = torch.empty((K0p, P), device=dev, dtype=f32)
-            _call("pw_conv_dgrad", 2.0 * K0p * Mp * P, lib.o3d_pw_dgrad, G.data_ptr(), None, None, None, None,
-                  Wts[0].data_ptr(), K0p, Mp, P, None, None, None, None, G.data_ptr() if cfg.residual else None,
-                  dX0.data_ptr(), None, st, dims=(K0p, Mp, True))
-        # ---- hidden layers: conv -> BatchNorm -> ReLU
-        for l in range(L - 2, -1, -1):
-            Cp = Ys[l].shape[0]
-            v = vecs[l]
-            coef = torch.empty((5, Cp), device=dev, dtype=f32)          # dgamma dbeta A1 A2 A3
-            fold = torch.empty((64, Cp), device=dev, dtype=f32)
-            _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize, part.data_ptr(), nparts, Cp, float(P),
-                  gammas[l].data_ptr(), v[0].data_ptr(), v[1].data_ptr(), coef[0].data_ptr(), coef[1].data_ptr(),
-                  coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr(), fold.data_ptr(), st)
-            if not cfg.training:
-                coef[3].zero_()
-                coef[4].zero_()
-            grads[4 * l + 2], grads[4 * l + 3] = coef[0], coef[1]
-            A = (coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr())
-            grads[4 * l] = wgrad(l, dN, Ys[l], A, Cp, coef)
-            if l > 0:
-                Cq = Ys[l - 1].shape[0]
-                dNp = torch.empty((Cq, P), device=dev, dtype=f32)
-                nparts_next = P // lib.o3d_pw_tile(P, Cq)
-                part_next = torch.empty((nparts_next, 2, Cq), device=dev, dtype=f32)
-                vp = vecs[l - 1]
-                _call("pw_conv_dgrad", 2.0 * Cq * Cp * P, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
-                      Wts[l].data_ptr(), Cq, Cp, P, Ys[l - 1].data_ptr(), vp[2].data_ptr(), vp[3].data_ptr(), vp[0].data_ptr(),
-                      None, dNp.data_ptr(), part_next.data_ptr(), st, dims=(Cq, Cp))
-                dN, part, nparts = dNp, part_next, nparts_next
-            elif want_x:
-                dX0 = torch.empty((K0p, P), device=dev, dtype=f32)
-                _call("pw_conv_dgrad", 2.0 * K0p * Cp * P, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1], A[2],
-                      Wts[0].data_ptr(), K0p, Cp, P, None, None, None, None, G.data_ptr() if cfg.residual else None,
-                      dX0.data_ptr(), None, st, dims=(K0p, Cp))
-        for j0 in range(0, len(jobs), 4):
-            chunk = jobs[j0:j0 + 4]
-            arr = (_WgradJob * len(chunk))(*[_WgradJob(*j[1]) for j in chunk])
-            _call("pw_conv_wgrad", sum(j[0] for j in chunk), lib.o3d_mlp_conv_wgrad2_group, ctypes.addressof(arr),
-                  len(chunk), st)
-        if side is not main:
-            main.wait_stream(side)       # join: every weight gradient is complete before autograd hands it on
-        del keep
-        gsrc, off = [], 0
-        for i, C in enumerate(src_C):
-            gsrc.append(dX0[off:off + C].view(C, B, N).permute(1, 0, 2) if (dX0 is not None and ctx.needs_input_grad[1 + i])
-                        else None)
-            off += C
-        return (None, *gsrc, *grads)
+        return (None, *_drive([_chain_backward(ctx.state, dOut, ctx.needs_input_grad[1:])])[0])
 
 
-def run_chain(sources, units, residual=False):
-    """sources [(B,C_i,N)] stacked along the channels -> the Conv1d stack `units` -> (B,Cout,N) (+ sources when
-    `residual`).  Caller has checked chain_supported."""
+class FlatChainPair(torch.autograd.Function):
+    """two independent stacks over the same columns, advanced side by side: apply(cfg_a, cfg_b, n_a, tensors_a...,
+    tensors_b...) -> (out_a, out_b), each as FlatChain.apply(cfg_x, *tensors_x) would return it (same launches' worth of
+    arithmetic, the same numbers; launches of the same kind merged two by two)"""
+
+    @staticmethod
+    @capi.on_tensor_device
+    def forward(ctx, cfg_a, cfg_b, n_a, *tensors):
+        ta, tb = tensors[:n_a], tensors[n_a:]
+        na, nb = ctx.needs_input_grad[3:3 + n_a], ctx.needs_input_grad[3 + n_a:]
+        (oa, sa), (ob, sb) = _drive([_chain_forward(cfg_a, ta, any(na)), _chain_forward(cfg_b, tb, any(nb))])
+        ctx.states, ctx.n_a = (sa, sb), n_a
+        return oa, ob
+
+    @staticmethod
+    @capi.on_tensor_device
+    def backward(ctx, da, db):
+        sa, sb = ctx.states
+        na, nb = ctx.needs_input_grad[3:3 + ctx.n_a], ctx.needs_input_grad[3 + ctx.n_a:]
+        gens, order = [], []
+        for state, d, needs, n in ((sa, da, na, ctx.n_a), (sb, db, nb, len(ctx.needs_input_grad) - 3 - ctx.n_a)):
+            if state is None:
+                order.append([None] * n)
+                continue
+            if d is None:      # this output did not reach the loss
+                B, N, L = state.geom[:3]
+                d = torch.zeros((B, state.saved[5][-1].shape[0], N), device=state.saved[0].device, dtype=torch.float32)
+            order.append(len(gens))
+            gens.append(_chain_backward(state, d, needs))
+        res = _drive(gens) if gens else []
+        out = []
+        for o in order:
+            out += o if isinstance(o, list) else res[o]
+        return (None, None, None, *out)
+
+
+def _chain_cfg(sources, units, residual):
     cfg = _Cfg()
     cfg.nsrc = len(sources)
     cfg.training = bool(units[0][1].training) if units[0][1] is not None else False
@@ -448,4 +577,22 @@ def run_chain(sources, units, residual=False):
     params = []
     for conv, bn, _ in units:
         params += [conv.weight, conv.bias, bn.weight if bn is not None else None, bn.bias if bn is not None else None]
+    return cfg, params
+
+
+def run_chain(sources, units, residual=False):
+    """sources [(B,C_i,N)] stacked along the channels -> the Conv1d stack `units` -> (B,Cout,N) (+ sources when
+    `residual`).  Caller has checked chain_supported."""
+    cfg, params = _chain_cfg(sources, units, residual)
     return FlatChain.apply(cfg, *sources, *params)
+
+
+def run_chain_pair(a, b):
+    """a, b = (sources, units, residual) of two independent stacks over the same (B, N): -> (out_a, out_b), launches
+    merged two by two where they match.  Caller has checked chain_supported for both."""
+    cfg_a, pa = _chain_cfg(*a)
+    cfg_b, pb = _chain_cfg(*b)
+    if not _PAIRS["on"] or a[0][0].shape[0] != b[0][0].shape[0] or a[0][0].shape[2] != b[0][0].shape[2]:
+        return FlatChain.apply(cfg_a, *a[0], *pa), FlatChain.apply(cfg_b, *b[0], *pb)
+    ta = (*a[0], *pa)
+    return FlatChainPair.apply(cfg_a, cfg_b, len(ta), *ta, *b[0], *pb)

@@ -51,6 +51,19 @@ def seq_apply(seq, parts, residual=False):
     return x + y if residual else y
 
 
+def seq_apply_pair(a, b):
+    """(seq_a, parts_a, residual_a), (seq_b, parts_b, residual_b): two independent pt_utils.Seq stacks over the same
+    (B, N) -- FC_layer_cla and vote_layer of models/head/rpn.py:44-54 -- -> (out_a, out_b) = (seq_apply(*a), seq_apply(*b)).
+    On the GPU the two stacks advance layer by layer in merged launches (open3dsot_amd/fused_heads.py::run_chain_pair)."""
+    ua = a[0]._flat_units() if (_FLAT["on"] and isinstance(a[0], Seq)) else None
+    ub = b[0]._flat_units() if (_FLAT["on"] and isinstance(b[0], Seq)) else None
+    if ua is not None and ub is not None and a[1][0].is_cuda:
+        from . import fused_heads
+        if fused_heads.chain_supported(a[1], ua) and fused_heads.chain_supported(b[1], ub):
+            return fused_heads.run_chain_pair((a[1], ua, a[2]), (b[1], ub, b[2]))
+    return seq_apply(*a), seq_apply(*b)
+
+
 _CONV = {1: nn.Conv1d, 2: nn.Conv2d, 3: nn.Conv3d}
 _BN = {1: nn.BatchNorm1d, 2: nn.BatchNorm2d, 3: nn.BatchNorm3d}
 

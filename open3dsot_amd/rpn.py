@@ -29,10 +29,12 @@ class P2BVoteNetRPN(nn.Module):
 
     def forward(self, xyz, feature):
         """xyz (B,N,3), feature (B,f,N) -> boxes (B,P,5), cla (B,N), vote_xyz (B,N,3), centres (B,P,3)"""
-        estimation_cla = self.FC_layer_cla(feature).squeeze(1)
+        # FC_layer_cla(feature) and vote = seeds + vote_layer(seeds), seeds = cat(xyz^T, feature) (B,3+f,N) (:44-54): two
+        # independent stacks over the same seeds, advanced side by side on the GPU (the parts are packed by the stack)
+        estimation_cla, vote = pt_utils.seq_apply_pair((self.FC_layer_cla, [feature], False),
+                                                       (self.vote_layer, [xyz.transpose(1, 2), feature], True))
+        estimation_cla = estimation_cla.squeeze(1)
         score = estimation_cla.sigmoid()
-        # vote = seeds + vote_layer(seeds), seeds = cat(xyz^T, feature) (B,3+f,N): the parts are packed by the stack
-        vote = pt_utils.seq_apply(self.vote_layer, [xyz.transpose(1, 2), feature], residual=True)
         # split instead of two slices: one backward node (a cat) instead of 2 x (zeros + copy) + add
         v_xyz, v_feat = vote.split([3, vote.shape[1] - 3], dim=1)
         vote_xyz = v_xyz.transpose(1, 2).contiguous()

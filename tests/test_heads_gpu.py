@@ -244,3 +244,44 @@ def test_p2b_xcorr_fused_vs_fp64(train, B, M, N):
         sa_modules.set_fused(True)
     got = mod2(t_feat.detach(), s_feat.detach(), t_xyz.detach())
     assert rel(got, whole) < 2e-3, rel(got, whole)
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("B,N", [(4, 64), (48, 128)])
+def test_chain_pair_equals_two_single_chains(train, B, N):
+    """FC_layer_cla and vote_layer (models/head/rpn.py:44-54) advanced side by side in merged launches
+    (fused_heads.run_chain_pair: direct_gemm_pair_kernel, bn_*finalize_pair_kernel) against the two stacks run one
+    after the other: the same kernels' arithmetic on the same operands, so outputs, every gradient and the running
+    statistics must be bitwise equal"""
+    from open3dsot_amd import fused_heads, nn_blocks
+    cla = build_seq(CASES["cla"][1], 256, 11).train(train)
+    vote = build_seq(CASES["vote"][1], 259, 12).train(train)
+    cla2, vote2 = copy.deepcopy(cla), copy.deepcopy(vote)
+    g = torch.Generator(device="cuda").manual_seed(8)
+    feat = torch.randn(B, 256, N, device="cuda", generator=g)
+    xyz = torch.randn(B, N, 3, device="cuda", generator=g)
+    f1, x1 = feat.clone().requires_grad_(True), xyz.clone().requires_grad_(True)
+    f2, x2 = feat.clone().requires_grad_(True), xyz.clone().requires_grad_(True)
+    assert fused_heads._PAIRS["on"]
+    oa, ob = nn_blocks.seq_apply_pair((cla, [f1], False), (vote, [x1.transpose(1, 2), f1], True))
+    fused_heads._PAIRS["on"] = False
+    try:
+        ra, rb = nn_blocks.seq_apply_pair((cla2, [f2], False), (vote2, [x2.transpose(1, 2), f2], True))
+    finally:
+        fused_heads._PAIRS["on"] = True
+    assert oa.shape == (B, 1, N) and ob.shape == (B, 259, N)
+    assert torch.equal(oa, ra) and torch.equal(ob, rb)
+    ca, cb = torch.randn(oa.shape, device="cuda", generator=g), torch.randn(ob.shape, device="cuda", generator=g)
+    ((oa * ca).sum() + (ob * cb).sum()).backward()
+    ((ra * ca).sum() + (rb * cb).sum()).backward()
+    assert torch.equal(f1.grad, f2.grad) and torch.equal(x1.grad, x2.grad)
+    for m1, m2 in ((cla, cla2), (vote, vote2)):
+        for (n1, p1), (_, p2) in zip(m1.named_parameters(), m2.named_parameters()):
+            assert p1.grad is not None and torch.equal(p1.grad, p2.grad), n1
+        for (n1, b1), (_, b2) in zip(m1.named_buffers(), m2.named_buffers()):
+            assert torch.equal(b1, b2), n1
+    # one output unused by the loss: the other stack's gradients still arrive
+    f3 = feat.clone().requires_grad_(True)
+    oa3, ob3 = nn_blocks.seq_apply_pair((cla, [f3], False), (vote, [xyz.transpose(1, 2), f3], True))
+    (oa3 * ca).sum().backward()
+    assert f3.grad is not None and torch.isfinite(f3.grad).all()
