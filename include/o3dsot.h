@@ -260,6 +260,14 @@ int o3d_compact_build(const int32_t* idx, int B, int npoint, int ns, int ld, int
                       int ball_base, int dummy_ball, int32_t* ball_cnt, int32_t* ball_off, int32_t* gp,
                       int32_t* cball, float* cw, int32_t* meta, void* stream);
 
+/* Weight gradient of an xyz-only layer 0 whose input gradient is not needed (set abstraction level 0 of the backbone:
+ * features None, models/backbone/pointnet.py:30-38), straight from the columns of the compact layout:
+ * dW0[c,k] = sum_q (A1*dN + w*(A2*Y0 + A3))[c,q] * (X[k, gp[q]] - centers[cball[q], k]), k < 3.  Replaces the list-sum
+ * reduction (o3d_group_reduce_gather), the K = 3 GEMM and the centre term.  part: (ldp/256)*C0*3 floats of scratch. */
+int o3d_group_dw0_xyz(const float* dN, const float* Y0, long ldp, const float* A1, const float* A2, const float* A3,
+                      const int32_t* gp, const int32_t* cball, const float* cw, const float* X, long ldz,
+                      const float* centers, const int32_t* meta, long start1, int C0, float* part, float* dW, void* stream);
+
 /* o3d_compact_build for the two segments of a paired call (template + search cloud through one shared module,
  * models/bat.py:89-90) in three launches instead of six: segment 0 at column / point / ball base 0, segment 1 at
  * col_base1 / pt_base1 / ball base B*npoint0; ball_cnt, ball_off: B*(npoint0+npoint1) (+1) entries, meta: 8 ints. */

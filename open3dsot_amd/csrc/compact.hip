@@ -734,6 +734,118 @@ extern "C" int o3d_compact_build(const int32_t* idx, int B, int npoint, int ns, 
     return o3d_launch_status();
 }
 
+// ---------------------------------------------------------------------------------------
+// Weight gradient of a layer 0 whose input is xyz ONLY and whose input gradient nobody needs (SA level 0 of the backbone,
+// models/backbone/pointnet.py:30-38: features None, the input cloud carries no gradient):
+//     dW0[c,k] = sum_q dY0[c,q] * (xyz[gp[q],k] - centre[cball[q],k]),   dY0 = A1*dN + w*(A2*Y0 + A3)
+// straight from the columns -- one streaming pass over dN / Y0 -- instead of the per-point list sums S (LDS atomics,
+// reduce_gather_kernel), the per-ball sums T, a K = 3 GEMM S.xyz^T on the generic kernel and the centre term.
+//   workgroup = 256 columns (lane = 4 consecutive columns, float4 rows), wave w takes channels w, w+4, ...; per lane
+//   3 accumulators per channel, folded over the wave at the end; partial rows [block][C0][3] (dead tiles write zeros),
+//   summed in a fixed order by dw0_reduce_kernel.
+// ---------------------------------------------------------------------------------------
+namespace {
+template <int CPW>        // channels per wave (C0 = 4 * CPW per pass)
+__global__ __launch_bounds__(256) void dw0_xyz_kernel(const float* __restrict__ dN, const float* __restrict__ Y0, long ldp,
+                                                      const float* __restrict__ A1, const float* __restrict__ A2,
+                                                      const float* __restrict__ A3, const int32_t* __restrict__ gp,
+                                                      const int32_t* __restrict__ cball, const float* __restrict__ cw,
+                                                      const float* __restrict__ X, long ldz,
+                                                      const float* __restrict__ centers,
+                                                      const int32_t* __restrict__ meta, long start1, int C0,
+                                                      float* __restrict__ part) {
+    const long q0 = (long)blockIdx.x * 256;
+    const int seg = (start1 > 0 && q0 >= start1) ? 1 : 0;
+    float* prow = part + (long)blockIdx.x * C0 * 3;
+    if (q0 - (seg ? start1 : 0) >= meta[4 * seg]) {       // dead tile: a zero row (the reduction sums every row)
+        for (int i = threadIdx.x; i < C0 * 3; i += 256) prow[i] = 0.f;
+        return;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long q = q0 + 4 * lane;
+    const int4 id = *reinterpret_cast<const int4*>(&gp[q]);
+    const int4 bj = *reinterpret_cast<const int4*>(&cball[q]);
+    const float4 w = *reinterpret_cast<const float4*>(&cw[q]);
+    const int ids[4] = {id.x, id.y, id.z, id.w}, bb[4] = {bj.x, bj.y, bj.z, bj.w};
+    const float wv[4] = {w.x, w.y, w.z, w.w};
+    float rel[4][3];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)      // (padding columns of the last live tile carry weight 0: they contribute nothing)
+            rel[t][k] = wv[t] != 0.f ? X[(long)k * ldz + ids[t]] - centers[(long)bb[t] * 3 + k] : 0.f;
+    const float* a1 = A1 + seg * C0;
+    const float* a2 = A2 + seg * C0;
+    const float* a3 = A3 + seg * C0;
+    for (int cbase = 0; cbase < C0; cbase += 4 * CPW) {
+        float acc[CPW][3];
+        float4 d[CPW], y[CPW];
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {            // all rows of the pass in flight first
+            const int c = cbase + wave + 4 * i;
+            const int cc = c < C0 ? c : C0 - 1;
+            d[i] = *reinterpret_cast<const float4*>(&dN[(long)cc * ldp + q]);
+            y[i] = *reinterpret_cast<const float4*>(&Y0[(long)cc * ldp + q]);
+        }
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            const int c = cbase + wave + 4 * i;
+            const int cc = c < C0 ? c : C0 - 1;
+            const float k1 = a1[cc], k2 = a2[cc], k3 = a3[cc];
+            const float dv[4] = {d[i].x, d[i].y, d[i].z, d[i].w}, yv[4] = {y[i].x, y[i].y, y[i].z, y[i].w};
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const float dy = fmaf(k1, dv[t], wv[t] * fmaf(k2, yv[t], k3));
+                s0 = fmaf(dy, rel[t][0], s0); s1 = fmaf(dy, rel[t][1], s1); s2 = fmaf(dy, rel[t][2], s2);
+            }
+            acc[i][0] = s0; acc[i][1] = s1; acc[i][2] = s2;
+        }
+#pragma unroll
+        for (int i = 0; i < CPW; ++i) {
+            const int c = cbase + wave + 4 * i;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float t = wave_sum(acc[i][k]);
+                if (lane == 0 && c < C0) prow[c * 3 + k] = t;
+            }
+        }
+    }
+}
+
+// out[i] = sum over the nblk partial rows of part[r][i], i < n: one workgroup per output, rows strided over the threads,
+// wave sums + 4 LDS entries -- a fixed order
+__global__ __launch_bounds__(256) void dw0_reduce_kernel(const float* __restrict__ part, int nblk, int n,
+                                                         float* __restrict__ out) {
+    __shared__ float sh[4];
+    const int i = blockIdx.x;
+    float s = 0.f;
+    for (int r = threadIdx.x; r < nblk; r += 256) s += part[(long)r * n + i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[i] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+}  // namespace
+
+// dW0 (C0, 3) of an xyz-only layer 0 straight from the columns (see dw0_xyz_kernel); X = the packed per-point operand
+// (rows 0..2 = the scaled coordinates, ldz columns), centers ((nballs+1), 3) scaled alike, A1..A3 (nseg, C0);
+// part: scratch of (ldp/256) * C0 * 3 floats.
+extern "C" int o3d_group_dw0_xyz(const float* dN, const float* Y0, long ldp, const float* A1, const float* A2,
+                                 const float* A3, const int32_t* gp, const int32_t* cball, const float* cw,
+                                 const float* X, long ldz, const float* centers, const int32_t* meta, long start1, int C0,
+                                 float* part, float* dW, void* stream) {
+    if (!dN || !Y0 || !A1 || !A2 || !A3 || !gp || !cball || !cw || !X || !centers || !meta || !part || !dW || C0 <= 0 ||
+        ldp <= 0 || ldp % 256 != 0 || ldz <= 0 || start1 < 0 || start1 % 256 != 0)
+        return O3D_EINVAL;
+    hipStream_t s = o3d_stream(stream);
+    const int nblk = (int)(ldp / 256);
+    hipLaunchKernelGGL(dw0_xyz_kernel<8>, dim3(nblk), dim3(256), 0, s, dN, Y0, ldp, A1, A2, A3, gp, cball, cw, X, ldz, centers,
+                       meta, start1, C0, part);
+    hipLaunchKernelGGL(dw0_reduce_kernel, dim3(C0 * 3), dim3(256), 0, s, part, nblk, C0 * 3, dW);
+    return o3d_launch_status();
+}
+
 // Both segments of a paired call (template + search cloud through one shared module) in THREE launches instead of six:
 // every kernel covers segment 0's workgroups first, then segment 1's.  Arguments per segment as o3d_compact_build.
 namespace {

@@ -126,7 +126,7 @@ extern "C" int o3d_pack_rows(const o3d_rows_src* srcs, int nsrc, int B, int N, i
 // jobs: DEVICE array of njobs x 6 longs {src, dst, rows, cols, dst_ld, transpose} (see prep_weights_kernel)
 extern "C" int o3d_prep_weights(const long* jobs, int njobs, void* stream) {
     if (!jobs || njobs <= 0) return O3D_EINVAL;
-    hipLaunchKernelGGL(prep_weights_kernel, dim3(njobs, 16), dim3(256), 0, o3d_stream(stream), jobs);
+    hipLaunchKernelGGL(prep_weights_kernel, dim3(njobs, 32), dim3(256), 0, o3d_stream(stream), jobs);
     return o3d_launch_status();
 }
 
@@ -172,7 +172,7 @@ extern "C" int o3d_adam_step(const long* jobs, int njobs, float* params, float* 
                              void* stream) {
     // hyper-parameters in double like torch's Python scalars: 1 - 0.999f is 4.7e-5 away from 0.001
     if (!jobs || njobs <= 0 || !params || !exp_avg || !exp_avg_sq || bc1 <= 0. || bc2 <= 0.) return O3D_EINVAL;
-    hipLaunchKernelGGL(adam_step_kernel, dim3(njobs, 8), dim3(256), 0, o3d_stream(stream), jobs, params, exp_avg,
+    hipLaunchKernelGGL(adam_step_kernel, dim3(njobs, 32), dim3(256), 0, o3d_stream(stream), jobs, params, exp_avg,
                        exp_avg_sq, (float)(lr / bc1), (float)beta1, (float)(1. - beta1), (float)beta2, (float)(1. - beta2),
                        (float)eps, (float)weight_decay, (float)(1.0 / sqrt(bc2)));
     return o3d_launch_status();

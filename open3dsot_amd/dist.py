@@ -236,7 +236,7 @@ class DataParallelStep:
     def make_batch(self, batch):
         """batch (dict of device tensors) -> a FlatBatch laid out like the captured step's static inputs (one device copy
         per step instead of one per field); before the capture, or for another layout, the dict itself"""
-        if self._static is None:
+        if self._static is None or os.environ.get("O3D_FLAT_BATCH", "1") == "0":      # (A/B switch)
             return batch
         fb = FlatBatch({k: v for k, v in batch.items() if k not in self._static.extra_keys},
                        {k: (self._static[k].shape, self._static[k].dtype) for k in self._static.extra_keys})

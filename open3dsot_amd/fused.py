@@ -49,6 +49,7 @@ capi.register("o3d_mlp_conv_wgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
 
 _l = ctypes.c_long
 capi.register("o3d_compact_build", [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_group_dw0_xyz", [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _l, _i, _vp, _vp, _vp])
 capi.register("o3d_compact_build2", [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_group_expand_c", [_vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _l, _vp, _vp, _vp, _vp])
 POOL_BWD_SPLIT = 8      # O3D_POOL_BWD_SPLIT of include/o3dsot.h
@@ -522,6 +523,7 @@ class FusedGroupedMLP(torch.autograd.Function):
 
 import os as _os
 _COMPACT = {"on": True}
+_DW0_FAST = {"on": _os.environ.get("O3D_DW0_FAST", "1") != "0"}       # xyz-only layer 0: dW0 straight from the columns (A/B switch)
 _COMPACT2 = {"on": _os.environ.get("O3D_COMPACT2", "1") != "0"}      # paired compaction in 3 launches (A/B switch)
 _SIDE = {}
 _USE_SIDE = {"on": _os.environ.get("O3D_SIDE_STREAM", "0") == "1"}
@@ -791,6 +793,17 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                 coef[4].zero_()
             grads[3 * l + 1], grads[3 * l + 2] = coef[0, 0], coef[1, 0]      # summed over the segments by the kernel
             A = (coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr())
+            if l == 0 and _DW0_FAST["on"] and C == 0 and nxyz == 3 and not (want_xyz or want_feats) and dN is not None:
+                # xyz-only layer 0, nobody wants the input gradient (SA level 0): dW0 straight from the columns, no list
+                # sums, no K = 3 GEMM, no centre term (csrc/compact.hip::dw0_xyz_kernel)
+                part0 = torch.empty((ldp // 256, Cout, 3), device=dev, dtype=f32)
+                dW = torch.empty((Cout, 3), device=dev, dtype=f32)
+                _call("group_dw0", 0.0, lib.o3d_group_dw0_xyz, dN.data_ptr(), Ys[0].data_ptr(), ldp, A[0], A[1], A[2],
+                      gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), X0n.data_ptr(), ldz, centers.data_ptr(), meta.data_ptr(),
+                      start1, Cout, part0.data_ptr(), dW.data_ptr(), st)
+                keep += [dN, coef, part0]
+                grads[0] = dW
+                continue
             if l == 0:
                 S = torch.empty((Cout, ldz), device=dev, dtype=f32)
                 T = torch.empty((Cout, nballs), device=dev, dtype=f32) if nxyz else None

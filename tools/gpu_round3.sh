@@ -38,7 +38,7 @@ if has qbench; then
   tail -2 $OUT/bench.err | cut -c1-300
 fi
 for p in $PARTS; do case "$p" in ab:*)
-  bash tools/ab.sh "${p#ab:}" 2 > $OUT/ab_$(echo "${p#ab:}" | tr -c 'A-Za-z0-9_=' '_').txt 2>&1; cat $OUT/ab_$(echo "${p#ab:}" | tr -c 'A-Za-z0-9_=' '_').txt | tail -3 ;;
+  bash tools/ab.sh "$(echo "${p#ab:}" | tr '+' ' ')" 2 > $OUT/ab_$(echo "${p#ab:}" | tr -c 'A-Za-z0-9_=' '_').txt 2>&1; cat $OUT/ab_$(echo "${p#ab:}" | tr -c 'A-Za-z0-9_=' '_').txt | tail -3 ;;
 esac; done
 if has trace; then
   cd /tmp
