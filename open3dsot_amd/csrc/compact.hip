@@ -796,7 +796,7 @@ __global__ __launch_bounds__(256) void dw0_xyz_kernel(const float* __restrict__ 
             float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const float dy = fmaf(k1, dv[t], wv[t] * fmaf(k2, yv[t], k3));
+                const float dy = wv[t] != 0.f ? fmaf(k1, dv[t], wv[t] * fmaf(k2, yv[t], k3)) : 0.f;
                 s0 = fmaf(dy, rel[t][0], s0); s1 = fmaf(dy, rel[t][1], s1); s2 = fmaf(dy, rel[t][2], s2);
             }
             acc[i][0] = s0; acc[i][1] = s1; acc[i][2] = s2;
