@@ -315,6 +315,13 @@ int o3d_pool_fwd_c(const float* Y, long ldp, const float* scale, const float* sh
                    const int32_t* ball_cnt, int B, int C, int npoint0, int npoint1, float* out, int32_t* argq,
                    float* yarg, void* stream);
 
+/* o3d_pool_fwd_c with the tile transposed through LDS (lane = channel, a wave walks one ball's columns: no idle lanes for
+ * the small balls the distinct-neighbour layout produces).  cball (ldp) = ball of every column, meta = the live counts of
+ * o3d_compact_build; C % 64 == 0, nsample <= 32 (else O3D_EINVAL: use o3d_pool_fwd_c).  Same results. */
+int o3d_pool_fwd_ct(const float* Y, long ldp, const float* scale, const float* shift, const int32_t* ball_off,
+                    const int32_t* ball_cnt, const int32_t* cball, const int32_t* meta, long start1, int B, int C,
+                    int npoint0, int npoint1, int nsample, float* out, int32_t* argq, float* yarg, void* stream);
+
 /* Backward of the pool: D (C,ldp) = dense class-sum gradient (zero on live columns, D[c,argq] = dOut where
  * out > 0) and the BatchNorm-backward partials of the pooled layer, O3D_POOL_BWD_SPLIT rows per segment:
  * part [nseg][O3D_POOL_BWD_SPLIT][2][C]. */

@@ -279,6 +279,70 @@ __global__ __launch_bounds__(256) void pool_c_kernel(const float* __restrict__ Y
     }
 }
 
+// The same pooling with the tile TRANSPOSED through LDS (round 3).  pool_c_kernel gives every ball 8 lanes x 4 clamped
+// loads per channel -- 32 slots for a ball that holds ~10 distinct neighbours on the tracker crops: the SQ counters show it
+// issue-bound (30 % active, 16 % waiting for memory), two thirds of the lane-operations spent on clamped duplicates.
+// Here a workgroup loads a (64 channels) x (256 + 32 columns) tile of Y with coalesced float4 rows into LDS, then
+// lane = channel and a wave walks ONE ball's columns at a time (a wave-uniform trip count, no idle lanes): one ds_read, one
+// fma and a compare / select per element.  A ball belongs to the 256-column chunk its first column lies in (it may run up
+// to 31 columns into the next chunk: the tile is 288 wide).  Strict `>` over ascending columns keeps the first maximum,
+// as pool_c_kernel does.  C % 64 == 0, balls of at most 32 columns.
+constexpr int PT_CH = 64, PT_COLS = 256, PT_OVER = 32, PT_LD = PT_COLS + PT_OVER + 1;     // odd stride: conflict-free
+
+__global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y, long ldp,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     const int32_t* __restrict__ ball_off,
+                                                     const int32_t* __restrict__ ball_cnt,
+                                                     const int32_t* __restrict__ cball,
+                                                     const int32_t* __restrict__ meta, long start1, int C,
+                                                     int seg1_ball, int np0, int np1, int nballs,
+                                                     float* __restrict__ out, int32_t* __restrict__ argq,
+                                                     float* __restrict__ yarg) {
+    extern __shared__ float pt_tile[];                  // [PT_CH][PT_LD]
+    const long q0 = (long)blockIdx.x * PT_COLS;
+    const int seg = (start1 > 0 && q0 >= start1) ? 1 : 0;
+    const long sbase = seg ? start1 : 0;
+    if (q0 - sbase >= meta[4 * seg]) return;            // dead chunk
+    const long qend = sbase + meta[4 * seg + 1];        // one past the segment's last real column
+    if (q0 >= qend) return;                             // (cannot happen: the rounding is to 256, like the chunks)
+    const int c0 = blockIdx.y * PT_CH;
+    // balls that START in this chunk: [bfirst, blast]
+    int bfirst = cball[q0];
+    if (ball_off[bfirst] < q0) ++bfirst;
+    const long qlast = (q0 + PT_COLS < qend ? q0 + PT_COLS : qend) - 1;
+    const int blast = cball[qlast];
+    // ---- tile: rows c0 .. c0+63, columns q0 .. q0+287 (clamped into the buffer), coalesced float4 along the columns
+    constexpr int F4 = (PT_COLS + PT_OVER) / 4;         // 72 float4 per row
+    for (int i = threadIdx.x; i < PT_CH * F4; i += 256) {
+        const int r = i / F4, f = i - r * F4;
+        long q = q0 + 4 * f;
+        if (q + 4 > ldp) q = ldp - 4;                    // beyond the buffer: columns no ball of this chunk reaches
+        const float4 v = *reinterpret_cast<const float4*>(&Y[(long)(c0 + r) * ldp + q]);
+        float* d = &pt_tile[r * PT_LD + 4 * f];
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = c0 + lane;
+    const float sc = scale[seg * C + c], sf = shift[seg * C + c];
+    __syncthreads();
+    const float* row = &pt_tile[lane * PT_LD];
+    for (int b = bfirst + wave; b <= blast; b += 4) {
+        const int bu = __builtin_amdgcn_readfirstlane(b);
+        const int off = ball_off[bu], cnt = ball_cnt[bu];
+        const int rel = (int)(off - q0);
+        float best = -INFINITY, yb = 0.f;
+        int bq = 0x7fffffff;
+        for (int k = 0; k < cnt; ++k) {
+            const float w = row[rel + k];
+            const float n = fmaf(w, sc, sf);
+            if (n > best) { best = n; bq = off + k; yb = w; }
+        }
+        const long o = pool_index(c, bu, C, seg1_ball, np0, np1);
+        out[o] = fmaxf(best, 0.f);
+        if (argq) { argq[o] = bq; yarg[o] = yb; }
+    }
+}
+
 // dense gradient of the pooled layer: zero the live columns, then one value per (c, ball)
 __global__ __launch_bounds__(256) void zero_cols_kernel(float* __restrict__ D, long ldp,
                                                         const int32_t* __restrict__ meta, long start1) {
@@ -987,6 +1051,26 @@ extern "C" int o3d_pool_fwd_c(const float* Y, long ldp, const float* scale, cons
     constexpr int POOL_CH = 8;
     hipLaunchKernelGGL(pool_c_kernel<8>, dim3(o3d_cdiv(nballs, 32), o3d_cdiv(C, POOL_CH)), dim3(256), 0,
                        o3d_stream(stream), Y, ldp, scale, shift, ball_off, ball_cnt, C, seg1_ball, npoint0,
+                       npoint1 > 0 ? npoint1 : npoint0, nballs, out, argq, yarg);
+    return o3d_launch_status();
+}
+
+// o3d_pool_fwd_c on the LDS-transposed tile (pool_t_kernel): additionally needs the column -> ball map and the live
+// counts; C % 64 == 0 and balls of at most 32 columns (nsample <= 32), else O3D_EINVAL (use o3d_pool_fwd_c)
+extern "C" int o3d_pool_fwd_ct(const float* Y, long ldp, const float* scale, const float* shift, const int32_t* ball_off,
+                               const int32_t* ball_cnt, const int32_t* cball, const int32_t* meta, long start1, int B, int C,
+                               int npoint0, int npoint1, int nsample, float* out, int32_t* argq, float* yarg, void* stream) {
+    if (!Y || !scale || !shift || !ball_off || !ball_cnt || !cball || !meta || !out || B <= 0 || C <= 0 || C % PT_CH != 0 ||
+        npoint0 <= 0 || npoint1 < 0 || nsample < 1 || nsample > PT_OVER || (argq && !yarg) || ldp < PT_COLS + PT_OVER ||
+        ldp % PT_COLS != 0 || start1 < 0 || start1 % PT_COLS != 0)
+        return O3D_EINVAL;
+    const int seg1_ball = B * npoint0, nballs = B * (npoint0 + npoint1);
+    const size_t lds = sizeof(float) * PT_CH * PT_LD;
+    static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_t_kernel),
+                                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+    if (!attr_ok) return O3D_ELAUNCH;
+    hipLaunchKernelGGL(pool_t_kernel, dim3((unsigned)(ldp / PT_COLS), C / PT_CH), dim3(256), lds, o3d_stream(stream), Y, ldp,
+                       scale, shift, ball_off, ball_cnt, cball, meta, start1, C, seg1_ball, npoint0,
                        npoint1 > 0 ? npoint1 : npoint0, nballs, out, argq, yarg);
     return o3d_launch_status();
 }

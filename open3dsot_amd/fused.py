@@ -61,6 +61,7 @@ capi.register("o3d_group_reduce_gather", [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp,
 capi.register("o3d_pack_points", [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp])
 capi.register("o3d_center_term", [_vp, _vp, _i, _i, _i, _vp, _vp])
 capi.register("o3d_pool_fwd_c", [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
+capi.register("o3d_pool_fwd_ct", [_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_bwd_c", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _l, _vp, _vp, _vp])
 capi.register("o3d_pool_bwd_pk", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_dgrad_cp", [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _l, _i, _vp, _vp, _vp,
@@ -523,6 +524,7 @@ class FusedGroupedMLP(torch.autograd.Function):
 
 import os as _os
 _COMPACT = {"on": True}
+_POOL_T = {"on": _os.environ.get("O3D_POOL_T", "1") != "0"}           # pool forward on the LDS-transposed tile (A/B switch)
 _DW0_FAST = {"on": _os.environ.get("O3D_DW0_FAST", "1") != "0"}       # xyz-only layer 0: dW0 straight from the columns (A/B switch)
 _COMPACT2 = {"on": _os.environ.get("O3D_COMPACT2", "1") != "0"}      # paired compaction in 3 launches (A/B switch)
 _SIDE = {}
@@ -692,8 +694,14 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         argq = torch.empty((nballs * Cl,), device=dev, dtype=i32) if need_bwd else None
         yarg = torch.empty((nballs * Cl,), device=dev, dtype=f32) if need_bwd else None
         np1 = npoints[1] if nseg == 2 else 0
-        _call("pool_fwd", 0.0, lib.o3d_pool_fwd_c, Ys[-1].data_ptr(), ldp, scales[-1].data_ptr(), shifts[-1].data_ptr(),
-              ball_off.data_ptr(), ball_cnt.data_ptr(), B, Cl, npoints[0], np1, out.data_ptr(), _ptr(argq), _ptr(yarg), st)
+        if _POOL_T["on"] and Cl % 64 == 0 and ns <= 32 and ldp >= 288:
+            # lane = channel, a wave per ball over an LDS-transposed tile (csrc/compact.hip::pool_t_kernel)
+            _call("pool_fwd", 0.0, lib.o3d_pool_fwd_ct, Ys[-1].data_ptr(), ldp, scales[-1].data_ptr(), shifts[-1].data_ptr(),
+                  ball_off.data_ptr(), ball_cnt.data_ptr(), cball.data_ptr(), meta.data_ptr(), start1, B, Cl, npoints[0], np1,
+                  ns, out.data_ptr(), _ptr(argq), _ptr(yarg), st)
+        else:
+            _call("pool_fwd", 0.0, lib.o3d_pool_fwd_c, Ys[-1].data_ptr(), ldp, scales[-1].data_ptr(), shifts[-1].data_ptr(),
+                  ball_off.data_ptr(), ball_cnt.data_ptr(), B, Cl, npoints[0], np1, out.data_ptr(), _ptr(argq), _ptr(yarg), st)
         if need_bwd:
             ctx.cfg = cfg
             ctx.versions = _versions(params)
