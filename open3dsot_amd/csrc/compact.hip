@@ -287,7 +287,7 @@ __global__ __launch_bounds__(256) void pool_c_kernel(const float* __restrict__ Y
 // fma and a compare / select per element.  A ball belongs to the 256-column chunk its first column lies in (it may run up
 // to 31 columns into the next chunk: the tile is 288 wide).  Strict `>` over ascending columns keeps the first maximum,
 // as pool_c_kernel does.  C % 64 == 0, balls of at most 32 columns.
-constexpr int PT_CH = 64, PT_COLS = 256, PT_OVER = 32, PT_LD = PT_COLS + PT_OVER + 1;     // odd stride: conflict-free
+constexpr int PT_CH = 64, PT_COLS = 256, PT_OVER = 32, PT_LD = PT_COLS + PT_OVER + 3;     // odd stride: conflict-free; +3: the 4-wide reads
 
 __global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y, long ldp,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
@@ -313,13 +313,26 @@ __global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y
     const int blast = cball[qlast];
     // ---- tile: rows c0 .. c0+63, columns q0 .. q0+287 (clamped into the buffer), coalesced float4 along the columns
     constexpr int F4 = (PT_COLS + PT_OVER) / 4;         // 72 float4 per row
-    for (int i = threadIdx.x; i < PT_CH * F4; i += 256) {
-        const int r = i / F4, f = i - r * F4;
-        long q = q0 + 4 * f;
-        if (q + 4 > ldp) q = ldp - 4;                    // beyond the buffer: columns no ball of this chunk reaches
-        const float4 v = *reinterpret_cast<const float4*>(&Y[(long)(c0 + r) * ldp + q]);
-        float* d = &pt_tile[r * PT_LD + 4 * f];
-        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    constexpr int NLD = PT_CH * F4 / 256;               // 18 float4 per thread: ALL in flight before the first LDS store
+    static_assert(PT_CH * F4 % 256 == 0, "tile loads must divide evenly over the workgroup");
+    {                                                   // (a load -> wait -> store loop was 18 exposed HBM latencies per tile)
+        float4 v[NLD];
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            const int r = i / F4, f = i - r * F4;
+            long q = q0 + 4 * f;
+            if (q + 4 > ldp) q = ldp - 4;                // beyond the buffer: columns no ball of this chunk reaches
+            v[u] = *reinterpret_cast<const float4*>(&Y[(long)(c0 + r) * ldp + q]);
+        }
+        __builtin_amdgcn_sched_barrier(0);              // (the scheduler otherwise sinks the stores between the loads)
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = threadIdx.x + 256 * u;
+            const int r = i / F4, f = i - r * F4;
+            float* d = &pt_tile[r * PT_LD + 4 * f];
+            d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = c0 + lane;
@@ -332,10 +345,13 @@ __global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y
         const int rel = (int)(off - q0);
         float best = -INFINITY, yb = 0.f;
         int bq = 0x7fffffff;
-        for (int k = 0; k < cnt; ++k) {
-            const float w = row[rel + k];
-            const float n = fmaf(w, sc, sf);
-            if (n > best) { best = n; bq = off + k; yb = w; }
+        for (int k = 0; k < cnt; k += 4) {              // four LDS reads in flight (within the row: rel + k + 3 <= 290)
+            const float w0 = row[rel + k], w1 = row[rel + k + 1], w2 = row[rel + k + 2], w3 = row[rel + k + 3];
+            const float n0 = fmaf(w0, sc, sf), n1 = fmaf(w1, sc, sf), n2 = fmaf(w2, sc, sf), n3 = fmaf(w3, sc, sf);
+            if (n0 > best) { best = n0; bq = off + k; yb = w0; }
+            if (k + 1 < cnt && n1 > best) { best = n1; bq = off + k + 1; yb = w1; }
+            if (k + 2 < cnt && n2 > best) { best = n2; bq = off + k + 2; yb = w2; }
+            if (k + 3 < cnt && n3 > best) { best = n3; bq = off + k + 3; yb = w3; }
         }
         const long o = pool_index(c, bu, C, seg1_ball, np0, np1);
         out[o] = fmaxf(best, 0.f);
