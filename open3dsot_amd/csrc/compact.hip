@@ -298,7 +298,9 @@ __global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y
                                                      int seg1_ball, int np0, int np1, int nballs,
                                                      float* __restrict__ out, int32_t* __restrict__ argq,
                                                      float* __restrict__ yarg) {
-    extern __shared__ float pt_tile[];                  // [PT_CH][PT_LD]
+    extern __shared__ float pt_tile[];                  // [PT_CH][PT_LD], then the chunk's ball table: off[256], cnt[256]
+    int* pt_off = reinterpret_cast<int*>(pt_tile + PT_CH * PT_LD);
+    int* pt_cnt = pt_off + PT_COLS;
     const long q0 = (long)blockIdx.x * PT_COLS;
     const int seg = (start1 > 0 && q0 >= start1) ? 1 : 0;
     const long sbase = seg ? start1 : 0;
@@ -306,17 +308,21 @@ __global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y
     const long qend = sbase + meta[4 * seg + 1];        // one past the segment's last real column
     if (q0 >= qend) return;                             // (cannot happen: the rounding is to 256, like the chunks)
     const int c0 = blockIdx.y * PT_CH;
-    // balls that START in this chunk: [bfirst, blast]
+    // balls that START in this chunk: [bfirst, blast] (at most 256: one per column)
     int bfirst = cball[q0];
     if (ball_off[bfirst] < q0) ++bfirst;
     const long qlast = (q0 + PT_COLS < qend ? q0 + PT_COLS : qend) - 1;
     const int blast = cball[qlast];
-    // ---- tile: rows c0 .. c0+63, columns q0 .. q0+287 (clamped into the buffer), coalesced float4 along the columns
+    const int nb = blast - bfirst + 1;
+    // ---- tile: rows c0 .. c0+63, columns q0 .. q0+287 (clamped into the buffer), coalesced float4 along the columns;
+    // the ball table of the chunk rides along (a per-ball global load inside the walk below was a ~1 us latency per ball)
     constexpr int F4 = (PT_COLS + PT_OVER) / 4;         // 72 float4 per row
     constexpr int NLD = PT_CH * F4 / 256;               // 18 float4 per thread: ALL in flight before the first LDS store
     static_assert(PT_CH * F4 % 256 == 0, "tile loads must divide evenly over the workgroup");
     {                                                   // (a load -> wait -> store loop was 18 exposed HBM latencies per tile)
         float4 v[NLD];
+        const int bt = bfirst + ((int)threadIdx.x < nb ? (int)threadIdx.x : (nb > 0 ? nb - 1 : 0));
+        const int bo = nb > 0 ? ball_off[bt] : 0, bc = nb > 0 ? ball_cnt[bt] : 0;
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int i = threadIdx.x + 256 * u;
@@ -333,15 +339,20 @@ __global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y
             float* d = &pt_tile[r * PT_LD + 4 * f];
             d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
         }
+        pt_off[threadIdx.x] = bo;
+        pt_cnt[threadIdx.x] = bc;
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = c0 + lane;
     const float sc = scale[seg * C + c], sf = shift[seg * C + c];
+    // pooled tensors: (B, C, npoint) blocks per segment; this lane's channel row of cloud b starts at obase(b)
+    const int np = seg ? np1 : np0;
+    const long segbase = seg ? (long)seg1_ball * C : 0;
+    const int ball0 = seg ? seg1_ball : 0;
     __syncthreads();
     const float* row = &pt_tile[lane * PT_LD];
-    for (int b = bfirst + wave; b <= blast; b += 4) {
-        const int bu = __builtin_amdgcn_readfirstlane(b);
-        const int off = ball_off[bu], cnt = ball_cnt[bu];
+    for (int jl = wave; jl < nb; jl += 4) {
+        const int off = pt_off[jl], cnt = pt_cnt[jl];   // LDS broadcasts
         const int rel = (int)(off - q0);
         float best = -INFINITY, yb = 0.f;
         int bq = 0x7fffffff;
@@ -353,7 +364,9 @@ __global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y
             if (k + 2 < cnt && n2 > best) { best = n2; bq = off + k + 2; yb = w2; }
             if (k + 3 < cnt && n3 > best) { best = n3; bq = off + k + 3; yb = w3; }
         }
-        const long o = pool_index(c, bu, C, seg1_ball, np0, np1);
+        const int local = bfirst + jl - ball0;
+        const int b = local / np, j = local - b * np;
+        const long o = segbase + ((long)b * C + c) * np + j;
         out[o] = fmaxf(best, 0.f);
         if (argq) { argq[o] = bq; yarg[o] = yb; }
     }
@@ -1081,7 +1094,7 @@ extern "C" int o3d_pool_fwd_ct(const float* Y, long ldp, const float* scale, con
         ldp % PT_COLS != 0 || start1 < 0 || start1 % PT_COLS != 0)
         return O3D_EINVAL;
     const int seg1_ball = B * npoint0, nballs = B * (npoint0 + npoint1);
-    const size_t lds = sizeof(float) * PT_CH * PT_LD;
+    const size_t lds = sizeof(float) * PT_CH * PT_LD + sizeof(int) * 2 * PT_COLS;
     static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_t_kernel),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
     if (!attr_ok) return O3D_ELAUNCH;
