@@ -282,12 +282,14 @@ __global__ __launch_bounds__(256) void pool_c_kernel(const float* __restrict__ Y
 // The same pooling with the tile TRANSPOSED through LDS (round 3).  pool_c_kernel gives every ball 8 lanes x 4 clamped
 // loads per channel -- 32 slots for a ball that holds ~10 distinct neighbours on the tracker crops: the SQ counters show it
 // issue-bound (30 % active, 16 % waiting for memory), two thirds of the lane-operations spent on clamped duplicates.
-// Here a workgroup loads a (64 channels) x (256 + 32 columns) tile of Y with coalesced float4 rows into LDS, then
+// Here a workgroup loads a (64 channels) x (128 + 32 columns) tile of Y with coalesced float4 rows into LDS, then
 // lane = channel and a wave walks ONE ball's columns at a time (a wave-uniform trip count, no idle lanes): one ds_read, one
 // fma and a compare / select per element.  A ball belongs to the 256-column chunk its first column lies in (it may run up
-// to 31 columns into the next chunk: the tile is 288 wide).  Strict `>` over ascending columns keeps the first maximum,
-// as pool_c_kernel does.  C % 64 == 0, balls of at most 32 columns.
-constexpr int PT_CH = 64, PT_COLS = 256, PT_OVER = 32, PT_LD = PT_COLS + PT_OVER + 3;     // odd stride: conflict-free; +3: the 4-wide reads
+// to 31 columns into the next chunk: the tile is 160 wide).  Strict `>` over ascending columns keeps the first maximum,
+// as pool_c_kernel does.  Results leave through a second LDS staging so that the stores run along the ball index.
+// C % 64 == 0, balls of at most 32 columns.
+constexpr int PT_CH = 64, PT_COLS = 128, PT_OVER = 32, PT_LD = PT_COLS + PT_OVER + 3;     // odd stride: conflict-free; +3: the 4-wide reads
+constexpr int PT_RB = 32, PT_RLD = PT_CH + 1;         // balls per output batch; padded row of the result staging
 
 __global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y, long ldp,
                                                      const float* __restrict__ scale, const float* __restrict__ shift,
@@ -298,31 +300,37 @@ __global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y
                                                      int seg1_ball, int np0, int np1, int nballs,
                                                      float* __restrict__ out, int32_t* __restrict__ argq,
                                                      float* __restrict__ yarg) {
-    extern __shared__ float pt_tile[];                  // [PT_CH][PT_LD], then the chunk's ball table: off[256], cnt[256]
+    // LDS: tile [PT_CH][PT_LD] | ball table off / cnt / output base [PT_COLS] each | results [3][PT_RB][PT_RLD]
+    extern __shared__ float pt_tile[];
     int* pt_off = reinterpret_cast<int*>(pt_tile + PT_CH * PT_LD);
     int* pt_cnt = pt_off + PT_COLS;
+    int* pt_ob = pt_cnt + PT_COLS;
+    float* pt_res = reinterpret_cast<float*>(pt_ob + PT_COLS);
     const long q0 = (long)blockIdx.x * PT_COLS;
     const int seg = (start1 > 0 && q0 >= start1) ? 1 : 0;
     const long sbase = seg ? start1 : 0;
     if (q0 - sbase >= meta[4 * seg]) return;            // dead chunk
     const long qend = sbase + meta[4 * seg + 1];        // one past the segment's last real column
-    if (q0 >= qend) return;                             // (cannot happen: the rounding is to 256, like the chunks)
+    if (q0 >= qend) return;                             // only padding columns: no ball starts here
     const int c0 = blockIdx.y * PT_CH;
-    // balls that START in this chunk: [bfirst, blast] (at most 256: one per column)
+    // balls that START in this chunk: [bfirst, blast] (at most PT_COLS: one per column)
     int bfirst = cball[q0];
     if (ball_off[bfirst] < q0) ++bfirst;
     const long qlast = (q0 + PT_COLS < qend ? q0 + PT_COLS : qend) - 1;
     const int blast = cball[qlast];
     const int nb = blast - bfirst + 1;
-    // ---- tile: rows c0 .. c0+63, columns q0 .. q0+287 (clamped into the buffer), coalesced float4 along the columns;
+    const int np = seg ? np1 : np0;
+    const long segbase = seg ? (long)seg1_ball * C : 0;
+    const int ball0 = seg ? seg1_ball : 0;
+    // ---- tile: rows c0 .. c0+63, columns q0 .. q0+159 (clamped into the buffer), coalesced float4 along the columns;
     // the ball table of the chunk rides along (a per-ball global load inside the walk below was a ~1 us latency per ball)
-    constexpr int F4 = (PT_COLS + PT_OVER) / 4;         // 72 float4 per row
-    constexpr int NLD = PT_CH * F4 / 256;               // 18 float4 per thread: ALL in flight before the first LDS store
+    constexpr int F4 = (PT_COLS + PT_OVER) / 4;         // 40 float4 per row
+    constexpr int NLD = PT_CH * F4 / 256;               // 10 float4 per thread: ALL in flight before the first LDS store
     static_assert(PT_CH * F4 % 256 == 0, "tile loads must divide evenly over the workgroup");
-    {                                                   // (a load -> wait -> store loop was 18 exposed HBM latencies per tile)
+    {                                                   // (a load -> wait -> store loop was one exposed HBM latency per row)
         float4 v[NLD];
-        const int bt = bfirst + ((int)threadIdx.x < nb ? (int)threadIdx.x : (nb > 0 ? nb - 1 : 0));
-        const int bo = nb > 0 ? ball_off[bt] : 0, bc = nb > 0 ? ball_cnt[bt] : 0;
+        int bo = 0, bc = 0;
+        if ((int)threadIdx.x < nb) { bo = ball_off[bfirst + threadIdx.x]; bc = ball_cnt[bfirst + threadIdx.x]; }
 #pragma unroll
         for (int u = 0; u < NLD; ++u) {
             const int i = threadIdx.x + 256 * u;
@@ -339,36 +347,57 @@ __global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y
             float* d = &pt_tile[r * PT_LD + 4 * f];
             d[0] = v[u].x; d[1] = v[u].y; d[2] = v[u].z; d[3] = v[u].w;
         }
-        pt_off[threadIdx.x] = bo;
-        pt_cnt[threadIdx.x] = bc;
+        if ((int)threadIdx.x < PT_COLS) {
+            const int local = bfirst + (int)threadIdx.x - ball0;       // pooled tensors: (B, C, npoint) blocks per segment
+            const int b = local / np, j = local - b * np;
+            pt_off[threadIdx.x] = bo;
+            pt_cnt[threadIdx.x] = bc;
+            pt_ob[threadIdx.x] = (int)(segbase + (long)b * C * np + j);   // + c * np: element (c, ball); < 2^31 (nballs*C)
+        }
     }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = c0 + lane;
-    const float sc = scale[seg * C + c], sf = shift[seg * C + c];
-    // pooled tensors: (B, C, npoint) blocks per segment; this lane's channel row of cloud b starts at obase(b)
-    const int np = seg ? np1 : np0;
-    const long segbase = seg ? (long)seg1_ball * C : 0;
-    const int ball0 = seg ? seg1_ball : 0;
+    const float sc = scale[seg * C + c0 + lane], sf = shift[seg * C + c0 + lane];
     __syncthreads();
     const float* row = &pt_tile[lane * PT_LD];
-    for (int jl = wave; jl < nb; jl += 4) {
-        const int off = pt_off[jl], cnt = pt_cnt[jl];   // LDS broadcasts
-        const int rel = (int)(off - q0);
-        float best = -INFINITY, yb = 0.f;
-        int bq = 0x7fffffff;
-        for (int k = 0; k < cnt; k += 4) {              // four LDS reads in flight (within the row: rel + k + 3 <= 290)
-            const float w0 = row[rel + k], w1 = row[rel + k + 1], w2 = row[rel + k + 2], w3 = row[rel + k + 3];
-            const float n0 = fmaf(w0, sc, sf), n1 = fmaf(w1, sc, sf), n2 = fmaf(w2, sc, sf), n3 = fmaf(w3, sc, sf);
-            if (n0 > best) { best = n0; bq = off + k; yb = w0; }
-            if (k + 1 < cnt && n1 > best) { best = n1; bq = off + k + 1; yb = w1; }
-            if (k + 2 < cnt && n2 > best) { best = n2; bq = off + k + 2; yb = w2; }
-            if (k + 3 < cnt && n3 > best) { best = n3; bq = off + k + 3; yb = w3; }
+    const int wj = threadIdx.x & 31, wc = threadIdx.x >> 5;      // write-out: lane bits 0-4 = ball of the batch, 8 channel lanes
+    for (int j0 = 0; j0 < nb; j0 += PT_RB) {
+        // ---- this wave's 8 balls of the batch: lane = channel, a wave-uniform walk over the ball's columns
+#pragma unroll 1
+        for (int t = 0; t < PT_RB / 4; ++t) {
+            const int jl = j0 + wave * (PT_RB / 4) + t;
+            if (jl >= nb) break;
+            const int off = pt_off[jl], cnt = pt_cnt[jl];        // LDS broadcasts
+            const int rel = (int)(off - q0);
+            float best = -INFINITY, yb = 0.f;
+            int bq = 0x7fffffff;
+            for (int k = 0; k < cnt; k += 4) {          // four LDS reads in flight (within the row: rel + k + 3 <= 162)
+                const float w0 = row[rel + k], w1 = row[rel + k + 1], w2 = row[rel + k + 2], w3 = row[rel + k + 3];
+                const float n0 = fmaf(w0, sc, sf), n1 = fmaf(w1, sc, sf), n2 = fmaf(w2, sc, sf), n3 = fmaf(w3, sc, sf);
+                if (n0 > best) { best = n0; bq = off + k; yb = w0; }
+                if (k + 1 < cnt && n1 > best) { best = n1; bq = off + k + 1; yb = w1; }
+                if (k + 2 < cnt && n2 > best) { best = n2; bq = off + k + 2; yb = w2; }
+                if (k + 3 < cnt && n3 > best) { best = n3; bq = off + k + 3; yb = w3; }
+            }
+            float* r = &pt_res[(jl - j0) * PT_RLD + lane];
+            r[0] = fmaxf(best, 0.f);
+            r[PT_RB * PT_RLD] = __int_as_float(bq);
+            r[2 * PT_RB * PT_RLD] = yb;
         }
-        const int local = bfirst + jl - ball0;
-        const int b = local / np, j = local - b * np;
-        const long o = segbase + ((long)b * C + c) * np + j;
-        out[o] = fmaxf(best, 0.f);
-        if (argq) { argq[o] = bq; yarg[o] = yb; }
+        __syncthreads();
+        // ---- write-out with lanes along the balls: (B, C, npoint) rows are contiguous in the ball index, so a wave
+        // stores two 128-byte runs per instruction (lane = channel scattered 64 four-byte writes over 64 lines: 16x
+        // the write requests, measured slower than the kernel it replaces)
+        if (j0 + wj < nb) {
+            const int ob = pt_ob[j0 + wj];
+#pragma unroll
+            for (int cc = wc; cc < PT_CH; cc += 8) {
+                const long o = (long)ob + (long)(c0 + cc) * np;
+                const float* r = &pt_res[wj * PT_RLD + cc];
+                out[o] = r[0];
+                if (argq) { argq[o] = __float_as_int(r[PT_RB * PT_RLD]); yarg[o] = r[2 * PT_RB * PT_RLD]; }
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1094,7 +1123,7 @@ extern "C" int o3d_pool_fwd_ct(const float* Y, long ldp, const float* scale, con
         ldp % PT_COLS != 0 || start1 < 0 || start1 % PT_COLS != 0)
         return O3D_EINVAL;
     const int seg1_ball = B * npoint0, nballs = B * (npoint0 + npoint1);
-    const size_t lds = sizeof(float) * PT_CH * PT_LD + sizeof(int) * 2 * PT_COLS;
+    const size_t lds = sizeof(float) * (PT_CH * PT_LD + 3 * PT_RB * PT_RLD) + sizeof(int) * 3 * PT_COLS;
     static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_t_kernel),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
     if (!attr_ok) return O3D_ELAUNCH;
