@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void pool_c_kernel(const float* __restrict__ Y
 // to 31 columns into the next chunk: the tile is 160 wide).  Strict `>` over ascending columns keeps the first maximum,
 // as pool_c_kernel does.  Results leave through a second LDS staging so that the stores run along the ball index.
 // C % 64 == 0, balls of at most 32 columns.
-constexpr int PT_CH = 64, PT_COLS = 128, PT_OVER = 32, PT_LD = PT_COLS + PT_OVER + 3;     // odd stride: conflict-free; +3: the 4-wide reads
+constexpr int PT_CH = 32, PT_COLS = 128, PT_OVER = 32, PT_LD = PT_COLS + PT_OVER + 3;     // odd stride: conflict-free; +3: the 4-wide reads
 constexpr int PT_RB = 32, PT_RLD = PT_CH + 1;         // balls per output batch; padded row of the result staging
 
 __global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y, long ldp,
@@ -355,18 +355,23 @@ __global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y
             pt_ob[threadIdx.x] = (int)(segbase + (long)b * C * np + j);   // + c * np: element (c, ball); < 2^31 (nballs*C)
         }
     }
+    // lane = (ball of a pair, channel): 32 channels per workgroup keep four workgroups resident per CU (a 64-channel tile
+    // with its staging is 68 KB: two), each half-wave walks its own ball
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const float sc = scale[seg * C + c0 + lane], sf = shift[seg * C + c0 + lane];
+    const int ch = lane & (PT_CH - 1), half = lane / PT_CH;
+    constexpr int BPW = 64 / PT_CH;                     // balls a wave walks at a time
+    const float sc = scale[seg * C + c0 + ch], sf = shift[seg * C + c0 + ch];
     __syncthreads();
-    const float* row = &pt_tile[lane * PT_LD];
+    const float* row = &pt_tile[ch * PT_LD];
     const int wj = threadIdx.x & 31, wc = threadIdx.x >> 5;      // write-out: lane bits 0-4 = ball of the batch, 8 channel lanes
     for (int j0 = 0; j0 < nb; j0 += PT_RB) {
         // ---- this wave's 8 balls of the batch: lane = channel, a wave-uniform walk over the ball's columns
 #pragma unroll 1
-        for (int t = 0; t < PT_RB / 4; ++t) {
-            const int jl = j0 + wave * (PT_RB / 4) + t;
-            if (jl >= nb) break;
-            const int off = pt_off[jl], cnt = pt_cnt[jl];        // LDS broadcasts
+        for (int t = 0; t < PT_RB / 4; t += BPW) {
+            const int jl = j0 + wave * (PT_RB / 4) + t + half;
+            if (jl - half >= nb) break;
+            const bool has = jl < nb;
+            const int off = has ? pt_off[jl] : 0, cnt = has ? pt_cnt[jl] : 0;        // LDS broadcasts
             const int rel = (int)(off - q0);
             float best = -INFINITY, yb = 0.f;
             int bq = 0x7fffffff;
@@ -378,10 +383,12 @@ __global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y
                 if (k + 2 < cnt && n2 > best) { best = n2; bq = off + k + 2; yb = w2; }
                 if (k + 3 < cnt && n3 > best) { best = n3; bq = off + k + 3; yb = w3; }
             }
-            float* r = &pt_res[(jl - j0) * PT_RLD + lane];
-            r[0] = fmaxf(best, 0.f);
-            r[PT_RB * PT_RLD] = __int_as_float(bq);
-            r[2 * PT_RB * PT_RLD] = yb;
+            if (has) {
+                float* r = &pt_res[(jl - j0) * PT_RLD + ch];
+                r[0] = fmaxf(best, 0.f);
+                r[PT_RB * PT_RLD] = __int_as_float(bq);
+                r[2 * PT_RB * PT_RLD] = yb;
+            }
         }
         __syncthreads();
         // ---- write-out with lanes along the balls: (B, C, npoint) rows are contiguous in the ball index, so a wave
