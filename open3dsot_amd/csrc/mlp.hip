@@ -275,12 +275,11 @@ __global__ __launch_bounds__(BM * 2) void conv_fwd_kernel(FwdArgs a) {
 // finalize kernels: FIN_CH channels x FIN_SL partial-list slices per 256-thread workgroup
 // (round 3 also tried folding the FIN_SL slices with fp64 butterflies instead of the serial LDS walk and fetching the
 // per-channel constants up front: +0.08 ms per step on the same box -- 16 ds_bpermute round trips per lane cost more than
-// 128 pipelined LDS reads by four lanes.  Not kept.)
+// 128 pipelined LDS reads by four lanes.  Not kept.  Likewise requesting the per-channel constants first and the first
+// partial rows beside the live count instead of behind it (the kernel looks like a chain of dependent global accesses):
+// 6.04 vs 6.04 / 6.06 vs 5.97 ms per step, 8.6 us per launch in the trace -- no gain, removed.)
 #ifndef O3D_FIN_FASTMATH
 #define O3D_FIN_FASTMATH 1
-#endif
-#ifndef O3D_FIN_EARLY
-#define O3D_FIN_EARLY 1
 #endif
 constexpr int FIN_CH = 4, FIN_SL = 64;      // measured: 2x128 and 8x32 are both slower (0.24 / 0.36 vs 0.17 ms per step)
 
@@ -306,52 +305,12 @@ __device__ __forceinline__ void bn_finalize_body(const BnFinArgs& a, const int b
     const int cl = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
     const int c = bx * FIN_CH + cl;
     const int nseg = a.nparts1 > 0 ? 2 : 1;
-#if O3D_FIN_EARLY
-    // The kernel is a chain of dependent global accesses (live count -> partial rows -> per-channel constants -> stores),
-    // each a ~2 us round trip behind the producing GEMM's write-back.  The chain is cut twice: the finalising thread's
-    // constants are requested before anything else, and the first FIN_EB partial rows per thread are requested
-    // UNCONDITIONALLY (clamped into the buffer) beside the live count instead of behind it.
-    const bool fin = sl == 0 && c < a.C;
-    float pg = 1.f, pb = 0.f, prm = 0.f, prv = 0.f, pcs[2] = {0.f, 0.f};
-    if (fin) {
-        if (a.gamma) pg = a.gamma[c];
-        if (a.beta) pb = a.beta[c];
-        if (a.running_mean && a.momentum >= 0.f) { prm = a.running_mean[c]; prv = a.running_var[c]; }
-        if (a.stat_c) { pcs[0] = a.stat_c[c]; if (nseg == 2) pcs[1] = a.stat_c[a.C + c]; }
-    }
-#endif
     for (int seg = 0; seg < nseg; ++seg) {
         const float* part = a.part + (seg ? (long)a.nparts * 2 * a.C : 0);
         const double count = seg ? a.count1 : a.count;
         const int off = seg * a.C;
         double s = 0.0, q = 0.0;
         int nparts = seg ? a.nparts1 : a.nparts;
-#if O3D_FIN_EARLY
-        constexpr int FIN_EB = 4;
-        const int nhost = nparts;
-        const int live_raw = a.meta ? a.meta[4 * seg] : 0;
-        float es[FIN_EB], eq[FIN_EB];
-        if (c < a.C) {
-#pragma unroll
-            for (int i = 0; i < FIN_EB; ++i) {
-                int t = sl + i * FIN_SL;
-                t = t < nhost ? t : nhost - 1;
-                es[i] = part[((long)t * 2 + 0) * a.C + c];
-                eq[i] = part[((long)t * 2 + 1) * a.C + c];
-            }
-        }
-        if (a.meta) { const int live = live_raw / a.tile; nparts = live < nparts ? live : nparts; }
-        if (c < a.C) {
-#pragma unroll
-            for (int i = 0; i < FIN_EB; ++i)
-                if (sl + i * FIN_SL < nparts) { s += (double)es[i]; q += (double)eq[i]; }
-#pragma unroll 8
-            for (int t = sl + FIN_EB * FIN_SL; t < nparts; t += FIN_SL) {
-                s += (double)part[((long)t * 2 + 0) * a.C + c];
-                q += (double)part[((long)t * 2 + 1) * a.C + c];
-            }
-        }
-#else
         if (a.meta) { const int live = a.meta[4 * seg] / a.tile; nparts = live < nparts ? live : nparts; }
         if (c < a.C) {
 #pragma unroll 8
@@ -360,7 +319,6 @@ __device__ __forceinline__ void bn_finalize_body(const BnFinArgs& a, const int b
                 q += (double)part[((long)t * 2 + 1) * a.C + c];
             }
         }
-#endif
         if (seg) __syncthreads();
         sh[0][sl][cl] = s;
         sh[1][sl][cl] = q;
@@ -368,11 +326,7 @@ __device__ __forceinline__ void bn_finalize_body(const BnFinArgs& a, const int b
         if (sl == 0 && c < a.C) {
             s = 0.0; q = 0.0;
             for (int i = 0; i < FIN_SL; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
-#if O3D_FIN_EARLY
-            const double cs = (double)pcs[seg];
-#else
             const double cs = a.stat_c ? (double)a.stat_c[off + c] : 0.0;
-#endif
 #if O3D_FIN_FASTMATH
             // no fp64 division / square root (software sequences of ~40 instructions each, on one lane per channel: measured
             // -0.05 ms per BAT step over the 24 forward finalizes, same-box A/B): v_rsq_f32 + one fp64 Newton step
@@ -391,11 +345,7 @@ __device__ __forceinline__ void bn_finalize_body(const BnFinArgs& a, const int b
             if (var < 0.0) var = 0.0;
             const float invstd = (float)(1.0 / sqrt(var + (double)a.eps));
 #endif
-#if O3D_FIN_EARLY
-            const float g = pg, bt = pb;
-#else
             const float g = a.gamma ? a.gamma[c] : 1.f, bt = a.beta ? a.beta[c] : 0.f;
-#endif
             a.mean[off + c] = (float)mean;
             a.invstd[off + c] = invstd;
             const float sc = g * invstd;
@@ -403,15 +353,8 @@ __device__ __forceinline__ void bn_finalize_body(const BnFinArgs& a, const int b
             a.shift[off + c] = bt - (float)mean * sc;
             if (a.running_mean && a.momentum >= 0.f) {
                 const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-#if O3D_FIN_EARLY
-                prm = (1.f - a.momentum) * prm + a.momentum * (float)mean;      // (segment 1 continues from segment 0's update)
-                prv = (1.f - a.momentum) * prv + a.momentum * (float)unbiased;
-                a.running_mean[c] = prm;
-                a.running_var[c] = prv;
-#else
                 a.running_mean[c] = (1.f - a.momentum) * a.running_mean[c] + a.momentum * (float)mean;
                 a.running_var[c] = (1.f - a.momentum) * a.running_var[c] + a.momentum * (float)unbiased;
-#endif
             }
         }
     }
@@ -577,47 +520,12 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const BnBwdFinArgs& a, cons
     const int c = bx * FIN_CH + cl;
     const int nseg = a.nparts1 > 0 ? 2 : 1;
     double dg = 0.0, db = 0.0;
-#if O3D_FIN_EARLY
-    const bool fin = sl == 0 && c < a.C;               // (see bn_finalize_body)
-    float pg = 1.f, pis[2] = {0.f, 0.f}, pmu[2] = {0.f, 0.f};
-    if (fin) {
-        if (a.gamma) pg = a.gamma[c];
-        pis[0] = a.invstd[c]; pmu[0] = a.mean[c];
-        if (nseg == 2) { pis[1] = a.invstd[a.C + c]; pmu[1] = a.mean[a.C + c]; }
-    }
-#endif
     for (int seg = 0; seg < nseg; ++seg) {
         const float* part = a.part + (seg ? (long)a.nparts * 2 * a.C : 0);
         const double count = seg ? a.count1 : a.count;
         const int off = seg * a.C;
         double s = 0.0, q = 0.0;
         int nparts = seg ? a.nparts1 : a.nparts;
-#if O3D_FIN_EARLY
-        constexpr int FIN_EB = 4;
-        const int nhost = nparts;
-        const int live_raw = a.meta ? a.meta[4 * seg] : 0;
-        float es[FIN_EB], eq[FIN_EB];
-        if (c < a.C) {
-#pragma unroll
-            for (int i = 0; i < FIN_EB; ++i) {
-                int t = sl + i * FIN_SL;
-                t = t < nhost ? t : nhost - 1;
-                es[i] = part[((long)t * 2 + 0) * a.C + c];
-                eq[i] = part[((long)t * 2 + 1) * a.C + c];
-            }
-        }
-        if (a.meta) { const int live = live_raw / a.tile; nparts = live < nparts ? live : nparts; }
-        if (c < a.C) {
-#pragma unroll
-            for (int i = 0; i < FIN_EB; ++i)
-                if (sl + i * FIN_SL < nparts) { s += (double)es[i]; q += (double)eq[i]; }
-#pragma unroll 8
-            for (int t = sl + FIN_EB * FIN_SL; t < nparts; t += FIN_SL) {
-                s += (double)part[((long)t * 2 + 0) * a.C + c];
-                q += (double)part[((long)t * 2 + 1) * a.C + c];
-            }
-        }
-#else
         if (a.meta) { const int live = a.meta[4 * seg] / a.tile; nparts = live < nparts ? live : nparts; }
         if (c < a.C) {
 #pragma unroll 8
@@ -626,7 +534,6 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const BnBwdFinArgs& a, cons
                 q += (double)part[((long)t * 2 + 1) * a.C + c];
             }
         }
-#endif
         if (seg) __syncthreads();
         sh[0][sl][cl] = s;
         sh[1][sl][cl] = q;
@@ -634,13 +541,8 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const BnBwdFinArgs& a, cons
         if (sl == 0 && c < a.C) {
             s = 0.0; q = 0.0;
             for (int i = 0; i < FIN_SL; ++i) { s += sh[0][i][cl]; q += sh[1][i][cl]; }
-#if O3D_FIN_EARLY
-            const double g = (double)pg;
-            const double is = (double)pis[seg], mu = (double)pmu[seg];
-#else
             const double g = a.gamma ? (double)a.gamma[c] : 1.0;
             const double is = (double)a.invstd[off + c], mu = (double)a.mean[off + c];
-#endif
             db += s;
             dg += q * is;
             const double a1 = g * is;
