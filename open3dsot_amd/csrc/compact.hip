@@ -441,7 +441,11 @@ __global__ __launch_bounds__(256) void pool_bwd_partials_c_kernel(const float* _
                                                                   int nballs, int seg1_ball, int np0, int np1,
                                                                   float* __restrict__ part,
                                                                   const int32_t* __restrict__ argq,
-                                                                  float2* __restrict__ pkc) {
+                                                                  float2* __restrict__ pkc,
+                                                                  float* __restrict__ D = nullptr, long ldp = 0) {
+    // D != NULL (round 3): the scatter of the dense gradient D[c, argq] = g rides along -- the same (channel, ball) walk as
+    // the statistics, so the separate pool_scatter_c_kernel launch and its second read of dOut / out are gone (D's live
+    // columns were zeroed by the launch in front of this one)
     __shared__ float sh[2][4];
     const int c = blockIdx.x, seg = blockIdx.y, k = blockIdx.z;
     // pkc (C, nballs + 1): {gradient where out > 0, bits(arg-max column)} per (channel, ball) -- the pooled layer's
@@ -454,8 +458,10 @@ __global__ __launch_bounds__(256) void pool_bwd_partials_c_kernel(const float* _
     float s = 0.f, q = 0.f;
     for (int ball = b0 + threadIdx.x; ball < b1; ball += 256) {
         const long o = pool_index(c, ball, C, seg1_ball, np0, np1);
-        const float g = out[o] > 0.f ? dOut[o] : 0.f;
+        const bool pos = out[o] > 0.f;
+        const float g = pos ? dOut[o] : 0.f;
         if (pkc) pkc[(long)c * (nballs + 1) + ball] = make_float2(g, __int_as_float(argq[o]));
+        if (D && pos) D[(long)c * ldp + argq[o]] = g;
         s += g;
         q += g * (yarg[o] - mu);
     }
@@ -1151,8 +1157,15 @@ extern "C" int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t
     hipStream_t s = o3d_stream(stream);
     const int nseg = npoint1 > 0 ? 2 : 1;
     const int seg1_ball = B * npoint0, nballs = B * (npoint0 + npoint1), np1 = npoint1 > 0 ? npoint1 : npoint0;
+    static const bool fuse = [] { const char* e = getenv("O3D_POOL_BWD_FUSE"); return !e || atoi(e) != 0; }();   // A/B switch
+    if (fuse) {       // zero the live columns, then statistics + scatter in one walk over (channel, ball)
+        hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)o3d_cdiv(ldp, 1024), C), dim3(256), 0, s, D, ldp, meta, start1);
+        hipLaunchKernelGGL(pool_bwd_partials_c_kernel, dim3(C, nseg, POOL_BWD_SPLIT), dim3(256), 0, s, dOut, out, yarg, mean, C,
+                           nballs, seg1_ball, npoint0, np1, part, argq, nullptr, D, ldp);
+        return o3d_launch_status();
+    }
     hipLaunchKernelGGL(pool_bwd_partials_c_kernel, dim3(C, nseg, POOL_BWD_SPLIT), dim3(256), 0, s, dOut, out, yarg, mean, C, nballs,
-                       seg1_ball, npoint0, np1, part, nullptr, nullptr);
+                       seg1_ball, npoint0, np1, part, nullptr, nullptr, nullptr, 0L);
     hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)o3d_cdiv(ldp, 1024), C), dim3(256), 0, s, D, ldp, meta, start1);
     const long total = (long)C * nballs;
     hipLaunchKernelGGL(pool_scatter_c_kernel, dim3(o3d_cdiv(total, 256)), dim3(256), 0, s, dOut, out, argq, C, nballs,
