@@ -282,6 +282,13 @@ int o3d_group_expand_c(const float* Z, long ldz, const int32_t* gp, const int32_
                        const float* centers, const float* W0, int ldw, int C0, const int32_t* meta, long start1,
                        long ldp, float* Y0, float* part, const float* stat_c, void* stream);
 
+/* o3d_group_expand_c for an xyz-only layer 0 (set abstraction level 0: features None) without the per-point GEMM:
+ * Y0[c,q] = W0[c,0:3] . (X3[:, gp[q]] - centers[cball[q]]) -- the relative coordinate first, as pointnet2_utils.py:319-320
+ * computes it; X3 = the packed coordinate operand (3 rows, ldz columns). */
+int o3d_group_expand_c3(const float* X3, long ldz, const int32_t* gp, const int32_t* cball, const float* cw,
+                        const float* centers, const float* W0, int ldw, int C0, const int32_t* meta, long start1, long ldp,
+                        float* Y0, float* part, const float* stat_c, void* stream);
+
 /* Inner layers on the compact layout: forward (BN+ReLU of the producer on load, weighted statistics),
  * data gradient (dY = A1*dN + w*(A2*Y + A3), ReLU mask, statistics; Wt = W^T), weight gradient.
  * tile = columns per wave tile = columns per statistics partial row: o3d_direct_tile(ldp, M, 1). */

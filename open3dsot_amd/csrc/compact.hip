@@ -99,7 +99,10 @@ __global__ __launch_bounds__(256) void compact_fill_kernel(const int32_t* __rest
 // expand: Y0[c,q] = Z[c,gp[q]] - W0[c,0:3].centre[cball[q]], weighted statistics partials
 //   workgroup = 256 columns, 4 waves; wave w takes channels w, w+4, ...; lane = 4 columns
 // ---------------------------------------------------------------------------------------
-template <bool CENTERS>      // compile-time: a run-time `if (centers)` around a load makes the compiler drain vmcnt at the join
+// DIRECT (round 3): an xyz-only layer 0 (SA level 0: no features) needs no per-point GEMM at all --
+// Y0[c,q] = W0[c,0:3].(xyz[gp[q]] - centre[cball[q]]): Z then IS the packed coordinate operand (3 rows), gathered once per
+// column, and the "centre term" carries the whole product (the relative coordinate first, as the reference computes it)
+template <bool CENTERS, bool DIRECT = false>      // compile-time: a run-time `if (centers)` around a load makes the compiler drain vmcnt at the join
 __global__ __launch_bounds__(256) void expand_c_kernel(const float* __restrict__ Z, long ldz,
                                                        const int32_t* __restrict__ gp,
                                                        const int32_t* __restrict__ cball,
@@ -126,6 +129,11 @@ __global__ __launch_bounds__(256) void expand_c_kernel(const float* __restrict__
             const float* c = centers + (long)bb[t] * 3;
             cx[t] = c[0]; cy[t] = c[1]; cz[t] = c[2];
         }
+        if constexpr (DIRECT) {
+            const int ids[4] = {id.x, id.y, id.z, id.w};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) { cx[t] -= Z[ids[t]]; cy[t] -= Z[ldz + ids[t]]; cz[t] -= Z[2 * ldz + ids[t]]; }
+        }
     }
     // channels in groups of EG per wave: all 4*EG gathers in flight first, and the EG x 2 statistics butterflies
     // interleave (one channel at a time the 12 dependent shuffles are a ~300-cycle chain per channel)
@@ -138,8 +146,12 @@ __global__ __launch_bounds__(256) void expand_c_kernel(const float* __restrict__
 #pragma unroll
         for (int g = 0; g < EG; ++g) {
             const int co = g0 + 4 * g < cend ? g0 + 4 * g : cend - 1;
-            const float* z = Z + (long)co * ldz;
-            y[g].x = z[id.x]; y[g].y = z[id.y]; y[g].z = z[id.z]; y[g].w = z[id.w];
+            if constexpr (DIRECT) {
+                y[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                const float* z = Z + (long)co * ldz;
+                y[g].x = z[id.x]; y[g].y = z[id.y]; y[g].z = z[id.z]; y[g].w = z[id.w];
+            }
             // the per-channel constants with the gathers, not between the stores below: a load issued after a store
             // makes the wait for it wait for the store as well (vmcnt counts both on gfx9) -- EG round trips per pass
             w0[g] = w1[g] = w2[g] = 0.f;
@@ -1094,6 +1106,20 @@ extern "C" int o3d_group_expand_c(const float* Z, long ldz, const int32_t* gp, c
     else
         hipLaunchKernelGGL(expand_c_kernel<false>, dim3((unsigned)(ldp / 256), ysplit), dim3(256), 0, o3d_stream(stream), Z,
                            ldz, gp, cball, cw, centers, W0, ldw, C0, meta, start1, ldp, Y0, part, stat_c);
+    return o3d_launch_status();
+}
+
+// o3d_group_expand_c for an xyz-only layer 0 WITHOUT the per-point GEMM: X3 = the packed coordinate operand (3 rows of
+// ldz point columns, scaled like `centers`), Y0[c,q] = W0[c,0:3].(X3[:, gp[q]] - centers[cball[q]])
+extern "C" int o3d_group_expand_c3(const float* X3, long ldz, const int32_t* gp, const int32_t* cball, const float* cw,
+                                   const float* centers, const float* W0, int ldw, int C0, const int32_t* meta,
+                                   long start1, long ldp, float* Y0, float* part, const float* stat_c, void* stream) {
+    if (!X3 || !gp || !cball || !cw || !centers || !W0 || ldw < 3 || !meta || !Y0 || C0 <= 0 || ldp <= 0 ||
+        ldp % 256 != 0 || start1 < 0 || start1 % 256 != 0)
+        return O3D_EINVAL;
+    const int ysplit = C0 >= 128 ? 4 : C0 >= 64 ? 2 : 1;
+    hipLaunchKernelGGL((expand_c_kernel<true, true>), dim3((unsigned)(ldp / 256), ysplit), dim3(256), 0, o3d_stream(stream),
+                       X3, ldz, gp, cball, cw, centers, W0, ldw, C0, meta, start1, ldp, Y0, part, stat_c);
     return o3d_launch_status();
 }
 

@@ -49,6 +49,7 @@ capi.register("o3d_mlp_conv_wgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp,
 
 _l = ctypes.c_long
 capi.register("o3d_compact_build", [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_group_expand_c3", [_vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _l, _vp, _vp, _vp, _vp])
 capi.register("o3d_group_dw0_xyz", [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _l, _vp, _vp, _l, _i, _vp, _vp, _vp])
 capi.register("o3d_compact_build2", [_vp, _i, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_group_expand_c", [_vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _l, _l, _vp, _vp, _vp, _vp])
@@ -524,6 +525,7 @@ class FusedGroupedMLP(torch.autograd.Function):
 
 import os as _os
 _COMPACT = {"on": True}
+_EXPAND3 = {"on": _os.environ.get("O3D_EXPAND3", "1") != "0"}         # xyz-only layer 0 without the per-point GEMM (A/B switch)
 _POOL_T = {"on": _os.environ.get("O3D_POOL_T", "1") != "0"}           # pool forward on the LDS-transposed tile (A/B switch)
 _DW0_FAST = {"on": _os.environ.get("O3D_DW0_FAST", "1") != "0"}       # xyz-only layer 0: dW0 straight from the columns (A/B switch)
 _COMPACT2 = {"on": _os.environ.get("O3D_COMPACT2", "1") != "0"}      # paired compaction in 3 launches (A/B switch)
@@ -636,14 +638,17 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             centers = torch.cat([sg[1].detach().reshape(-1, 3) for sg in segs] + [_const_vec(dev, 3, 0.0).view(1, 3)])
             if not unit:
                 centers = centers * cfg.inv_radius
-        Z = torch.empty((C0, ldz), device=dev, dtype=f32)
         # zero-padded / transposed weight copies come from the device's WeightPrep table (open3dsot_amd/fused_heads.py):
         # inside a tracker forward they were all refreshed by ONE launch, otherwise `get` copies on the spot
         from .fused_heads import prep_for
         prep = prep_for(dev)
-        W0p = prep.get(params[0], C0, Cin0p)
-        _call("conv_fwd_points", 2.0 * Cin0p * C0 * ldz, lib.o3d_mlp_conv_fwd, X0n.data_ptr(), W0p.data_ptr(),
-              None, None, 1, Cin0p, C0, ldz, Z.data_ptr(), None, None, st, dims=(Cin0p, C0))
+        direct3 = _EXPAND3["on"] and C == 0 and nxyz == 3        # xyz-only layer 0: no per-point GEMM, see group_expand below
+        Z = None
+        if not direct3:
+            Z = torch.empty((C0, ldz), device=dev, dtype=f32)
+            W0p = prep.get(params[0], C0, Cin0p)
+            _call("conv_fwd_points", 2.0 * Cin0p * C0 * ldz, lib.o3d_mlp_conv_fwd, X0n.data_ptr(), W0p.data_ptr(),
+                  None, None, 1, Cin0p, C0, ldz, Z.data_ptr(), None, None, st, dims=(Cin0p, C0))
         counts = [float(pm) for pm in Pmaxs]          # BatchNorm counts every slot (copies included)
         Ys, means, invstds, scales, shifts = [], [], [], [], []
         if cfg.training:       # shift of the second moment: the running means before this call, one row per segment
@@ -663,7 +668,11 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             Y = torch.empty((Cout, ldp), device=dev, dtype=f32)
             part = torch.empty((ldp // tile, 2, Cout), device=dev, dtype=f32) if cfg.training else None
             statc = statcs[l] if cfg.training else None
-            if l == 0:
+            if l == 0 and direct3:
+                _call("group_expand", 0.0, lib.o3d_group_expand_c3, X0n.data_ptr(), ldz, gp.data_ptr(), cball.data_ptr(),
+                      cw.data_ptr(), centers.data_ptr(), Ws[0].data_ptr(), Cin0, C0, meta.data_ptr(), start1, ldp,
+                      Y.data_ptr(), _ptr(part), _ptr(statc), st)
+            elif l == 0:
                 _call("group_expand", 0.0, lib.o3d_group_expand_c, Z.data_ptr(), ldz, gp.data_ptr(), cball.data_ptr(),
                       cw.data_ptr(), _ptr(centers), Ws[0].data_ptr(), Cin0, C0, meta.data_ptr(), start1, ldp, Y.data_ptr(),
                       _ptr(part), _ptr(statc), st)
