@@ -184,9 +184,8 @@ def cpu_baseline(model_name, sd, batch_size, budget_s=150.0):
     vfull, nfull = sample(batch_size, 2, 10, t_begin + 0.7 * budget_s)
     v1, n1 = sample(1, 3, 10, t_begin + 0.75 * budget_s)
     par = None
-    if cores >= 2 * best:      # always taken (its own time limit): ~1 warm-up + 2 steps per process, all processes at once
-        par = cpu_process_parallel(model_name, sd, batch_size, best, cores,
-                                   timeout_s=max(60.0, t_begin + budget_s + 60.0 - time.perf_counter()))
+    if cores >= 16:      # every physical core: 8 processes x cores/8 threads (its own time limit: 1 warm-up + 2 steps each, all
+        par = cpu_process_parallel(model_name, sd, batch_size, cores // 8, cores, timeout_s=180.0)      # processes at once)
     res = {"value": round(vfull, 3), "unit": "pairs/s", "cores": best, "kind": "port",
            "batch1_value": round(v1, 3), "host_physical_cores": cores, "thread_sweep_batch8_pairs_per_s": sweep,
            "timed_iterations": nfull,

@@ -458,8 +458,11 @@ def test_graph_step_equals_eager_step_bookkeeping():
     # compared: the objectness / box terms threshold the predicted centres (dist < 0.3, > 0.6, base_model.py:140-147),
     # so with 4 pairs a 1e-6 weight difference (atomics in the backward) can flip a label and move the loss by 1 %
     # (eager runs themselves scatter by ~1e-4 here from step 1 on, occasionally more: step 0 is the tight one)
+    # (round 3: 0.6 % seen at step 2 on one box -- one flipped objectness label; 2 % bounds a couple of flips, a capture
+    # that replayed stale weights or a wrong batch is off by tens of percent; the exact check of a replay against an
+    # eager step is test_graph_replay_gradients_equal_eager_gradients, at lr = 0)
     for i, (a, b) in enumerate(zip(le[:3], lg[:3])):
-        assert abs(a - b) <= (1e-4 if i == 0 else 5e-3) * (1 + abs(a)), (le, lg)
+        assert abs(a - b) <= (1e-4 if i == 0 else 2e-2) * (1 + abs(a)), (le, lg)
     assert all(np.isfinite(v) for v in lg)
     for k, v in results[False][1].items():
         w = results[True][1][k]
