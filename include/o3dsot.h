@@ -490,7 +490,9 @@ int o3d_pw_dgrad_pair(const o3d_pw_dgrad_args* a, const o3d_pw_dgrad_args* b, vo
 /* Several independent weight gradients of the flat (C, P) layout in one launch (+ one reduction launch): the 1-D conv
  * stacks of the heads (models/head/rpn.py:16-39, models/head/xcorr.py:14-17, models/bat.py:22-26).  Job i computes what
  * o3d_mlp_conv_wgrad2(dN, NULL, 4, Y, A1, A2, A3, X, in_scale, in_shift, 1, Cin, Cout, P, scratch, dW, stream) computes
- * (same tile plan and summation order); njobs <= 4; scratch: o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, P) floats each. */
+ * (same tile plan and summation order); njobs <= 4; scratch: o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, P) floats each.
+ * A job with X == NULL and Y == NULL is a ROW-SUM job (the bias gradient of a stack's last layer, o3d_row_sum):
+ * dW (Cout) = row sums of dN (Cout, P). */
 typedef struct {
     const float* dN; const float* Y; const float* A1; const float* A2; const float* A3;
     const float* X; const float* in_scale; const float* in_shift;

@@ -237,9 +237,26 @@ constexpr int WG_MAXJOBS = 4;
 struct Wgrad2Group {
     Wgrad2Args job[WG_MAXJOBS];
     int first[WG_MAXJOBS + 1];     // first workgroup of every job
-    int kind[WG_MAXJOBS];          // 0: <128,128>  1: <128,64>  2: <64,128>  3: <64,64>
+    int kind[WG_MAXJOBS];          // 0: <128,128>  1: <128,64>  2: <64,128>  3: <64,64>  4: row sums (bias gradient)
     int njobs;
 };
+
+// kind 4: out[c] = sum_p G[c, p] -- the bias gradient of a stack's last layer rides in the stack's grouped launch (it was a
+// launch of its own, csrc/heads.hip::row_sum_kernel: same arithmetic, same order).  Wgrad2Args: dN = G (Cout rows of P
+// columns), part = out.
+__device__ __forceinline__ void row_sum_body(const Wgrad2Args& a, const int bid, float* smem) {
+    const float* g = a.dN + (long)bid * a.P;
+    float s = 0.f;
+    for (long p = 4L * threadIdx.x; p < a.P; p += 1024) {
+        const float4 v = *reinterpret_cast<const float4*>(g + p);
+        s += (v.x + v.y) + (v.z + v.w);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    if ((threadIdx.x & 63) == 0) smem[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) a.part[bid] = (smem[0] + smem[1]) + (smem[2] + smem[3]);
+}
 
 __global__ __launch_bounds__(256) void wgrad2_group_kernel(Wgrad2Group g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -250,7 +267,8 @@ __global__ __launch_bounds__(256) void wgrad2_group_kernel(Wgrad2Group g) {
         case 0: wgrad2_body<128, 128, 0>(g.job[j], bid, smem); break;
         case 1: wgrad2_body<128, 64, 0>(g.job[j], bid, smem); break;
         case 2: wgrad2_body<64, 128, 0>(g.job[j], bid, smem); break;
-        default: wgrad2_body<64, 64, 0>(g.job[j], bid, smem); break;
+        case 3: wgrad2_body<64, 64, 0>(g.job[j], bid, smem); break;
+        default: row_sum_body(g.job[j], bid, smem); break;
     }
 }
 
@@ -662,6 +680,17 @@ extern "C" int o3d_mlp_conv_wgrad2_group(const o3d_wgrad_job* jobs, int njobs, v
     int nblk = 0, rblk = 0;
     for (int i = 0; i < njobs; ++i) {
         const o3d_wgrad_job& q = jobs[i];
+        if (q.dN && !q.X && !q.Y && q.dW && q.Cout > 0 && q.P > 0 && q.P % 4 == 0 && q.P <= 0x7fffffff) {
+            // a row-sum job (the bias gradient): dW (Cout) = row sums of dN (Cout, P); no reduction stage
+            Wgrad2Args& a = g.job[i];
+            a.dN = q.dN; a.P = (int)q.P; a.Cout = q.Cout; a.part = q.dW;
+            g.kind[i] = 4;
+            g.first[i] = nblk;
+            nblk += q.Cout;
+            r.part[i] = q.dW; r.out[i] = q.dW; r.n[i] = 0; r.nslices[i] = 0;
+            r.first[i] = rblk;
+            continue;
+        }
         if (!q.dN || !q.Y || !q.A1 || !q.A2 || !q.A3 || !q.X || (q.in_scale == nullptr) != (q.in_shift == nullptr) ||
             !q.scratch || !q.dW || q.Cin <= 0 || q.Cout <= 0 || q.Cin % 64 || q.Cout % 64 || q.P <= 0 || q.P % 64 ||
             q.P > 0x7fffffff)
@@ -690,8 +719,9 @@ extern "C" int o3d_mlp_conv_wgrad2_group(const o3d_wgrad_job* jobs, int njobs, v
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) == hipSuccess;
     if (!attr_ok || lds > 80 * 1024) return O3D_ELAUNCH;
     hipStream_t s = o3d_stream(stream);
+    if (lds < 16) lds = 16;            // (row-sum jobs only: four floats of staging)
     hipLaunchKernelGGL(wgrad2_group_kernel, dim3(nblk), dim3(256), lds, s, g);
-    hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3(rblk), dim3(256), 0, s, r);
+    if (rblk > 0) hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3(rblk), dim3(256), 0, s, r);
     return o3d_launch_status();
 }
 

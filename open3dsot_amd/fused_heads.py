@@ -442,11 +442,15 @@ def _chain_backward(state, dOut, needs):
     # ---- last layer: plain conv (+ bias, + residual)
     l = L - 1
     if needs[cfg.nsrc + 4 * l + 1]:
-        if side is not main:
-            side.wait_stream(main)
-        with torch.cuda.stream(side):
+        if _GROUP["on"] and side is main:        # the bias gradient rides in the stack's grouped weight-gradient launch
             db = torch.empty((Mp,), device=dev, dtype=f32)
-            _call("row_sum", 0.0, lib.o3d_row_sum, G.data_ptr(), Mp, P, db.data_ptr(), side.cuda_stream)
+            jobs.append((0.0, (G.data_ptr(), None, None, None, None, None, None, None, 0, Mp, P, None, db.data_ptr())))
+        else:
+            if side is not main:
+                side.wait_stream(main)
+            with torch.cuda.stream(side):
+                db = torch.empty((Mp,), device=dev, dtype=f32)
+                _call("row_sum", 0.0, lib.o3d_row_sum, G.data_ptr(), Mp, P, db.data_ptr(), side.cuda_stream)
         keep.extend((G, db))
         grads[4 * l + 1] = db[:Cl]
     grads[4 * l] = wgrad(l, G, G, (one.data_ptr(), zero.data_ptr(), zero.data_ptr()), Mp)
