@@ -375,6 +375,9 @@ int o3d_pack_points(const float* xyz0, const float* feats0, int N0, int ld0, con
 /* Centre term of the layer-0 weight gradient (grouped_xyz = xyz[idx] - new_xyz, pointnet2_utils.py:322-324):
  * dW (C0,ldw) columns 0..2 -= T (C0,nballs) . centers (nballs,3) */
 int o3d_center_term(const float* T, const float* centers, int C0, int nballs, int ldw, float* dW, void* stream);
+/* the same into a compact gradient: out (C0, ncols) = dW[:, :ncols], columns 0..2 minus the centre term (dW untouched) */
+int o3d_center_term_out(const float* T, const float* centers, int C0, int nballs, int ldw, const float* dW, int ncols,
+                        float* out, void* stream);
 
 /* Layer-0 backward sums of dY = A1*dN + w*(A2*Y0 + A3): S (C0, point columns) per source point
  * (= group_points_grad, pointnet2_utils.py:237), T (C0, balls) per ball (may be NULL). */
@@ -490,7 +493,7 @@ int o3d_pw_dgrad_pair(const o3d_pw_dgrad_args* a, const o3d_pw_dgrad_args* b, vo
 /* Several independent weight gradients of the flat (C, P) layout in one launch (+ one reduction launch): the 1-D conv
  * stacks of the heads (models/head/rpn.py:16-39, models/head/xcorr.py:14-17, models/bat.py:22-26).  Job i computes what
  * o3d_mlp_conv_wgrad2(dN, NULL, 4, Y, A1, A2, A3, X, in_scale, in_shift, 1, Cin, Cout, P, scratch, dW, stream) computes
- * (same tile plan and summation order); njobs <= 4; scratch: o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, P) floats each.
+ * (same tile plan and summation order); njobs <= 8; scratch: o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, P) floats each.
  * A job with X == NULL and Y == NULL is a ROW-SUM job (the bias gradient of a stack's last layer, o3d_row_sum):
  * dW (Cout) = row sums of dN (Cout, P). */
 typedef struct {

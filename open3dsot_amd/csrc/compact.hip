@@ -805,9 +805,12 @@ __global__ __launch_bounds__(256) void reduce_gather_kernel(const float* __restr
 // dW[c, 0..2] -= sum over balls of T[c, ball] * centers[ball, :]: the centre term of
 // grouped_xyz = xyz[idx] - new_xyz (pointnet2_utils.py:322-324) in the layer-0 weight gradient.
 // One 1024-thread workgroup per channel, fixed summation order.
+// out != NULL (round 3): the finished row goes to the COMPACT (C0, ncols) gradient instead -- out[c, k] = dW[c, k] (- the
+// centre term for k < 3) -- which was a strided torch copy of dW[:, :ncols] behind this launch.
 __global__ __launch_bounds__(1024) void center_term_kernel(const float* __restrict__ T,
                                                            const float* __restrict__ centers, int nballs, int ldw,
-                                                           float* __restrict__ dW) {
+                                                           float* __restrict__ dW, float* __restrict__ out = nullptr,
+                                                           int ncols = 0) {
     __shared__ float red[16][3];
     const int c = blockIdx.x, tid = threadIdx.x;
     const float* t = T + (long)c * nballs;
@@ -830,8 +833,11 @@ __global__ __launch_bounds__(1024) void center_term_kernel(const float* __restri
         float a = 0.f;
 #pragma unroll
         for (int w = 0; w < 16; ++w) a += red[w][tid];
-        dW[(long)c * ldw + tid] -= a;
+        if (out) out[(long)c * ncols + tid] = dW[(long)c * ldw + tid] - a;
+        else dW[(long)c * ldw + tid] -= a;
     }
+    if (out)
+        for (int k = 3 + tid; k < ncols; k += 1024) out[(long)c * ncols + k] = dW[(long)c * ldw + k];
 }
 
 // Per-point operand of layer 0: X0 (rows, ldz) = [xyz * inv_radius ; feats ; zero rows] with every cloud's N points
@@ -1275,7 +1281,18 @@ extern "C" int o3d_group_reduce_c(const float* dN, const float* Y0, long ldp, co
 extern "C" int o3d_center_term(const float* T, const float* centers, int C0, int nballs, int ldw, float* dW,
                                void* stream) {
     if (!T || !centers || !dW || C0 <= 0 || nballs <= 0 || ldw < 3) return O3D_EINVAL;
-    hipLaunchKernelGGL(center_term_kernel, dim3(C0), dim3(1024), 0, o3d_stream(stream), T, centers, nballs, ldw, dW);
+    hipLaunchKernelGGL(center_term_kernel, dim3(C0), dim3(1024), 0, o3d_stream(stream), T, centers, nballs, ldw, dW,
+                       static_cast<float*>(nullptr), 0);
+    return o3d_launch_status();
+}
+
+// o3d_center_term writing the finished gradient compactly: out (C0, ncols) = dW[:, :ncols] with the centre term taken off
+// columns 0..2 (dW (C0, ldw), ldw >= ncols >= 3, is left as it was)
+extern "C" int o3d_center_term_out(const float* T, const float* centers, int C0, int nballs, int ldw, const float* dW,
+                                   int ncols, float* out, void* stream) {
+    if (!T || !centers || !dW || !out || C0 <= 0 || nballs <= 0 || ncols < 3 || ldw < ncols) return O3D_EINVAL;
+    hipLaunchKernelGGL(center_term_kernel, dim3(C0), dim3(1024), 0, o3d_stream(stream), T, centers, nballs, ldw,
+                       const_cast<float*>(dW), out, ncols);
     return o3d_launch_status();
 }
 

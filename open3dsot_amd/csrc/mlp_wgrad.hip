@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void wgrad2_kernel(Wgrad2Args a) {
 // (models/head/rpn.py:16-39 ...) depend only on operands the data-gradient chain has already produced, and each of them is
 // a sub-round launch (192 workgroups of 4 short chunks for a 256 x 256 x 6144 problem: 22 us for 6 us of matrix work, plus
 // its slice reduction).  Grouped, their workgroups fill the chip together and overlap each other's staging latencies.
-constexpr int WG_MAXJOBS = 4;
+constexpr int WG_MAXJOBS = 8;
 struct Wgrad2Group {
     Wgrad2Args job[WG_MAXJOBS];
     int first[WG_MAXJOBS + 1];     // first workgroup of every job

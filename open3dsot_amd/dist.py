@@ -44,6 +44,14 @@ def shard_indices(step, rank, world, per_rank_batch):
     return first, per_rank_batch
 
 
+def _defer_wgrads():
+    if torch.cuda.is_available():
+        from . import fused_heads
+        return fused_heads.defer_wgrads()
+    import contextlib
+    return contextlib.nullcontext()
+
+
 class FlatBatch(dict):
     """A batch whose tensors are views of ONE flat device buffer (fields 256-byte aligned).  A captured step reads its
     inputs from static buffers; handing it a new batch is then one device copy of `flat` instead of one copy node per
@@ -163,7 +171,8 @@ class DataParallelStep:
             batch = {k: v for k, v in batch.items() if k not in batch.extra_keys}   # an eager step samples for itself
         self.grads.clear()
         loss, _ = self.model.training_loss(batch)
-        loss.backward()
+        with _defer_wgrads():         # the heads' weight gradients of the whole backward in a few grouped launches
+            loss.backward()
         if self.world > 1:
             # pack the gradients autograd produced into the exchange buffer: one multi-tensor copy, part of the captured
             # HIP graph when there is one (so a replayed step ends with the message ready to be reduced)

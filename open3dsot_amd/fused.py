@@ -61,6 +61,7 @@ capi.register("o3d_group_reduce_gather", [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _vp, _vp, _vp])
 capi.register("o3d_pack_points", [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp])
 capi.register("o3d_center_term", [_vp, _vp, _i, _i, _i, _vp, _vp])
+capi.register("o3d_center_term_out", [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp])
 capi.register("o3d_pool_fwd_c", [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_fwd_ct", [_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_bwd_c", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _l, _vp, _vp, _vp])
@@ -860,10 +861,18 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                               None, None, None, None, None, 0, 0, 0, 1.0, 1, Cin, Cout, ldz, nsl, wpart.data_ptr(),
                               dWm.data_ptr(), side.cuda_stream)
                     keep += [wpart, dWm]
-                    if nxyz:      # the centre term of grouped_xyz = xyz[idx] - new_xyz
-                        _call("center_term", 0.0, lib.o3d_center_term, T.data_ptr(), centers.data_ptr(), Cout, nballs,
-                              dWm.shape[1], dWm.data_ptr(), side.cuda_stream)
-                    dW = dWm if dWm.shape[1] == Cin else dWm[:, :Cin].contiguous()
+                    if nxyz and dWm.shape[1] != Cin:
+                        # the centre term of grouped_xyz = xyz[idx] - new_xyz and the compaction of the padded rows in one
+                        # launch (was: the term in place, then a strided torch copy of dWm[:, :Cin])
+                        dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
+                        _call("center_term", 0.0, lib.o3d_center_term_out, T.data_ptr(), centers.data_ptr(), Cout, nballs,
+                              dWm.shape[1], dWm.data_ptr(), Cin, dW.data_ptr(), side.cuda_stream)
+                        keep.append(dW)
+                    else:
+                        if nxyz:      # the centre term of grouped_xyz = xyz[idx] - new_xyz
+                            _call("center_term", 0.0, lib.o3d_center_term, T.data_ptr(), centers.data_ptr(), Cout, nballs,
+                                  dWm.shape[1], dWm.data_ptr(), side.cuda_stream)
+                        dW = dWm if dWm.shape[1] == Cin else dWm[:, :Cin].contiguous()
                 grads[0] = dW
                 if want_xyz or want_feats:
                     # dX = W0^T . S as a plain forward GEMM on the direct MFMA kernel: rows padded to a multiple of 64

@@ -43,6 +43,39 @@ class _WgradJob(ctypes.Structure):        # o3d_wgrad_job of include/o3dsot.h
 # the weight gradients of a stack as ONE grouped launch (+ one reduction launch) at the end of its backward instead of a
 # launch + reduction per layer (csrc/mlp_wgrad.hip::wgrad2_group_kernel); O3D_WGRAD_GROUP=0: one launch per layer
 _GROUP = {"on": __import__("os").environ.get("O3D_WGRAD_GROUP", "1") != "0"}
+_MAXJOBS = 8                # WG_MAXJOBS of csrc/mlp_wgrad.hip
+# Deferred weight gradients: inside `defer_wgrads()` (the training step of open3dsot_amd/dist.py wraps loss.backward() in
+# it) the stacks do not launch their grouped weight gradients at the end of their own backward but queue the jobs; the
+# queue is flushed in groups of 8 when the scope ends -- the heads' 23 jobs of a BAT step in 3 launches + 3 reductions
+# instead of 7 + 7.  The gradient tensors autograd was handed are filled by the flush: the scope must end before anything
+# reads them (AccumulateGrad only stores them).  O3D_WGRAD_DEFER=0: every stack flushes for itself.
+_DEFER = {"on": __import__("os").environ.get("O3D_WGRAD_DEFER", "1") != "0", "queue": None}
+
+
+def _flush_jobs(jobs, st):
+    lib = capi.load()
+    for j0 in range(0, len(jobs), _MAXJOBS):
+        chunk = jobs[j0:j0 + _MAXJOBS]
+        arr = (_WgradJob * len(chunk))(*[_WgradJob(*j[1]) for j in chunk])
+        _call("pw_conv_wgrad", sum(j[0] for j in chunk), lib.o3d_mlp_conv_wgrad2_group, ctypes.addressof(arr), len(chunk), st)
+
+
+@contextlib.contextmanager
+def defer_wgrads():
+    if not _DEFER["on"] or _DEFER["queue"] is not None:
+        yield
+        return
+    _DEFER["queue"] = []
+    try:
+        yield
+    finally:
+        q, _DEFER["queue"] = _DEFER["queue"], None
+        by_stream = {}
+        for jobs, keep, st in q:
+            by_stream.setdefault(st, []).extend(jobs)
+        for st, jobs in by_stream.items():
+            _flush_jobs(jobs, st)
+        del q
 
 import os as _os
 
@@ -505,11 +538,11 @@ def _chain_backward(state, dOut, needs):
                                                                         Wts[0].data_ptr(), K0p, Cp, P, None, None, None, None,
                                                                         G.data_ptr() if cfg.residual else None, dX0.data_ptr(),
                                                                         None, st], (K0p, Cp))
-    for j0 in range(0, len(jobs), 4):
-        chunk = jobs[j0:j0 + 4]
-        arr = (_WgradJob * len(chunk))(*[_WgradJob(*j[1]) for j in chunk])
-        _call("pw_conv_wgrad", sum(j[0] for j in chunk), lib.o3d_mlp_conv_wgrad2_group, ctypes.addressof(arr),
-              len(chunk), st)
+    if jobs and _DEFER["queue"] is not None:
+        _DEFER["queue"].append((jobs, keep, st))      # (the queue keeps the operands alive until the flush)
+        keep = []
+    else:
+        _flush_jobs(jobs, st)
     if side is not main:
         main.wait_stream(side)       # join: every weight gradient is complete before autograd hands it on
     del keep

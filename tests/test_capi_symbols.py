@@ -135,7 +135,7 @@ def test_fused_backward_entry_validates_shapes_without_a_device():
     assert lib.o3d_gather_rows(None, None, 2, 8, 3, 4, None, None) == EINVAL
     assert lib.o3d_gather_rows(None, None, 2, 8, 3, 0, None, None) == 0                                         # nothing to gather
     assert lib.o3d_adam_step(None, 0, None, None, None, 1e-3, 0.5, 0.999, 1e-6, 0.0, 0.5, 1e-3, None) == EINVAL
-    assert lib.o3d_mlp_conv_wgrad2_group(None, 1, None) == EINVAL and lib.o3d_mlp_conv_wgrad2_group(p, 5, None) == EINVAL
+    assert lib.o3d_mlp_conv_wgrad2_group(None, 1, None) == EINVAL and lib.o3d_mlp_conv_wgrad2_group(p, 9, None) == EINVAL
     assert lib.o3d_compact_build2(None, 8, 8, None, 8, 8, 1, 4, 0, 8, 16, *([None] * 7)) == EINVAL
     assert lib.o3d_best_proposal(None, 1, 64, p, None, None) == EINVAL and lib.o3d_best_proposal(p, 0, 64, p, None, None) == EINVAL
     assert lib.o3d_adam_step(p, 1, p, p, p, 1e-3, 0.5, 0.999, 1e-6, 0.0, 0.0, 1e-3, None) == EINVAL             # bc1 = 0: step 0
