@@ -436,6 +436,10 @@ typedef struct { const float* p; long sb, sc, sn; int C; } o3d_rows_src;
  * (torch.cat(dim=1) of e.g. [xyz^T ; features]: rpn.py:50, bat.py:94); rows beyond sum C_i are zero.
  * srcs: HOST array. */
 int o3d_pack_rows(const o3d_rows_src* srcs, int nsrc, int B, int N, int rows, float* X, void* stream);
+/* the same into a column block of a wider operand (X = the block's first column, ld = the operand's row stride): two sets
+ * of clouds of different sizes as the columns of ONE GEMM -- conv_final on the template and on the search feature,
+ * models/bat.py:91-92 */
+int o3d_pack_rows_ld(const o3d_rows_src* srcs, int nsrc, int B, int N, int rows, float* X, long ld, void* stream);
 
 /* Every padded / transposed weight copy of a step in one launch.  jobs: DEVICE array of njobs x 6 longs
  * {src ptr, dst ptr, rows, cols, dst_ld, transpose}: src (rows, cols) row-major -> dst[r*ld + c], or

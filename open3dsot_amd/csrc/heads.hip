@@ -16,6 +16,7 @@ struct PackRowsArgs {
     o3d_rows_src s[4];
     int nsrc, B, N, rows;
     float* X;
+    long ld;           // row stride of X (0: B*N) -- a column block of a wider operand
 };
 
 __global__ __launch_bounds__(256) void pack_rows_kernel(PackRowsArgs a) {
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void pack_rows_kernel(PackRowsArgs a) {
             r -= a.s[i].C;
         }
     }
-    a.X[(long)blockIdx.y * P + col] = v;
+    a.X[(long)blockIdx.y * (a.ld ? a.ld : P) + col] = v;
 }
 
 // job = {src, dst, rows, cols, dst_ld, transpose}: src (rows, cols) row-major ->
@@ -118,6 +119,25 @@ extern "C" int o3d_pack_rows(const o3d_rows_src* srcs, int nsrc, int B, int N, i
     }
     if (total > rows) return O3D_EINVAL;
     a.nsrc = nsrc; a.B = B; a.N = N; a.rows = rows; a.X = X;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)o3d_cdiv((long)B * N, 256), rows), dim3(256), 0,
+                       o3d_stream(stream), a);
+    return o3d_launch_status();
+}
+
+// o3d_pack_rows into a column block of a wider operand: X points at the block's first column, ld = the operand's row
+// stride (two sets of clouds of different sizes side by side as the columns of ONE GEMM: conv_final on the template and
+// on the search feature, models/bat.py:91-92)
+extern "C" int o3d_pack_rows_ld(const o3d_rows_src* srcs, int nsrc, int B, int N, int rows, float* X, long ld, void* stream) {
+    if (!srcs || nsrc < 1 || nsrc > 4 || B <= 0 || N <= 0 || rows <= 0 || !X || ld < (long)B * N) return O3D_EINVAL;
+    PackRowsArgs a = {};
+    int total = 0;
+    for (int i = 0; i < nsrc; ++i) {
+        if (!srcs[i].p || srcs[i].C <= 0) return O3D_EINVAL;
+        a.s[i] = srcs[i];
+        total += srcs[i].C;
+    }
+    if (total > rows) return O3D_EINVAL;
+    a.nsrc = nsrc; a.B = B; a.N = N; a.rows = rows; a.X = X; a.ld = ld;
     hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)o3d_cdiv((long)B * N, 256), rows), dim3(256), 0,
                        o3d_stream(stream), a);
     return o3d_launch_status();

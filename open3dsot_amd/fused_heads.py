@@ -27,6 +27,7 @@ from .fused import _call, _const_vec, _eval_consts, _ptr, _stream, count_batches
 
 _vp, _i, _l, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_double
 capi.register("o3d_pack_rows", [_vp, _i, _i, _i, _i, _vp, _vp])
+capi.register("o3d_pack_rows_ld", [_vp, _i, _i, _i, _i, _vp, _l, _vp])
 capi.register("o3d_prep_weights", [_vp, _i, _vp])
 capi.register("o3d_row_sum", [_vp, _i, _l, _vp, _vp])
 capi.register("o3d_pw_tile", [_l, _i])
@@ -125,6 +126,16 @@ def pack_rows(sources, rows):
         arr[i].p, arr[i].sb, arr[i].sc, arr[i].sn, arr[i].C = t.data_ptr(), sb, sc, sn, t.shape[1]
     _call("pack_rows", 0.0, lib.o3d_pack_rows, ctypes.addressof(arr), len(sources), B, N, rows, X.data_ptr(), _stream())
     return X
+
+
+def pack_rows_into(t, X, col0):
+    """(B,C,N) tensor (any strides) -> the columns [col0, col0 + B*N) of the rows [0, C) of X (rows, ld)"""
+    lib = capi.load()
+    B, C, N = t.shape
+    arr = (_RowsSrc * 1)()
+    sb, sc, sn = t.stride()
+    arr[0].p, arr[0].sb, arr[0].sc, arr[0].sn, arr[0].C = t.data_ptr(), sb, sc, sn, C
+    _call("pack_rows", 0.0, lib.o3d_pack_rows_ld, ctypes.addressof(arr), 1, B, N, C, X[0, col0:].data_ptr(), X.shape[1], _stream())
 
 
 def _as_flat(t):
@@ -633,3 +644,90 @@ def run_chain_pair(a, b):
         return FlatChain.apply(cfg_a, *a[0], *pa), FlatChain.apply(cfg_b, *b[0], *pb)
     ta = (*a[0], *pa)
     return FlatChainPair.apply(cfg_a, cfg_b, len(ta), *ta, *b[0], *pb)
+
+
+class SharedConvPair(torch.autograd.Function):
+    """One nn.Conv1d (kernel 1, bias) applied to TWO sets of clouds of different sizes -- `conv_final` on the template
+    and on the search feature (models/bat.py:91-92, models/p2b.py:35-36) -- as ONE GEMM over the columns of both:
+    apply(W (Cout,Cin,1), bias, xa (B,Cin,Na), xb (B,Cin,Nb)) -> (ya (B,Cout,Na), yb (B,Cout,Nb)), views of one flat
+    (Cout, B*Na + B*Nb) output.  Backward: one data gradient, one weight gradient (the sum over both sets: the weights
+    are shared) and one bias row sum, the latter two as jobs of the grouped weight-gradient launch."""
+
+    @staticmethod
+    @capi.on_tensor_device
+    def forward(ctx, W, bias, xa, xb):
+        lib = capi.load()
+        B, Cin, Na = xa.shape
+        Nb = xb.shape[2]
+        Cout = W.shape[0]
+        Pa, Pb = B * Na, B * Nb
+        P = Pa + Pb
+        dev, f32 = xa.device, torch.float32
+        st = _stream()
+        prep = prep_for(dev)
+        X0 = torch.empty((Cin, P), device=dev, dtype=f32)
+        pack_rows_into(xa.detach(), X0, 0)
+        pack_rows_into(xb.detach(), X0, Pa)
+        Wp = prep.get(W, Cout, Cin)
+        bp = prep.get(bias, 1, Cout) if bias is not None else _const_vec(dev, Cout, 0.0)
+        Y = torch.empty((Cout, P), device=dev, dtype=f32)
+        _call("pw_conv_fwd", 2.0 * Cin * Cout * P, lib.o3d_pw_fwd, X0.data_ptr(), Wp.data_ptr(), None, None, bp.data_ptr(), None,
+              Cin, Cout, P, Y.data_ptr(), None, None, st, dims=(Cin, Cout))
+        if any(ctx.needs_input_grad):
+            ctx.saved = (X0, prep.get(W, Cin, Cout, transpose=True), W, bias)
+            ctx.geom = (B, Cin, Cout, Na, Nb)
+            ctx.versions = [(p_, p_._version) for p_ in (W, bias) if p_ is not None]
+        return Y[:, :Pa].view(Cout, B, Na).permute(1, 0, 2), Y[:, Pa:].view(Cout, B, Nb).permute(1, 0, 2)
+
+    @staticmethod
+    @capi.on_tensor_device
+    def backward(ctx, da, db):
+        lib = capi.load()
+        X0, Wt, W, bias = ctx.saved
+        B, Cin, Cout, Na, Nb = ctx.geom
+        for p_, v in ctx.versions:
+            if p_._version != v:
+                raise RuntimeError("a parameter of a fused conv stack was modified in place between forward and backward")
+        Pa, Pb = B * Na, B * Nb
+        P = Pa + Pb
+        dev, f32 = X0.device, torch.float32
+        st = _stream()
+        G = torch.empty((Cout, P), device=dev, dtype=f32)
+        for d, col0, n in ((da, 0, Na), (db, Pa, Nb)):
+            if d is None:
+                G[:, col0:col0 + B * n].zero_()
+            else:
+                pack_rows_into(d, G, col0)
+        dxa = dxb = None
+        if ctx.needs_input_grad[2] or ctx.needs_input_grad[3]:
+            dX = torch.empty((Cin, P), device=dev, dtype=f32)
+            _call("pw_conv_dgrad", 2.0 * Cin * Cout * P, lib.o3d_pw_dgrad, G.data_ptr(), None, None, None, None, Wt.data_ptr(), Cin,
+                  Cout, P, None, None, None, None, None, dX.data_ptr(), None, st, dims=(Cin, Cout, True))
+            dxa = dX[:, :Pa].view(Cin, B, Na).permute(1, 0, 2) if ctx.needs_input_grad[2] else None
+            dxb = dX[:, Pa:].view(Cin, B, Nb).permute(1, 0, 2) if ctx.needs_input_grad[3] else None
+        one, zero = _const_vec(dev, Cout, 1.0), _const_vec(dev, Cout, 0.0)
+        dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
+        scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, P),), device=dev, dtype=f32)
+        jobs = [(2.0 * Cin * Cout * P, (G.data_ptr(), G.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(),
+                                       X0.data_ptr(), None, None, Cin, Cout, P, scratch.data_ptr(), dW.data_ptr()))]
+        dbias = None
+        if bias is not None and ctx.needs_input_grad[1]:
+            dbias = torch.empty((Cout,), device=dev, dtype=f32)
+            jobs.append((0.0, (G.data_ptr(), None, None, None, None, None, None, None, 0, Cout, P, None, dbias.data_ptr())))
+        keep = [G, X0, scratch, dW, dbias, one, zero]
+        if _DEFER["queue"] is not None:
+            _DEFER["queue"].append((jobs, keep, st))
+        else:
+            _flush_jobs(jobs, st)
+        return dW.view(W.shape), dbias, dxa, dxb
+
+
+def shared_conv_pair_supported(conv, xa, xb):
+    return (_ON["on"] and _SHARED["on"] and xa.is_cuda and xa.dtype == torch.float32 and xb.dtype == torch.float32 and
+            xa.dim() == 3 and xb.dim() == 3 and xa.shape[0] == xb.shape[0] and xa.shape[1] == xb.shape[1] == conv.in_channels and
+            conv.kernel_size == (1,) and conv.stride == (1,) and conv.padding == (0,) and conv.groups == 1 and
+            conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and
+            (xa.shape[0] * (xa.shape[2] + xb.shape[2])) % 128 == 0 and _GROUP["on"])
+
+
+_SHARED = {"on": _os.environ.get("O3D_SHARED_CONV", "1") != "0"}      # A/B switch

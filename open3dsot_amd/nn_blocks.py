@@ -37,6 +37,17 @@ def pointwise_conv1d(conv, x):
     return h.reshape(-1, B, N).permute(1, 0, 2).contiguous()
 
 
+def pointwise_conv1d_pair(conv, xa, xb):
+    """(pointwise_conv1d(conv, xa), pointwise_conv1d(conv, xb)) for two sets of clouds of different sizes through the SAME
+    convolution (conv_final on the template and on the search feature, models/bat.py:91-92): on the GPU one GEMM over the
+    columns of both (open3dsot_amd/fused_heads.py::SharedConvPair)"""
+    if _FLAT["on"] and xa.is_cuda:
+        from . import fused_heads
+        if fused_heads.shared_conv_pair_supported(conv, xa, xb):
+            return fused_heads.SharedConvPair.apply(conv.weight, conv.bias, xa, xb)
+    return pointwise_conv1d(conv, xa), pointwise_conv1d(conv, xb)
+
+
 def seq_apply(seq, parts, residual=False):
     """seq(torch.cat(parts, dim=1)) (+ the concatenated input when `residual`: `seeds + vote_layer(seeds)`,
     models/head/rpn.py:50-54) for a pt_utils.Seq of kernel-1 Conv1d units.  On the GPU the parts go straight into the

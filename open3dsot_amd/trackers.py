@@ -152,8 +152,7 @@ class P2B(MatchingBaseModel):
         M, N = template.shape[1], search.shape[1]
         (template_xyz, template_feature, _), (search_xyz, search_feature, sample_idxs) = self.backbone.forward_pair(
             template, [M // 2, M // 4, M // 8], search, [N // 2, N // 4, N // 8], self._given_sampling(input_dict))
-        template_feature = pt_utils.pointwise_conv1d(self.conv_final, template_feature)
-        search_feature = pt_utils.pointwise_conv1d(self.conv_final, search_feature)
+        template_feature, search_feature = pt_utils.pointwise_conv1d_pair(self.conv_final, template_feature, search_feature)
         fusion = self.xcorr(template_feature, search_feature, template_xyz)
         boxes, cla, vote_xyz, centers = self.rpn(search_xyz, fusion)
         return {"estimation_boxes": boxes, "vote_center": vote_xyz, "pred_seg_score": cla,
@@ -221,8 +220,7 @@ class BAT(MatchingBaseModel):
         (template_xyz, template_feature, sample_idxs_t), (search_xyz, search_feature, sample_idxs) = \
             self.backbone.forward_pair(template, [M // 2, M // 4, M // 8], search, [N // 2, N // 4, N // 8],
                                        self._given_sampling(input_dict))
-        template_feature = pt_utils.pointwise_conv1d(self.conv_final, template_feature)
-        search_feature = pt_utils.pointwise_conv1d(self.conv_final, search_feature)
+        template_feature, search_feature = pt_utils.pointwise_conv1d_pair(self.conv_final, template_feature, search_feature)
         pred_search_bc = pt_utils.seq_apply(self.mlp_bc, [search_xyz.transpose(1, 2), search_feature])
         pred_search_bc = pred_search_bc.transpose(1, 2)                                    # (B,N/8,9)
         t_idx = sample_idxs_t[:, :M // 8, None].long().expand(-1, -1, self.config.bc_channel)

@@ -285,3 +285,37 @@ def test_chain_pair_equals_two_single_chains(train, B, N):
     oa3, ob3 = nn_blocks.seq_apply_pair((cla, [f3], False), (vote, [xyz.transpose(1, 2), f3], True))
     (oa3 * ca).sum().backward()
     assert f3.grad is not None and torch.isfinite(f3.grad).all()
+
+
+@pytest.mark.parametrize("B,Na,Nb", [(4, 64, 128), (48, 64, 128), (2, 32, 96)])
+def test_shared_conv_pair_equals_two_convs(B, Na, Nb):
+    """conv_final on the template and on the search feature (models/bat.py:91-92) as ONE GEMM over the columns of both
+    (fused_heads.SharedConvPair) against the two separate calls and against nn.Conv1d in fp64: outputs (bitwise the
+    single calls': every column is the same dot product), input gradients, the weight gradient summed over both sets,
+    the bias gradient"""
+    from open3dsot_amd import fused_heads, nn_blocks
+    torch.manual_seed(5)
+    conv = torch.nn.Conv1d(256, 256, 1).cuda()
+    conv2 = copy.deepcopy(conv)
+    ref = copy.deepcopy(conv).double()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    xa = torch.randn(B, 256, Na, device="cuda", generator=g)
+    xb = torch.randn(Nb, B, 256, device="cuda", generator=g).permute(1, 2, 0)          # a strided (B, C, N) view
+    a1, b1 = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+    a2, b2 = xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)
+    a3, b3 = xa.double().requires_grad_(True), xb.double().requires_grad_(True)
+    assert fused_heads.shared_conv_pair_supported(conv, a1, b1) == ((B * (Na + Nb)) % 128 == 0)
+    ya, yb = nn_blocks.pointwise_conv1d_pair(conv, a1, b1)
+    ra, rb = nn_blocks.pointwise_conv1d(conv2, a2), nn_blocks.pointwise_conv1d(conv2, b2)
+    wa, wb = ref(a3), ref(b3)
+    assert ya.shape == ra.shape and yb.shape == rb.shape
+    assert torch.equal(ya, ra) and torch.equal(yb, rb)
+    assert rel(ya, wa) < 2e-5 and rel(yb, wb) < 2e-5
+    ca, cb = torch.randn(ya.shape, device="cuda", generator=g), torch.randn(yb.shape, device="cuda", generator=g)
+    ((ya * ca).sum() + (yb * cb).sum()).backward()
+    ((ra * ca).sum() + (rb * cb).sum()).backward()
+    ((wa * ca.double()).sum() + (wb * cb.double()).sum()).backward()
+    assert torch.equal(a1.grad, a2.grad) and torch.equal(b1.grad, b2.grad)
+    assert l2rel(a1.grad, a3.grad) < 5e-4 and l2rel(b1.grad, b3.grad) < 5e-4
+    assert l2rel(conv.weight.grad, ref.weight.grad) < 5e-4 and l2rel(conv.bias.grad, ref.bias.grad) < 5e-4
+    assert l2rel(conv.weight.grad, conv2.weight.grad) < 1e-5
