@@ -469,7 +469,9 @@ def _chain_backward(state, dOut, needs):
             scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Kp, Cout_p, P),), device=dev, dtype=f32)
             jobs.append((2.0 * Kp * Cout_p * P, (dN.data_ptr(), Y.data_ptr(), A[0], A[1], A[2], Xs.data_ptr(), sc, sh, Kp,
                                                  Cout_p, P, scratch.data_ptr(), dW.data_ptr())))
-            keep.extend((dN, Y, scratch, dW, coef))
+            # everything the (possibly deferred) launch reads: the layer input and its BatchNorm constants belong to the
+            # autograd node, which is released -- and its memory reused -- as soon as this backward returns
+            keep.extend((dN, Y, scratch, dW, coef, Xs, vecs[l - 1] if l > 0 else None))
             return (dW if (Cout, Cin) == (Cout_p, Kp) else dW[:Cout, :Cin]).reshape(Wl.shape)
         if side is not main:
             side.wait_stream(main)           # dN and the BatchNorm-backward constants of this layer are ready
