@@ -50,7 +50,7 @@ _MAXJOBS = 8                # WG_MAXJOBS of csrc/mlp_wgrad.hip
 # queue is flushed in groups of 8 when the scope ends -- the heads' 23 jobs of a BAT step in 3 launches + 3 reductions
 # instead of 7 + 7.  The gradient tensors autograd was handed are filled by the flush: the scope must end before anything
 # reads them (AccumulateGrad only stores them).  O3D_WGRAD_DEFER=0: every stack flushes for itself.
-_DEFER = {"on": __import__("os").environ.get("O3D_WGRAD_DEFER", "1") != "0", "queue": None}
+_DEFER = {"on": __import__("os").environ.get("O3D_WGRAD_DEFER", "1") != "0", "queue": None, "keys": None}
 
 
 def _flush_jobs(jobs, st):
@@ -61,22 +61,45 @@ def _flush_jobs(jobs, st):
         _call("pw_conv_wgrad", sum(j[0] for j in chunk), lib.o3d_mlp_conv_wgrad2_group, ctypes.addressof(arr), len(chunk), st)
 
 
+def _flush_queue():
+    q = _DEFER["queue"]
+    _DEFER["queue"], _DEFER["keys"] = [], set()
+    by_stream = {}
+    for jobs, keep, st in q:
+        by_stream.setdefault(st, []).extend(jobs)
+    for st, jobs in by_stream.items():
+        _flush_jobs(jobs, st)
+    del q
+
+
+def _submit_jobs(jobs, keep, st, keys):
+    """launch the jobs now, or queue them inside a `defer_wgrads` scope.  keys: identities of the parameters whose
+    gradients the jobs produce -- a parameter that is used TWICE in the step (conv_final on the template and on the
+    search feature when the two calls are not merged) gets its second gradient ADDED to the first by autograd as soon as
+    this backward returns, so both must be complete by then: a repeated key flushes the queue on the spot."""
+    if not jobs:
+        return
+    if _DEFER["queue"] is None:
+        _flush_jobs(jobs, st)
+        return
+    _DEFER["queue"].append((jobs, keep, st))      # (the queue keeps the operands alive until the flush)
+    if _DEFER["keys"] & set(keys):
+        _flush_queue()
+    else:
+        _DEFER["keys"] |= set(keys)
+
+
 @contextlib.contextmanager
 def defer_wgrads():
     if not _DEFER["on"] or _DEFER["queue"] is not None:
         yield
         return
-    _DEFER["queue"] = []
+    _DEFER["queue"], _DEFER["keys"] = [], set()
     try:
         yield
     finally:
-        q, _DEFER["queue"] = _DEFER["queue"], None
-        by_stream = {}
-        for jobs, keep, st in q:
-            by_stream.setdefault(st, []).extend(jobs)
-        for st, jobs in by_stream.items():
-            _flush_jobs(jobs, st)
-        del q
+        _flush_queue()
+        _DEFER["queue"] = _DEFER["keys"] = None
 
 import os as _os
 
@@ -425,6 +448,7 @@ def _chain_forward(cfg, tensors, need_bwd):
         state.geom = (B, N, L, K0, K0p, [t.shape[1] for t in srcs])
         state.versions = [(p, p._version) for p in params if p is not None]
         state.saved = (X0, Ys, vecs, Wts, [params[4 * l + 2] for l in range(L)], [params[4 * l] for l in range(L)])
+        state.biases = [params[4 * l + 1] for l in range(L)]
     return Ys[-1][:Cl].view(Cl, B, N).permute(1, 0, 2), state
 
 
@@ -551,11 +575,8 @@ def _chain_backward(state, dOut, needs):
                                                                         Wts[0].data_ptr(), K0p, Cp, P, None, None, None, None,
                                                                         G.data_ptr() if cfg.residual else None, dX0.data_ptr(),
                                                                         None, st], (K0p, Cp))
-    if jobs and _DEFER["queue"] is not None:
-        _DEFER["queue"].append((jobs, keep, st))      # (the queue keeps the operands alive until the flush)
-        keep = []
-    else:
-        _flush_jobs(jobs, st)
+    _submit_jobs(jobs, keep, st, [id(w_) for w_ in Ws] + [id(b_) for b_ in state.biases if b_ is not None])
+    keep = []
     if side is not main:
         main.wait_stream(side)       # join: every weight gradient is complete before autograd hands it on
     del keep
@@ -716,11 +737,7 @@ class SharedConvPair(torch.autograd.Function):
         if bias is not None and ctx.needs_input_grad[1]:
             dbias = torch.empty((Cout,), device=dev, dtype=f32)
             jobs.append((0.0, (G.data_ptr(), None, None, None, None, None, None, None, 0, Cout, P, None, dbias.data_ptr())))
-        keep = [G, X0, scratch, dW, dbias, one, zero]
-        if _DEFER["queue"] is not None:
-            _DEFER["queue"].append((jobs, keep, st))
-        else:
-            _flush_jobs(jobs, st)
+        _submit_jobs(jobs, [G, X0, scratch, dW, dbias, one, zero], st, [id(W)] + ([id(bias)] if bias is not None else []))
         return dW.view(W.shape), dbias, dxa, dxb
 
 
