@@ -505,6 +505,8 @@ typedef struct {
     const float* X; const float* in_scale; const float* in_shift;
     int Cin, Cout; long P;
     float* scratch; float* dW;
+    int out_rows, out_cols;      /* 0, 0: dW is (Cout, Cin); else dW is the COMPACT (out_rows, out_cols) top-left block of it
+                                  * (the parameter's own shape when Cout / Cin are its zero-padded sizes) */
 } o3d_wgrad_job;
 int o3d_mlp_conv_wgrad2_group(const o3d_wgrad_job* jobs, int njobs, void* stream);
 

@@ -275,6 +275,10 @@ __global__ __launch_bounds__(256) void wgrad2_group_kernel(Wgrad2Group g) {
 struct ReduceGroup {
     const float* part[WG_MAXJOBS]; float* out[WG_MAXJOBS];
     long n[WG_MAXJOBS]; int nslices[WG_MAXJOBS]; int first[WG_MAXJOBS + 1]; int njobs;
+    // compact output: element (row, col) of the padded (rows_p, ld[j]) gradient goes to out[row * ocols[j] + col] when
+    // row < orows[j] and col < ocols[j] -- the gradient autograd receives is then contiguous in the parameter's own
+    // shape (a strided slice of the padded buffer made AccumulateGrad clone it: one more launch per padded layer)
+    int ld[WG_MAXJOBS], orows[WG_MAXJOBS], ocols[WG_MAXJOBS];
 };
 
 // the slice reductions of a group in one launch: wgrad_reduce1_kernel's arithmetic (mlp.hip), same fixed order
@@ -305,7 +309,10 @@ __global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(ReduceGroup r) 
         float t = 0.f;
 #pragma unroll
         for (int g = 0; g < 8; ++g) t += sh[g][col];
-        r.out[j][i] = t;
+        const int ld = r.ld[j];
+        const long row = i / ld;
+        const int cc = (int)(i - row * ld);
+        if (row < r.orows[j] && cc < r.ocols[j]) r.out[j][row * r.ocols[j] + cc] = t;
     }
 }
 
@@ -687,7 +694,7 @@ extern "C" int o3d_mlp_conv_wgrad2_group(const o3d_wgrad_job* jobs, int njobs, v
             g.kind[i] = 4;
             g.first[i] = nblk;
             nblk += q.Cout;
-            r.part[i] = q.dW; r.out[i] = q.dW; r.n[i] = 0; r.nslices[i] = 0;
+            r.part[i] = q.dW; r.out[i] = q.dW; r.n[i] = 0; r.nslices[i] = 0; r.ld[i] = 1; r.orows[i] = r.ocols[i] = 0;
             r.first[i] = rblk;
             continue;
         }
@@ -709,7 +716,9 @@ extern "C" int o3d_mlp_conv_wgrad2_group(const o3d_wgrad_job* jobs, int njobs, v
         nblk += (q.Cout / TM) * (q.Cin / TN) * nsl;
         const size_t l = sizeof(float) * 2 * (TM + TN) * (CP + 4);
         lds = l > lds ? l : lds;
+        if (q.out_rows < 0 || q.out_rows > q.Cout || q.out_cols < 0 || q.out_cols > q.Cin) return O3D_EINVAL;
         r.part[i] = q.scratch; r.out[i] = q.dW; r.n[i] = (long)q.Cout * q.Cin; r.nslices[i] = nsl * WK;
+        r.ld[i] = q.Cin; r.orows[i] = q.out_rows > 0 ? q.out_rows : q.Cout; r.ocols[i] = q.out_cols > 0 ? q.out_cols : q.Cin;
         r.first[i] = rblk;
         rblk += o3d_cdiv(r.n[i], 32);
     }

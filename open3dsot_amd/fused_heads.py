@@ -38,7 +38,8 @@ capi.register("o3d_mlp_conv_wgrad2_group", [_vp, _i, _vp])
 
 class _WgradJob(ctypes.Structure):        # o3d_wgrad_job of include/o3dsot.h
     _fields_ = [("dN", _vp), ("Y", _vp), ("A1", _vp), ("A2", _vp), ("A3", _vp), ("X", _vp), ("in_scale", _vp),
-                ("in_shift", _vp), ("Cin", _i), ("Cout", _i), ("P", _l), ("scratch", _vp), ("dW", _vp)]
+                ("in_shift", _vp), ("Cin", _i), ("Cout", _i), ("P", _l), ("scratch", _vp), ("dW", _vp), ("out_rows", _i),
+                ("out_cols", _i)]
 
 
 # the weight gradients of a stack as ONE grouped launch (+ one reduction launch) at the end of its backward instead of a
@@ -489,14 +490,17 @@ def _chain_backward(state, dOut, needs):
         Wl = Ws[l]
         Cout, Cin = Wl.shape[0], Wl.shape[1]
         if _GROUP["on"] and side is main:
-            dW = torch.empty((Cout_p, Kp), device=dev, dtype=f32)
+            # the gradient in the parameter's OWN (Cout, Cin) shape, written compactly by the group's reduction: what
+            # autograd receives is contiguous (a slice of the padded buffer is cloned by AccumulateGrad -- one more launch,
+            # and with deferred launches a clone of a buffer that is not filled yet)
+            dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
             scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Kp, Cout_p, P),), device=dev, dtype=f32)
             jobs.append((2.0 * Kp * Cout_p * P, (dN.data_ptr(), Y.data_ptr(), A[0], A[1], A[2], Xs.data_ptr(), sc, sh, Kp,
-                                                 Cout_p, P, scratch.data_ptr(), dW.data_ptr())))
+                                                 Cout_p, P, scratch.data_ptr(), dW.data_ptr(), Cout, Cin)))
             # everything the (possibly deferred) launch reads: the layer input and its BatchNorm constants belong to the
             # autograd node, which is released -- and its memory reused -- as soon as this backward returns
             keep.extend((dN, Y, scratch, dW, coef, Xs, vecs[l - 1] if l > 0 else None))
-            return (dW if (Cout, Cin) == (Cout_p, Kp) else dW[:Cout, :Cin]).reshape(Wl.shape)
+            return dW.view(Wl.shape)
         if side is not main:
             side.wait_stream(main)           # dN and the BatchNorm-backward constants of this layer are ready
         with torch.cuda.stream(side):
@@ -514,7 +518,7 @@ def _chain_backward(state, dOut, needs):
     if needs[cfg.nsrc + 4 * l + 1]:
         if _GROUP["on"] and side is main:        # the bias gradient rides in the stack's grouped weight-gradient launch
             db = torch.empty((Mp,), device=dev, dtype=f32)
-            jobs.append((0.0, (G.data_ptr(), None, None, None, None, None, None, None, 0, Mp, P, None, db.data_ptr())))
+            jobs.append((0.0, (G.data_ptr(), None, None, None, None, None, None, None, 0, Mp, P, None, db.data_ptr(), 0, 0)))
         else:
             if side is not main:
                 side.wait_stream(main)
@@ -732,11 +736,11 @@ class SharedConvPair(torch.autograd.Function):
         dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
         scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, P),), device=dev, dtype=f32)
         jobs = [(2.0 * Cin * Cout * P, (G.data_ptr(), G.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(),
-                                       X0.data_ptr(), None, None, Cin, Cout, P, scratch.data_ptr(), dW.data_ptr()))]
+                                       X0.data_ptr(), None, None, Cin, Cout, P, scratch.data_ptr(), dW.data_ptr(), 0, 0))]
         dbias = None
         if bias is not None and ctx.needs_input_grad[1]:
             dbias = torch.empty((Cout,), device=dev, dtype=f32)
-            jobs.append((0.0, (G.data_ptr(), None, None, None, None, None, None, None, 0, Cout, P, None, dbias.data_ptr())))
+            jobs.append((0.0, (G.data_ptr(), None, None, None, None, None, None, None, 0, Cout, P, None, dbias.data_ptr(), 0, 0)))
         _submit_jobs(jobs, [G, X0, scratch, dW, dbias, one, zero], st, [id(W)] + ([id(bias)] if bias is not None else []))
         return dW.view(W.shape), dbias, dxa, dxb
 
