@@ -153,6 +153,12 @@ class DataParallelStep:
         self._sampling = getattr(model, "sampling_inputs", None) if os.environ.get("O3D_FPS_PREFETCH", "1") != "0" else None
         self._side = None
         self._prefetched = None        # (batch object, {key: tensor}, event)
+        # the constant 1 that seeds `loss.backward`: allocated here, outside any capture (open3dsot_amd/fused_loss.py::one)
+        first = next(iter(model.parameters()), None)
+        self._one = None
+        if first is not None and first.is_cuda and os.environ.get("O3D_GLUE_TRIM", "1") != "0":
+            from . import fused_loss
+            self._one = fused_loss.one(first.device)
 
     def reduce_gradients(self):
         """flat exchange buffer (packed by `_forward_backward`) -> mean over ranks, p.grad = its views.  One collective on
@@ -172,7 +178,10 @@ class DataParallelStep:
         self.grads.clear()
         loss, _ = self.model.training_loss(batch)
         with _defer_wgrads():         # the heads' weight gradients of the whole backward in a few grouped launches
-            loss.backward()
+            if self._one is not None and loss.dim() == 0 and loss.device == self._one.device:
+                loss.backward(gradient=self._one)      # no ones_like launch; the fused loss skips its scaling launch
+            else:
+                loss.backward()
         if self.world > 1:
             # pack the gradients autograd produced into the exchange buffer: one multi-tensor copy, part of the captured
             # HIP graph when there is one (so a replayed step ends with the message ready to be reduced)

@@ -16,6 +16,7 @@ running_var, momentum 0.1); the NEXT kernel applies BN+ReLU while loading.  Save
 backward: Y_l and four per-channel vectors per layer, plus arg-max of the pool.
 """
 import ctypes
+import os as _os
 
 import torch
 from torch import nn
@@ -153,8 +154,25 @@ def counters_begin():
 
 def counters_end():
     pending, _COUNTERS["pending"] = _COUNTERS["pending"], None
-    for inc, tensors in (pending or {}).items():
-        torch._foreach_add_(tensors, inc)
+    if not pending:
+        return
+    if not _GLUE_TRIM["on"]:
+        for inc, tensors in pending.items():
+            torch._foreach_add_(tensors, inc)
+        return
+    # one multi-tensor launch for every increment of the forward (was: one per distinct increment -- 1 for a module
+    # called once, 2 for a paired one); a counter that was collected twice gets the sum, not two racing updates
+    total = {}
+    for inc, tensors in pending.items():
+        for t in tensors:
+            ent = total.setdefault(id(t), [t, 0])
+            ent[1] += inc
+    torch._foreach_add_([e[0] for e in total.values()], [e[1] for e in total.values()])
+
+
+# round 3: launch trimming of the torch glue around the kernels (O3D_GLUE_TRIM=0 restores the previous forms for A/B):
+# see also open3dsot_amd/fused_loss.py, dist.py::DataParallelStep._forward_backward, trackers.py::BAT._forward
+_GLUE_TRIM = {"on": _os.environ.get("O3D_GLUE_TRIM", "1") != "0"}
 
 
 def _versions(params):
@@ -881,7 +899,12 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                     dX = torch.empty((Cinm, ldz), device=dev, dtype=f32)
                     _call("conv_dgrad_points", 2.0 * Cinm * Cout * ldz, lib.o3d_mlp_conv_fwd, S.data_ptr(), W0t.data_ptr(),
                           None, None, 1, Cout, Cinm, ldz, dX.data_ptr(), None, None, st, dims=(Cout, Cinm))
-                    dnew_all = ((-cfg.inv_radius) * Ws[0][:, :3]).t() @ T if want_xyz else None       # (3, balls)
+                    if not want_xyz:
+                        dnew_all = None
+                    elif _GLUE_TRIM["on"]:      # -inv_radius * W0[:, :3]^T . T as ONE GEMM call (beta = 0: T[:3] is only a shape)
+                        dnew_all = torch.addmm(T[:3], Ws[0][:, :3].t(), T, beta=0.0, alpha=-float(cfg.inv_radius))
+                    else:
+                        dnew_all = ((-cfg.inv_radius) * Ws[0][:, :3]).t() @ T                        # (3, balls)
                     for s_ in range(nseg):
                         view = dX[:Cin, pt_bases[s_]:pt_bases[s_] + B * Npads[s_]].view(Cin, B, Npads[s_])
                         if want_feats:

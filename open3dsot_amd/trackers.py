@@ -17,7 +17,7 @@ from torch import nn
 
 import ctypes
 
-from . import capi, fused_heads, fused_loss, optim
+from . import capi, fused, fused_heads, fused_loss, optim
 from . import nn_blocks as pt_utils
 from .backbone import Pointnet_Backbone
 from .rpn import P2BVoteNetRPN
@@ -223,6 +223,10 @@ class BAT(MatchingBaseModel):
         template_feature, search_feature = pt_utils.pointwise_conv1d_pair(self.conv_final, template_feature, search_feature)
         pred_search_bc = pt_utils.seq_apply(self.mlp_bc, [search_xyz.transpose(1, 2), search_feature])
         pred_search_bc = pred_search_bc.transpose(1, 2)                                    # (B,N/8,9)
+        if fused._GLUE_TRIM["on"] and pred_search_bc.is_cuda:
+            # its two consumers on the device (the kNN kernel and the fused loss) both want it point-major and dense: one
+            # copy here instead of one in each
+            pred_search_bc = pred_search_bc.contiguous()
         t_idx = sample_idxs_t[:, :M // 8, None].long().expand(-1, -1, self.config.bc_channel)
         template_bc = template_bc.gather(dim=1, index=t_idx)                               # (B,M/8,9)
         fusion = self.xcorr(template_feature, search_feature, template_xyz, search_xyz, template_bc,

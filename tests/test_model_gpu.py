@@ -388,6 +388,36 @@ def test_fused_track_loss_matches_compute_loss(with_bc, seed):
     assert og["center_xyz"].grad is None
 
 
+def test_backward_seeded_with_the_constant_one_equals_plain_backward():
+    """DataParallelStep seeds `loss.backward` with fused_loss.one(device): no `ones_like`, and the fused loss recognises the
+    constant and skips its scaling launch.  Same gradients, bit for bit, as the plain `loss.backward()`; any OTHER seed
+    (here 0.5 at a different address, and a fresh tensor holding 1.0) still goes through the multiply."""
+    from open3dsot_amd import fused_loss, synth
+    dev = torch.device("cuda", 0)
+    model = make_model("BAT", 12)
+    batch = synth.to_torch(synth.make_batch(77, 4, 512, 1024), dev)
+
+    saved = {k: v.clone() for k, v in model.state_dict().items()}
+
+    def grads(seed):
+        model.load_state_dict(saved)          # running statistics (the shift of the second moments) as in the first run
+        model.zero_grad(set_to_none=True)
+        loss, _ = model.training_loss(batch)
+        assert loss.dim() == 0 and loss.requires_grad
+        loss.backward() if seed is None else loss.backward(gradient=seed)
+        return [p.grad.clone() for p in model.parameters()]
+
+    plain = grads(None)
+    one = fused_loss.one(dev)
+    assert one.dim() == 0 and float(one) == 1.0 and fused_loss.one(dev) is one
+    seeded = grads(one)
+    fresh = grads(torch.ones((), device=dev))
+    half = grads(torch.full((), 0.5, device=dev))
+    for a, b, c, d in zip(plain, seeded, fresh, half):
+        assert torch.equal(a, b) and torch.equal(a, c)
+        assert float((d * 2 - a).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-12
+
+
 @pytest.mark.parametrize("model_name", ["BAT", "P2B"])
 def test_inference_graph_replay_matches_eager_and_oracle(model_name):
     """the tracking-inference path -- eval mode (BatchNorm on running statistics), batch 1,

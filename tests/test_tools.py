@@ -60,3 +60,30 @@ def test_asm_helpers_count_the_serialised_pattern(tmp_path):
     assert "global_load_dword | s_waitcnt vmcnt(0) | global_store_dword | global_load_dword | s_waitcnt vmcnt(0)" in seq, seq
     phases = run("asm_phases.py", str(f))
     assert "my_kernel<4,2>" in phases and "(1 mfma)" in phases, phases
+
+
+def test_batch_counter_increments_are_merged_into_one_update():
+    """open3dsot_amd.fused.count_batches inside a counters_begin / counters_end scope (a tracker forward): every
+    `num_batches_tracked` increment of the forward is applied by one multi-tensor update at the end -- a module called once
+    (+1), a paired module (+2), and a counter that is collected twice gets the sum.  Host logic only (CPU tensors)."""
+    import torch
+    from open3dsot_amd import fused
+    bns = [torch.nn.BatchNorm1d(4) for _ in range(4)]
+    assert fused.counters_begin()
+    assert not fused.counters_begin()                      # nested scopes join the outer one
+    fused.count_batches(bns[:2], 1)
+    fused.count_batches(bns[2:3], 2)
+    fused.count_batches(bns[1:2], 1)                       # the same module again
+    assert all(int(bn.num_batches_tracked) == 0 for bn in bns)
+    calls = []
+    real = torch._foreach_add_
+    torch._foreach_add_ = lambda *a, **k: (calls.append(len(a[0])), real(*a, **k))[1]
+    try:
+        fused.counters_end()
+    finally:
+        torch._foreach_add_ = real
+    assert [int(bn.num_batches_tracked) for bn in bns] == [1, 2, 2, 0]
+    assert calls == [3] or not fused._GLUE_TRIM["on"]
+    fused.count_batches(bns[3:], 1)                         # outside a scope: applied at once
+    assert int(bns[3].num_batches_tracked) == 1
+    fused.counters_end()                                    # nothing pending: a no-op
