@@ -390,7 +390,7 @@ def test_fused_track_loss_matches_compute_loss(with_bc, seed):
 
 def test_backward_seeded_with_the_constant_one_equals_plain_backward():
     """DataParallelStep seeds `loss.backward` with fused_loss.one(device): no `ones_like`, and the fused loss recognises the
-    constant and skips its scaling launch.  Same gradients, bit for bit, as the plain `loss.backward()`; any OTHER seed
+    constant and skips its scaling launch.  Same gradients as the plain `loss.backward()` (to run-to-run rounding); any OTHER seed
     (here 0.5 at a different address, and a fresh tensor holding 1.0) still goes through the multiply."""
     from open3dsot_amd import fused_loss, synth
     dev = torch.device("cuda", 0)
@@ -413,9 +413,13 @@ def test_backward_seeded_with_the_constant_one_equals_plain_backward():
     seeded = grads(one)
     fresh = grads(torch.ones((), device=dev))
     half = grads(torch.full((), 0.5, device=dev))
+    # not bit for bit: the layer-0 list sums use LDS float atomics (csrc/compact.hip::reduce_gather_kernel), so two runs of
+    # the SAME backward differ in the last bits; the seeds must not add anything beyond that
+    gmax = max(float(a.abs().max()) for a in plain)     # conv biases in front of a BatchNorm: the true gradient is 0, the computed one noise
     for a, b, c, d in zip(plain, seeded, fresh, half):
-        assert torch.equal(a, b) and torch.equal(a, c)
-        assert float((d * 2 - a).abs().max()) <= 1e-6 * float(a.abs().max()) + 1e-12
+        tol = 4e-6 * float(a.abs().max()) + 1e-6 * gmax
+        assert float((b - a).abs().max()) <= tol and float((c - a).abs().max()) <= tol
+        assert float((d * 2 - a).abs().max()) <= tol
 
 
 @pytest.mark.parametrize("model_name", ["BAT", "P2B"])
