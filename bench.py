@@ -344,7 +344,7 @@ def secondary_lines(args):
             else:
                 r = measure(a, 0, 0, 1, full=False)
             out[tag] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
-                        "workload": r["config"]["workload"]}
+                        "workload": r["config"]["workload"], "hip_graph": bool(r["config"].get("hip_graph"))}
         except Exception as e:  # a secondary line must never take the main line down
             out[tag] = {"error": "%s: %s" % (type(e).__name__, e)}
         torch.cuda.empty_cache()

@@ -151,7 +151,7 @@ class MiniPointNet(nn.Module):
         self._n_point = len(seq)
         seq += [nn.AdaptiveMaxPool1d(output_size=1), nn.Flatten()]
         for width in hidden_mlp:
-            seq += [nn.Linear(c, width), nn.BatchNorm1d(width), nn.ReLU()]
+            seq += [nn.Linear(c, width), nn_blocks.RowBatchNorm1d(width), nn.ReLU()]
             c = width
         self.features = nn.Sequential(*seq)
         self.output_size = output_size

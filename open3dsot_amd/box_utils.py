@@ -8,12 +8,39 @@ its `points` argument in place (`points -= ...`); these functions do not (same v
 import torch
 
 
-def rotz_batch_tensor(t):
-    """rotation matrices about z for angles t (...,) -> (...,3,3)"""
+_ROTZ = {}        # device -> (basis (2, 9), constant part (9,)) of the z rotation as a linear map of (cos, sin)
+
+
+def _rotz_constants(dev):
+    key = str(dev)
+    hit = _ROTZ.get(key)
+    if hit is None:
+        if dev.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            return None               # host data cannot be uploaded by a capturing stream: the stacked form below
+        basis = torch.tensor([[1.0, 0, 0, 0, 1, 0, 0, 0, 0], [0, -1.0, 0, 1, 0, 0, 0, 0, 0]], device=dev)
+        const = torch.tensor([0.0, 0, 0, 0, 0, 0, 0, 0, 1], device=dev)      # 1-D: the GEMM's bias epilogue, no broadcast copy
+        hit = _ROTZ[key] = (basis, const)
+    return hit
+
+
+def rotz_batch_tensor_stacked(t):
+    """the reference's formulation (datasets/points_utils.py:377-387): nine launches and a four-stack backward"""
     c, s = torch.cos(t), torch.sin(t)
     zero, one = torch.zeros_like(c), torch.ones_like(c)
     rows = [torch.stack([c, -s, zero], -1), torch.stack([s, c, zero], -1), torch.stack([zero, zero, one], -1)]
     return torch.stack(rows, -2).to(torch.float32)
+
+
+def rotz_batch_tensor(t):
+    """rotation matrices about z for angles t (...,) -> (...,3,3).
+    The same nine entries as the stacked form, bit for bit (c*1 + s*0 + 0 and c*0 + s*(-1) + 0 are exact), written as
+    ONE small GEMM [cos t, sin t] . basis + const: four launches instead of nine, and a backward of one GEMM instead of
+    four stack-backwards with their zero fills (the M2-Track step builds five of these per forward)."""
+    consts = _rotz_constants(t.device) if t.dtype == torch.float32 else None
+    if consts is None:
+        return rotz_batch_tensor_stacked(t)
+    cs = torch.stack([torch.cos(t), torch.sin(t)], -1).reshape(-1, 2)
+    return torch.addmm(consts[1], cs, consts[0]).view(*t.shape, 3, 3)
 
 
 def get_offset_box_tensor(ref_box, offset_box):

@@ -14,6 +14,7 @@ import torch
 
 from . import capi
 from .fused import _call, _check_versions, _const_vec, _eval_consts, _ptr, _stream, _versions, count_batches, POOL_BWD_SPLIT, TILE
+from .fused import _GLUE_TRIM
 
 _vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
 capi.register("o3d_bn_relu_apply", [_vp, _vp, _vp, _i, _l, _vp, _vp])
@@ -53,6 +54,7 @@ class FusedPointwiseChain(torch.autograd.Function):
         X0 = x.detach().permute(1, 0, 2).reshape(Cin0, P).contiguous()
         ntiles = P // TILE
         Ys, means, invstds, scales, shifts = [], [], [], [], []
+        bias_fix = {}
         for l in range(L):
             Cout, Cin = Ws[l].shape
             bn = cfg.bns[l]
@@ -77,11 +79,18 @@ class FusedPointwiseChain(torch.autograd.Function):
                       float(bn.momentum), float(bn.eps), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
                       vec[3].data_ptr(), fold.data_ptr(), st)
                 if b is not None:       # statistics were taken without the bias: mean(Y + b) = mean(Y) + b
-                    bn.running_mean.add_(b, alpha=float(bn.momentum))
+                    if _GLUE_TRIM["on"]:
+                        bias_fix.setdefault(float(bn.momentum), ([], []))
+                        bias_fix[float(bn.momentum)][0].append(bn.running_mean)
+                        bias_fix[float(bn.momentum)][1].append(b)
+                    else:
+                        bn.running_mean.add_(b, alpha=float(bn.momentum))
             else:
                 _eval_consts(lib, bn, gammas[l], betas[l], vec, 1, st, conv_bias=b)
             Ys.append(Y)
             means.append(vec[0]); invstds.append(vec[1]); scales.append(vec[2]); shifts.append(vec[3])
+        for mom, (rms, bs) in bias_fix.items():      # one multi-tensor launch per stack instead of one per layer
+            torch._foreach_add_(rms, bs, alpha=mom)
         if cfg.training:
             count_batches(cfg.bns, 1)
         Cl = Ws[-1].shape[0]

@@ -16,6 +16,7 @@ from torch import nn
 
 from . import box_utils
 from .backbone import MiniPointNet, SegPointNet
+from .nn_blocks import RowBatchNorm1d
 
 # cfgs/M2_track_kitti.yaml (model / loss keys)
 M2_KITTI = dict(net_model="m2track", box_aware=True, use_motion_cls=True, use_second_stage=True,
@@ -24,9 +25,23 @@ M2_KITTI = dict(net_model="m2track", box_aware=True, use_motion_cls=True, use_se
                 lr_decay_step=20, lr_decay_rate=0.1, batch_size=100)
 
 
+_CONSTS = {}
+
+
+def _const(dev, values):
+    """a small constant vector on `dev`, uploaded once: host data inside the step would make it impossible to capture (the
+    class weights of the segmentation loss were a `torch.tensor(..., device=...)` per call, and the HIP-graph capture of
+    the M2-Track step failed on exactly that until round 3)"""
+    key = (str(dev), values)
+    t = _CONSTS.get(key)
+    if t is None:
+        t = _CONSTS[key] = torch.tensor(values, device=dev, dtype=torch.float32)
+    return t
+
+
 def _head(out):
-    return nn.Sequential(nn.Linear(256, 128), nn.BatchNorm1d(128), nn.ReLU(),
-                         nn.Linear(128, 128), nn.BatchNorm1d(128), nn.ReLU(), nn.Linear(128, out))
+    return nn.Sequential(nn.Linear(256, 128), RowBatchNorm1d(128), nn.ReLU(),
+                         nn.Linear(128, 128), RowBatchNorm1d(128), nn.ReLU(), nn.Linear(128, out))
 
 
 class M2TRACK(nn.Module):
@@ -57,6 +72,13 @@ class M2TRACK(nn.Module):
 
     def forward(self, input_dict):
         """points (B,N,5) [+ candidate_bc (B,N,9)] -> dict with estimation_boxes (B,4), seg_logits (B,2,N), ..."""
+        from . import fused_heads
+        # one forward = one scope: the prepared weight copies refreshed by one launch, every BatchNorm counter of the
+        # forward (five stacks, twelve row BatchNorms) updated by one launch at the end
+        with fused_heads.prep_scope(input_dict["points"].device):
+            return self._forward(input_dict)
+
+    def _forward(self, input_dict):
         out = {}
         x = input_dict["points"].transpose(1, 2)
         if self.box_aware:
@@ -101,6 +123,59 @@ class M2TRACK(nn.Module):
         return out
 
     def compute_loss(self, data, output):
+        """models/m2track.py:153-231.  Same terms, same weights, same dict; the four (centre, angle) pairs -- first-stage
+        box, refined box, previous-frame box, motion -- are evaluated as ONE stacked smooth-L1 each and the weighted total
+        as one dot product, about half the launches of the term-by-term form (`compute_loss_reference`, which it equals
+        to fp32 rounding: tests/test_golden_m2track.py)."""
+        from . import fused
+        if not fused._GLUE_TRIM["on"]:
+            return self.compute_loss_reference(data, output)
+        c = self.config
+        aux, motion_pred, seg_logits = output["aux_estimation_boxes"], output["motion_pred"], output["seg_logits"]
+        state = data["motion_state_label"]
+        dev = seg_logits.device
+        # rows of the stacked problem: (name suffix, prediction (B,4), label (B,4)); the motion row last
+        rows = [("aux", aux, data["box_label"])]
+        if self.use_second_stage:
+            rows.append(("", output["estimation_boxes"], data["box_label"]))
+        if self.use_prev_refinement:
+            rows.append(("prev", output["estimation_boxes_prev"], data["box_label_prev"]))
+        rows.append(("motion", motion_pred, data["motion_label"]))
+        K, B = len(rows), aux.shape[0]
+        pred = torch.stack([r[1] for r in rows])                                        # (K,B,4)
+        label = torch.stack([r[2] for r in rows])
+        per_center = F.smooth_l1_loss(pred[..., :3], label[..., :3], reduction="none").mean(dim=2)            # (K,B)
+        per_angle = F.smooth_l1_loss(torch.sin(pred[..., 3]), torch.sin(label[..., 3]), reduction="none")     # (K,B)
+        per = torch.stack([per_center, per_angle])                                      # (2,K,B)
+        if self.use_motion_cls:      # the motion row averages over the moving samples only (:196-203), the others over B
+            moving = state / (state.sum() + 1e-6)
+            sample_w = torch.cat([torch.full((K - 1, B), 1.0 / B, device=dev, dtype=per.dtype), moving[None].to(per.dtype)])
+            terms = (per * sample_w).sum(dim=2)                                         # (2,K)
+        else:
+            terms = per.mean(dim=2)
+        ld, names, weights = {}, [], []
+        for k, (suffix, _, _) in enumerate(rows):
+            tag = "_" + suffix if suffix else ""
+            ld["loss_center" + tag], ld["loss_angle" + tag] = terms[0, k], terms[1, k]
+        extra = []
+        loss_seg = F.cross_entropy(seg_logits, data["seg_label"], weight=_const(dev, (0.5, 2.0)).to(seg_logits.dtype))
+        ld["loss_seg"] = loss_seg
+        extra.append((loss_seg, c.seg_weight))
+        if self.use_motion_cls:
+            ld["loss_motion_cls"] = F.cross_entropy(output["motion_cls"], state)
+            extra.append((ld["loss_motion_cls"], c.motion_cls_seg_weight))
+        if self.box_aware:
+            bc_label = torch.cat([data["prev_bc"], data["this_bc"]], dim=1)
+            ld["loss_bc"] = F.smooth_l1_loss(output["pred_bc"], bc_label)
+            extra.append((ld["loss_bc"], c.bc_weight))
+        wvec = _const(dev, tuple([float(c.center_weight)] * K + [float(c.angle_weight)] * K + [float(w) for _, w in extra]))
+        allterms = torch.cat([terms.reshape(-1), torch.stack([t for t, _ in extra])])
+        ld["loss_total"] = torch.dot(allterms, wvec.to(allterms.dtype))
+        return ld
+
+    def compute_loss_reference(self, data, output):
+        """the loss term by term as models/m2track.py:153-231 writes it (~60 launches forward, ~120 backward): the
+        specification `compute_loss` is tested against, and what runs with O3D_GLUE_TRIM=0"""
         c = self.config
         total = 0.0
         ld = {}
@@ -110,7 +185,7 @@ class M2TRACK(nn.Module):
         center, angle = box_label[:, :3], torch.sin(box_label[:, 3])
         center_prev, angle_prev = box_prev[:, :3], torch.sin(box_prev[:, 3])
         center_motion, angle_motion = motion_label[:, :3], torch.sin(motion_label[:, 3])
-        cls_w = torch.tensor([0.5, 2.0], device=seg_logits.device, dtype=seg_logits.dtype)
+        cls_w = _const(seg_logits.device, (0.5, 2.0)).to(seg_logits.dtype)
         loss_seg = F.cross_entropy(seg_logits, data["seg_label"], weight=cls_w)
         if self.use_motion_cls:
             loss_cls = F.cross_entropy(output["motion_cls"], state)

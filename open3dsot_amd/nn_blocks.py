@@ -79,6 +79,24 @@ _CONV = {1: nn.Conv1d, 2: nn.Conv2d, 3: nn.Conv3d}
 _BN = {1: nn.BatchNorm1d, 2: nn.BatchNorm2d, 3: nn.BatchNorm3d}
 
 
+class RowBatchNorm1d(nn.BatchNorm1d):
+    """nn.BatchNorm1d (same parameters, buffers and state_dict keys) for the (B, C) rows of the M2-Track heads
+    (models/m2track.py:47-71, models/backbone/pointnet.py:118-126).  Inside a tracker forward on the GPU its
+    `num_batches_tracked += 1` joins the forward's ONE multi-tensor counter update (open3dsot_amd/fused.py::count_batches)
+    instead of launching its own: twelve such modules per M2-Track step.  Everywhere else it IS nn.BatchNorm1d."""
+
+    def forward(self, x):
+        if self.training and self.track_running_stats and self.momentum is not None and x.is_cuda:
+            from . import fused
+            if fused._GLUE_TRIM["on"] and fused._COUNTERS["pending"] is not None:
+                self._check_input_dim(x)
+                out = nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True,
+                                               self.momentum, self.eps)
+                fused.count_batches([self], 1)
+                return out
+        return super().forward(x)
+
+
 class _BNWrap(nn.Sequential):
     """BatchNorm nested one level down (`bn`) with gamma=1, beta=0."""
 

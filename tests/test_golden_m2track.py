@@ -77,3 +77,42 @@ def test_m2track_backward_and_synthetic_contract():
     loss, ld = net.training_loss(b)
     loss.backward()
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters())
+
+
+def test_batched_loss_equals_the_term_by_term_reference_form():
+    """M2TRACK.compute_loss (four stacked (centre, angle) pairs, one dot product for the total) against
+    compute_loss_reference (models/m2track.py:153-231 term by term), batch 48, every configuration switch: each entry of
+    the dict and every gradient to fp32 rounding"""
+    import itertools
+    import torch
+    from open3dsot_amd import m2track, synth
+    batch = synth.to_torch(synth.make_motion_batch(11, 48, 256))
+    for cls, second, prev in itertools.product([True, False], repeat=3):
+        torch.manual_seed(3)
+        model = m2track.M2TRACK(use_motion_cls=cls, use_second_stage=second, use_prev_refinement=prev).train()
+        out = model(batch)
+        new, ref = model.compute_loss(batch, out), model.compute_loss_reference(batch, out)
+        assert set(new) == set(ref)
+        for k in ref:
+            assert abs(float(new[k].detach()) - float(ref[k].detach())) <= 2e-6 * (1 + abs(float(ref[k].detach()))), (k, cls, second, prev)
+        params = [p for p in model.parameters()]
+        gn = torch.autograd.grad(new["loss_total"], params, retain_graph=True, allow_unused=True)
+        gr = torch.autograd.grad(ref["loss_total"], params, allow_unused=True)
+        gmax = max(float(b.abs().max()) for b in gr if b is not None)     # biases in front of a BatchNorm: true gradient 0, computed noise
+        for a, b in zip(gn, gr):
+            assert (a is None) == (b is None)
+            if a is not None:
+                assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-6 * gmax
+
+
+def test_rotz_as_one_gemm_is_the_stacked_matrix_bit_for_bit():
+    import torch
+    from open3dsot_amd import box_utils
+    t = torch.linspace(-7.0, 7.0, 97, requires_grad=True)
+    a, b = box_utils.rotz_batch_tensor(t), box_utils.rotz_batch_tensor_stacked(t)
+    assert a.shape == (97, 3, 3) and torch.equal(a, b)
+    g = torch.randn(97, 3, 3, generator=torch.Generator().manual_seed(0))
+    ga, = torch.autograd.grad(a, t, g)
+    gb, = torch.autograd.grad(b, t, g)
+    assert float((ga - gb).abs().max()) <= 1e-6
+    assert torch.equal(box_utils.rotz_batch_tensor(t.detach().double()), box_utils.rotz_batch_tensor_stacked(t.detach().double()))

@@ -306,6 +306,31 @@ def test_m2track_gpu_matches_cpu_mirror():
             assert rel(v, w) < 1e-3, k
 
 
+def test_m2track_step_is_captured_and_replays_like_the_eager_step():
+    """The M2-Track training step must CAPTURE (until round 3 it silently ran eagerly: the class weights of its
+    segmentation loss were uploaded from the host inside the step, `operation not permitted when stream is capturing`):
+    graph present after the warm-up, replayed losses equal the eager trainer's, every BatchNorm counter advanced once per
+    step by the forward's single counter launch."""
+    import copy
+    from open3dsot_amd import dist as D, m2track, synth
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(21)
+    model_g = m2track.M2TRACK().to(dev).train()
+    model_e = copy.deepcopy(model_g)
+    tg = D.DataParallelStep(model_g, optimizer=torch.optim.SGD(model_g.parameters(), lr=0.0), world=1, graph=True, graph_warmup=2)
+    te = D.DataParallelStep(model_e, optimizer=torch.optim.SGD(model_e.parameters(), lr=0.0), world=1, graph=False)
+    batches = [synth.to_torch(synth.make_motion_batch(40 + 8 * i, 8, 512), dev) for i in range(3)]
+    for i in range(6):
+        lg, le = float(tg.step(batches[i % 3])), float(te.step(batches[i % 3]))
+        assert abs(lg - le) <= 2e-4 * (1 + abs(le)), (i, lg, le)
+    assert tg.graph is not None, tg.graph_error
+    counters = {k: int(v) for k, v in model_g.state_dict().items() if k.endswith("num_batches_tracked")}
+    assert len(counters) >= 20 and set(counters.values()) == {6}, counters
+    for (k, v), (_, w) in zip(model_g.state_dict().items(), model_e.state_dict().items()):
+        if "running" in k:
+            assert rel(v, w) < 1e-3, k
+
+
 @pytest.mark.parametrize("mode", ["act", "gmax"])
 @pytest.mark.parametrize("train", [True, False])
 def test_fused_pointwise_chain_vs_fp64(mode, train):

@@ -4,7 +4,7 @@ innermost frame inside this repo.  Forward ops and the backward of the repo's ow
 issued by C++ autograd nodes (CatBackward, TransposeBackward, ...) run without a Python stack and print `<autograd>` plus
 the forward/backward phase -- their shapes identify them.  torch.profiler's with_stack attribution comes back empty on
 this ROCm build (tools/trace_glue.py prints `?`), hence this tool.
-usage: trace_dispatch.py [BAT|P2B] > profiles/rNN_torch_glue.txt"""
+usage: trace_dispatch.py [BAT|P2B|M2TRACK] > profiles/rNN_torch_glue.txt"""
 import collections
 import os
 import sys
@@ -17,8 +17,8 @@ from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
 
 from open3dsot_amd import dist as D, synth, trackers  # noqa: E402
 
-SKIP = ("aten.view", "aten._unsafe_view", "aten.reshape", "aten.t.", "aten.transpose", "aten.permute", "aten.slice",
-        "aten.select", "aten.expand", "aten.unsqueeze", "aten.squeeze", "aten.detach", "aten.alias", "aten.as_strided",
+SKIP = ("aten.view", "aten._unsafe_view", "aten.reshape", "aten.t.", "aten.transpose", "aten.permute", "aten.slice.", "aten.slice_copy",
+        "aten.select.int", "aten.expand", "aten.unsqueeze", "aten.squeeze", "aten.detach", "aten.alias", "aten.as_strided",
         "aten.split", "aten.unbind", "aten.narrow", "aten.empty", "aten.new_empty", "aten._local_scalar", "aten.is_",
         "aten.sym_", "aten.stride", "aten.size", "aten.numel", "aten.dim", "aten.storage_offset", "aten.lift",
         "aten.record_stream", "aten.empty_like", "aten.empty_strided", "aten.new_empty_strided", "aten.unfold",
@@ -60,9 +60,14 @@ def main():
     name = sys.argv[1] if len(sys.argv) > 1 else "BAT"
     dev = torch.device("cuda", 0)
     torch.manual_seed(1234)
-    model = trackers.get_model(name)().to(dev).train()
+    if name.upper() == "M2TRACK":
+        from open3dsot_amd import m2track
+        model = m2track.M2TRACK().to(dev).train()
+        batch = synth.to_torch(synth.make_motion_batch(0, 48, 1024), dev)
+    else:
+        model = trackers.get_model(name)().to(dev).train()
+        batch = synth.to_torch(synth.make_batch(0, 48), dev)
     trainer = D.DataParallelStep(model, world=1, graph=False)
-    batch = synth.to_torch(synth.make_batch(0, 48), dev)
     for _ in range(2):
         trainer._forward_backward(batch)
         trainer.optimizer.step()
