@@ -132,10 +132,13 @@ def touch(tensors):
         _increment_version(tensors)
 
 
-def count_batches(bns, inc=1):
+def count_batches(bns, inc=1, raw_writes=True):
     """a training forward through `bns` has happened: its finalize kernels wrote the running statistics through raw
-    pointers (version counters bumped here) and `num_batches_tracked` is due `inc` increments"""
-    touch([t for bn in bns for t in (bn.running_mean, bn.running_var)])
+    pointers (version counters bumped here) and `num_batches_tracked` is due `inc` increments.  raw_writes=False: the
+    statistics were updated by a torch op that did its own version bookkeeping (nn_blocks.RowBatchNorm1d) -- a second bump
+    would trip autograd's saved-tensor check of that op's backward"""
+    if raw_writes:
+        touch([t for bn in bns for t in (bn.running_mean, bn.running_var)])
     tensors = [bn.num_batches_tracked for bn in bns if bn.num_batches_tracked is not None]
     if not tensors:
         return

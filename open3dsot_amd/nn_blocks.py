@@ -92,7 +92,7 @@ class RowBatchNorm1d(nn.BatchNorm1d):
                 self._check_input_dim(x)
                 out = nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True,
                                                self.momentum, self.eps)
-                fused.count_batches([self], 1)
+                fused.count_batches([self], 1, raw_writes=False)
                 return out
         return super().forward(x)
 
