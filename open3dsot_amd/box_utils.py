@@ -43,22 +43,34 @@ def rotz_batch_tensor(t):
     return torch.addmm(consts[1], cs, consts[0]).view(*t.shape, 3, 3)
 
 
+def _parts(box):
+    """(B,4) -> centre (B,3), yaw (B,): ONE split node (its backward is one concatenation) where two slices would each
+    cost a zero fill + a copy + an accumulation in the backward"""
+    center, yaw = box.split([3, 1], dim=1)
+    return center, yaw.squeeze(1)
+
+
 def get_offset_box_tensor(ref_box, offset_box):
     """box `ref_box` moved by `offset_box` expressed in the ref box frame: (B,4),(B,4) -> (B,4)"""
-    rot = rotz_batch_tensor(ref_box[:, 3])
-    center = torch.matmul(rot, offset_box[:, :3, None]).squeeze(-1) + ref_box[:, :3]
-    return torch.cat([center, (ref_box[:, 3] + offset_box[:, 3])[:, None]], dim=-1)
+    ref_c, ref_t = _parts(ref_box)
+    off_c, off_t = _parts(offset_box)
+    rot = rotz_batch_tensor(ref_t)
+    center = torch.matmul(rot, off_c.unsqueeze(-1)).squeeze(-1) + ref_c
+    return torch.cat([center, (ref_t + off_t)[:, None]], dim=-1)
 
 
 def remove_transform_points_tensor(points, ref_box):
     """world -> frame of `ref_box`: points (B,N,3), ref_box (B,4)"""
-    rot = rotz_batch_tensor(-ref_box[:, 3])
-    return torch.matmul(points - ref_box[:, None, :3], rot.transpose(1, 2))
+    ref_c, ref_t = _parts(ref_box)
+    rot = rotz_batch_tensor(-ref_t)
+    return torch.matmul(points - ref_c[:, None, :], rot.transpose(1, 2))
 
 
 def get_offset_points_tensor(points, ref_box, offset_box):
     """apply the rigid motion `offset_box` (given in the frame of `ref_box`) to world points (B,N,3)"""
-    rot = rotz_batch_tensor(-ref_box[:, 3])
-    p = torch.matmul(points - ref_box[:, None, :3], rot.transpose(1, 2))          # into the box frame
-    p = torch.matmul(p, rotz_batch_tensor(offset_box[:, 3]).transpose(1, 2)) + offset_box[:, None, :3]
-    return torch.matmul(p, rot) + ref_box[:, None, :3]                             # back to the world
+    ref_c, ref_t = _parts(ref_box)
+    off_c, off_t = _parts(offset_box)
+    rot = rotz_batch_tensor(-ref_t)
+    p = torch.matmul(points - ref_c[:, None, :], rot.transpose(1, 2))             # into the box frame
+    p = torch.matmul(p, rotz_batch_tensor(off_t).transpose(1, 2)) + off_c[:, None, :]
+    return torch.matmul(p, rot) + ref_c[:, None, :]                                # back to the world

@@ -108,6 +108,13 @@ class FusedPointwiseChain(torch.autograd.Function):
             _call("pw_gmax", 0.0, lib.o3d_gmax_fwd, Ys[-1].data_ptr(), scales[-1].data_ptr(), shifts[-1].data_ptr(), B, Cl,
                   N, out.data_ptr(), _ptr(argq), _ptr(yarg), st)
         if need_bwd:
+            # W^T of the inner layers for the data gradient: from the device's WeightPrep table (inside a tracker forward
+            # all of them were refreshed by ONE launch) instead of one transposing copy per layer in the backward
+            ctx.Wts = None
+            if _GLUE_TRIM["on"] and all(isinstance(params[4 * l], torch.nn.Parameter) for l in range(1, L)):
+                from .fused_heads import prep_for
+                prep = prep_for(dev)
+                ctx.Wts = [None] + [prep.get(params[4 * l], Ws[l].shape[1], Ws[l].shape[0], transpose=True) for l in range(1, L)]
             ctx.cfg = cfg
             ctx.versions = _versions(params)
             ctx.dims = (B, N, L)
@@ -146,6 +153,14 @@ class FusedPointwiseChain(torch.autograd.Function):
             nparts = POOL_BWD_SPLIT
         grads = [None] * (4 * L)
         dx = dcb = None
+        zero_bias = None      # dL/db behind a training-mode BatchNorm is exactly zero: one fill for all layers of the stack
+        if _GLUE_TRIM["on"] and cfg.training and any(ctx.has_bias):
+            widths = [Ws[l].shape[0] if ctx.has_bias[l] else 0 for l in range(L)]
+            flat0 = torch.zeros((sum(widths),), device=dev, dtype=f32)
+            zero_bias, o = [], 0
+            for w in widths:
+                zero_bias.append(flat0[o:o + w])
+                o += w
         for l in range(L - 1, -1, -1):
             Cout, Cin = Ws[l].shape
             coef = torch.empty((5, Cout), device=dev, dtype=f32)
@@ -158,7 +173,10 @@ class FusedPointwiseChain(torch.autograd.Function):
                 coef[4].zero_()
             grads[4 * l + 2], grads[4 * l + 3] = coef[0], coef[1]
             if ctx.has_bias[l]:      # dL/db = sum dY: zero behind a training-mode BatchNorm, A1 * sum dN in eval mode
-                grads[4 * l + 1] = torch.zeros_like(coef[0]) if cfg.training else coef[2] * coef[1]
+                if cfg.training:
+                    grads[4 * l + 1] = zero_bias[l] if zero_bias is not None else torch.zeros_like(coef[0])
+                else:
+                    grads[4 * l + 1] = coef[2] * coef[1]
             A = (coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr())
             dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
             flops = 2.0 * Cin * Cout * P
@@ -183,7 +201,7 @@ class FusedPointwiseChain(torch.autograd.Function):
                       wpart.data_ptr(), dW.data_ptr(), st, dims=(Cin, Cout))
             grads[4 * l] = dW.unsqueeze(-1)
             if l >= 1:
-                Wt = Ws[l].t().contiguous()
+                Wt = ctx.Wts[l] if ctx.Wts is not None else Ws[l].t().contiguous()
                 dNp = torch.empty((Cin, P), device=dev, dtype=f32)
                 part = torch.empty((ntiles, 2, Cin), device=dev, dtype=f32)
                 _call("pw_conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_wt, dN.data_ptr(), None, None, None, 4,

@@ -85,12 +85,14 @@ class M2TRACK(nn.Module):
             x = torch.cat([x, input_dict["candidate_bc"].transpose(1, 2)], dim=1)
         N = x.shape[2]
         seg_out = self.seg_pointnet(x)
-        seg_logits = seg_out[:, :2, :]
+        if self.box_aware:       # one split node instead of two slices (whose backward is 2 x (fill + copy) + an add)
+            seg_logits, pred_bc = seg_out.split([2, seg_out.shape[1] - 2], dim=1)
+        else:
+            seg_logits = seg_out[:, :2, :]
         pred_cls = torch.argmax(seg_logits, dim=1, keepdim=True)                  # (B,1,N) hard mask, no gradient
         mask_points = x[:, :4, :] * pred_cls
         mask_xyz_t0, mask_xyz_t1 = mask_points[:, :3, :N // 2], mask_points[:, :3, N // 2:]
         if self.box_aware:
-            pred_bc = seg_out[:, 2:, :]
             mask_pred_bc = pred_bc * pred_cls
             mask_points = torch.cat([mask_points, mask_pred_bc], dim=1)
             out["pred_bc"] = pred_bc.transpose(1, 2)
@@ -104,12 +106,12 @@ class M2TRACK(nn.Module):
             motion_pred_masked = motion_pred
         if self.use_prev_refinement:
             prev_boxes = self.final_mlp(point_feature)
-            out["estimation_boxes_prev"] = prev_boxes[:, :4]
+            out["estimation_boxes_prev"] = prev_boxes[:, :4] if prev_boxes.shape[1] != 4 else prev_boxes
         else:
             prev_boxes = torch.zeros_like(motion_pred)
         aux_box = box_utils.get_offset_box_tensor(prev_boxes, motion_pred_masked)  # first-stage box
         if self.use_second_stage:
-            moved = box_utils.get_offset_points_tensor(mask_xyz_t0.transpose(1, 2), prev_boxes[:, :4],
+            moved = box_utils.get_offset_points_tensor(mask_xyz_t0.transpose(1, 2), out.get("estimation_boxes_prev", prev_boxes[:, :4]),
                                                        motion_pred_masked).transpose(1, 2)
             merged = torch.cat([moved, mask_xyz_t1], dim=-1)                       # (B,3,N)
             merged = box_utils.remove_transform_points_tensor(merged.transpose(1, 2), aux_box).transpose(1, 2)
@@ -144,8 +146,9 @@ class M2TRACK(nn.Module):
         K, B = len(rows), aux.shape[0]
         pred = torch.stack([r[1] for r in rows])                                        # (K,B,4)
         label = torch.stack([r[2] for r in rows])
-        per_center = F.smooth_l1_loss(pred[..., :3], label[..., :3], reduction="none").mean(dim=2)            # (K,B)
-        per_angle = F.smooth_l1_loss(torch.sin(pred[..., 3]), torch.sin(label[..., 3]), reduction="none")     # (K,B)
+        pred_c, pred_t = pred.split([3, 1], dim=2)          # one split node: the backward is one concatenation
+        per_center = F.smooth_l1_loss(pred_c, label[..., :3], reduction="none").mean(dim=2)                   # (K,B)
+        per_angle = F.smooth_l1_loss(torch.sin(pred_t.squeeze(2)), torch.sin(label[..., 3]), reduction="none")  # (K,B)
         per = torch.stack([per_center, per_angle])                                      # (2,K,B)
         if self.use_motion_cls:      # the motion row averages over the moving samples only (:196-203), the others over B
             moving = state / (state.sum() + 1e-6)
