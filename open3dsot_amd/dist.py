@@ -298,6 +298,13 @@ class DataParallelStep:
                     self.graph_requested = False
                     self.graph = None
                     torch.cuda.synchronize()
+                    if os.environ.get("O3D_REQUIRE_GRAPH", "0") == "1":
+                        raise RuntimeError("HIP-graph capture of the training step failed: " + self.graph_error) from e
+                    # loudly: an eager step is several times slower on the launch-bound models, and a failed capture went
+                    # unnoticed for two rounds on M2-Track
+                    import warnings
+                    warnings.warn("open3dsot_amd: HIP-graph capture of the training step failed, running eagerly (%s)"
+                                  % self.graph_error.splitlines()[0][:300], RuntimeWarning, stacklevel=2)
             if self.graph is not None:
                 return self.step(batch, next_batch)
             loss = self._forward_backward(batch)
