@@ -986,10 +986,11 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
 # step: a point referenced by hundreds of balls serialised on one thread, and the per-list insertion sort was
 # quadratic); the balanced walk (equal shares of the sorted entries per thread, one atomic per run of equal points)
 # takes 0.50 ms including the index build.  ON by default; O3D_REDUCE_GATHER=0 selects the atomic kernel.
-# data + weight gradient of the 64 -> 64 layers in one kernel (O3D_FUSED_BWD=0: the wgrad2 + direct-dgrad pair);
-# O3D_FUSED_BWD_MAX_COUT=128 also takes the 64 -> 128 layers (measured 4 % faster in isolation, not yet in the step)
+# data + weight gradient of the 64 -> 64 and 64 -> 128 layers in one kernel (O3D_FUSED_BWD=0: the wgrad2 + direct-dgrad
+# pair).  The 64 -> 128 layer (SA level 0's pooled layer) joined at the end of round 3: same box, alternating, 5.878 -> 5.800
+# ms per BAT step (O3D_FUSED_BWD_MAX_COUT=64 restores the pair for it)
 _FUSED_BWD = {"on": _os.environ.get("O3D_FUSED_BWD", "1") != "0",
-              "max_cout": int(_os.environ.get("O3D_FUSED_BWD_MAX_COUT", "64"))}
+              "max_cout": int(_os.environ.get("O3D_FUSED_BWD_MAX_COUT", "128"))}
 _REDUCE_GATHER = {"on": _os.environ.get("O3D_REDUCE_GATHER", "1") != "0"}
 
 
