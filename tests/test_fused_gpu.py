@@ -838,8 +838,11 @@ def test_pooled_pairs_match_dense_pooled_gradient(kind, B, full):
     new_t = xyz_t[:, :npoint // 2, :].contiguous()
     feats_t = torch.randn(feats_s.shape[0], feats_s.shape[1], N // 2, device="cuda") if feats_s is not None else None
     grads = []
-    was, was_rg = fused._POOLED_PK["on"], fused.reduce_gather_enabled()
+    was, was_rg, was_fb = fused._POOLED_PK["on"], fused.reduce_gather_enabled(), fused._FUSED_BWD["max_cout"]
     fused.set_reduce_gather(False)          # (the LDS-atomic orders of the layer-0 reduce differ run to run either way)
+    # the dense side on the unfused data / weight gradient pair, whose summation order the pair-gathering kernels share:
+    # the one-kernel backward that takes a dense 64 -> 128 pooled layer by default sums in its own order
+    fused._FUSED_BWD["max_cout"] = 64
     try:
         for pk in (False, True):
             fused.set_pooled_pk(pk)
@@ -853,6 +856,7 @@ def test_pooled_pairs_match_dense_pooled_gradient(kind, B, full):
     finally:
         fused.set_pooled_pk(was)
         fused.set_reduce_gather(was_rg)
+        fused._FUSED_BWD["max_cout"] = was_fb
     for (n1, a), (_, b) in zip(*grads):
         if n1.startswith("layer0"):        # behind the atomic layer-0 reduce: equal up to its summation order
             assert l2rel(a, b) < 5e-5, (n1, l2rel(a, b))
