@@ -187,6 +187,38 @@ def test_two_rank_gloo_real_tracker(tmp_path):
         sa_modules.set_fused(True)
 
 
+def _m2_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(2)
+    from open3dsot_amd import dist as D, m2track, synth
+    r, _, w = D.init_distributed("gloo")
+    torch.manual_seed(3 + rank)           # different init per rank: the constructor's broadcast must fix it
+    model = m2track.M2TRACK().train()
+    trainer = D.DataParallelStep(model, optimizer=torch.optim.SGD(model.parameters(), lr=0.01))
+    losses = []
+    for step in range(2):
+        first, n = D.shard_indices(step, r, w, 4)
+        losses.append(float(trainer.step(synth.to_torch(synth.make_motion_batch(first, n, 128)))))
+    torch.save({"sd": {k: v.clone() for k, v in model.state_dict().items()}, "losses": losses},
+               os.path.join(out, "m2%d.pt" % rank))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_m2track(tmp_path):
+    """the M2-Track step (no pointnet2 operator, so its CPU mirror runs as is) through the same
+    data-parallel step on two gloo ranks: identical parameters after two steps from different initialisations, per-rank
+    BatchNorm statistics, finite losses that differ between the shards"""
+    port = _free_port()
+    mp.spawn(_m2_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(tmp_path / "m20.pt"), torch.load(tmp_path / "m21.pt")
+    stat = lambda k: "running" in k or "num_batches" in k
+    assert all(torch.equal(r0["sd"][k], r1["sd"][k]) for k in r0["sd"] if not stat(k))
+    assert any(not torch.equal(r0["sd"][k], r1["sd"][k]) for k in r0["sd"] if "running_mean" in k)
+    assert all(int(v) == 2 for k, v in r0["sd"].items() if "num_batches" in k)
+    assert all(l == l and abs(l) < 1e4 for l in r0["losses"] + r1["losses"]) and r0["losses"] != r1["losses"]
+
+
 def test_bench_refuses_to_report_fewer_gpus_than_asked():
     """`python bench.py --gpus N` outside torchrun spawns N ranks itself; with fewer than N GPUs visible it must stop
     with an error, never print a line for a smaller job (here: no GPU at all, or one)"""

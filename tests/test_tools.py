@@ -87,3 +87,22 @@ def test_batch_counter_increments_are_merged_into_one_update():
     fused.count_batches(bns[3:], 1)                         # outside a scope: applied at once
     assert int(bns[3].num_batches_tracked) == 1
     fused.counters_end()                                    # nothing pending: a no-op
+
+
+def test_trace_families_sums_by_family(tmp_path):
+    f = tmp_path / "steps.txt"
+    f.write_text("wall 1.000 ms/step | header\n"
+                 "  0.500 ms   2.0 x  void (anonymous namespace)::direct_gemm_kernel<4, 1, 0, 4, 2>(args)\n"
+                 "  0.100 ms   1.0 x  void (anonymous namespace)::direct_gemm_pair_kernel<4, 0, 0, 2, 1>(a, b)\n"
+                 "  0.050 ms  10.0 x  (anonymous namespace)::bn_finalize_kernel(args)\n"
+                 "  0.025 ms   5.0 x  (anonymous namespace)::bn_bwd_finalize_pair_kernel(a, b)\n"
+                 "  0.010 ms   2.0 x  void at::native::elementwise_kernel_manual_unroll<128, 4>(x)\n"
+                 "  0.001 ms   1.0 x  something_else\n")
+    out = run("trace_families.py", str(f)).splitlines()
+    assert out[0].startswith("wall 1.000")
+    rows = {l.split("x  ", 1)[1]: l for l in out[1:]}
+    assert "0.500 ms    2.0" in rows["GEMM forward / data gradient (direct_gemm)"]
+    assert "0.100 ms    1.0" in rows["GEMM pair launches (two stacks side by side)"]
+    assert "0.075 ms   15.0" in rows["BatchNorm finalizes (forward + backward)"]
+    assert "0.010 ms    2.0" in rows["torch launches"] and "0.001 ms    1.0" in rows["other"]
+    assert "0.686 ms   21.0" in rows["total of the listed kernels"]
