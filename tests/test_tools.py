@@ -106,3 +106,25 @@ def test_trace_families_sums_by_family(tmp_path):
     assert "0.075 ms   15.0" in rows["BatchNorm finalizes (forward + backward)"]
     assert "0.010 ms    2.0" in rows["torch launches"] and "0.001 ms    1.0" in rows["other"]
     assert "0.686 ms   21.0" in rows["total of the listed kernels"]
+
+
+def test_trace_dispatch_log_lists_working_calls_with_phase_and_shapes():
+    """tools/trace_dispatch.py's TorchDispatchMode on a small CPU graph: views are skipped, copies / cats / arithmetic
+    and the ops of the C++ backward nodes (slice_backward included) are listed with their phase and operand strides"""
+    import importlib.util
+    import torch
+    spec = importlib.util.spec_from_file_location("trace_dispatch", os.path.join(ROOT, "tools", "trace_dispatch.py"))
+    td = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(td)
+    log = td.Log()
+    x = torch.randn(4, 6, requires_grad=True)
+    with log:
+        y = torch.cat((x.t().contiguous(), x.t() * 2), 0)[:, :3].sigmoid().sum()
+        log.phase = "backward"
+        y.backward()
+    names = [(p, n) for p, n, _, _ in log.rows]
+    assert ("forward", "clone.default") in names and ("forward", "cat.default") in names
+    assert ("backward", "slice_backward.default") in names and ("backward", "sigmoid_backward.default") in names
+    assert not any(n.startswith(("t.", "transpose", "slice.Tensor", "view")) for _, n in names)
+    clone = next(r for r in log.rows if r[1] == "clone.default")
+    assert clone[2] == "(6, 4)s(1, 6)" and clone[3] == "<autograd>"
