@@ -353,6 +353,7 @@ def secondary_lines(args):
     one("m2track_batch48", model="M2TRACK")
     one("bat_nuscenes_search2048_batch48", search_size=2048)
     one("bat_nuscenes_yaml_batch100", batch=100)
+    one("bat_nuscenes_search2048_batch100", search_size=2048, batch=100)       # config 5 as one workload
     one("bat_dense_worst_case", dense=True)
     one("bat_infer_batch1", infer=True)
     one("p2b_infer_batch1", infer=True, model="P2B")
@@ -469,7 +470,10 @@ def measure(args, rank, local_rank, world, full=True):
                                             "built from %s: not reported" % (str(t.get("kernel_source_sha256"))[:12],
                                                                             _build.source_hash()[:12]))
             elif t.get("workload_batch") == args.batch and t.get("model") == args.model:
-                roofline["traffic"] = t["gemm_family_hbm_bytes_per_launch"]
+                # bytes per STEP of the family's device kernels (tools/hbm_traffic.py, same symbol list as the launches
+                # counted here) over THIS line's launch count: traffic x launches_per_step = the PMC table's family rows
+                roofline["traffic_bytes_per_step"] = t["gemm_family_bytes_per_step"]
+                roofline["traffic"] = int(t["gemm_family_bytes_per_step"] / max(1, roofline["launches_per_step"]))
                 roofline["traffic_source"] = t["source"]
                 # the same launches against the other roof.  FETCH_SIZE / WRITE_SIZE count the L2's memory-side (fabric)
                 # requests, Infinity-Cache hits included (MI355X_MICROARCH.md, HBM section): an UPPER bound of the HBM

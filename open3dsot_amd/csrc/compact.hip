@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void compact_count_kernel(const int32_t* __res
     if (k == 0 && s < nslots) ball_cnt[s / ns] = other ? (63 - __clzll((long long)other)) - base + 1 : 1;
 }
 
-// exclusive scan of ball_cnt (n <= 65536) by one workgroup; meta = {Ptot rounded up to 256, Ptot, n, 0}
+// exclusive scan of ball_cnt (any n: ceil(n / 1024) balls per thread) by one workgroup; meta = {Ptot rounded up to 256, Ptot, n, 0}
 __global__ __launch_bounds__(1024) void compact_scan_kernel(const int32_t* __restrict__ ball_cnt, int n,
                                                             int col_base, int32_t* __restrict__ ball_off,
                                                             int32_t* __restrict__ meta) {
@@ -866,6 +866,9 @@ __global__ __launch_bounds__(256) void pack_points_kernel(PackSeg s0, PackSeg s1
 }  // namespace
 
 static bool pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
+// balls per segment: bounded only by 32-bit column arithmetic (balls * nsample slots); BAT_CAR_NUSCENES at its YAML batch
+// (100 pairs x 1024 balls of the 2048-point search cloud, cfgs/BAT_CAR_NUSCENES.yaml:11,56) has 102 400
+constexpr long O3D_MAX_BALLS = 1L << 20;
 
 // One segment of the compact layout: idx (B,npoint,ns) -> ball_cnt (B*npoint), ball_off (B*npoint+1, absolute
 // columns), and per column gp / cball / cw written at [col_base, col_base + live); meta (4 ints) = {live rounded
@@ -876,7 +879,7 @@ extern "C" int o3d_compact_build(const int32_t* idx, int B, int npoint, int ns, 
                                  int32_t* cball, float* cw, int32_t* meta, void* stream) {
     const long nballs = (long)B * npoint, nslots = nballs * ns;
     if (!idx || !ball_cnt || !ball_off || !gp || !cball || !cw || !meta || B <= 0 || npoint <= 0 || ns < 1 ||
-        ns > 64 || !pow2(ns) || nballs > 65536 || nslots % 256 != 0 || ld <= 0 || col_base < 0 || col_base % 256 != 0)
+        ns > 64 || !pow2(ns) || nballs > O3D_MAX_BALLS || nslots % 256 != 0 || ld <= 0 || col_base < 0 || col_base % 256 != 0)
         return O3D_EINVAL;
     hipStream_t s = o3d_stream(stream);
     const int blocks = (int)(nslots / 256);
@@ -1080,7 +1083,7 @@ extern "C" int o3d_compact_build2(const int32_t* idx0, int npoint0, int ld0, con
                                   int32_t* ball_off, int32_t* gp, int32_t* cball, float* cw, int32_t* meta, void* stream) {
     const long nb0 = (long)B * npoint0, nb1 = (long)B * npoint1;
     if (!idx0 || !idx1 || !ball_cnt || !ball_off || !gp || !cball || !cw || !meta || B <= 0 || npoint0 <= 0 ||
-        npoint1 <= 0 || ns < 1 || ns > 64 || !pow2(ns) || nb0 > 65536 || nb1 > 65536 || (nb0 * ns) % 256 != 0 ||
+        npoint1 <= 0 || ns < 1 || ns > 64 || !pow2(ns) || nb0 > O3D_MAX_BALLS || nb1 > O3D_MAX_BALLS || (nb0 * ns) % 256 != 0 ||
         (nb1 * ns) % 256 != 0 || ld0 <= 0 || ld1 <= 0 || col_base1 < 0 || col_base1 % 256 != 0 || pt_base1 < 0)
         return O3D_EINVAL;
     CompactSeg s0 = {idx0, nb0 * ns, npoint0, ld0, 0, 0, 0, (int)nb0, ball_cnt, ball_off, meta};

@@ -193,6 +193,21 @@ def _check_versions(saved, what):
 
 GEMM_KERNELS = ("conv_fwd", "conv_fwd_points", "conv_dgrad", "conv_dgrad_points", "conv_wgrad", "conv_wgrad_points", "conv_bwd_fused",
                 "pw_conv_fwd", "pw_conv_dgrad", "pw_conv_wgrad")
+# The device kernels behind those launch names -- the ONE definition of the "GEMM family" that bench.py's roofline, the PMC
+# traffic accounting (tools/hbm_traffic.py) and the SQ-counter table (tools/sq_summary.py) share.  Matched as
+# "<name>(" or "<name><" against the demangled kernel name, so `direct_gemm_kernel` does not swallow (or, as in round 3,
+# silently miss) `direct_gemm_pair_kernel`.  GEMM_REDUCE_SYMBOLS: the slice reductions of the weight gradients -- their
+# bytes belong to the family, they are not counted as launches.
+GEMM_KERNEL_SYMBOLS = ("direct_gemm_kernel", "direct_gemm_pair_kernel", "wgrad2_kernel", "wgrad2_group_kernel", "fused_bwd_kernel",
+                       "conv_fwd_kernel", "conv_dgrad_kernel", "conv_wgrad_kernel")
+GEMM_REDUCE_SYMBOLS = ("wgrad_reduce_kernel", "wgrad_reduce1_kernel", "wgrad_reduce_group_kernel")
+
+
+def kernel_symbol(demangled):
+    """'void (anonymous namespace)::wgrad2_kernel<128, 64, 0>(...)' -> 'wgrad2_kernel' (None when it is not a kernel name)"""
+    import re
+    m = re.search(r"(\w+)\s*(<[^()]*>)?\s*\(", demangled.replace("(anonymous namespace)::", ""))
+    return m.group(1) if m else None
 
 
 def profile_step(step_fn, peak_tflops, repeats=3):
@@ -1098,7 +1113,7 @@ def _run_eval(mlp, layers, segs, nxyz, inv_radius):
 
 
 def _compact_ok(layers, npoint, ns, B):
-    if ns > 64 or B * npoint > 65536:
+    if ns > 64 or B * npoint > (1 << 20) or B * npoint * ns >= (1 << 30):      # O3D_MAX_BALLS of csrc/compact.hip
         return False
     for i, (conv, _) in enumerate(layers):
         if i >= 1 and (conv.in_channels % 64 or conv.out_channels % 64):

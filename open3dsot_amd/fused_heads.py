@@ -73,21 +73,39 @@ def _flush_queue():
     del q
 
 
-def _submit_jobs(jobs, keep, st, keys):
-    """launch the jobs now, or queue them inside a `defer_wgrads` scope.  keys: identities of the parameters whose
-    gradients the jobs produce -- a parameter that is used TWICE in the step (conv_final on the template and on the
-    search feature when the two calls are not merged) gets its second gradient ADDED to the first by autograd as soon as
-    this backward returns, so both must be complete by then: a repeated key flushes the queue on the spot."""
+def _deferrable(params):
+    """Deferral hands autograd gradient tensors that are FILLED LATER (at the flush).  That is only sound when autograd
+    does nothing with them but store them: the parameter has no gradient yet (else AccumulateGrad runs `grad += new` on
+    the unfilled buffer) and carries no tensor / post-accumulate hooks (which would read it)."""
+    for p in params:
+        if p is None:
+            continue
+        if p.grad is not None or getattr(p, "_backward_hooks", None) or getattr(p, "_post_accumulate_grad_hooks", None):
+            return False
+    return True
+
+
+def _submit_jobs(jobs, keep, st, params):
+    """launch the jobs now, or queue them inside a `defer_wgrads` scope.  params: the parameters whose gradients the
+    jobs produce.  Contract of the deferred path (tests/test_heads_gpu.py::test_deferred_wgrads_*):
+      * a parameter that is used TWICE in the step (conv_final on the template and on the search feature when the two
+        calls are not merged) gets its second gradient ADDED to the first by autograd as soon as this backward returns,
+        so both must be complete by then: a repeated parameter flushes the queue on the spot;
+      * a parameter that already holds a gradient, or carries hooks, is never deferred (`_deferrable`);
+      * a parameter that is ALSO used by a non-fused torch op in the same step is not supported inside the scope
+        (autograd's input buffer would sum an unfilled tensor): the trackers have none, DataParallelStep is the only
+        caller that opens the scope, and it clears the gradients first."""
     if not jobs:
         return
     if _DEFER["queue"] is None:
         _flush_jobs(jobs, st)
         return
+    keys = {id(p) for p in params if p is not None}
     _DEFER["queue"].append((jobs, keep, st))      # (the queue keeps the operands alive until the flush)
-    if _DEFER["keys"] & set(keys):
+    if (_DEFER["keys"] & keys) or not _deferrable(params):
         _flush_queue()
     else:
-        _DEFER["keys"] |= set(keys)
+        _DEFER["keys"] |= keys
 
 
 @contextlib.contextmanager
@@ -579,7 +597,7 @@ def _chain_backward(state, dOut, needs):
                                                                         Wts[0].data_ptr(), K0p, Cp, P, None, None, None, None,
                                                                         G.data_ptr() if cfg.residual else None, dX0.data_ptr(),
                                                                         None, st], (K0p, Cp))
-    _submit_jobs(jobs, keep, st, [id(w_) for w_ in Ws] + [id(b_) for b_ in state.biases if b_ is not None])
+    _submit_jobs(jobs, keep, st, list(Ws) + [b_ for b_ in state.biases if b_ is not None])
     keep = []
     if side is not main:
         main.wait_stream(side)       # join: every weight gradient is complete before autograd hands it on
@@ -741,8 +759,10 @@ class SharedConvPair(torch.autograd.Function):
         if bias is not None and ctx.needs_input_grad[1]:
             dbias = torch.empty((Cout,), device=dev, dtype=f32)
             jobs.append((0.0, (G.data_ptr(), None, None, None, None, None, None, None, 0, Cout, P, None, dbias.data_ptr(), 0, 0)))
-        _submit_jobs(jobs, [G, X0, scratch, dW, dbias, one, zero], st, [id(W)] + ([id(bias)] if bias is not None else []))
-        return dW.view(W.shape), dbias, dxa, dxb
+        _submit_jobs(jobs, [G, X0, scratch, dW, dbias, one, zero], st, [W, bias])
+        # fresh views: autograd must hold the ONLY reference to what it is handed, or AccumulateGrad clones it -- with
+        # deferred launches a clone of a buffer the flush has not filled yet (round-3 advisor finding on dbias)
+        return dW.view(W.shape), dbias.view(Cout) if dbias is not None else None, dxa, dxb
 
 
 def shared_conv_pair_supported(conv, xa, xb):

@@ -116,3 +116,27 @@ def test_rotz_as_one_gemm_is_the_stacked_matrix_bit_for_bit():
     gb, = torch.autograd.grad(b, t, g)
     assert float((ga - gb).abs().max()) <= 1e-6
     assert torch.equal(box_utils.rotz_batch_tensor(t.detach().double()), box_utils.rotz_batch_tensor_stacked(t.detach().double()))
+
+
+@pytest.fixture(scope="module")
+def gold48():
+    return np.load(os.path.join(ROOT, "tests", "golden", "ref_m2track_b48.npz"))
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+def test_m2track_matches_reference_at_batch48(gold, gold48, mode):
+    """the reference model (state dict of ref_m2track.npz) on 48 frame pairs -- the benchmarked batch, where the heads'
+    BatchNorm1d over the batch is well conditioned: every loss term of the flat-GEMM path within 1e-4"""
+    net = build(gold, mode == "train")
+    b = batch(gold48)
+    out = net(b)
+    ld = net.compute_loss(b, out)
+    for k in ld:
+        want = float(gold48["%s.loss.%s" % (mode, k)])
+        assert abs(float(ld[k]) - want) <= 1e-4 * (1 + abs(want)), (k, float(ld[k]), want)
+    for k in ("estimation_boxes", "motion_cls", "estimation_boxes_prev"):
+        np.testing.assert_allclose(out[k].detach().numpy(), gold48["%s.out.%s" % (mode, k)], err_msg=k, rtol=1e-3, atol=2e-4)
+    if mode == "train":
+        for k, v in net.state_dict().items():
+            if "running" in k:
+                np.testing.assert_allclose(v.numpy(), gold48["train.sd_after." + k], rtol=1e-4, atol=1e-5, err_msg=k)

