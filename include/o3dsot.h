@@ -125,15 +125,6 @@ int o3d_mlp_conv_fwd(const float* X, const float* W, const float* in_scale, cons
                      int B, int Cin, int Cout, int P, float* Y, float* part, const float* stat_c,
                      void* stream);
 
-/* Layer 0 with the grouping gather fused into operand staging:
- * X[b,ci,j*ns+k] = ci < nxyz ? (xyz[b,idx[b,j,k],ci] - new_xyz[b,j,ci]) * inv_radius
- *                            : feats[b,ci-nxyz,idx[b,j,k]],      Cin = nxyz + C, nxyz in {0,3}.
- * xyz (B,N,3), new_xyz (B,npoint,3), feats (B,C,N) or NULL, idx (B,npoint,ns) int32. */
-int o3d_mlp_conv_grouped_fwd(const float* xyz, const float* new_xyz, const float* feats,
-                             const int32_t* idx, const float* W, int B, int N, int C, int npoint,
-                             int ns, int nxyz, float inv_radius, int Cout, float* Y, float* part,
-                             const float* stat_c, void* stream);
-
 /* (fold: optional scratch of 64*C floats; long partial lists are first folded into 32 parts by a
  * wide kernel so the finalize does not walk thousands of rows from a handful of workgroups.)
  * Training-mode BatchNorm statistics from the partials: mean, invstd = 1/sqrt(var_biased+eps),
@@ -148,13 +139,6 @@ int o3d_bn_finalize(const float* part, int nparts, int C, double count, const fl
  * yarg (raw Y at that k) for the backward pass. */
 int o3d_bn_relu_maxpool_fwd(const float* Y, const float* scale, const float* shift, int B, int C,
                             int npoint, int ns, float* out, int32_t* arg, float* yarg, void* stream);
-
-/* Backward statistics of the pooled layer: part [B][2][C] = {sum g, sum g*(yarg-mean)},
- * g = dOut where out > 0.  pk != NULL (needs arg): also writes the packed pooled-gradient source
- * pk (B,C,npoint) float2 = {g, bits(arg)} that o3d_mlp_conv_dgrad_wt reads. */
-int o3d_pool_bwd_partials(const float* dOut, const float* out, const float* yarg, const float* mean,
-                          int B, int C, int npoint, float* part, const int32_t* arg, float* pk,
-                          void* stream);
 
 /* The same for ONE cloud of npoint balls in the flat (C, npoint) layout (the P2B fusion: npoint = B*N), the balls of
  * a channel split over nsplit workgroups: part [nsplit][2][C]. */
@@ -179,7 +163,7 @@ int o3d_mlp_conv_dgrad(const float* dN, const float* dOut, const float* out, con
 
 /* o3d_mlp_conv_dgrad with the transposed weights Wt (Cin,Cout) supplied as well: aligned shapes
  * (Cin % 64 == 0, Cout % 16 == 0) run the LDS-free kernel, which reads its A operand along Cout
- * and, for the pooled source, the packed pk of o3d_pool_bwd_partials instead of (dOut,out,arg). */
+ * and, for the pooled source, the packed pk of o3d_pool_bwd_partials_split instead of (dOut,out,arg). */
 int o3d_mlp_conv_dgrad_wt(const float* dN, const float* dOut, const float* out, const int32_t* arg,
                           int ns, const float* Y, const float* A1, const float* A2, const float* A3,
                           const float* W, const float* Wt, const float* pk, int B, int Cin, int Cout, int P,
@@ -192,48 +176,10 @@ int o3d_mlp_conv_dgrad_plain(const float* dN, const float* Y, const float* A1, c
                              const float* A3, const float* W, int B, int Cin, int Cout, int P,
                              float* dX, void* stream);
 
-/* ---- layer 0 of a grouped MLP on the N points instead of the P positions (csrc/group.hip) ----
- * A 1x1 convolution commutes with the grouping gather: Z = W0.[xyz;feats] over the points, then
- * Y0[b,co,p] = Z[b,co,idx[b,p]] - W0[co,0:3].new_xyz[b,j(p)]  (QueryAndGroup + layer 0,
- * pointnet2_utils.py:299-339, pytorch_utils.py:12-37).  ld = row stride of the per-point tensors. */
-
-/* cnt[b,n] = number of positions referencing point n; R[b,n,:] = sum of the centres of those
- * positions (R / new_xyz may be NULL).  cnt (B,ld), R (B,ld,3).  N <= 8192. */
-int o3d_group_meta(const int32_t* idx, const float* new_xyz, int B, int N, int ld, int npoint, int ns,
-                   float* cnt, float* R, void* stream);
-
-/* Y0 (B,C0,P) from Z (B,C0,ldz); part [B*P/256][2][C0] statistics partials (may be NULL); GY
- * (B,C0,npoint) = per-ball sums of Y0 (may be NULL).  ns a power of two in 4..256, P % 256 == 0. */
-int o3d_group_expand_fwd(const float* Z, int ldz, const int32_t* idx, const float* new_xyz,
-                         const float* W0, int ldw, int B, int C0, int npoint, int ns, float* Y0,
-                         float* part, const float* stat_c, float* GY, void* stream);
-
-/* SdN[b,co,n] = sum over positions p with idx[b,p]==n of dN[b,co,p] (= group_points_grad,
- * pointnet2_utils.py:237); TdN[b,co,j] = sum_k dN[b,co,j*ns+k] (may be NULL).  cnt != NULL: also
- * produces cnt / R of o3d_group_meta in the same pass (R needs new_xyz). */
-int o3d_group_reduce_bwd(const float* dN, const int32_t* idx, int B, int C0, int ld, int npoint, int ns,
-                         float* SdN, float* TdN, const float* new_xyz, float* cnt, float* R, void* stream);
-
-/* In place: S = A1*S + A2*(cnt*Z - W0[:,0:3].R) + A3*cnt, T = A1*T + A2*GY + A3*ns: the list / ball
- * sums of dY0 = A1*dN0 + A2*Y0 + A3 without reading Y0. */
-int o3d_group_bwd_combine(float* S, float* T, const float* Z, const float* GY, const float* cnt,
-                          const float* R, const float* W0, int ldw, const float* A1, const float* A2,
-                          const float* A3, int B, int C0, int ld, int npoint, int ns, void* stream);
-
-/* Data gradient of grouped layer 0.  GT (B,P,M), M = Cin - c_lo, receives (W[:, c_lo:]^T dY)^T
- * (caller scratch, left filled); dgrouped (B,M,N) receives its sum through the grouping map:
- * dgrouped[b,m,n] = sum over positions p with idx[b,p] == n of GT[b,p,m]  (= group_points_grad,
- * pointnet2_utils.py:237, as a CSR gather instead of global atomics).  offsets (B,N+1) and perm
- * (B,P) int32 are caller scratch (the inverse grouping map).  N <= 8192. */
-int o3d_mlp_conv_grouped_dgrad(const float* dN, const float* dOut, const float* out,
-                               const int32_t* arg, const float* Y, const float* A1, const float* A2,
-                               const float* A3, const float* W, const int32_t* idx, int B, int N,
-                               int Cin, int npoint, int ns, int Cout, int c_lo, float* GT,
-                               int32_t* offsets, int32_t* perm, float* dgrouped, void* stream);
-
 /* Weight gradient dW (Cout,Cin) = sum_{b,p} dY[b,co,p] * X[b,ci,p]; X = f(X raw) as in
- * o3d_mlp_conv_fwd, or the layer-0 gather when X == NULL.  part: scratch of
- * (nslices+16)*Cout*Cin floats (split over positions, reduced in a fixed order). */
+ * o3d_mlp_conv_fwd.  part: scratch of (nslices+16)*Cout*Cin floats (split over positions, reduced in a fixed
+ * order).  xyz .. inv_radius: arguments of the slot-wise layer-0 gather retired in round 4 (layer 0 runs on the
+ * points, csrc/compact.hip); pass NULL / 0, X must not be NULL. */
 int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const float* out, const int32_t* arg, int ns,
                        const float* Y, const float* A1, const float* A2, const float* A3,
                        const float* X, const float* in_scale, const float* in_shift, const float* xyz,
@@ -337,28 +283,10 @@ int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t* argq, con
                    const float* mean, int B, int C, int npoint0, int npoint1, const int32_t* meta, long start1,
                    long ldp, float* D, float* part, void* stream);
 
-/* Backward of the pool WITHOUT the dense gradient of the pooled layer: part as above, and pkc (C, nballs + 1) pairs
- * {dOut where out > 0, bits(arg-max column)} per (channel, ball); entry [c][nballs] = {0, -1} serves the padding
- * columns (cball = nballs).  Consumed by o3d_mlp_conv_dgrad_cp / o3d_mlp_conv_wgrad2_cp. */
-int o3d_pool_bwd_pk(const float* dOut, const float* out, const int32_t* argq, const float* yarg, const float* mean, int B,
-                    int C, int npoint0, int npoint1, float* part, float* pkc, void* stream);
-
-/* o3d_mlp_conv_dgrad_c / o3d_mlp_conv_wgrad2_c for the pooled (last) layer of the compact layout: dN[c, q] =
- * pkc[c][cball[q]].value where pkc[c][cball[q]].arg == q, else 0 -- gathered on the fly, never materialised. */
-int o3d_mlp_conv_dgrad_cp(const float* pkc, const int32_t* cball, int nb1, const float* Y, const float* A1,
-                          const float* A2, const float* A3, const float* Wt, int Cin, int Cout, long ldp, const float* w,
-                          const int32_t* meta, long start1, int tile, const float* Yprev, const float* scale_p,
-                          const float* shift_p, const float* mean_p, float* dNprev, float* part, void* stream);
-int o3d_mlp_conv_wgrad2_cp(const float* pkc, const int32_t* cball, int nb1, const float* Y, const float* A1,
-                           const float* A2, const float* A3, const float* X, const float* in_scale,
-                           const float* in_shift, int Cin, int Cout, long ldp, const float* w, const int32_t* meta,
-                           long start1, float* scratch, float* dW, void* stream);
-
-
 /* The same sums as o3d_group_reduce_c without float atomics: the cloud's columns are sorted by (column chunk,
  * point) once per call (perm: ldp ints; poff: o3d_group_reduce_gather_scratch(...) ints, -1 = shape not covered,
  * use o3d_group_reduce_c) and every sum is a gather from an LDS-staged chunk in a fixed order (bitwise
- * reproducible).  spanmax = npoint*nsample of the largest segment.  Experimental (O3D_REDUCE_GATHER=1). */
+ * reproducible).  spanmax = npoint*nsample of the largest segment. */
 long o3d_group_reduce_gather_scratch(int B, int nseg, int npoint0, int ld0, int npoint1, int ld1, int spanmax);
 int o3d_group_reduce_gather(const float* dN, const float* Y0, long ldp, const float* A1, const float* A2,
                             const float* A3, const int32_t* gp, const float* cw, const int32_t* ball_off,
@@ -401,7 +329,7 @@ int o3d_gmax_fwd(const float* Y, const float* scale, const float* shift, int B, 
 
 /* Weight gradient of an aligned inner layer (Cin, Cout multiples of 64; P multiple of 128), workgroup
  * tile matched to the layer: dW (Cout,Cin) = sum dY * f(X), dY = A1*dN + A2*Y + A3 from dN (dense) or,
- * when dN == NULL, from the packed pooled source pk of o3d_pool_bwd_partials; f(x) =
+ * when dN == NULL, from the packed pooled source pk of o3d_pool_bwd_partials_split; f(x) =
  * max(x*in_scale+in_shift, 0), or x when in_scale == in_shift == NULL.  scratch:
  * o3d_mlp_conv_wgrad2_scratch(...) floats. */
 long o3d_mlp_conv_wgrad2_scratch(int B, int Cin, int Cout, int P);
@@ -581,6 +509,17 @@ int o3d_xcorr_reduce(const float* dN, const float* Y0, const float* A1, const fl
 int o3d_sa_eval_fused(const float* Z, long ldz, const int32_t* idx, const float* centers, const float* W0, int ldw,
                       const float* v0, const float* W1, const float* v1, const float* W2, const float* v2, int C0, int C1,
                       int C2, int B, int np, int ns, int ld, long pt_base, float* out, void* stream);
+
+/* ---- P2B_XCorr's cosine similarity map (models/head/xcorr.py:37-38, nn.CosineSimilarity(dim=1, eps=1e-8)) ----------
+ * sim (B,N,M)[b,j,i] = <t[b,:,i], s[b,:,j]> / (max(|t_i|, eps) * max(|s_j|, eps));  t (B,f,M), s (B,f,N) with ELEMENT
+ * strides (batch, channel, point) -- the features are views of a flat conv output; tn (B,M), sn (B,N) = the clamped
+ * norms (kept for the backward).  f % 32 == 0, M <= 64, M % 4 == 0, N <= 128.
+ * Backward: dt (B,f,M), ds (B,f,N) contiguous from dsim (B,N,M). */
+int o3d_cosine_sim_fwd(const float* t, long tsb, long tsc, long tsn, const float* s, long ssb, long ssc, long ssn, int B, int f,
+                       int M, int N, float* sim, float* tn, float* sn, void* stream);
+int o3d_cosine_sim_bwd(const float* dsim, const float* sim, const float* tn, const float* sn, const float* t, long tsb, long tsc,
+                       long tsn, const float* s, long ssb, long ssc, long ssn, int B, int f, int M, int N, float* dt, float* ds,
+                       void* stream);
 
 /* ---- tracker losses (next row of SURVEY.md section 8f: the loss as one launch) ----------------------
  * MatchingBaseModel.compute_loss (models/base_model.py:122-164) + the BoxCloud term (models/bat.py:57-65)

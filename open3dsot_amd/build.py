@@ -20,7 +20,6 @@ SOURCES = [
     ("mlp.hip", []),
     ("mlp_direct.hip", []),
     ("mlp_wgrad.hip", []),
-    ("group.hip", []),
     ("compact.hip", []),
     ("pointwise.hip", []),
     ("heads.hip", []),

@@ -430,19 +430,6 @@ __global__ __launch_bounds__(256) void zero_cols_kernel(float* __restrict__ D, l
     *reinterpret_cast<float4*>(&D[(long)blockIdx.y * ldp + q]) = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
-// D[c, argq[c,ball]] = dOut where out > 0
-__global__ __launch_bounds__(256) void pool_scatter_c_kernel(const float* __restrict__ dOut,
-                                                             const float* __restrict__ out,
-                                                             const int32_t* __restrict__ argq, int C, int nballs,
-                                                             int seg1_ball, int np0, int np1, long total, long ldp,
-                                                             float* __restrict__ D) {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x;     // (c, ball), ball fastest
-    if (t >= total) return;
-    const int c = (int)(t / nballs), ball = (int)(t - (long)c * nballs);
-    const long o = pool_index(c, ball, C, seg1_ball, np0, np1);
-    if (out[o] > 0.f) D[(long)c * ldp + argq[o]] = dOut[o];
-}
-
 // BatchNorm-backward partials of the pooled layer, POOL_BWD_SPLIT rows per segment:
 // part[seg*SPLIT + k][0][c] = sum g, part[..][1][c] = sum g*(yarg - mean), g = dOut where out > 0, over the
 // k-th share of the segment's balls.  grid (C, nseg, SPLIT).
@@ -453,16 +440,11 @@ __global__ __launch_bounds__(256) void pool_bwd_partials_c_kernel(const float* _
                                                                   int nballs, int seg1_ball, int np0, int np1,
                                                                   float* __restrict__ part,
                                                                   const int32_t* __restrict__ argq,
-                                                                  float2* __restrict__ pkc,
-                                                                  float* __restrict__ D = nullptr, long ldp = 0) {
-    // D != NULL (round 3): the scatter of the dense gradient D[c, argq] = g rides along -- the same (channel, ball) walk as
-    // the statistics, so the separate pool_scatter_c_kernel launch and its second read of dOut / out are gone (D's live
-    // columns were zeroed by the launch in front of this one)
+                                                                  float* __restrict__ D, long ldp) {
+    // the scatter of the dense gradient D[c, argq] = g rides along -- the same (channel, ball) walk as the statistics (D's
+    // live columns were zeroed by the launch in front of this one)
     __shared__ float sh[2][4];
     const int c = blockIdx.x, seg = blockIdx.y, k = blockIdx.z;
-    // pkc (C, nballs + 1): {gradient where out > 0, bits(arg-max column)} per (channel, ball) -- the pooled layer's
-    // gradient as the data / weight gradient kernels gather it; the dummy ball of the padding columns holds {0, -1}
-    if (pkc && seg == 0 && k == 0 && threadIdx.x == 0) pkc[(long)c * (nballs + 1) + nballs] = make_float2(0.f, __int_as_float(-1));
     const int s0 = seg ? seg1_ball : 0, s1 = seg ? nballs : seg1_ball;
     const int share = (s1 - s0 + POOL_BWD_SPLIT - 1) / POOL_BWD_SPLIT;
     const int b0 = s0 + k * share, b1 = min(b0 + share, s1);
@@ -472,7 +454,6 @@ __global__ __launch_bounds__(256) void pool_bwd_partials_c_kernel(const float* _
         const long o = pool_index(c, ball, C, seg1_ball, np0, np1);
         const bool pos = out[o] > 0.f;
         const float g = pos ? dOut[o] : 0.f;
-        if (pkc) pkc[(long)c * (nballs + 1) + ball] = make_float2(g, __int_as_float(argq[o]));
         if (D && pos) D[(long)c * ldp + argq[o]] = g;
         s += g;
         q += g * (yarg[o] - mu);
@@ -604,15 +585,12 @@ __global__ __launch_bounds__(BT) void reduce_c_kernel(const float* __restrict__ 
 //                      poff[cloud][chunk*ld + n] (relative to the cloud's first column), total at [nchunk*ld].
 //   reduce_gather_kernel  per (cloud, CS channels): the chunk's dY staged in LDS with plain stores; thread n
 //                      gathers its own list, thread j sums its ball's contiguous range.
-// Behind O3D_REDUCE_GATHER=1 (open3dsot_amd/fused.py) until it has been through the GPU parity tests.
+// The default since round 2; reduce_c_kernel (one LDS atomic per column) remains for clouds whose index does not fit.
 // ---------------------------------------------------------------------------------------
 constexpr int RG_CH = 2048;     // columns per chunk (16-bit list entries: <= 65536)
-// channels per workgroup: 2, or 4 with O3D_RG_CS=4 (the chunk's index is re-read once per channel group, but 4 channels
-// double the LDS footprint: measured on the MI355X, same run A/B, 0.55 vs 0.50 ms per step for 2)
-static int rg_cs() {
-    static const int v = [] { const char* e = getenv("O3D_RG_CS"); const int c = e ? atoi(e) : 2; return c == 4 ? 4 : 2; }();
-    return v;
-}
+// channels per workgroup: 2 (4 re-read the chunk's index half as often but double the LDS footprint: measured on the
+// MI355X, same run A/B, 0.55 vs 0.50 ms per step)
+static int rg_cs() { return 2; }
 
 __global__ __launch_bounds__(1024) void csr_build_kernel(const int32_t* __restrict__ gp,
                                                          const int32_t* __restrict__ ball_off,
@@ -1107,8 +1085,7 @@ extern "C" int o3d_group_expand_c(const float* Z, long ldz, const int32_t* gp, c
         return O3D_EINVAL;
     // channel ranges per column tile: measured on the MI355X (same run A/B, ms per step of this kernel) 1 range
     // 0.26, 2 ranges 0.20, 4 ranges 0.19; a range keeps >= 32 channels = one full pass of its 4 waves
-    static const int ysplit_env = [] { const char* e = getenv("O3D_EXPAND_SPLIT"); return e ? atoi(e) : 0; }();
-    const int ysplit = ysplit_env > 0 ? ysplit_env : (C0 >= 128 ? 4 : C0 >= 64 ? 2 : 1);
+    const int ysplit = C0 >= 128 ? 4 : C0 >= 64 ? 2 : 1;
     if (centers)
         hipLaunchKernelGGL(expand_c_kernel<true>, dim3((unsigned)(ldp / 256), ysplit), dim3(256), 0, o3d_stream(stream), Z,
                            ldz, gp, cball, cw, centers, W0, ldw, C0, meta, start1, ldp, Y0, part, stat_c);
@@ -1141,19 +1118,7 @@ extern "C" int o3d_pool_fwd_c(const float* Y, long ldp, const float* scale, cons
         (argq && !yarg))
         return O3D_EINVAL;
     const int seg1_ball = B * npoint0, nballs = B * (npoint0 + npoint1);
-    static const int pch = [] { const char* e = getenv("O3D_POOL_CH"); return e ? atoi(e) : 8; }();   // experiment switch
-    if (pch == 4) {
-        hipLaunchKernelGGL(pool_c_kernel<4>, dim3(o3d_cdiv(nballs, 32), o3d_cdiv(C, 4)), dim3(256), 0, o3d_stream(stream), Y,
-                           ldp, scale, shift, ball_off, ball_cnt, C, seg1_ball, npoint0, npoint1 > 0 ? npoint1 : npoint0,
-                           nballs, out, argq, yarg);
-        return o3d_launch_status();
-    }
-    if (pch == 16) {
-        hipLaunchKernelGGL(pool_c_kernel<16>, dim3(o3d_cdiv(nballs, 32), o3d_cdiv(C, 16)), dim3(256), 0, o3d_stream(stream), Y,
-                           ldp, scale, shift, ball_off, ball_cnt, C, seg1_ball, npoint0, npoint1 > 0 ? npoint1 : npoint0,
-                           nballs, out, argq, yarg);
-        return o3d_launch_status();
-    }
+    // 8 channels per workgroup (4 / 16 measured: 0.37 / 0.42 vs 0.36 ms per step)
     constexpr int POOL_CH = 8;
     hipLaunchKernelGGL(pool_c_kernel<8>, dim3(o3d_cdiv(nballs, 32), o3d_cdiv(C, POOL_CH)), dim3(256), 0,
                        o3d_stream(stream), Y, ldp, scale, shift, ball_off, ball_cnt, C, seg1_ball, npoint0,
@@ -1192,35 +1157,10 @@ extern "C" int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t
     hipStream_t s = o3d_stream(stream);
     const int nseg = npoint1 > 0 ? 2 : 1;
     const int seg1_ball = B * npoint0, nballs = B * (npoint0 + npoint1), np1 = npoint1 > 0 ? npoint1 : npoint0;
-    static const bool fuse = [] { const char* e = getenv("O3D_POOL_BWD_FUSE"); return !e || atoi(e) != 0; }();   // A/B switch
-    if (fuse) {       // zero the live columns, then statistics + scatter in one walk over (channel, ball)
-        hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)o3d_cdiv(ldp, 1024), C), dim3(256), 0, s, D, ldp, meta, start1);
-        hipLaunchKernelGGL(pool_bwd_partials_c_kernel, dim3(C, nseg, POOL_BWD_SPLIT), dim3(256), 0, s, dOut, out, yarg, mean, C,
-                           nballs, seg1_ball, npoint0, np1, part, argq, nullptr, D, ldp);
-        return o3d_launch_status();
-    }
-    hipLaunchKernelGGL(pool_bwd_partials_c_kernel, dim3(C, nseg, POOL_BWD_SPLIT), dim3(256), 0, s, dOut, out, yarg, mean, C, nballs,
-                       seg1_ball, npoint0, np1, part, nullptr, nullptr, nullptr, 0L);
+    // zero the live columns, then statistics + scatter in one walk over (channel, ball)
     hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)o3d_cdiv(ldp, 1024), C), dim3(256), 0, s, D, ldp, meta, start1);
-    const long total = (long)C * nballs;
-    hipLaunchKernelGGL(pool_scatter_c_kernel, dim3(o3d_cdiv(total, 256)), dim3(256), 0, s, dOut, out, argq, C, nballs,
-                       seg1_ball, npoint0, np1, total, ldp, D);
-    return o3d_launch_status();
-}
-
-// Backward of the pool WITHOUT the dense gradient: the BatchNorm-backward partials as in o3d_pool_bwd_c plus
-// pkc (C, nballs + 1) = {masked gradient, bits(arg-max column)} per (channel, ball), which o3d_mlp_conv_dgrad_cp /
-// o3d_mlp_conv_wgrad2_cp gather through the column -> ball map.  Replaces a zero fill + a scatter of a (C, live columns)
-// tensor that the two gradient kernels then read back (about 1.5 GB of traffic per BAT step at batch 48).
-extern "C" int o3d_pool_bwd_pk(const float* dOut, const float* out, const int32_t* argq, const float* yarg,
-                               const float* mean, int B, int C, int npoint0, int npoint1, float* part, float* pkc,
-                               void* stream) {
-    if (!dOut || !out || !argq || !yarg || !mean || !part || !pkc || B <= 0 || C <= 0 || npoint0 <= 0 || npoint1 < 0)
-        return O3D_EINVAL;
-    const int nseg = npoint1 > 0 ? 2 : 1;
-    const int seg1_ball = B * npoint0, nballs = B * (npoint0 + npoint1), np1 = npoint1 > 0 ? npoint1 : npoint0;
-    hipLaunchKernelGGL(pool_bwd_partials_c_kernel, dim3(C, nseg, POOL_BWD_SPLIT), dim3(256), 0, o3d_stream(stream), dOut, out,
-                       yarg, mean, C, nballs, seg1_ball, npoint0, np1, part, argq, reinterpret_cast<float2*>(pkc));
+    hipLaunchKernelGGL(pool_bwd_partials_c_kernel, dim3(C, nseg, POOL_BWD_SPLIT), dim3(256), 0, s, dOut, out, yarg, mean, C,
+                       nballs, seg1_ball, npoint0, np1, part, argq, D, ldp);
     return o3d_launch_status();
 }
 
@@ -1258,26 +1198,10 @@ extern "C" int o3d_group_reduce_c(const float* dN, const float* Y0, long ldp, co
     const SegParams sp1 = nseg == 2 ? SegParams{npoint1, ld1, B * ld0, B * npoint0} : sp0;
     const long lds_row = (long)B * ld0 + (nseg == 2 ? (long)B * ld1 : 0);
     const int nballs = B * npoint0 + (nseg == 2 ? B * npoint1 : 0);
-    const int span = (sp0.ld + sp0.npoint) > (sp1.ld + sp1.npoint) ? (sp0.ld + sp0.npoint) : (sp1.ld + sp1.npoint);
     // channels per workgroup: 1 (measured on the MI355X, same run A/B, ms per step of this kernel: 4 channels
-    // 0.76, 2 channels 0.71, 1 channel 0.65 -- more, smaller workgroups win over amortising the column
-    // metadata loads; O3D_REDUCE_CS overrides for experiments)
-    static const int cs = [] { const char* e = getenv("O3D_REDUCE_CS"); return e ? atoi(e) : 1; }();
-    if (cs == 4 && sizeof(float) * 4 * (size_t)span <= 64 * 1024)
-        return launch_reduce_c<4>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, ball_cnt, B, nseg, sp0, sp1, C0,
-                                  lds_row, nballs, S, T, s);
-    static const int bt = [] { const char* e = getenv("O3D_REDUCE_BT"); return e ? atoi(e) : 256; }();   // experiment switch
-    if (cs == 1 && bt == 128)
-        return launch_reduce_c<1, 128>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, ball_cnt, B, nseg, sp0, sp1, C0,
-                                       lds_row, nballs, S, T, s);
-    if (cs == 1 && bt == 512)
-        return launch_reduce_c<1, 512>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, ball_cnt, B, nseg, sp0, sp1, C0,
-                                       lds_row, nballs, S, T, s);
-    if (cs == 1)
-        return launch_reduce_c<1>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, ball_cnt, B, nseg, sp0, sp1, C0,
-                                  lds_row, nballs, S, T, s);
-    return launch_reduce_c<2>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, ball_cnt, B, nseg, sp0, sp1, C0, lds_row,
-                              nballs, S, T, s);
+    // 0.76, 2 channels 0.71, 1 channel 0.65 -- more, smaller workgroups win over amortising the column metadata loads)
+    return launch_reduce_c<1>(dN, Y0, ldp, A1, A2, A3, gp, cball, cw, ball_off, ball_cnt, B, nseg, sp0, sp1, C0,
+                              lds_row, nballs, S, T, s);
 }
 
 // dW (C0, ldw): columns 0..2 -= T (C0, nballs) . centers (nballs, 3)
@@ -1355,19 +1279,14 @@ extern "C" int o3d_group_reduce_gather(const float* dN, const float* Y0, long ld
         hipFuncSetAttribute(reinterpret_cast<const void*>(csr_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds_csr) != hipSuccess)
         return O3D_ELAUNCH;
-    const void* rgk = cs == 4 ? reinterpret_cast<const void*>(reduce_gather_kernel<4>)
-                              : reinterpret_cast<const void*>(reduce_gather_kernel<2>);
+    const void* rgk = reinterpret_cast<const void*>(reduce_gather_kernel<2>);
     if (lds_red > 48 * 1024 &&
         hipFuncSetAttribute(rgk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_red) != hipSuccess)
         return O3D_ELAUNCH;
     hipLaunchKernelGGL(csr_build_kernel, dim3(B * nseg), dim3(1024), lds_csr, s, gp, ball_off, ball_cnt, B, sp0, sp1, nchunk,
                        stride, perm, poff);
     const int slabs = (C0 + cs - 1) / cs;
-    if (cs == 4)
-        hipLaunchKernelGGL(reduce_gather_kernel<4>, dim3(B * nseg * slabs), dim3(256), lds_red, s, dN, Y0, ldp, A1, A2, A3, cw,
-                           ball_off, ball_cnt, perm, poff, stride, B, sp0, sp1, C0, lds_row, S, T, nballs);
-    else
-        hipLaunchKernelGGL(reduce_gather_kernel<2>, dim3(B * nseg * slabs), dim3(256), lds_red, s, dN, Y0, ldp, A1, A2, A3, cw,
+    hipLaunchKernelGGL(reduce_gather_kernel<2>, dim3(B * nseg * slabs), dim3(256), lds_red, s, dN, Y0, ldp, A1, A2, A3, cw,
                            ball_off, ball_cnt, perm, poff, stride, B, sp0, sp1, C0, lds_row, S, T, nballs);
     return o3d_launch_status();
 }

@@ -222,14 +222,10 @@ static void fps_rank_params(int N, int& bs_log2, int& cpb) {
     cpb = (N + (1 << bs_log2) - 1) >> bs_log2;
 }
 
-// waves per cloud for 256 < N <= 2048: 1 (no hand-off), or 4 with O3D_FPS_NW=4 (a quarter of the per-round distance
-// updates per wave, one LDS hand-off + barrier per round).  Measured on the MI355X, same-box A/B at 512 / 1024 points:
-// the 4-wave form is SLOWER (BAT step 6.45 vs 6.43 ms, batch-1 frame 1.021 vs 1.006 ms) -- the round is ~100 VALU
-// instructions shorter, the barrier and the LDS round trip cost more.  Kept as a switch.
-static int fps_nw() {
-    static const int v = [] { const char* e = getenv("O3D_FPS_NW"); return e && atoi(e) == 4 ? 4 : 1; }();
-    return v;
-}
+// waves per cloud for 256 < N <= 2048: 1 (no hand-off).  The 4-wave form (a quarter of the per-round distance updates per
+// wave, one LDS hand-off + barrier per round) measured SLOWER on the MI355X, same-box A/B at 512 / 1024 points: BAT step
+// 6.45 vs 6.43 ms, batch-1 frame 1.021 vs 1.006 ms -- the round is ~100 VALU instructions shorter, the barrier and the LDS
+// round trip cost more.  Multi-wave instantiations stay for N > 2048 (the cloud no longer fits one wave's registers).
 
 // both sets in one launch of the register kernel sized for the larger cloud
 template <int PPT, int NW>
@@ -256,11 +252,6 @@ int fps_dispatch(const float* xyz, int B, int N, int npoint, float* temp, int32_
     if (N <= 64) return launch_reg<1, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
     if (N <= 128) return launch_reg<2, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
     if (N <= 256) return launch_reg<4, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
-    if (fps_nw() == 4 && N <= 2048) {
-        if (N <= 512) return launch_reg<2, 4, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
-        if (N <= 1024) return launch_reg<4, 4, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
-        return launch_reg<8, 4, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
-    }
     if (N <= 512) return launch_reg<8, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
     if (N <= 1024) return launch_reg<16, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
     if (N <= 2048) return launch_reg<32, 1, USE_DPP>(xyz, B, N, npoint, bs_log2, cpb, idx, s);
@@ -294,11 +285,6 @@ extern "C" int o3d_furthest_point_sampling_pair(const float* xyz0, int N0, int n
         return O3D_EINVAL;
     hipStream_t s = o3d_stream(stream);
     if (Nmax <= 256) return launch_pair<4, 1>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
-    if (fps_nw() == 4) {
-        if (Nmax <= 512) return launch_pair<2, 4>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
-        if (Nmax <= 1024) return launch_pair<4, 4>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
-        return launch_pair<8, 4>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
-    }
     if (Nmax <= 512) return launch_pair<8, 1>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
     if (Nmax <= 1024) return launch_pair<16, 1>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);
     return launch_pair<32, 1>(xyz0, N0, npoint0, idx0, xyz1, N1, npoint1, idx1, B, s);

@@ -87,25 +87,17 @@ __device__ __forceinline__ void mma_chunk(const float* __restrict__ As, int lda,
 // K1: forward layer   Y[b,co,p] = sum_ci W[co,ci] * f(X[b,ci,p])
 // ======================================================================================
 struct FwdArgs {
-    const float* X;         // (B,Cin,P) pre-activation of the producer layer, or NULL (GATHER)
+    const float* X;         // (B,Cin,P) pre-activation of the producer layer
     const float* W;         // (Cout,Cin)
     float* Y;               // (B,Cout,P) raw conv output
     const float* in_scale;  // (Cin) f(x) = max(x*scale+shift,0) when XFORM
     const float* in_shift;
     float* part;            // [B*P/128][2][Cout] per-tile {sum y, sum (y-c)^2} or NULL
     const float* stat_c;    // (Cout) shift c of the second moment (running_mean) or NULL (=0)
-    // GATHER mode (layer 0 of a grouped MLP):
-    //   X[b,ci,j*ns+k] = ci < nxyz ? xyz[b,idx[b,j,k],ci] - new_xyz[b,j,ci] : feats[b,ci-nxyz,idx[b,j,k]]
-    const float* xyz;       // (B,N,3) or NULL when nxyz == 0
-    const float* new_xyz;   // (B,npoint,3)
-    const float* feats;     // (B,C,N) or NULL
-    const int32_t* idx;     // (B,npoint*ns)
-    int N, C, ns, nxyz;
-    float inv_radius;       // grouped xyz is multiplied by this (1 unless normalize_xyz)
     int B, Cin, Cout, P;
 };
 
-template <int BM, bool GATHER, bool XFORM>
+template <int BM, bool XFORM>
 __global__ __launch_bounds__(BM * 2) void conv_fwd_kernel(FwdArgs a) {
     constexpr int T = BM * 2;            // threads
     constexpr int NB4 = 512 / T;         // float4 of the X tile per thread (16x128 floats)
@@ -126,13 +118,6 @@ __global__ __launch_bounds__(BM * 2) void conv_fwd_kernel(FwdArgs a) {
     // fixed per-thread staging coordinates
     const int bc4 = tid & 31;            // float4 column of the X tile (positions 4*bc4..+3)
     const int br0 = tid >> 5;            // first k row; further rows at +T/32
-    int gid[4] = {0, 0, 0, 0};
-    int gj = 0;
-    if (GATHER) {
-        const int4 v = *reinterpret_cast<const int4*>(&a.idx[(long)b * a.P + p0 + 4 * bc4]);
-        gid[0] = v.x; gid[1] = v.y; gid[2] = v.z; gid[3] = v.w;
-        gj = (p0 + 4 * bc4) / a.ns;      // ns % 4 == 0: the four positions share one centre
-    }
 
     // Operand staging is split in two so that nothing waits on HBM in front of the MFMAs:
     //   load_chunk  -- only issues the global loads of chunk t+1 (raw values + per-row constants)
@@ -164,19 +149,8 @@ __global__ __launch_bounds__(BM * 2) void conv_fwd_kernel(FwdArgs a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             float c0 = 0.f, c1 = 0.f;
             if (ci < a.Cin) {
-                if (GATHER) {
-                    if (ci < a.nxyz) {
-                        c0 = a.new_xyz[((long)b * (a.P / a.ns) + gj) * 3 + ci];
-                        const float* px = a.xyz + (long)b * a.N * 3 + ci;
-                        v.x = px[3 * gid[0]]; v.y = px[3 * gid[1]]; v.z = px[3 * gid[2]]; v.w = px[3 * gid[3]];
-                    } else {
-                        const float* pf = a.feats + ((long)b * a.C + (ci - a.nxyz)) * a.N;
-                        v.x = pf[gid[0]]; v.y = pf[gid[1]]; v.z = pf[gid[2]]; v.w = pf[gid[3]];
-                    }
-                } else {
-                    v = *reinterpret_cast<const float4*>(&a.X[((long)b * a.Cin + ci) * a.P + p0 + 4 * bc4]);
-                    if (XFORM) { c0 = a.in_scale[ci]; c1 = a.in_shift[ci]; }
-                }
+                v = *reinterpret_cast<const float4*>(&a.X[((long)b * a.Cin + ci) * a.P + p0 + 4 * bc4]);
+                if (XFORM) { c0 = a.in_scale[ci]; c1 = a.in_shift[ci]; }
             }
             rb[i] = v; rc0[i] = c0; rc1[i] = c1;
         }
@@ -192,13 +166,7 @@ __global__ __launch_bounds__(BM * 2) void conv_fwd_kernel(FwdArgs a) {
             const int r = br0 + (T / 32) * i;
             const int ci = k0 + r;
             float4 v = rb[i];
-            if (GATHER) {
-                if (ci < a.nxyz) {
-                    const float c = rc0[i];
-                    v.x = (v.x - c) * a.inv_radius; v.y = (v.y - c) * a.inv_radius;
-                    v.z = (v.z - c) * a.inv_radius; v.w = (v.w - c) * a.inv_radius;
-                }
-            } else if (XFORM) {
+            if (XFORM) {
                 if (ci < a.Cin) {
                     const float sc = rc0[i], sh = rc1[i];
                     v.x = fmaxf(fmaf(v.x, sc, sh), 0.f); v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
@@ -439,38 +407,9 @@ __global__ __launch_bounds__(256) void pool_fwd_kernel(const float* __restrict__
     }
 }
 
-// Backward statistics of the pooled layer: per (b,c) partial {sum g, sum g*(yarg-mean)} with
-// g = dOut where the pooled activation is positive.  One wave per (b,c).
-__global__ __launch_bounds__(256) void pool_bwd_partials_kernel(const float* __restrict__ dOut,
-                                                                const float* __restrict__ out,
-                                                                const float* __restrict__ yarg,
-                                                                const float* __restrict__ mean, int B,
-                                                                int C, int npoint,
-                                                                float* __restrict__ part,
-                                                                const int32_t* __restrict__ arg,
-                                                                float2* __restrict__ pk) {
-    const int lane = threadIdx.x & 63;
-    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);  // (b,c)
-    if (w >= (long)B * C) return;
-    const int b = (int)(w / C), c = (int)(w % C);
-    const float mu = mean[c];
-    float s = 0.f, q = 0.f;
-    for (int j = lane; j < npoint; j += 64) {
-        const long i = w * npoint + j;
-        const float g = out[i] > 0.f ? dOut[i] : 0.f;
-        if (pk) pk[i] = make_float2(g, __int_as_float(arg[i]));   // packed source of the pooled dN
-        s += g;
-        q += g * (yarg[i] - mu);
-    }
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) { s += __shfl_xor(s, off, 64); q += __shfl_xor(q, off, 64); }
-    if (lane == 0) {
-        part[((long)b * 2 + 0) * C + c] = s;
-        part[((long)b * 2 + 1) * C + c] = q;
-    }
-}
-
-// The same for ONE cloud of many balls (the flat (C, npoint) layout of the P2B fusion: npoint = B*N balls): a channel's
+// Backward statistics of the pooled layer: partial {sum g, sum g*(yarg-mean)} with g = dOut where the pooled activation is
+// positive (+ the packed {g, bits(arg-max slot)} pairs the pooled-source gradient kernels read), for ONE cloud of many
+// balls (the flat (C, npoint) layout of the P2B fusion: npoint = B*N balls): a channel's
 // balls are split over gridDim.y workgroups, part [gridDim.y][2][C].
 __global__ __launch_bounds__(256) void pool_bwd_partials_split_kernel(const float* __restrict__ dOut,
                                                                       const float* __restrict__ out,
@@ -792,104 +731,6 @@ __global__ __launch_bounds__(BM * 2) void conv_dgrad_kernel(DgradArgs a) {
             }
     }
 }
-
-// Inverse of the grouping map: for every source point n of cloud b the list of positions p with
-// idx[b,p] == n  (offsets (B,N+1), perm (B,P)).  One workgroup per cloud, counting sort in LDS.
-__global__ __launch_bounds__(256) void group_csr_kernel(const int32_t* __restrict__ idx, int P, int N,
-                                                        int32_t* __restrict__ offsets,
-                                                        int32_t* __restrict__ perm) {
-    extern __shared__ __attribute__((aligned(16))) int scnt[];   // [N] counts -> cursors, then [256] scan
-    int* sscan = scnt + N;
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int32_t* id_b = idx + (long)b * P;
-    for (int n = tid; n < N; n += 256) scnt[n] = 0;
-    __syncthreads();
-    for (int p = tid; p < P; p += 256) atomicAdd(&scnt[id_b[p]], 1);
-    __syncthreads();
-    const int per = (N + 255) / 256;
-    const int n0 = tid * per;
-    int local = 0;
-    for (int n = n0; n < n0 + per && n < N; ++n) local += scnt[n];
-    sscan[tid] = local;
-    __syncthreads();
-    if (tid == 0) {
-        int run = 0;
-        for (int t = 0; t < 256; ++t) { const int v = sscan[t]; sscan[t] = run; run += v; }
-    }
-    __syncthreads();
-    int run = sscan[tid];
-    int32_t* off_b = offsets + (long)b * (N + 1);
-    for (int n = n0; n < n0 + per && n < N; ++n) {
-        const int v = scnt[n];
-        off_b[n] = run;
-        scnt[n] = run;       // becomes the fill cursor
-        run += v;
-    }
-    if (tid == 255) off_b[N] = P;
-    __syncthreads();
-    int32_t* perm_b = perm + (long)b * P;
-    for (int p = tid; p < P; p += 256) perm_b[atomicAdd(&scnt[id_b[p]], 1)] = p;
-}
-
-// out[b,m,n] = sum over positions p in list(b,n) of GT[b,p,m]   (= group_points_grad of G).
-// One workgroup per (cloud, 32 source points); a wave walks one point's list and accumulates whole
-// channel rows (coalesced float4 per lane); the 32 x M tile is transposed through LDS so the
-// (B,M,N) output is written in 128-byte rows.  No atomics; list order = counting-sort fill order.
-constexpr int SG_NB = 32;
-__global__ __launch_bounds__(256) void scatter_gt_kernel(const float* __restrict__ GT,
-                                                         const int32_t* __restrict__ offsets,
-                                                         const int32_t* __restrict__ perm, int M, int P,
-                                                         int N, float* __restrict__ out) {
-    extern __shared__ __attribute__((aligned(16))) float tile[];   // [SG_NB][Mc + 1], Mc = channel chunk
-    const int b = blockIdx.x, n0 = blockIdx.y * SG_NB;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int32_t* off_b = offsets + (long)b * (N + 1);
-    const int32_t* perm_b = perm + (long)b * P;
-    const float* g_b = GT + (long)b * P * M;
-    for (int cb = 0; cb < M; cb += 256) {
-        const int mc = (M - cb) < 256 ? (M - cb) : 256;
-        const int ld = mc + 1;
-        const int c = cb + 4 * lane;
-        for (int nl = wave; nl < SG_NB; nl += 4) {
-            const int n = n0 + nl;
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n < N) {
-                const int beg = off_b[n], end = off_b[n + 1];
-                for (int base = beg; base < end; base += 64) {
-                    const int cnt = (end - base) < 64 ? (end - base) : 64;
-                    const int mine = lane < cnt ? perm_b[base + lane] : 0;   // 64 list entries at once
-                    for (int i = 0; i < cnt; ++i) {
-                        const int p = __shfl(mine, i, 64);
-                        const float* row = g_b + (long)p * M + c;
-                        if (c + 3 < M) {
-                            if ((M & 3) == 0) {
-                                const float4 v = *reinterpret_cast<const float4*>(row);
-                                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-                            } else {
-                                acc.x += row[0]; acc.y += row[1]; acc.z += row[2]; acc.w += row[3];
-                            }
-                        } else {
-                            if (c + 0 < M) acc.x += row[0];
-                            if (c + 1 < M) acc.y += row[1];
-                            if (c + 2 < M) acc.z += row[2];
-                        }
-                    }
-                }
-            }
-            const int cl = 4 * lane;
-            if (cl + 0 < mc) tile[nl * ld + cl + 0] = acc.x;
-            if (cl + 1 < mc) tile[nl * ld + cl + 1] = acc.y;
-            if (cl + 2 < mc) tile[nl * ld + cl + 2] = acc.z;
-            if (cl + 3 < mc) tile[nl * ld + cl + 3] = acc.w;
-        }
-        __syncthreads();
-        const int nl = tid & 31;
-        for (int cl = tid >> 5; cl < mc; cl += 8)
-            if (n0 + nl < N) out[((long)b * M + cb + cl) * N + n0 + nl] = tile[nl * ld + cl];
-        __syncthreads();
-    }
-}
-
 // ======================================================================================
 // K3: weight gradient   dW[co,ci] = sum_{b,p} dY[b,co,p] * X[b,ci,p]   (split over positions)
 //   X: transform-on-load of the producer's raw output, or the layer-0 gather.
@@ -898,16 +739,14 @@ __global__ __launch_bounds__(256) void scatter_gt_kernel(const float* __restrict
 // ======================================================================================
 struct WgradArgs {
     DyArgs dy;
-    const float* X; const float* in_scale; const float* in_shift;  // non-gather source
-    const float* xyz; const float* new_xyz; const float* feats; const int32_t* idx;  // gather
-    int N, C, ns, nxyz; float inv_radius;
+    const float* X; const float* in_scale; const float* in_shift;
     int B, Cin, Cout, P;
     int chunks_per_block, total_chunks;
     int tiles_ci, tiles_co, nslices;
     float* part;   // [nslices][Cout][Cin]
 };
 
-template <bool POOLED, bool GATHER, bool XFORM>
+template <bool POOLED, bool XFORM>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     auto As = [&](int buf) -> float* { return smem + buf * (128 * WLD); };        // dY^T  [co][pos]
@@ -935,25 +774,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int chunks_per_b = a.P / WBK;
     const int r0 = tid >> 3, c4 = tid & 7;   // row (+32*i) and float4 column inside a chunk
 
-    // staging split like the forward kernel: raw global loads before the MFMAs, transforms after;
-    // the grouping indices of chunk t+2 are fetched together with the operands of chunk t+1 so the
-    // dependent gather never waits for its index load.
+    // staging split like the forward kernel: raw global loads before the MFMAs, transforms after
     RawDy ra[4];
     float4 rb[4];
     float rc0[4], rc1[4];
-    int gid[4] = {0, 0, 0, 0}, gnext[4] = {0, 0, 0, 0};
-    auto load_idx = [&](int ch, int (&dst)[4]) {
-        if (GATHER && ch < c_end) {
-            const long b = ch / chunks_per_b;
-            const int p = (ch - (int)b * chunks_per_b) * WBK + 4 * c4;
-            const int4 v = *reinterpret_cast<const int4*>(&a.idx[b * a.P + p]);
-            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
-        }
-    };
     auto load_chunk = [&](int ch) {
         const long b = ch / chunks_per_b;
         const int p = (ch - (int)b * chunks_per_b) * WBK + 4 * c4;
-        const int gj = GATHER ? p / a.ns : 0;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int co = co0 + r0 + 32 * i;
@@ -962,23 +789,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             float c0 = 0.f, c1 = 0.f;
             if (ci < a.Cin) {
-                if (GATHER) {
-                    if (ci < a.nxyz) {
-                        c0 = a.new_xyz[(b * (a.P / a.ns) + gj) * 3 + ci];
-                        const float* px = a.xyz + b * a.N * 3 + ci;
-                        v.x = px[3 * gid[0]]; v.y = px[3 * gid[1]]; v.z = px[3 * gid[2]]; v.w = px[3 * gid[3]];
-                    } else {
-                        const float* pf = a.feats + (b * a.C + (ci - a.nxyz)) * a.N;
-                        v.x = pf[gid[0]]; v.y = pf[gid[1]]; v.z = pf[gid[2]]; v.w = pf[gid[3]];
-                    }
-                } else {
-                    v = *reinterpret_cast<const float4*>(&a.X[(b * a.Cin + ci) * a.P + p]);
-                    if (XFORM) { c0 = a.in_scale[ci]; c1 = a.in_shift[ci]; }
-                }
+                v = *reinterpret_cast<const float4*>(&a.X[(b * a.Cin + ci) * a.P + p]);
+                if (XFORM) { c0 = a.in_scale[ci]; c1 = a.in_shift[ci]; }
             }
             rb[i] = v; rc0[i] = c0; rc1[i] = c1;
         }
-        load_idx(ch + 1, gnext);
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
@@ -988,13 +803,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                 co < a.Cout ? finish_dy<POOLED>(ra[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
             const int ci = ci0 + r0 + 32 * i;
             float4 v = rb[i];
-            if (GATHER) {
-                if (ci < a.nxyz) {
-                    const float c = rc0[i];
-                    v.x = (v.x - c) * a.inv_radius; v.y = (v.y - c) * a.inv_radius;
-                    v.z = (v.z - c) * a.inv_radius; v.w = (v.w - c) * a.inv_radius;
-                }
-            } else if (XFORM) {
+            if (XFORM) {
                 if (ci < a.Cin) {
                     const float sc = rc0[i], sh = rc1[i];
                     v.x = fmaxf(fmaf(v.x, sc, sh), 0.f); v.y = fmaxf(fmaf(v.y, sc, sh), 0.f);
@@ -1003,8 +812,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             }
             *reinterpret_cast<float4*>(&Bs(buf)[(r0 + 32 * i) * WLD + 4 * c4]) = v;
         }
-#pragma unroll
-        for (int e = 0; e < 4; ++e) gid[e] = gnext[e];
     };
 
     f32x16 acc[2][2];
@@ -1016,7 +823,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (c_begin < c_end) {
-        load_idx(c_begin, gid);
         load_chunk(c_begin);
         store_chunk(0);
         __syncthreads();
@@ -1110,16 +916,16 @@ inline size_t dgrad_lds(int BM) {
     return stage > red ? stage : red;
 }
 
-template <bool GATHER, bool XFORM>
+template <bool XFORM>
 int launch_fwd(const FwdArgs& a, hipStream_t s) {
     const int tiles = a.B * (a.P / BN_POS);
     if (a.Cout > 128) {
-        return launch(conv_fwd_kernel<256, GATHER, XFORM>, dim3(tiles, o3d_cdiv(a.Cout, 256)), dim3(512),
+        return launch(conv_fwd_kernel<256, XFORM>, dim3(tiles, o3d_cdiv(a.Cout, 256)), dim3(512),
                       fwd_lds(256), s, a);
     } else if (a.Cout > 64) {
-        return launch(conv_fwd_kernel<128, GATHER, XFORM>, dim3(tiles, 1), dim3(256), fwd_lds(128), s, a);
+        return launch(conv_fwd_kernel<128, XFORM>, dim3(tiles, 1), dim3(256), fwd_lds(128), s, a);
     }
-    return launch(conv_fwd_kernel<64, GATHER, XFORM>, dim3(tiles, 1), dim3(128), fwd_lds(64), s, a);
+    return launch(conv_fwd_kernel<64, XFORM>, dim3(tiles, 1), dim3(128), fwd_lds(64), s, a);
 }
 
 template <bool POOLED, int EPI>
@@ -1149,25 +955,8 @@ extern "C" int o3d_mlp_conv_fwd(const float* X, const float* W, const float* in_
                               part ? 128 : o3d_direct_tile((long)B * P, Cout, 0), o3d_stream(stream));
     FwdArgs a = {};
     a.X = X; a.W = W; a.Y = Y; a.in_scale = in_scale; a.in_shift = in_shift; a.part = part; a.stat_c = stat_c;
-    a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = P; a.ns = 4; a.inv_radius = 1.f;
-    return in_scale ? launch_fwd<false, true>(a, o3d_stream(stream)) : launch_fwd<false, false>(a, o3d_stream(stream));
-}
-
-extern "C" int o3d_mlp_conv_grouped_fwd(const float* xyz, const float* new_xyz, const float* feats,
-                                        const int32_t* idx, const float* W, int B, int N, int C,
-                                        int npoint, int ns, int nxyz, float inv_radius, int Cout,
-                                        float* Y, float* part, const float* stat_c, void* stream) {
-    const long P = (long)npoint * ns;
-    if (B <= 0 || N <= 0 || C < 0 || npoint <= 0 || ns <= 0 || ns % 4 != 0 || P % BN_POS != 0 ||
-        (nxyz != 0 && nxyz != 3) || nxyz + C <= 0 || !idx || !W || !Y || (nxyz && (!xyz || !new_xyz)) ||
-        (C && !feats))
-        return O3D_EINVAL;
-    FwdArgs a = {};
-    a.W = W; a.Y = Y; a.part = part; a.stat_c = stat_c;
-    a.xyz = xyz; a.new_xyz = new_xyz; a.feats = feats; a.idx = idx;
-    a.N = N; a.C = C; a.ns = ns; a.nxyz = nxyz; a.inv_radius = inv_radius;
-    a.B = B; a.Cin = nxyz + C; a.Cout = Cout; a.P = (int)P;
-    return launch_fwd<true, false>(a, o3d_stream(stream));
+    a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = P;
+    return in_scale ? launch_fwd<true>(a, o3d_stream(stream)) : launch_fwd<false>(a, o3d_stream(stream));
 }
 
 extern "C" int o3d_bn_finalize(const float* part, int nparts, int C, double count, const float* stat_c,
@@ -1223,17 +1012,6 @@ extern "C" int o3d_bn_relu_maxpool_fwd(const float* Y, const float* scale, const
     const long total = (long)B * C * npoint;
     hipLaunchKernelGGL(pool_fwd_kernel, dim3(o3d_cdiv(total * 8, 256)), dim3(256), 0, o3d_stream(stream), Y,
                        scale, shift, C, npoint, ns, total, out, arg, yarg);
-    return o3d_launch_status();
-}
-
-extern "C" int o3d_pool_bwd_partials(const float* dOut, const float* out, const float* yarg,
-                                     const float* mean, int B, int C, int npoint, float* part,
-                                     const int32_t* arg, float* pk, void* stream) {
-    if (B <= 0 || C <= 0 || npoint <= 0 || !dOut || !out || !yarg || !mean || !part || (pk && !arg))
-        return O3D_EINVAL;
-    hipLaunchKernelGGL(pool_bwd_partials_kernel, dim3(o3d_cdiv((long)B * C, 4)), dim3(256), 0,
-                       o3d_stream(stream), dOut, out, yarg, mean, B, C, npoint, part, arg,
-                       reinterpret_cast<float2*>(pk));
     return o3d_launch_status();
 }
 
@@ -1374,26 +1152,6 @@ extern "C" int o3d_mlp_conv_dgrad_c(const float* dN, const float* Y, const float
 
 // dX (B,Cin,P) = W^T dY with dY = A1*dN + A2*Y + A3, no mask, no statistics: the gradient w.r.t. an
 // operand that is not the BN+ReLU output of a previous layer (the per-point operand of layer 0).
-int o3d_direct_dgrad_pooled_c(const float* pkc, const int32_t* cball, int nb1, const float* Y, const float* A1,
-                              const float* A2, const float* A3, const float* Wt, int Cin, int Cout, int P,
-                              const float* Yprev, const float* scale_p, const float* shift_p, const float* mean_p,
-                              float* dNprev, float* part, const float* w, const int32_t* meta, long start1, int tile,
-                              hipStream_t st);
-
-// o3d_mlp_conv_dgrad_c for the pooled (last) layer: its gradient comes from the pooled tensors (o3d_pool_bwd_pk)
-extern "C" int o3d_mlp_conv_dgrad_cp(const float* pkc, const int32_t* cball, int nb1, const float* Y, const float* A1,
-                                     const float* A2, const float* A3, const float* Wt, int Cin, int Cout, long ldp,
-                                     const float* w, const int32_t* meta, long start1, int tile, const float* Yprev,
-                                     const float* scale_p, const float* shift_p, const float* mean_p, float* dNprev,
-                                     float* part, void* stream) {
-    if (!pkc || !cball || nb1 <= 0 || !Y || !A1 || !A2 || !A3 || !Wt || !w || !meta || !Yprev || !scale_p || !shift_p ||
-        !mean_p || !dNprev || !part || ldp <= 0 || ldp > 0x7fffffff || !o3d_direct_ok(Cin, Cout, (int)ldp) ||
-        (tile != 64 && tile != 128))
-        return O3D_EINVAL;
-    return o3d_direct_dgrad_pooled_c(pkc, cball, nb1, Y, A1, A2, A3, Wt, Cin, Cout, (int)ldp, Yprev, scale_p, shift_p,
-                                     mean_p, dNprev, part, w, meta, start1, tile, o3d_stream(stream));
-}
-
 extern "C" int o3d_mlp_conv_dgrad_plain(const float* dN, const float* Y, const float* A1, const float* A2,
                                         const float* A3, const float* W, int B, int Cin, int Cout, int P,
                                         float* dX, void* stream) {
@@ -1404,35 +1162,6 @@ extern "C" int o3d_mlp_conv_dgrad_plain(const float* dN, const float* Y, const f
     return launch_dgrad<false, 2>(a, o3d_stream(stream));
 }
 
-// data gradient of grouped layer 0: GT (B,P,M) = (W[:, c_lo:]^T dY)^T, M = Cin - c_lo, then gathered
-// through the inverse grouping map into dgrouped (B,M,N).  GT (B*P*M floats), offsets (B*(N+1)
-// ints) and perm (B*P ints) are caller scratch; GT is left filled (the caller reads its xyz
-// columns for the centre gradient).
-extern "C" int o3d_mlp_conv_grouped_dgrad(const float* dN, const float* dOut, const float* out,
-                                          const int32_t* arg, const float* Y, const float* A1,
-                                          const float* A2, const float* A3, const float* W,
-                                          const int32_t* idx, int B, int N, int Cin, int npoint, int ns,
-                                          int Cout, int c_lo, float* GT, int32_t* offsets, int32_t* perm,
-                                          float* dgrouped, void* stream) {
-    const long P = (long)npoint * ns;
-    if (B <= 0 || N <= 0 || N > 8192 || Cin <= 0 || npoint <= 0 || ns <= 0 || ns % 4 != 0 || P % BN_POS != 0 ||
-        Cout <= 0 || c_lo < 0 || c_lo >= Cin || !W || !idx || !GT || !offsets || !perm || !dgrouped || B > 65535)
-        return O3D_EINVAL;
-    DgradArgs a = {};
-    if (fill_dy(a.dy, dN, dOut, out, arg, Y, A1, A2, A3, ns) != O3D_OK) return O3D_EINVAL;
-    a.W = W; a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = (int)P; a.c_lo = c_lo; a.M = Cin - c_lo;
-    a.dNprev = GT;
-    hipStream_t s = o3d_stream(stream);
-    int rc = launch(group_csr_kernel, dim3(B), dim3(256), sizeof(int) * (size_t)(N + 256), s, idx, (int)P, N,
-                    offsets, perm);
-    if (rc != O3D_OK) return rc;
-    rc = dN ? launch_dgrad<false, 1>(a, s) : launch_dgrad<true, 1>(a, s);
-    if (rc != O3D_OK) return rc;
-    const int mc = a.M < 256 ? a.M : 256;
-    return launch(scatter_gt_kernel, dim3(B, o3d_cdiv(N, SG_NB)), dim3(256), sizeof(float) * SG_NB * (mc + 1), s,
-                  GT, offsets, perm, a.M, (int)P, N, dgrouped);
-}
-
 // dW[i] = sum over slices of part[z][i], in a fixed order (two stages above 32 slices; scratch2 holds
 // 16 * n floats)
 void o3d_wgrad_reduce(const float* part, int nslices, long n, float* scratch2, float* dW, hipStream_t s) {
@@ -1441,8 +1170,8 @@ void o3d_wgrad_reduce(const float* part, int nslices, long n, float* scratch2, f
 }
 
 // weight gradient.  `part` is scratch of (nslices+16)*Cout*Cin floats; dW (Cout,Cin) is overwritten.
-// X source: (X, in_scale, in_shift) for inner layers (in_scale NULL = identity), or the layer-0
-// gather (xyz,new_xyz,feats,idx,N,C,nxyz) when X == NULL.
+// X source: (X, in_scale, in_shift) (in_scale NULL = identity).  The gather arguments (xyz ... inv_radius) belonged to
+// the slot-wise layer-0 path retired in round 4 (layer 0 runs on the points, csrc/compact.hip): pass NULL / 0.
 extern "C" int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const float* out, const int32_t* arg,
                                   int ns, const float* Y, const float* A1, const float* A2, const float* A3,
                                   const float* X, const float* in_scale, const float* in_shift,
@@ -1452,14 +1181,11 @@ extern "C" int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const floa
                                   void* stream) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || P <= 0 || P % WBK != 0 || nslices <= 0 || !part || !dW)
         return O3D_EINVAL;
-    const bool gather = X == nullptr;
-    if (gather && (!idx || ns <= 0 || ns % 4 != 0 || nxyz + C != Cin || (nxyz && (!xyz || !new_xyz)) || (C && !feats)))
-        return O3D_EINVAL;
+    (void)xyz; (void)new_xyz; (void)feats; (void)idx; (void)N; (void)C; (void)nxyz; (void)inv_radius;
+    if (!X) return O3D_EINVAL;
     WgradArgs a = {};
     if (fill_dy(a.dy, dN, dOut, out, arg, Y, A1, A2, A3, ns) != O3D_OK) return O3D_EINVAL;
     a.X = X; a.in_scale = in_scale; a.in_shift = in_shift;
-    a.xyz = xyz; a.new_xyz = new_xyz; a.feats = feats; a.idx = idx;
-    a.N = N; a.C = C; a.ns = ns > 0 ? ns : 4; a.nxyz = nxyz; a.inv_radius = inv_radius;
     a.B = B; a.Cin = Cin; a.Cout = Cout; a.P = P;
     a.total_chunks = B * (P / WBK);
     a.chunks_per_block = (a.total_chunks + nslices - 1) / nslices;
@@ -1470,15 +1196,12 @@ extern "C" int o3d_mlp_conv_wgrad(const float* dN, const float* dOut, const floa
     hipStream_t s = o3d_stream(stream);
     int rc;
     const bool pooled = dN == nullptr;
-    if (gather) {
-        rc = pooled ? launch(conv_wgrad_kernel<true, true, false>, grid, block, lds, s, a)
-                    : launch(conv_wgrad_kernel<false, true, false>, grid, block, lds, s, a);
-    } else if (in_scale) {
-        rc = pooled ? launch(conv_wgrad_kernel<true, false, true>, grid, block, lds, s, a)
-                    : launch(conv_wgrad_kernel<false, false, true>, grid, block, lds, s, a);
+    if (in_scale) {
+        rc = pooled ? launch(conv_wgrad_kernel<true, true>, grid, block, lds, s, a)
+                    : launch(conv_wgrad_kernel<false, true>, grid, block, lds, s, a);
     } else {
-        rc = pooled ? launch(conv_wgrad_kernel<true, false, false>, grid, block, lds, s, a)
-                    : launch(conv_wgrad_kernel<false, false, false>, grid, block, lds, s, a);
+        rc = pooled ? launch(conv_wgrad_kernel<true, false>, grid, block, lds, s, a)
+                    : launch(conv_wgrad_kernel<false, false>, grid, block, lds, s, a);
     }
     if (rc != O3D_OK) return rc;
     o3d_wgrad_reduce(part, nslices, (long)Cout * Cin, part + (long)nslices * Cout * Cin, dW, s);

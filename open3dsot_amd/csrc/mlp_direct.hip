@@ -54,11 +54,10 @@ template <int NT>
 struct RawB {
     float v[4][NT];   // the main tensor (X, or dN); pooled: v[s][0..1] = {dOut masked by out > 0, bits(arg)}
     float y[4][NT];   // DY: raw conv output Y
-    float ar[4][NT];  // compact pooled source: bits of the ball's arg-max column, per (k row, column)
     float4 c1, c2, c3;  // per-k constants: (scale, shift, -) or (A1, A2, A3)
 };
 
-enum BMode { B_PLAIN = 0, B_XFORM = 1, B_DY = 2, B_DYPOOL = 3, B_DYPOOLC = 4 };
+enum BMode { B_PLAIN = 0, B_XFORM = 1, B_DY = 2, B_DYPOOL = 3 };
 
 struct DirectArgs {
     const float* A;        // (M, K) row-major: W for forward, W^T for the data gradient
@@ -66,9 +65,6 @@ struct DirectArgs {
     const float* Y;        // DY modes: raw output of this layer (B, K, P)
     const float* c1; const float* c2; const float* c3;   // per-k constants (K each)
     const float2* pk; int ns;   // pooled source (B, K, P/ns): {dOut masked by out > 0, bits(arg)}
-    // pooled source of the COMPACT layout (B_DYPOOLC): pk = (K, nb1) pairs {masked dOut, bits(arg-max column)} per
-    // (channel, ball), cball (P) = ball of every column (padding columns: the dummy ball nb1 - 1, pair {0, -1})
-    const int32_t* cball; int nb1;
     float* Out;            // (B, M, P)
     int M, K, P, B;
     // compact (distinct-neighbour) layout, csrc/compact.hip: per-position weights and the live column count
@@ -93,17 +89,10 @@ struct DirectArgs {
 
 template <int MODE, int NT>
 __device__ __forceinline__ void load_b(const DirectArgs& a, const float* xb, const float* yb, long rowP, int kb,
-                                       long pool_base, int np, const int (&cb)[NT], RawB<NT>& f) {
+                                       long pool_base, int np, RawB<NT>& f) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) {
-        if (MODE != B_DYPOOL && MODE != B_DYPOOLC) ldv<NT>(f.v[s], xb + (long)(kb + s) * rowP);
-        if constexpr (MODE == B_DYPOOLC) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const float2 g = a.pk[(long)(kb + s) * a.nb1 + cb[t]];
-                f.v[s][t] = g.x; f.ar[s][t] = g.y;
-            }
-        }
+        if (MODE != B_DYPOOL) ldv<NT>(f.v[s], xb + (long)(kb + s) * rowP);
         if (MODE >= B_DY) ldv<NT>(f.y[s], yb + (long)(kb + s) * rowP);
         if constexpr (MODE == B_DYPOOL && NT >= 2) {
             const float2 t = a.pk[pool_base + (long)(kb + s) * np];
@@ -132,9 +121,6 @@ __device__ __forceinline__ void compute_group(const RawB<NT>& f, const float4& a
             const int ak = __float_as_int(f.v[s][1]);
 #pragma unroll
             for (int t = 0; t < NT; ++t) bv[t] = (kk + t == ak) ? go : 0.f;
-        } else if constexpr (MODE == B_DYPOOLC) {        // kk = the lane's first column: non-zero only at the arg-max
-#pragma unroll
-            for (int t = 0; t < NT; ++t) bv[t] = (__float_as_int(f.ar[s][t]) == kk + t) ? f.v[s][t] : 0.f;
         } else {
 #pragma unroll
             for (int t = 0; t < NT; ++t) bv[t] = f.v[s][t];
@@ -162,8 +148,7 @@ __device__ __forceinline__ void compute_group(const RawB<NT>& f, const float4& a
 //        pytorch_utils.py:124-155 with bn=False / activation=None, and the input gradient of a stack)
 // NT = 4: 128 columns per wave (one dwordx4 B load per k row); NT = 2: 64 columns (dwordx2) -- twice the waves
 // of half the length for launches that do not fill the chip (everything after compaction at batch 48).
-// MT = 2: 64 output rows per wave; MT = 1: 32 rows -- half the MFMA chain per wave for the launch-latency-bound
-// problems of the heads (256 x 256 x 6144: 96 column tiles; a 64x64 wave tile is a 512-MFMA = 14 us serial chain).
+// MT = 2: 64 output rows per wave (MT = 1, 32 rows, is only used by the split-K tile further down).
 template <int WAVES, int MODE, int EPI, int NT, int MT = 2>
 __device__ __forceinline__ void direct_gemm_body(DirectArgs& a, const int bx, const int by) {
     constexpr int POS = 32 * NT;
@@ -192,20 +177,12 @@ __device__ __forceinline__ void direct_gemm_body(DirectArgs& a, const int bx, co
     for (int t = 0; t < NT; ++t) wv[t] = 1.f;
     if (a.w) ldv<NT>(wv, a.w + (long)b * a.P + p);
     const long rowP = a.P;
-    const float* xb = (MODE != B_DYPOOL && MODE != B_DYPOOLC) ? a.X + (long)b * a.K * rowP + p : nullptr;
+    const float* xb = (MODE != B_DYPOOL) ? a.X + (long)b * a.K * rowP + p : nullptr;
     const float* yb = (MODE >= B_DY) ? a.Y + (long)b * a.K * rowP + p : nullptr;
     const float* wa = a.A + (long)(m0 + l31) * a.K + 4 * h;
     const long wstep = 32L * a.K;
     int np = 1, kk = 0;
     long pool_base = 0;
-    int cb[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) cb[t] = 0;
-    if constexpr (MODE == B_DYPOOLC) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) cb[t] = a.cball[p + t];
-        kk = p;                  // compared against the absolute arg-max column
-    }
     if (MODE == B_DYPOOL) {
         np = a.P / a.ns;
         const int j = p / a.ns;
@@ -221,30 +198,22 @@ __device__ __forceinline__ void direct_gemm_body(DirectArgs& a, const int bx, co
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][t][r] = 0.f;
 
-    // Ring of R fragment sets, R-1 groups of loads in flight ahead of the MFMAs.  A group of 8 k's is 8*MT*NT/2 MFMAs
-    // of 64 cycles; with 2 waves per SIMD and 64-row tiles (MT = 2) one group ahead covers a ~2000-cycle miss, the
-    // 32-row tiles of the heads' small launches (one wave per SIMD, 8 MFMAs = 512 cycles per group) were bound by
-    // load latency x groups (measured: 15-20 us for a 256x256x6144 GEMM, 15 us even at K = 64): they run 3 ahead.
-    #ifndef O3D_RING_MT2
-#define O3D_RING_MT2 2
-#endif
-    // O3D_RING_FWD: build-time experiment switch (tools/build_variant.sh): ring depth of the forward (EPI 0) 64-row tiles
-#ifndef O3D_RING_FWD
-#define O3D_RING_FWD O3D_RING_MT2
-#endif
-    constexpr int R = MT == 1 ? 4 : (EPI == 0 ? O3D_RING_FWD : O3D_RING_MT2);
-    const int G = a.K / 8;       // multiple of R (K % 16 == 0; K % 32 == 0 for MT == 1)
-    RawB<NT> f[R];
-    float4 wa0[R], wa1[R];
+    // Ring of 2 fragment sets: one group of loads in flight ahead of the MFMAs.  A group of 8 k's is 8*MT*NT/2 MFMAs of 64
+    // cycles; with 2 waves per SIMD and 64-row tiles one group ahead covers a ~2000-cycle miss.  (Deeper rings were measured
+    // in rounds 2-3: 3-deep for the forward 7.17 -> 7.20 ms per step, 4-deep for 32-row tiles no change -- the small
+    // launches those were meant for run on the split-K tile below since round 4.)
+    const int G = a.K / 8;       // even (K % 16 == 0)
+    RawB<NT> f[2];
+    float4 wa0[2], wa1[2];
     auto load = [&](auto stc, int g) {
         constexpr int st = decltype(stc)::value;
         const int kb = 8 * g + 4 * h;
-        load_b<MODE, NT>(a, xb, yb, rowP, kb, pool_base, np, cb, f[st]);
+        load_b<MODE, NT>(a, xb, yb, rowP, kb, pool_base, np, f[st]);
         wa0[st] = *reinterpret_cast<const float4*>(wa + 8 * g);
         if constexpr (MT == 2) wa1[st] = *reinterpret_cast<const float4*>(wa + 8 * g + wstep);
         else wa1[st] = wa0[st];
     };
-    if constexpr (R == 2) {
+    {
         load(std::integral_constant<int, 0>{}, 0);
         for (int g = 0; g < G; g += 2) {
             load(std::integral_constant<int, 1>{}, g + 1);
@@ -254,50 +223,6 @@ __device__ __forceinline__ void direct_gemm_body(DirectArgs& a, const int bx, co
             load(std::integral_constant<int, 0>{}, g + 2 < G ? g + 2 : G - 1);       // tail: harmless re-load of the last group
             __builtin_amdgcn_sched_barrier(0);
             compute_group<MODE, NT, MT>(f[1], wa0[1], wa1[1], kk, wv, acc);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    } else if constexpr (R == 3) {      // 2 groups ahead; G is not a multiple of 3: whole rounds, then 1 or 2 tail groups
-        const int last = G - 1;
-        const int G3 = G - G % 3;
-        load(std::integral_constant<int, 0>{}, 0);
-        load(std::integral_constant<int, 1>{}, 1 < last ? 1 : last);
-        for (int g = 0; g < G3; g += 3) {
-            load(std::integral_constant<int, 2>{}, g + 2 < last ? g + 2 : last);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_group<MODE, NT, MT>(f[0], wa0[0], wa1[0], kk, wv, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            load(std::integral_constant<int, 0>{}, g + 3 < last ? g + 3 : last);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_group<MODE, NT, MT>(f[1], wa0[1], wa1[1], kk, wv, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            load(std::integral_constant<int, 1>{}, g + 4 < last ? g + 4 : last);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_group<MODE, NT, MT>(f[2], wa0[2], wa1[2], kk, wv, acc);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (G3 < G) compute_group<MODE, NT, MT>(f[0], wa0[0], wa1[0], kk, wv, acc);          // group G3 (stage 0)
-        if (G3 + 1 < G) compute_group<MODE, NT, MT>(f[1], wa0[1], wa1[1], kk, wv, acc);      // group G3 + 1 (stage 1)
-    } else {
-        const int last = G - 1;
-        load(std::integral_constant<int, 0>{}, 0);
-        load(std::integral_constant<int, 1>{}, 1 < last ? 1 : last);
-        load(std::integral_constant<int, 2>{}, 2 < last ? 2 : last);
-        for (int g = 0; g < G; g += 4) {
-            load(std::integral_constant<int, 3>{}, g + 3 < last ? g + 3 : last);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_group<MODE, NT, MT>(f[0], wa0[0], wa1[0], kk, wv, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            load(std::integral_constant<int, 0>{}, g + 4 < last ? g + 4 : last);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_group<MODE, NT, MT>(f[1], wa0[1], wa1[1], kk, wv, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            load(std::integral_constant<int, 1>{}, g + 5 < last ? g + 5 : last);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_group<MODE, NT, MT>(f[2], wa0[2], wa1[2], kk, wv, acc);
-            __builtin_amdgcn_sched_barrier(0);
-            load(std::integral_constant<int, 2>{}, g + 6 < last ? g + 6 : last);
-            __builtin_amdgcn_sched_barrier(0);
-            compute_group<MODE, NT, MT>(f[3], wa0[3], wa1[3], kk, wv, acc);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -425,6 +350,207 @@ void direct_gemm_pair_kernel(DirectArgs a0, DirectArgs a1) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Split-K tile for the launch-latency-bound problems (round 4): the 1-D conv stacks of the heads (256 x 256 x 6 144: 5 us of
+// matrix-pipe work that took 20-23 us as 768 one-wave-per-SIMD chains of 256 MFMAs behind a cold prologue), the per-point
+// layer-0 GEMMs and the set-abstraction launches with few worst-case columns.  One workgroup = one 32-row x 64-column
+// output tile; its FOUR WAVES EACH CONTRACT A QUARTER OF K (a quarter of the chain, four times the waves: 3 072 waves of 64
+// MFMAs for the problem above, three per SIMD), the four partial tiles meet in LDS (32 KB), and wave w finishes rows
+// [8w, 8w + 8) of the tile: BatchNorm statistics / ReLU mask / bias + residual exactly as direct_gemm_body's epilogues
+// (same partial-row layout: one row per 64 columns).  Summation order over k: the four quarters in fixed order --
+// deterministic, but not bitwise the unsplit kernel's.  Operand modes: B_PLAIN / B_XFORM / B_DY (no pooled sources).
+constexpr int SK_ROWS = 32, SK_COLS = 64;
+
+// 8 per-lane values over the 32 lanes of a half-wave: afterwards lane l31 < 8 holds the sum of value index l31
+__device__ __forceinline__ float reduce_scatter8(float (&x)[8], int l31) {
+#pragma unroll
+    for (int m = 4; m >= 1; m >>= 1) {
+        const bool up = (l31 & m) != 0;
+#pragma unroll
+        for (int v = 0; v < m; ++v) {
+            float lo = x[v], hi = x[v + m];
+            asm volatile("" : "+v"(lo), "+v"(hi));
+            const float keep = up ? hi : lo;
+            const float send = up ? lo : hi;
+            x[v] = keep + __shfl_xor(send, m, 64);
+        }
+    }
+    float r = x[0];
+    r += __shfl_xor(r, 8, 64);
+    r += __shfl_xor(r, 16, 64);
+    return r;
+}
+
+template <int MODE, int EPI>
+__device__ __forceinline__ void splitk_body(DirectArgs& a, const int bx, const int by, float* __restrict__ red) {
+    static_assert(MODE <= B_DY && EPI <= 2, "split-K tile: plain / transformed / BatchNorm-backward operands only");
+    constexpr int NT = 2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int l31 = lane & 31, h = lane >> 5;
+    const int tiles_per_b = a.P / SK_COLS;
+    const int tile = bx;
+    const int b = tile / tiles_per_b, p0 = (tile - b * tiles_per_b) * SK_COLS;
+    if (a.meta) {                                             // compact layout: dead tile?  which segment?
+        const long c0 = (long)tile * SK_COLS;
+        const int seg = (a.start1 > 0 && c0 >= a.start1) ? 1 : 0;
+        if (c0 - (seg ? a.start1 : 0) >= a.meta[4 * seg]) return;      // (the whole workgroup: before any barrier)
+        if (seg) {
+            if (a.c1) a.c1 += a.K;
+            if (a.c2) a.c2 += a.K;
+            if (a.c3) a.c3 += a.K;
+            if (a.stat_c) a.stat_c += a.M;
+            if (a.scale_p) { a.scale_p += a.M; a.shift_p += a.M; a.mean_p += a.M; }
+        }
+    }
+    const int m0 = by * SK_ROWS;
+    const int p = p0 + NT * l31;
+    float wv[NT] = {1.f, 1.f};
+    if (a.w) ldv<NT>(wv, a.w + (long)b * a.P + p);
+    const long rowP = a.P;
+    const float* xb = a.X + (long)b * a.K * rowP + p;
+    const float* yb = (MODE >= B_DY) ? a.Y + (long)b * a.K * rowP + p : nullptr;
+    const float* wa = a.A + (long)(m0 + l31) * a.K + 4 * h;
+
+    // ---- what the epilogue needs besides the accumulators: requested now, consumed after the LDS exchange
+    const int mrow = m0 + 8 * wave + 4 * h;                  // this lane's rows: mrow + j, j < 4; positions p, p + 1
+    const long ob = ((long)b * a.M + mrow) * rowP + p;
+    float ex[4][NT];
+    float4 k1 = make_float4(0.f, 0.f, 0.f, 0.f), k2 = k1, k3 = k1;
+    if constexpr (EPI == 1 || EPI == 2) {
+        const float* src = EPI == 1 ? a.Yprev : a.resid;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            ex[j][0] = ex[j][1] = 0.f;
+            if (EPI == 1 || src) ldv<NT>(ex[j], src + ob + (long)j * rowP);
+        }
+    }
+    if constexpr (EPI == 1) {
+        k1 = *reinterpret_cast<const float4*>(a.scale_p + mrow);
+        k2 = *reinterpret_cast<const float4*>(a.shift_p + mrow);
+        k3 = *reinterpret_cast<const float4*>(a.mean_p + mrow);
+    } else if constexpr (EPI == 2) {
+        if (a.bias) k1 = *reinterpret_cast<const float4*>(a.bias + mrow);
+    } else {
+        if (a.stat_c) k1 = *reinterpret_cast<const float4*>(a.stat_c + mrow);
+    }
+
+    f32x16 acc[1][NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][t][r] = 0.f;
+
+    // this wave's share of the K / 16 pairs of 8-k groups (contiguous; the first K/16 % 4 waves take one pair more)
+    const int npair = a.K / 16;
+    const int q = npair / 4, rem = npair - 4 * q;
+    const int ps = wave * q + (wave < rem ? wave : rem);
+    const int gs = 2 * ps, ge = 2 * (ps + q + (wave < rem ? 1 : 0));
+    RawB<NT> f[2];
+    float4 wa0[2];
+    auto load = [&](auto stc, int g) {
+        constexpr int st = decltype(stc)::value;
+        load_b<MODE, NT>(a, xb, yb, rowP, 8 * g + 4 * h, 0, 1, f[st]);
+        wa0[st] = *reinterpret_cast<const float4*>(wa + 8 * g);
+    };
+    if (gs < ge) {
+        load(std::integral_constant<int, 0>{}, gs);
+        for (int g = gs; g < ge; g += 2) {
+            load(std::integral_constant<int, 1>{}, g + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group<MODE, NT, 1>(f[0], wa0[0], wa0[0], 0, wv, acc);
+            __builtin_amdgcn_sched_barrier(0);
+            load(std::integral_constant<int, 0>{}, g + 2 < ge ? g + 2 : ge - 1);       // tail: harmless re-load
+            __builtin_amdgcn_sched_barrier(0);
+            compute_group<MODE, NT, 1>(f[1], wa0[1], wa0[1], 0, wv, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+
+    // ---- the four partial tiles meet in LDS: red[wave][row][column], a lane's two positions as one 8-byte access
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        *reinterpret_cast<float2*>(red + ((wave * SK_ROWS + acc_row(r, h)) * SK_COLS + NT * l31)) =
+            make_float2(acc[0][0][r], acc[0][1][r]);
+    __syncthreads();
+    float x8[8];
+    const bool stats = EPI != 2 && a.part != nullptr;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int row = 8 * wave + 4 * h + j;
+        float v[NT] = {0.f, 0.f};
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) {
+            const float2 t = *reinterpret_cast<const float2*>(red + ((w4 * SK_ROWS + row) * SK_COLS + NT * l31));
+            v[0] += t.x; v[1] += t.y;
+        }
+        const float c1 = j == 0 ? k1.x : j == 1 ? k1.y : j == 2 ? k1.z : k1.w;
+        const float c2 = j == 0 ? k2.x : j == 1 ? k2.y : j == 2 ? k2.z : k2.w;
+        const float c3 = j == 0 ? k3.x : j == 1 ? k3.y : j == 2 ? k3.z : k3.w;
+        float s1 = 0.f, s2 = 0.f;
+        if constexpr (EPI == 1) {          // mask by the producer's ReLU; {sum g, sum g*(yprev-mean)}
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                v[t] = fmaf(ex[j][t], c1, c2) > 0.f ? v[t] : 0.f;
+                s1 += v[t];
+                s2 = fmaf(v[t], ex[j][t] - c3, s2);
+            }
+        } else if constexpr (EPI == 2) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) v[t] = (v[t] + c1) + ex[j][t];
+        } else {                           // {sum w*y, sum w*(y-c)^2}
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                s1 = fmaf(wv[t], v[t], s1);
+                s2 += wv[t] * (v[t] - c1) * (v[t] - c1);
+            }
+        }
+        stv<NT>(a.Out + ob + (long)j * rowP, v);
+        x8[j] = s1;
+        x8[4 + j] = s2;
+    }
+    if (stats) {       // lane l31 < 8 of half h: statistic l31 >> 2 of row mrow + (l31 & 3)
+        const float r = reduce_scatter8(x8, l31);
+        if (l31 < 8) a.part[(long)tile * 2 * a.M + (long)(l31 >> 2) * a.M + mrow + (l31 & 3)] = r;
+    }
+}
+
+template <int MODE, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4)))
+void splitk_gemm_kernel(DirectArgs a) {
+    __shared__ float red[4 * SK_ROWS * SK_COLS];
+    splitk_body<MODE, EPI>(a, blockIdx.x, blockIdx.y, red);
+}
+
+template <int MODE, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 4)))
+void splitk_gemm_pair_kernel(DirectArgs a0, DirectArgs a1) {
+    __shared__ float red[4 * SK_ROWS * SK_COLS];
+    if (blockIdx.z == 0) {
+        if ((int)blockIdx.y * SK_ROWS < a0.M) splitk_body<MODE, EPI>(a0, blockIdx.x, blockIdx.y, red);
+    } else {
+        if ((int)blockIdx.y * SK_ROWS < a1.M) splitk_body<MODE, EPI>(a1, blockIdx.x, blockIdx.y, red);
+    }
+}
+
+// which problems take the split-K tile: 64-column partial rows (the caller's `tile`), K in whole pairs of 8-k groups with
+// at least one pair per wave, and at most splitk_max() output elements in the worst case (beyond that the 8 row slabs of a
+// column tile re-reading their B panel from L2 costs more than the shorter chains gain: DESIGN.md section 7c)
+// (measured, same-box A/B of a BAT step: 0 -> 5.73 / 5.76 ms, 4 M (the heads only) -> 5.60, 16 M -> 5.50 / 5.54)
+static long splitk_max() { return 16L << 20; }
+static bool splitk_ok(const DirectArgs& a, int tile) {
+    return tile == 64 && a.K % 16 == 0 && a.K >= 64 && a.M % SK_ROWS == 0 && a.P % SK_COLS == 0 && !a.pk &&
+           (long)a.M * a.B * a.P <= splitk_max();
+}
+template <int MODE, int EPI>
+int launch_splitk(const DirectArgs& a, hipStream_t st) {
+    if constexpr (MODE <= B_DY && EPI <= 2) {
+        hipLaunchKernelGGL((splitk_gemm_kernel<MODE, EPI>), dim3(a.B * (a.P / SK_COLS), a.M / SK_ROWS), dim3(256), 0, st, a);
+        return o3d_launch_status();
+    } else {
+        return O3D_EINVAL;
+    }
+}
+
 // All M/64 row slabs of a position tile run as the waves of ONE workgroup: they read the same B rows,
 // so those come from HBM once and from L1/L2 for the other slabs (rocprofv3 FETCH_SIZE of the
 // two-workgroup variant showed every slab re-reading HBM: 604 MB instead of 350 MB per launch).
@@ -442,41 +568,21 @@ int launch_direct_nt(const DirectArgs& a, hipStream_t st) {
     return o3d_launch_status();
 }
 
-// the heads' launches: 64-column tiles, and 32-row (x 32-column, O3D_PW_NT1=1) wave tiles while the whole problem is
-// a few waves per SIMD
-static long pw_small_max() {
-    static const long v = [] { const char* e = getenv("O3D_PW_SMALL_MAX"); return e ? atol(e) : (4L << 20); }();
-    return v;
-}
-static bool pw_nt1() {
-    static const bool v = [] { const char* e = getenv("O3D_PW_NT1"); return e && atoi(e) != 0; }();
-    return v;
-}
-static int pw_tile(long P, int M) {
-    const int t = o3d_direct_tile(P, M, 0);
-    return (t == 64 && pw_nt1() && P % 32 == 0 && (long)M * P <= pw_small_max()) ? 32 : t;
-}
+static int pw_tile(long P, int M) { return o3d_direct_tile(P, M, 0); }
 
 template <int MODE, int EPI>
 int launch_direct_small(const DirectArgs& a, int tile, hipStream_t st) {
-    if (a.K % 32 == 0) {        // the 32-row tiles keep 3 groups of 8 k in flight: whole rounds of 4 groups
-        if (tile == 32) return launch_direct_nt<MODE, EPI, 1, 1>(a, st);
-        if (tile == 64 && (long)a.M * a.P <= pw_small_max()) return launch_direct_nt<MODE, EPI, 2, 1>(a, st);
+    if constexpr (MODE <= B_DY && EPI <= 2) {
+        if (splitk_ok(a, tile)) return launch_splitk<MODE, EPI>(a, st);
     }
     return tile == 64 ? launch_direct_nt<MODE, EPI, 2>(a, st) : launch_direct_nt<MODE, EPI, 4>(a, st);
 }
 
-// 32-row wave tiles for the set-abstraction launches whose WORST-CASE column count is small (the vote aggregation:
-// 49 152 slots of which ~15 % are live -- 116 workgroups of four 64-row waves, i.e. 464 waves of a 512-MFMA chain on 1 024
-// SIMDs): twice the waves of half the chain.  O3D_SA_MT1_MAX = largest B*P taking them (0: never).
-static long sa_mt1_max() {
-    static const long v = [] { const char* e = getenv("O3D_SA_MT1_MAX"); return e ? atol(e) : 0L; }();
-    return v;
-}
-
 template <int MODE, int EPI>
 int launch_direct(const DirectArgs& a, int tile, hipStream_t st) {
-    if (tile == 64 && a.K % 32 == 0 && (long)a.B * a.P <= sa_mt1_max()) return launch_direct_nt<MODE, EPI, 2, 1>(a, st);
+    if constexpr (MODE <= B_DY && EPI <= 2) {
+        if (splitk_ok(a, tile)) return launch_splitk<MODE, EPI>(a, st);
+    }
     return tile == 64 ? launch_direct_nt<MODE, EPI, 2>(a, st) : launch_direct_nt<MODE, EPI, 4>(a, st);
 }
 
@@ -491,9 +597,10 @@ extern "C" int o3d_direct_tile(long P, int M, int compact) {
     (void)M; (void)compact;
     // measured on the MI355X (batch 48, same run A/B): 64-column tiles for every launch lose 1.3 % (more loads
     // per MFMA); 64-column tiles only for the small launches (vote aggregation, BoxCloud xcorr: <= 64 K slots,
-    // too few 128-column tiles for the 256 CUs) gain 0.8 % (7.705 -> 7.642 ms per step)
-    static const long max64 = [] { const char* e = getenv("O3D_TILE64_MAX"); return e ? atol(e) : 65536L; }();   // experiment switch
-    return P <= max64 ? 64 : 128;
+    // too few 128-column tiles for the 256 CUs) gain 0.8 % (7.705 -> 7.642 ms per step).  Round 4: with the split-K tile
+    // behind the 64-column class, 300 K / 600 K slots (SA levels 2 / 1 on it) LOSE 0.15 / 0.57 ms per step
+    // (profiles/r04_ab_splitk.txt)
+    return P <= 65536L ? 64 : 128;
 }
 
 // forward: Y = W . f(X), see o3d_mlp_conv_fwd
@@ -519,21 +626,6 @@ int o3d_direct_dgrad(const float* dN, const float* pk, int ns,
     a.Out = dNprev; a.M = Cin; a.K = Cout; a.P = P; a.B = B; a.part = part;
     a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p;
     return dN ? launch_direct<B_DY, 1>(a, tile, st) : launch_direct<B_DYPOOL, 1>(a, tile, st);
-}
-
-// the same from the pooled tensors of the compact layout: pkc (Cout, nb1) pairs per (channel, ball), cball (P)
-int o3d_direct_dgrad_pooled_c(const float* pkc, const int32_t* cball, int nb1, const float* Y, const float* A1,
-                              const float* A2, const float* A3, const float* Wt, int Cin, int Cout, int P,
-                              const float* Yprev, const float* scale_p, const float* shift_p, const float* mean_p,
-                              float* dNprev, float* part, const float* w, const int32_t* meta, long start1, int tile,
-                              hipStream_t st) {
-    DirectArgs a = {};
-    a.w = w; a.meta = meta; a.start1 = start1;
-    a.A = Wt; a.Y = Y; a.c1 = A1; a.c2 = A2; a.c3 = A3; a.pk = reinterpret_cast<const float2*>(pkc); a.ns = 4;
-    a.cball = cball; a.nb1 = nb1;
-    a.Out = dNprev; a.M = Cin; a.K = Cout; a.P = P; a.B = 1; a.part = part;
-    a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p;
-    return launch_direct<B_DYPOOLC, 1>(a, tile, st);
 }
 
 // ---- 1-D conv stacks (the trackers' heads) on the flat (C, P) layout, P = B*N columns -------------------------
@@ -600,23 +692,20 @@ int launch_pair_nt(const DirectArgs& a, const DirectArgs& b, hipStream_t st) {
     return o3d_launch_status();
 }
 
-// the wave tile launch_direct_small picks: 0 = <1,1>, 1 = <2,1>, 2 = <2,2>, 3 = <4,2>
+// the tile launch_direct_small picks: 2 = 64 x 64 wave tiles, 3 = 64 x 128, 4 = the split-K tile
 static int small_class(const DirectArgs& a, int tile) {
-    if (a.K % 32 == 0) {
-        if (tile == 32) return 0;
-        if (tile == 64 && (long)a.M * a.P <= pw_small_max()) return 1;
-    }
+    if (splitk_ok(a, tile)) return 4;
     return tile == 64 ? 2 : 3;
 }
 
 template <int MODE, int EPI>
 int launch_pair(const DirectArgs& a, const DirectArgs& b, int cls, hipStream_t st) {
-    switch (cls) {
-        case 0: return launch_pair_nt<MODE, EPI, 1, 1>(a, b, st);
-        case 1: return launch_pair_nt<MODE, EPI, 2, 1>(a, b, st);
-        case 2: return launch_pair_nt<MODE, EPI, 2, 2>(a, b, st);
-        default: return launch_pair_nt<MODE, EPI, 4, 2>(a, b, st);
+    if (cls == 4) {
+        const int sa = a.M / SK_ROWS, sb = b.M / SK_ROWS;
+        hipLaunchKernelGGL((splitk_gemm_pair_kernel<MODE, EPI>), dim3(a.P / SK_COLS, sa > sb ? sa : sb, 2), dim3(256), 0, st, a, b);
+        return o3d_launch_status();
     }
+    return cls == 2 ? launch_pair_nt<MODE, EPI, 2, 2>(a, b, st) : launch_pair_nt<MODE, EPI, 4, 2>(a, b, st);
 }
 
 static bool pw_fwd_args_ok(const o3d_pw_fwd_args& q) {

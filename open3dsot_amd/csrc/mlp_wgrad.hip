@@ -19,10 +19,8 @@ namespace {
 
 struct Wgrad2Args {
     const float* dN;       // (B,Cout,P) dense source or NULL
-    const float2* pk;      // pooled source (B,Cout,P/ns); compact pooled source (POOLED == 2): (Cout, nb1) pairs
-                           // {masked dOut, bits(arg-max column)} per (channel, ball)
+    const float2* pk;      // pooled source (B,Cout,P/ns): {masked dOut, bits(arg-max slot)} per (channel, ball)
     int ns;
-    const int32_t* cball; int nb1;   // POOLED == 2: ball of every column (padding columns: the dummy ball nb1 - 1)
     const float* Y;        // (B,Cout,P)
     const float* A1; const float* A2; const float* A3;
     const float* X;        // (B,Cin,P) raw output of the producer
@@ -110,7 +108,6 @@ __device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, const int bid, 
     }
 
     float4 rg[PA], ry[PA], rx[PB];
-    float4 rg2[POOLED == 2 ? PA : 1];      // compact pooled source: the second pair of (value, arg) per row
     float4 rw = make_float4(1.f, 1.f, 1.f, 1.f);
     int rk = 0;
     auto load_chunk = [&](int chl) {
@@ -118,18 +115,11 @@ __device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, const int bid, 
         const long b = chg / chunks_per_b;
         const int p = (int)(chg - b * chunks_per_b) * CP + 4 * c4;
         if (a.w) rw = *reinterpret_cast<const float4*>(&a.w[b * a.P + p]);
-        int4 cb = make_int4(0, 0, 0, 0);
-        if constexpr (POOLED == 2) { cb = *reinterpret_cast<const int4*>(&a.cball[p]); rk = p; }
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const long row = b * a.Cout + co0 + r0 + RPP * i;
             ry[i] = *reinterpret_cast<const float4*>(&a.Y[row * a.P + p]);
-            if constexpr (POOLED == 2) {
-                const float2* pr = a.pk + row * a.nb1;
-                const float2 g0 = pr[cb.x], g1 = pr[cb.y], g2 = pr[cb.z], g3 = pr[cb.w];
-                rg[i] = make_float4(g0.x, g0.y, g1.x, g1.y);
-                rg2[i] = make_float4(g2.x, g2.y, g3.x, g3.y);
-            } else if (POOLED) {
+            if (POOLED) {
                 const int j = p / a.ns;
                 const float2 t = a.pk[row * np + j];
                 rg[i].x = t.x; rg[i].y = t.y;
@@ -146,12 +136,7 @@ __device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, const int bid, 
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             float4 g;
-            if constexpr (POOLED == 2) {       // rk = first column of the thread's four: non-zero only at the arg-max
-                g.x = (__float_as_int(rg[i].y) == rk + 0) ? rg[i].x : 0.f;
-                g.y = (__float_as_int(rg[i].w) == rk + 1) ? rg[i].z : 0.f;
-                g.z = (__float_as_int(rg2[i].y) == rk + 2) ? rg2[i].x : 0.f;
-                g.w = (__float_as_int(rg2[i].w) == rk + 3) ? rg2[i].z : 0.f;
-            } else if (POOLED) {
+            if (POOLED) {
                 const int ak = __float_as_int(rg[i].y);
                 const float go = rg[i].x;
                 g.x = (rk + 0 == ak) ? go : 0.f; g.y = (rk + 1 == ak) ? go : 0.f;
@@ -321,15 +306,13 @@ int launch_wgrad2(const Wgrad2Args& a, hipStream_t s) {
     constexpr int CP = (TM + TN == 128) ? 64 : 32;
     const size_t lds = sizeof(float) * 2 * (TM + TN) * (CP + 4);
     const void* fn = a.dN ? reinterpret_cast<const void*>(wgrad2_kernel<TM, TN, 0>)
-                   : a.cball ? reinterpret_cast<const void*>(wgrad2_kernel<TM, TN, 2>)
-                             : reinterpret_cast<const void*>(wgrad2_kernel<TM, TN, 1>);
+                          : reinterpret_cast<const void*>(wgrad2_kernel<TM, TN, 1>);
     if (lds > 48 * 1024 &&
         hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return O3D_ELAUNCH;
     const int ntile = (a.Cout / TM) * (a.Cin / TN);
-    if (a.dN)         hipLaunchKernelGGL((wgrad2_kernel<TM, TN, 0>), dim3(ntile * a.nslices), dim3(256), lds, s, a);
-    else if (a.cball) hipLaunchKernelGGL((wgrad2_kernel<TM, TN, 2>), dim3(ntile * a.nslices), dim3(256), lds, s, a);
-    else              hipLaunchKernelGGL((wgrad2_kernel<TM, TN, 1>), dim3(ntile * a.nslices), dim3(256), lds, s, a);
+    if (a.dN) hipLaunchKernelGGL((wgrad2_kernel<TM, TN, 0>), dim3(ntile * a.nslices), dim3(256), lds, s, a);
+    else      hipLaunchKernelGGL((wgrad2_kernel<TM, TN, 1>), dim3(ntile * a.nslices), dim3(256), lds, s, a);
     return o3d_launch_status();
 }
 
@@ -592,7 +575,7 @@ static void wgrad2_plan(int Cin, int Cout, int B, int P, int& TM, int& TN, int& 
     CP = (TM + TN == 128) ? 64 : 32;
     const int ntile = (Cout / TM) * (Cin / TN);
     const long total = (long)B * (P / CP);
-    static const int wgs = [] { const char* e = getenv("O3D_WGRAD_WGS"); return e ? atoi(e) : 512; }();   // experiment switch
+    constexpr int wgs = 512;          // (256 / 384 / 1024 workgroups measured in rounds 1-2: 7.65 / +0.14 / 7.87 vs 7.68 ms per step)
     nsl = wgs / ntile;                 // 512: one resident round, 2 workgroups per CU x 256 CUs
     if (nsl < 8) nsl = 8;
     while (nsl > 8 && total / nsl < 4) nsl -= 8;
@@ -612,7 +595,7 @@ extern "C" long o3d_mlp_conv_wgrad2_scratch(int B, int Cin, int Cout, int P) {
 static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y, const float* A1, const float* A2,
                        const float* A3, const float* X, const float* in_scale, const float* in_shift, int B, int Cin,
                        int Cout, int P, const float* w, const int32_t* meta, long start1, float* scratch, float* dW,
-                       void* stream, const int32_t* cball = nullptr, int nb1 = 0);
+                       void* stream);
 
 extern "C" int o3d_mlp_conv_wgrad2(const float* dN, const float* pk, int ns, const float* Y, const float* A1,
                                    const float* A2, const float* A3, const float* X, const float* in_scale,
@@ -632,21 +615,10 @@ extern "C" int o3d_mlp_conv_wgrad2_c(const float* dN, const float* Y, const floa
                        scratch, dW, stream);
 }
 
-// compact layout with the pooled layer's gradient read from the pooled tensors (pkc (Cout, nb1), cball (ldp))
-extern "C" int o3d_mlp_conv_wgrad2_cp(const float* pkc, const int32_t* cball, int nb1, const float* Y, const float* A1,
-                                      const float* A2, const float* A3, const float* X, const float* in_scale,
-                                      const float* in_shift, int Cin, int Cout, long ldp, const float* w,
-                                      const int32_t* meta, long start1, float* scratch, float* dW, void* stream) {
-    if (!pkc || !cball || nb1 <= 0 || !w || !meta || ldp <= 0 || ldp > 0x7fffffff || start1 < 0 || start1 % 256 != 0)
-        return O3D_EINVAL;
-    return wgrad2_impl(nullptr, pkc, 4, Y, A1, A2, A3, X, in_scale, in_shift, 1, Cin, Cout, (int)ldp, w, meta, start1,
-                       scratch, dW, stream, cball, nb1);
-}
-
 static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y, const float* A1, const float* A2,
                        const float* A3, const float* X, const float* in_scale, const float* in_shift, int B, int Cin,
                        int Cout, int P, const float* w, const int32_t* meta, long start1, float* scratch, float* dW,
-                       void* stream, const int32_t* cball, int nb1) {
+                       void* stream) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || P <= 0 || P % 64 || !Y || !A1 || !A2 || !A3 ||
         !X || (in_scale == nullptr) != (in_shift == nullptr) || !scratch || !dW || (!dN && (!pk || ns < 4 || ns % 4)))
         return O3D_EINVAL;
@@ -660,7 +632,7 @@ static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y,
     a.chunks_per_block = (a.total_chunks + nsl - 1) / nsl;
     a.nslices = nsl;
     a.part = scratch;
-    a.w = w; a.meta = meta; a.start1 = start1; a.cball = cball; a.nb1 = nb1;
+    a.w = w; a.meta = meta; a.start1 = start1;
     hipStream_t s = o3d_stream(stream);
     int rc;
     if (TM == 128 && TN == 128) rc = launch_wgrad2<128, 128>(a, s);
@@ -737,7 +709,7 @@ extern "C" int o3d_mlp_conv_wgrad2_group(const o3d_wgrad_job* jobs, int njobs, v
 
 // ---- fused data + weight gradient (fused_bwd_kernel above) ----------------------------------------------------------
 static int fused_bwd_slices(int Cout, long P) {
-    static const int wgs = [] { const char* e = getenv("O3D_FUSED_BWD_WGS"); return e ? atoi(e) : 256; }();   // experiment switch
+    constexpr int wgs = 256;          // one workgroup per CU (~305 registers)
     const int CP = (Cout + 64 == 128) ? 64 : 32;
     const long total = P / CP;
     int nsl = wgs;

@@ -204,3 +204,195 @@ extern "C" int o3d_xcorr_reduce(const float* dN, const float* Y0, const float* A
                        sim, W0, ldw, C0, M, cpc, P, S, lds, dsim_part, dw_part);
     return o3d_launch_status();
 }
+
+// =====================================================================================================================
+// Cosine similarity map of P2B_XCorr (models/head/xcorr.py:37-38: nn.CosineSimilarity(dim=1, eps=1e-8) on the expanded
+// (B,f,M,N) features): sim[b,j,i] = <t[b,:,i], s[b,:,j]> / (max(|t_i|, eps) * max(|s_j|, eps)).  Round 4: one kernel each
+// way instead of torch.bmm + norm + clamp + outer product + division (and autograd's mirror of them): 4 rocBLAS launches and
+// ~12 elementwise ones per step.  The products are small (f = 256, M = 64, N = 128 per pair: 4 MFLOP forward) -- plain
+// LDS-tiled FMA, no MFMA: the work is latency, not arithmetic.
+//   forward : workgroup = (pair b, 32 search points): t/s chunks of 32 channels through LDS, thread = 2 search x 4 template
+//             points; the two norms ride in the same pass.
+//   backward: workgroup = (pair b, 32 channels): G[j,i] = dsim/(tn_i sn_j) and the row / column sums of dsim*sim in LDS;
+//             dt[c,i] = sum_j G[j,i] s[c,j] - t[c,i] a_i / tn_i^2,  ds[c,j] = sum_i G[j,i] t[c,i] - s[c,j] b_j / sn_j^2
+//             (a_i = sum_j dsim*sim, b_j = sum_i dsim*sim; a clamped norm has no gradient through the norm).
+// t (B,f,M), s (B,f,N): arbitrary element strides (the features are views of the flat conv_final output).
+// =====================================================================================================================
+namespace {
+constexpr int CS_J = 32, CS_K = 32, CS_MMAX = 64, CS_NMAX = 128;
+constexpr float CS_EPS = 1e-8f;
+
+struct CosArgs {
+    const float* t; long tsb, tsc, tsn;
+    const float* s; long ssb, ssc, ssn;
+    int B, f, M, N;
+    float* sim; float* tn; float* sn;            // (B,N,M), (B,M), (B,N)
+    const float* dsim; float* dt; float* ds;     // backward: (B,N,M) in, (B,f,M), (B,f,N) out (contiguous)
+};
+
+__global__ __launch_bounds__(256) void cosine_sim_fwd_kernel(CosArgs a) {
+    __shared__ float T[CS_K][CS_MMAX + 4], S[CS_K][CS_J + 4];
+    __shared__ float tns[CS_MMAX], sns[CS_J];
+    const int b = blockIdx.x, j0 = blockIdx.y * CS_J;
+    const int tid = threadIdx.x, ti = tid & 15, tj = tid >> 4;          // template points 4ti..4ti+3, search 2tj, 2tj+1
+    const float* tb = a.t + (long)b * a.tsb;
+    const float* sb = a.s + (long)b * a.ssb;
+    float acc[2][4] = {};
+    float n2t[4] = {}, n2s[2] = {};
+    for (int k0 = 0; k0 < a.f; k0 += CS_K) {
+        for (int e = tid; e < CS_K * CS_MMAX; e += 256) {
+            const int k = e / CS_MMAX, i = e - k * CS_MMAX;
+            T[k][i] = (i < a.M) ? tb[(long)(k0 + k) * a.tsc + (long)i * a.tsn] : 0.f;
+        }
+        for (int e = tid; e < CS_K * CS_J; e += 256) {
+            const int k = e / CS_J, j = e - k * CS_J;
+            S[k][j] = (j0 + j < a.N) ? sb[(long)(k0 + k) * a.ssc + (long)(j0 + j) * a.ssn] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll 8
+        for (int k = 0; k < CS_K; ++k) {
+            const float4 tv = *reinterpret_cast<const float4*>(&T[k][4 * ti]);
+            const float2 sv = *reinterpret_cast<const float2*>(&S[k][2 * tj]);
+            const float t4[4] = {tv.x, tv.y, tv.z, tv.w}, s2[2] = {sv.x, sv.y};
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] = fmaf(s2[u], t4[v], acc[u][v]);
+            if (tj == 0) {
+#pragma unroll
+                for (int v = 0; v < 4; ++v) n2t[v] = fmaf(t4[v], t4[v], n2t[v]);
+            }
+            if (ti == 0) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u) n2s[u] = fmaf(s2[u], s2[u], n2s[u]);
+            }
+        }
+        __syncthreads();
+    }
+    if (tj == 0)
+        for (int v = 0; v < 4; ++v) tns[4 * ti + v] = fmaxf(sqrtf(n2t[v]), CS_EPS);
+    if (ti == 0)
+        for (int u = 0; u < 2; ++u) sns[2 * tj + u] = fmaxf(sqrtf(n2s[u]), CS_EPS);
+    __syncthreads();
+    if (blockIdx.y == 0 && tid < a.M) a.tn[(long)b * a.M + tid] = tns[tid];
+    if (tid < CS_J && j0 + tid < a.N) a.sn[(long)b * a.N + j0 + tid] = sns[tid];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int j = j0 + 2 * tj + u;
+        if (j >= a.N) continue;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int i = 4 * ti + v;
+            if (i < a.M) a.sim[((long)b * a.N + j) * a.M + i] = acc[u][v] / (sns[2 * tj + u] * tns[i]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cosine_sim_bwd_kernel(CosArgs a) {
+    extern __shared__ float lds[];
+    const int b = blockIdx.x, c0 = blockIdx.y * 32;
+    const int tid = threadIdx.x;
+    const int M = a.M, N = a.N;
+    float* G = lds;                       // [N][M + 1]
+    float* Sc = G + N * (M + 1);          // [32][N + 1]
+    float* Tc = Sc + 32 * (N + 1);        // [32][M + 1]
+    float* ai = Tc + 32 * (M + 1);        // [M]  sum_j dsim*sim / tn_i^2
+    float* bj = ai + M;                   // [N]  sum_i dsim*sim / sn_j^2
+    const float* dsim = a.dsim + (long)b * N * M;
+    const float* sim = a.sim + (long)b * N * M;
+    const float* tn = a.tn + (long)b * M;
+    const float* sn = a.sn + (long)b * N;
+    for (int e = tid; e < N * M; e += 256) {
+        const int j = e / M, i = e - j * M;
+        G[j * (M + 1) + i] = dsim[e] * sim[e];              // first the products for the two sums ...
+    }
+    const float* tb = a.t + (long)b * a.tsb;
+    const float* sb = a.s + (long)b * a.ssb;
+    for (int e = tid; e < 32 * N; e += 256) {
+        const int c = e / N, j = e - c * N;
+        Sc[c * (N + 1) + j] = sb[(long)(c0 + c) * a.ssc + (long)j * a.ssn];
+    }
+    for (int e = tid; e < 32 * M; e += 256) {
+        const int c = e / M, i = e - c * M;
+        Tc[c * (M + 1) + i] = tb[(long)(c0 + c) * a.tsc + (long)i * a.tsn];
+    }
+    __syncthreads();
+    if (tid < M) {                       // a clamped norm (|x| <= eps) is a constant: no gradient through it
+        float s = 0.f;
+        for (int j = 0; j < N; ++j) s += G[j * (M + 1) + tid];
+        const float n = tn[tid];
+        ai[tid] = n > CS_EPS ? s / (n * n) : 0.f;
+    }
+    if (tid >= 64 && tid - 64 < N) {
+        const int j = tid - 64;
+        float s = 0.f;
+        for (int i = 0; i < M; ++i) s += G[j * (M + 1) + i];
+        const float n = sn[j];
+        bj[j] = n > CS_EPS ? s / (n * n) : 0.f;
+    }
+    __syncthreads();
+    for (int e = tid; e < N * M; e += 256) {                // ... then G itself
+        const int j = e / M, i = e - j * M;
+        G[j * (M + 1) + i] = dsim[e] / (tn[i] * sn[j]);
+    }
+    __syncthreads();
+    // dt[c, i]: 32 x M outputs, thread = (channel c = tid / 8, template points i = tid % 8 + 8 v)
+    {
+        const int c = tid >> 3, i8 = tid & 7;
+        float acc[CS_MMAX / 8] = {};
+        for (int j = 0; j < N; ++j) {
+            const float sv = Sc[c * (N + 1) + j];
+#pragma unroll
+            for (int v = 0; v < CS_MMAX / 8; ++v)
+                if (i8 + 8 * v < M) acc[v] = fmaf(G[j * (M + 1) + i8 + 8 * v], sv, acc[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < CS_MMAX / 8; ++v) {
+            const int i = i8 + 8 * v;
+            if (i < M) a.dt[((long)b * a.f + c0 + c) * M + i] = acc[v] - Tc[c * (M + 1) + i] * ai[i];
+        }
+    }
+    // ds[c, j]: 32 x N outputs, thread = (channel c = tid / 8, search points j = tid % 8 + 8 v)
+    {
+        const int c = tid >> 3, j8 = tid & 7;
+        float acc[CS_NMAX / 8] = {};
+        for (int i = 0; i < M; ++i) {
+            const float tv = Tc[c * (M + 1) + i];
+#pragma unroll
+            for (int v = 0; v < CS_NMAX / 8; ++v)
+                if (j8 + 8 * v < N) acc[v] = fmaf(G[(j8 + 8 * v) * (M + 1) + i], tv, acc[v]);
+        }
+#pragma unroll
+        for (int v = 0; v < CS_NMAX / 8; ++v) {
+            const int j = j8 + 8 * v;
+            if (j < N) a.ds[((long)b * a.f + c0 + c) * N + j] = acc[v] - Sc[c * (N + 1) + j] * bj[j];
+        }
+    }
+}
+}  // namespace
+
+extern "C" int o3d_cosine_sim_fwd(const float* t, long tsb, long tsc, long tsn, const float* s, long ssb, long ssc, long ssn,
+                                  int B, int f, int M, int N, float* sim, float* tn, float* sn, void* stream) {
+    if (!t || !s || !sim || !tn || !sn || B <= 0 || B > 65535 || f <= 0 || f % CS_K != 0 || M <= 0 || M > CS_MMAX || M % 4 != 0 ||
+        N <= 0 || N > CS_NMAX)
+        return O3D_EINVAL;
+    CosArgs a = {t, tsb, tsc, tsn, s, ssb, ssc, ssn, B, f, M, N, sim, tn, sn, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL(cosine_sim_fwd_kernel, dim3(B, o3d_cdiv(N, CS_J)), dim3(256), 0, o3d_stream(stream), a);
+    return o3d_launch_status();
+}
+
+extern "C" int o3d_cosine_sim_bwd(const float* dsim, const float* sim, const float* tn, const float* sn, const float* t,
+                                  long tsb, long tsc, long tsn, const float* s, long ssb, long ssc, long ssn, int B, int f, int M,
+                                  int N, float* dt, float* ds, void* stream) {
+    if (!dsim || !sim || !tn || !sn || !t || !s || !dt || !ds || B <= 0 || B > 65535 || f <= 0 || f % 32 != 0 || M <= 0 ||
+        M > CS_MMAX || N <= 0 || N > CS_NMAX)
+        return O3D_EINVAL;
+    CosArgs a = {t, tsb, tsc, tsn, s, ssb, ssc, ssn, B, f, M, N, const_cast<float*>(sim), const_cast<float*>(tn),
+                 const_cast<float*>(sn), dsim, dt, ds};
+    const size_t lds = sizeof(float) * ((size_t)N * (M + 1) + 32 * (N + 1) + 32 * (M + 1) + M + N);
+    const void* fn = reinterpret_cast<const void*>(cosine_sim_bwd_kernel);
+    if (lds > 48 * 1024 && hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return O3D_ELAUNCH;
+    hipLaunchKernelGGL(cosine_sim_bwd_kernel, dim3(B, f / 32), dim3(256), lds, o3d_stream(stream), a);
+    return o3d_launch_status();
+}

@@ -73,7 +73,6 @@ class FlatBatch(dict):
         self.flat = torch.zeros(off, dtype=torch.uint8, device=dev)
         self.layout = tuple(fields)
         self.extra_keys = tuple((extra or {}).keys())
-        self.extra_valid = False
         for (k, shape, dtype), o in zip(fields, offs):
             n = 1
             for d in shape:
@@ -126,7 +125,8 @@ class DataParallelStep:
     same work with none of the per-launch host overhead.  The all-reduce and the optimizer stay
     outside the graph (eagerly enqueued while the graph runs)."""
 
-    def __init__(self, model, optimizer=None, world=None, graph=False, graph_warmup=3):
+    def __init__(self, model, optimizer=None, world=None, graph=False, graph_warmup=3, prefetch_sampling=True,
+                 require_graph=None):
         self.model = model
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         if self.world > 1:  # identical replicas: rank 0's parameters and buffers everywhere
@@ -139,6 +139,10 @@ class DataParallelStep:
             optimizer, self.scheduler = conf["optimizer"], conf.get("lr_scheduler")   # StepLR of base_model.py:34-35
         self.optimizer = optimizer
         self.graph_requested = bool(graph) and torch.cuda.is_available()
+        # require_graph: a failed capture raises instead of falling back to the (several times slower) eager step;
+        # default: the O3D_REQUIRE_GRAPH=1 environment switch (CI / benchmarking)
+        self.require_graph = (os.environ.get("O3D_REQUIRE_GRAPH", "0") == "1") if require_graph is None else bool(require_graph)
+        self._views_bound = False
         self.graph_warmup = graph_warmup
         self.graph = None
         self.graph_error = None
@@ -149,14 +153,15 @@ class DataParallelStep:
         self._buffers = [b for b in model.buffers()]
         # sampling prefetch: the farthest-point-sampling indices of batch t+1 are computed on a second
         # stream while the graph of step t replays -- 766 strictly serial rounds on 96 of 1024 SIMDs otherwise head every
-        # step with the rest of the chip idle.  O3D_FPS_PREFETCH=0 keeps the sampling inside the captured step.
-        self._sampling = getattr(model, "sampling_inputs", None) if os.environ.get("O3D_FPS_PREFETCH", "1") != "0" else None
+        # step with the rest of the chip idle.  prefetch_sampling=False keeps the sampling inside the captured step (what
+        # tests/test_model_gpu.py::test_sampling_prefetch_* compares against).
+        self._sampling = getattr(model, "sampling_inputs", None) if prefetch_sampling else None
         self._side = None
         self._prefetched = None        # (batch object, {key: tensor}, event)
         # the constant 1 that seeds `loss.backward`: allocated here, outside any capture (open3dsot_amd/fused_loss.py::one)
         first = next(iter(model.parameters()), None)
         self._one = None
-        if first is not None and first.is_cuda and os.environ.get("O3D_GLUE_TRIM", "1") != "0":
+        if first is not None and first.is_cuda:
             from . import fused_loss
             self._one = fused_loss.one(first.device)
 
@@ -170,7 +175,12 @@ class DataParallelStep:
             else:
                 dist.all_reduce(self.grads.flat, op=dist.ReduceOp.SUM)
                 self.grads.flat.div_(self.world)
-            self.grads.bind_views()
+            # p.grad = the views of the exchange buffer.  An eager step cleared them (autograd ASSIGNS fresh tensors, which
+            # `_forward_backward` packs into the buffer), so they are bound again; a replayed graph never touches p.grad,
+            # so once bound they stay bound: no per-step host loop over the 76 parameters (round-3 review)
+            if self.graph is None or not self._views_bound or self.grads.params[0].grad is not self.grads.views[0]:
+                self.grads.bind_views()
+                self._views_bound = self.graph is not None
 
     def _forward_backward(self, batch):
         if isinstance(batch, FlatBatch) and batch is not self._static and batch.extra_keys:
@@ -254,7 +264,7 @@ class DataParallelStep:
     def make_batch(self, batch):
         """batch (dict of device tensors) -> a FlatBatch laid out like the captured step's static inputs (one device copy
         per step instead of one per field); before the capture, or for another layout, the dict itself"""
-        if self._static is None or os.environ.get("O3D_FLAT_BATCH", "1") == "0":      # (A/B switch)
+        if self._static is None:
             return batch
         fb = FlatBatch({k: v for k, v in batch.items() if k not in self._static.extra_keys},
                        {k: (self._static[k].shape, self._static[k].dtype) for k in self._static.extra_keys})
@@ -285,9 +295,11 @@ class DataParallelStep:
             # the replayed finalize kernels rewrote the BatchNorm running statistics through raw pointers: bump their
             # version counters (host only) so version-keyed caches -- eval-mode constants -- see a training step
             increment_version(self._buffers)
-            if self.world == 1:     # (world > 1: the replay packed them into the exchange buffer, reduce_gradients binds its views)
-                for p, g in zip(self.grads.params, self._static_grads):   # replay rewrote these buffers in place
+            if self.world == 1 and (not self._views_bound or self.grads.params[0].grad is not self._static_grads[0]):
+                # (world > 1: the replay packed them into the exchange buffer, reduce_gradients binds its views)
+                for p, g in zip(self.grads.params, self._static_grads):   # the replay rewrites these very buffers: bound once
                     p.grad = g
+                self._views_bound = True
             loss = self._static_loss.clone()      # the graph rewrites its own buffer at the next replay
         else:
             if self.graph_requested and self._eager_steps >= self.graph_warmup:
@@ -298,7 +310,7 @@ class DataParallelStep:
                     self.graph_requested = False
                     self.graph = None
                     torch.cuda.synchronize()
-                    if os.environ.get("O3D_REQUIRE_GRAPH", "0") == "1":
+                    if self.require_graph:
                         raise RuntimeError("HIP-graph capture of the training step failed: " + self.graph_error) from e
                     # loudly: an eager step is several times slower on the launch-bound models, and a failed capture went
                     # unnoticed for two rounds on M2-Track

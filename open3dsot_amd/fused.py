@@ -1,5 +1,6 @@
-"""Fused grouped-MLP path: gather + 1x1 conv + BatchNorm + ReLU + max-pool (+ full backward)
-on the fp32-MFMA kernels of csrc/mlp.hip, behind the reference's module boundary.
+"""Fused grouped-MLP path: gather + 1x1 conv + BatchNorm + ReLU + max-pool (+ full backward) on the distinct-neighbour
+(compact) layout of csrc/compact.hip and the fp32-MFMA kernels of csrc/mlp_direct.hip / csrc/mlp_wgrad.hip, behind the
+reference's module boundary.  ONE fused path (round 4): a shape it does not take runs operator by operator (`_composed`).
 
 What it replaces, numerically identical within fp32 rounding (tests/test_fused_gpu.py):
   QueryAndGroup.forward            pointnet2/utils/pointnet2_utils.py:299-339
@@ -16,7 +17,6 @@ running_var, momentum 0.1); the NEXT kernel applies BN+ReLU while loading.  Save
 backward: Y_l and four per-channel vectors per layer, plus arg-max of the pool.
 """
 import ctypes
-import os as _os
 
 import torch
 from torch import nn
@@ -27,24 +27,17 @@ from .ops import QueryAndGroup
 
 _vp, _i, _f, _d = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_double
 capi.register("o3d_mlp_conv_fwd", [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
-capi.register("o3d_group_meta", [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp])
-capi.register("o3d_group_expand_fwd", [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp])
-capi.register("o3d_group_reduce_bwd", [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp])
-capi.register("o3d_group_bwd_combine", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp])
 capi.register("o3d_mlp_conv_dgrad_wt", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
                                         _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_dgrad_plain", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp])
 capi.register("o3d_mlp_conv_wgrad2", [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_wgrad2_scratch", [_i, _i, _i, _i])
 capi.register("o3d_mlp_conv_bwd_fused_rows", [_i, _i, ctypes.c_long])
 capi.register("o3d_mlp_conv_bwd_fused_scratch", [_i, _i, ctypes.c_long])
 capi.register("o3d_mlp_conv_bwd_fused_c", [_vp] * 10 + [_i, _i, ctypes.c_long, _vp, _vp, ctypes.c_long, _vp, _vp, _vp, _vp, _vp])
-capi.register("o3d_mlp_conv_dgrad_plain", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp])
 capi.register("o3d_bn_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_bn_relu_maxpool_fwd", [_vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
-capi.register("o3d_pool_bwd_partials", [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_bn_bwd_finalize", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
-capi.register("o3d_mlp_conv_dgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i,
-                                     _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_mlp_conv_wgrad", [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _i, _i, _i, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp])
 
@@ -66,11 +59,6 @@ capi.register("o3d_center_term_out", [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp])
 capi.register("o3d_pool_fwd_c", [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_fwd_ct", [_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_bwd_c", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _l, _vp, _vp, _vp])
-capi.register("o3d_pool_bwd_pk", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp])
-capi.register("o3d_mlp_conv_dgrad_cp", [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _l, _i, _vp, _vp, _vp,
-                                        _vp, _vp, _vp, _vp])
-capi.register("o3d_mlp_conv_wgrad2_cp", [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _l, _vp, _vp,
-                                         _vp])
 capi.register("o3d_sa_eval_fused", [_vp, _l, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _l, _vp, _vp])
 capi.register("o3d_group_reduce_c", [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp,
                                      _vp, _vp])
@@ -83,8 +71,8 @@ capi.register("o3d_mlp_conv_wgrad2_c", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, 
 capi.register("o3d_bn_finalize_c", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp])
 capi.register("o3d_bn_bwd_finalize_c", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp])
 
-TILE = 128   # positions per workgroup tile of the GEMM kernels (csrc/mlp.hip BN_POS)
-ETILE = 256  # positions per workgroup tile of the layer-0 expand kernel (csrc/group.hip EXP_TP)
+TILE = 128   # point columns are padded to this (the widest wave tile of the GEMM kernels, csrc/mlp_direct.hip)
+ETILE = 256  # columns per workgroup tile of the layer-0 expand kernel (csrc/compact.hip expand_c_kernel)
 
 # ---- optional per-kernel timing (bench.py's roofline leg) ---------------------------------
 _PROF = {"on": False, "events": []}
@@ -159,10 +147,6 @@ def counters_end():
     pending, _COUNTERS["pending"] = _COUNTERS["pending"], None
     if not pending:
         return
-    if not _GLUE_TRIM["on"]:
-        for inc, tensors in pending.items():
-            torch._foreach_add_(tensors, inc)
-        return
     # one multi-tensor launch for every increment of the forward (was: one per distinct increment -- 1 for a module
     # called once, 2 for a paired one); a counter that was collected twice gets the sum, not two racing updates
     total = {}
@@ -171,11 +155,6 @@ def counters_end():
             ent = total.setdefault(id(t), [t, 0])
             ent[1] += inc
     torch._foreach_add_([e[0] for e in total.values()], [e[1] for e in total.values()])
-
-
-# round 3: launch trimming of the torch glue around the kernels (O3D_GLUE_TRIM=0 restores the previous forms for A/B):
-# see also open3dsot_amd/fused_loss.py, dist.py::DataParallelStep._forward_backward, trackers.py::BAT._forward
-_GLUE_TRIM = {"on": _os.environ.get("O3D_GLUE_TRIM", "1") != "0"}
 
 
 def _versions(params):
@@ -198,7 +177,7 @@ GEMM_KERNELS = ("conv_fwd", "conv_fwd_points", "conv_dgrad", "conv_dgrad_points"
 # "<name>(" or "<name><" against the demangled kernel name, so `direct_gemm_kernel` does not swallow (or, as in round 3,
 # silently miss) `direct_gemm_pair_kernel`.  GEMM_REDUCE_SYMBOLS: the slice reductions of the weight gradients -- their
 # bytes belong to the family, they are not counted as launches.
-GEMM_KERNEL_SYMBOLS = ("direct_gemm_kernel", "direct_gemm_pair_kernel", "wgrad2_kernel", "wgrad2_group_kernel", "fused_bwd_kernel",
+GEMM_KERNEL_SYMBOLS = ("direct_gemm_kernel", "direct_gemm_pair_kernel", "splitk_gemm_kernel", "splitk_gemm_pair_kernel", "wgrad2_kernel", "wgrad2_group_kernel", "fused_bwd_kernel",
                        "conv_fwd_kernel", "conv_dgrad_kernel", "conv_wgrad_kernel")
 GEMM_REDUCE_SYMBOLS = ("wgrad_reduce_kernel", "wgrad_reduce1_kernel", "wgrad_reduce_group_kernel")
 
@@ -364,243 +343,13 @@ class _Cfg:
     __slots__ = ("nxyz", "inv_radius", "training", "bns", "eps", "momentum")
 
 
-class FusedGroupedMLP(torch.autograd.Function):
-    """(xyz, new_xyz, feats, idx, cfg, W0,g0,b0, W1,g1,b1, ...) -> pooled (B, C_last, npoint)"""
-
-    @staticmethod
-    @capi.on_tensor_device
-    def forward(ctx, xyz, new_xyz, feats, idx, cfg, *params):
-        lib = capi.load()
-        L = len(params) // 3
-        Ws = [params[3 * l].detach().reshape(params[3 * l].shape[0], -1).contiguous() for l in range(L)]
-        gammas = [params[3 * l + 1].detach().contiguous() for l in range(L)]
-        betas = [params[3 * l + 2].detach().contiguous() for l in range(L)]
-        B, npoint, ns = idx.shape
-        P = npoint * ns
-        dev = idx.device
-        nxyz = cfg.nxyz
-        C = feats.shape[1] if feats is not None else 0
-        N = feats.shape[2] if feats is not None else xyz.shape[1]
-        # per-point operand of layer 0: [xyz * inv_radius ; feats] as (B, nxyz+C, Npad), zero padded to
-        # the GEMM's position tile
-        Npad = -(-N // TILE) * TILE
-        X0n = (torch.zeros if Npad != N else torch.empty)((B, nxyz + C, Npad), device=dev, dtype=torch.float32)
-        if nxyz:
-            X0n[:, :3, :N] = xyz.detach().transpose(1, 2) * cfg.inv_radius
-        if C:
-            X0n[:, nxyz:, :N] = feats.detach()
-        new_c = (new_xyz.detach() * cfg.inv_radius).contiguous() if nxyz else None
-        Z = torch.empty((B, Ws[0].shape[0], Npad), device=dev, dtype=torch.float32)
-        need_bwd = any(ctx.needs_input_grad)
-        ntiles = B * (P // TILE)
-        st = _stream()
-        Ys, means, invstds, scales, shifts = [], [], [], [], []
-        GY = None
-        for l in range(L):
-            Cout, Cin = Ws[l].shape
-            bn = cfg.bns[l]
-            Y = torch.empty((B, Cout, P), device=dev, dtype=torch.float32)
-            part = torch.empty((ntiles, 2, Cout), device=dev, dtype=torch.float32) if cfg.training else None
-            stat_c = bn.running_mean if cfg.training else None
-            flops = 2.0 * Cin * Cout * B * P
-            if l == 0:
-                # layer 0 = one small GEMM over the N points + gather-expand (csrc/group.hip)
-                _call("conv_fwd_points", 2.0 * Cin * Cout * B * Npad, lib.o3d_mlp_conv_fwd, X0n.data_ptr(),
-                      Ws[0].data_ptr(), None, None, B, Cin, Cout, Npad, Z.data_ptr(), None, None, st)
-                part = torch.empty((B * (P // ETILE), 2, Cout), device=dev, dtype=torch.float32) if cfg.training else None
-                GY = torch.empty((B, Cout, npoint), device=dev, dtype=torch.float32) if (need_bwd and nxyz) else None
-                _call("group_expand", 0.0, lib.o3d_group_expand_fwd, Z.data_ptr(), Npad, idx.data_ptr(), _ptr(new_c),
-                      Ws[0].data_ptr(), Cin, B, Cout, npoint, ns, Y.data_ptr(), _ptr(part), _ptr(stat_c), _ptr(GY), st)
-                nparts = B * (P // ETILE)
-            else:
-                nparts = ntiles
-                _call("conv_fwd", flops, lib.o3d_mlp_conv_fwd, Ys[-1].data_ptr(), Ws[l].data_ptr(),
-                      scales[-1].data_ptr(), shifts[-1].data_ptr(), B, Cin, Cout, P, Y.data_ptr(), _ptr(part),
-                      _ptr(stat_c), st)
-            vec = torch.empty((4, Cout), device=dev, dtype=torch.float32)
-            fold = torch.empty((64, Cout), device=dev, dtype=torch.float32)     # scratch: folded partials
-            if cfg.training:
-                _call("bn_finalize", 0.0, lib.o3d_bn_finalize, part.data_ptr(), nparts, Cout, float(B) * P,
-                      stat_c.data_ptr(), gammas[l].data_ptr(), betas[l].data_ptr(), bn.running_mean.data_ptr(),
-                      bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps), vec[0].data_ptr(),
-                      vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(), fold.data_ptr(), st)
-            else:
-                _eval_consts(lib, bn, gammas[l], betas[l], vec, 1, st)
-            Ys.append(Y)
-            means.append(vec[0]); invstds.append(vec[1]); scales.append(vec[2]); shifts.append(vec[3])
-        if cfg.training:
-            count_batches(cfg.bns, 1)
-        Cl = Ws[-1].shape[0]
-        out = torch.empty((B, Cl, npoint), device=dev, dtype=torch.float32)
-        arg = torch.empty((B, Cl, npoint), device=dev, dtype=torch.int32) if need_bwd else None
-        yarg = torch.empty((B, Cl, npoint), device=dev, dtype=torch.float32) if need_bwd else None
-        _call("pool_fwd", 0.0, lib.o3d_bn_relu_maxpool_fwd, Ys[-1].data_ptr(), scales[-1].data_ptr(),
-              shifts[-1].data_ptr(), B, Cl, npoint, ns, out.data_ptr(), _ptr(arg), _ptr(yarg), st)
-        if need_bwd:
-            ctx.cfg = cfg
-            ctx.versions = _versions(params)
-            ctx.dims = (B, N, C, npoint, ns, L)
-            # NB: `out` itself must not be stored on ctx (out.grad_fn is this node: a reference cycle
-            # that keeps the whole graph -- and last step's AccumulateGrad nodes -- alive until the GC runs)
-            ctx.saved = (X0n, new_c, Z, GY, idx, Ws, gammas, Ys, means, invstds, scales, shifts,
-                         out.detach(), arg, yarg)
-        return out
-
-    @staticmethod
-    @capi.on_tensor_device
-    def backward(ctx, dOut):
-        lib = capi.load()
-        cfg = ctx.cfg
-        _check_versions(ctx.versions, "FusedGroupedMLP")
-        B, N, C, npoint, ns, L = ctx.dims
-        X0n, new_c, Z, GY, idx, Ws, gammas, Ys, means, invstds, scales, shifts, out, arg, yarg = ctx.saved
-        Npad = X0n.shape[2]
-        P = npoint * ns
-        dev = idx.device
-        st = _stream()
-        dOut = dOut.contiguous()
-        nxyz = cfg.nxyz
-        count = float(B) * P
-        ntiles = B * (P // TILE)
-        grads = [None] * (3 * L)
-        want_xyz = nxyz > 0 and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
-        want_feats = C > 0 and ctx.needs_input_grad[2]
-
-        # BN-backward coefficients of the last (pooled) layer
-        Cl = Ws[-1].shape[0]
-        part = torch.empty((B, 2, Cl), device=dev, dtype=torch.float32)
-        pk = torch.empty((B, Cl, npoint, 2), device=dev, dtype=torch.float32)   # {masked dOut, bits(arg)}
-        _call("pool_bwd_partials", 0.0, lib.o3d_pool_bwd_partials, dOut.data_ptr(), out.data_ptr(), yarg.data_ptr(),
-              means[-1].data_ptr(), B, Cl, npoint, part.data_ptr(), arg.data_ptr(), pk.data_ptr(), st)
-        nparts = B
-        dN = None  # dense dN of the current layer (None = pooled source)
-        dfeats = dxyz = dnew = None
-        for l in range(L - 1, -1, -1):
-            Cout, Cin = Ws[l].shape
-            coef = torch.empty((5, Cout), device=dev, dtype=torch.float32)  # dgamma dbeta A1 A2 A3
-            fold = torch.empty((64, Cout), device=dev, dtype=torch.float32)
-            _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize, part.data_ptr(), nparts, Cout, count,
-                  gammas[l].data_ptr(), means[l].data_ptr(), invstds[l].data_ptr(), coef[0].data_ptr(),
-                  coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr(), fold.data_ptr(), st)
-            if not cfg.training:      # eval-mode BN is a fixed affine map: dY = scale * dN
-                coef[3].zero_()
-                coef[4].zero_()
-            grads[3 * l + 1], grads[3 * l + 2] = coef[0], coef[1]
-            src = (_ptr(dN), dOut.data_ptr(), out.data_ptr(), arg.data_ptr()) if dN is None else \
-                  (dN.data_ptr(), None, None, None)
-            A = (coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr())
-            flops = 2.0 * Cin * Cout * B * P
-            if l == 0:
-                # layer 0 on the N points: S = sum of dY0 over each point's list, T = per-ball sums
-                one, zero = _const_vec(dev, Cout, 1.0), _const_vec(dev, Cout, 0.0)
-                cnt = torch.empty((B, Npad), device=dev, dtype=torch.float32)
-                R = torch.empty((B, Npad, 3), device=dev, dtype=torch.float32) if nxyz else None
-                S = torch.empty((B, Cout, Npad), device=dev, dtype=torch.float32)
-                T = torch.empty((B, Cout, npoint), device=dev, dtype=torch.float32) if nxyz else None
-                _call("group_reduce", 0.0, lib.o3d_group_reduce_bwd, dN.data_ptr(), idx.data_ptr(), B, Cout, Npad,
-                      npoint, ns, S.data_ptr(), _ptr(T), _ptr(new_c), cnt.data_ptr(), _ptr(R), st)
-                _call("group_combine", 0.0, lib.o3d_group_bwd_combine, S.data_ptr(), _ptr(T), Z.data_ptr(), _ptr(GY),
-                      cnt.data_ptr(), _ptr(R), Ws[0].data_ptr(), Cin, A[0], A[1], A[2], B, Cout, Npad, npoint, ns, st)
-                tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
-                total_chunks = B * (Npad // 32)
-                nsl = max(1, min(total_chunks // 4 if total_chunks >= 4 else 1, 768 // tiles))
-                wpart = torch.empty((nsl + 16, Cout, Cin), device=dev, dtype=torch.float32)
-                dW = torch.empty((Cout, Cin), device=dev, dtype=torch.float32)
-                _call("conv_wgrad_points", 2.0 * Cin * Cout * B * Npad, lib.o3d_mlp_conv_wgrad, S.data_ptr(), None,
-                      None, None, 4, S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(),
-                      None, None, None, None, None, None, 0, 0, 0, 1.0, B, Cin, Cout, Npad, nsl, wpart.data_ptr(),
-                      dW.data_ptr(), st)
-                if nxyz:      # the centre term of grouped_xyz = xyz[idx] - new_xyz
-                    dW[:, :3] -= torch.einsum("bcj,bjk->ck", T, new_c)
-                grads[0] = dW
-                if want_xyz or want_feats:
-                    dX = torch.empty((B, Cin, Npad), device=dev, dtype=torch.float32)
-                    _call("conv_dgrad_points", 2.0 * Cin * Cout * B * Npad, lib.o3d_mlp_conv_dgrad_plain,
-                          S.data_ptr(), S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(),
-                          Ws[0].data_ptr(), B, Cin, Cout, Npad, dX.data_ptr(), st)
-                    if want_feats:
-                        dfeats = dX[:, nxyz:, :N]
-                    if want_xyz:
-                        dxyz = dX[:, :3, :N].transpose(1, 2) * cfg.inv_radius
-                        dnew = torch.einsum("bcj,ck->bjk", T, Ws[0][:, :3]) * (-cfg.inv_radius)
-                continue
-            # ---- weight gradient
-            dW = torch.empty((Cout, Cin), device=dev, dtype=torch.float32)
-            if Cin % 64 == 0 and Cout % 64 == 0:
-                lib.o3d_mlp_conv_wgrad2_scratch.restype = ctypes.c_long
-                wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(B, Cin, Cout, P),), device=dev, dtype=torch.float32)
-                _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2, _ptr(dN), pk.data_ptr(), ns, Ys[l].data_ptr(),
-                      A[0], A[1], A[2], Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), B, Cin,
-                      Cout, P, wpart.data_ptr(), dW.data_ptr(), st)
-            else:
-                tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
-                total_chunks = B * (P // 32)
-                nsl = max(1, min(total_chunks // 4 if total_chunks >= 4 else 1, 768 // tiles))
-                wpart = torch.empty((nsl + 16, Cout, Cin), device=dev, dtype=torch.float32)
-                _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad, src[0], src[1], src[2], src[3], ns, Ys[l].data_ptr(),
-                      A[0], A[1], A[2], Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), None,
-                      None, None, None, 0, 0, 0, 1.0, B, Cin, Cout, P, nsl, wpart.data_ptr(), dW.data_ptr(), st)
-            grads[3 * l] = dW
-            # ---- data gradient: masked by the producer's ReLU, with its BN-backward partials
-            dNp = torch.empty((B, Cin, P), device=dev, dtype=torch.float32)
-            part = torch.empty((ntiles, 2, Cin), device=dev, dtype=torch.float32)
-            Wt = Ws[l].t().contiguous()      # (Cin, Cout): the LDS-free kernel reads its A operand along Cout
-            _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_wt, src[0], src[1], src[2], src[3], ns,
-                  Ys[l].data_ptr(), A[0], A[1], A[2], Ws[l].data_ptr(), Wt.data_ptr(), pk.data_ptr(), B, Cin, Cout, P,
-                  Ys[l - 1].data_ptr(),
-                  scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),
-                  part.data_ptr(), st)
-            nparts = ntiles
-            dN = dNp
-        gw = []
-        for l in range(L):
-            shape = (Ws[l].shape[0], Ws[l].shape[1], 1, 1)
-            gw += [grads[3 * l].view(shape), grads[3 * l + 1], grads[3 * l + 2]]
-        return (dxyz if ctx.needs_input_grad[0] else None, dnew if ctx.needs_input_grad[1] else None,
-                dfeats if ctx.needs_input_grad[2] else None, None, None, *gw)
-
-
-import os as _os
-_COMPACT = {"on": True}
-_EXPAND3 = {"on": _os.environ.get("O3D_EXPAND3", "1") != "0"}         # xyz-only layer 0 without the per-point GEMM (A/B switch)
-_POOL_T = {"on": _os.environ.get("O3D_POOL_T", "1") != "0"}           # pool forward on the LDS-transposed tile (A/B switch)
-_DW0_FAST = {"on": _os.environ.get("O3D_DW0_FAST", "1") != "0"}       # xyz-only layer 0: dW0 straight from the columns (A/B switch)
-_COMPACT2 = {"on": _os.environ.get("O3D_COMPACT2", "1") != "0"}      # paired compaction in 3 launches (A/B switch)
-_SIDE = {}
-_USE_SIDE = {"on": _os.environ.get("O3D_SIDE_STREAM", "0") == "1"}
-
-
 def _direct_tile(lib, pmax, m):
-    t = _os.environ.get("O3D_DIRECT_TILE")          # experiment switch: force 64 / 128 columns per wave tile
-    if t:
-        return int(t)
-    small = _os.environ.get("O3D_DIRECT_TILE_SMALL")   # experiment switch: 64-column tiles up to this many slots
-    if small and pmax <= int(small):
-        return 64
+    """columns per wave tile (= per statistics partial row) of the GEMM launches of a level with `pmax` worst-case columns"""
     return lib.o3d_direct_tile(pmax, m, 1)
 
 
-def _side_stream(dev):
-    """second HIP stream per device: the weight-gradient kernels of a layer run beside its data-gradient
-    kernel (both only read dN / Y).  OFF by default (O3D_SIDE_STREAM=1 enables it): measured on the
-    MI355X it LOSES 8 % (11.9 vs 11.0 ms/step) -- the two kernels contend for the same CUs and L2 and
-    the fork/join adds graph nodes; kept as a switch for larger batches."""
-    if not _USE_SIDE["on"]:
-        return torch.cuda.current_stream()
-    key = (dev.type, dev.index)
-    if key not in _SIDE:
-        _SIDE[key] = torch.cuda.Stream(device=dev)
-    return _SIDE[key]
-
-
-
-def set_compact(enabled):
-    """distinct-neighbour (compact) layout on/off (off = one column per ball slot, for A/B tests)"""
-    _COMPACT["on"] = bool(enabled)
-
-
 class FusedGroupedMLPCompact(torch.autograd.Function):
-    """Same contract as FusedGroupedMLP on the compact layout of csrc/compact.hip: one column per
+    """QueryAndGroup + SharedMLP + max-pool (+ the whole backward) on the compact layout of csrc/compact.hip: one column per
     DISTINCT neighbour of a ball (ball_query pads with copies of the first hit; copies are folded into
     a weight), flat (C, ldp) activations with the live column counts in device memory.
 
@@ -647,7 +396,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         cball = torch.empty((ldp,), device=dev, dtype=i32)
         cw = torch.empty((ldp,), device=dev, dtype=f32)
         meta = torch.empty((nseg, 4), device=dev, dtype=i32)
-        if nseg == 2 and _COMPACT2["on"]:      # both segments: three launches instead of six
+        if nseg == 2:      # both segments: three launches instead of six
             _call("compact_build", 0.0, lib.o3d_compact_build2, segs[0][3].data_ptr(), npoints[0], Npads[0],
                   segs[1][3].data_ptr(), npoints[1], Npads[1], B, ns, starts[1], pt_bases[1], nballs, ball_cnt.data_ptr(),
                   ball_off.data_ptr(), gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), meta.data_ptr(), st)
@@ -679,7 +428,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         # inside a tracker forward they were all refreshed by ONE launch, otherwise `get` copies on the spot
         from .fused_heads import prep_for
         prep = prep_for(dev)
-        direct3 = _EXPAND3["on"] and C == 0 and nxyz == 3        # xyz-only layer 0: no per-point GEMM, see group_expand below
+        direct3 = C == 0 and nxyz == 3        # xyz-only layer 0: no per-point GEMM, see group_expand below
         Z = None
         if not direct3:
             Z = torch.empty((C0, ldz), device=dev, dtype=f32)
@@ -740,12 +489,12 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         argq = torch.empty((nballs * Cl,), device=dev, dtype=i32) if need_bwd else None
         yarg = torch.empty((nballs * Cl,), device=dev, dtype=f32) if need_bwd else None
         np1 = npoints[1] if nseg == 2 else 0
-        if _POOL_T["on"] and Cl % 64 == 0 and ns <= 32 and ldp >= 288:
+        if Cl % 64 == 0 and ns <= 32 and ldp >= 288:
             # lane = channel, a wave per ball over an LDS-transposed tile (csrc/compact.hip::pool_t_kernel)
             _call("pool_fwd", 0.0, lib.o3d_pool_fwd_ct, Ys[-1].data_ptr(), ldp, scales[-1].data_ptr(), shifts[-1].data_ptr(),
                   ball_off.data_ptr(), ball_cnt.data_ptr(), cball.data_ptr(), meta.data_ptr(), start1, B, Cl, npoints[0], np1,
                   ns, out.data_ptr(), _ptr(argq), _ptr(yarg), st)
-        else:
+        else:       # shapes the transposed tile does not take (nsample 64, channels % 64): lanes along the ball's columns
             _call("pool_fwd", 0.0, lib.o3d_pool_fwd_c, Ys[-1].data_ptr(), ldp, scales[-1].data_ptr(), shifts[-1].data_ptr(),
                   ball_off.data_ptr(), ball_cnt.data_ptr(), B, Cl, npoints[0], np1, out.data_ptr(), _ptr(argq), _ptr(yarg), st)
         if need_bwd:
@@ -797,23 +546,12 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                     dst.copy_(dOuts[s_])
         part = torch.empty((nseg, POOL_BWD_SPLIT, 2, Cl), device=dev, dtype=f32)
         np1 = npoints[1] if nseg == 2 else 0
-        pkc = None
-        if _POOLED_PK["on"]:
-            # the dense gradient of the pooled layer (one non-zero per ball and channel) is never written: its two
-            # consumers gather {gradient, arg-max column} pairs per (channel, ball) through the column -> ball map
-            dN = None
-            pkc = torch.empty((Cl, nballs + 1, 2), device=dev, dtype=f32)
-            _call("pool_bwd", 0.0, lib.o3d_pool_bwd_pk, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
-                  means[-1].data_ptr(), B, Cl, npoints[0], np1, part.data_ptr(), pkc.data_ptr(), st)
-        else:
-            dN = torch.empty((Cl, ldp), device=dev, dtype=f32)          # dense class-sum gradient of the pooled layer
-            _call("pool_bwd", 0.0, lib.o3d_pool_bwd_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
-                  means[-1].data_ptr(), B, Cl, npoints[0], np1, meta.data_ptr(), start1, ldp, dN.data_ptr(),
-                  part.data_ptr(), st)
+        dN = torch.empty((Cl, ldp), device=dev, dtype=f32)          # dense class-sum gradient of the pooled layer
+        _call("pool_bwd", 0.0, lib.o3d_pool_bwd_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
+              means[-1].data_ptr(), B, Cl, npoints[0], np1, meta.data_ptr(), start1, ldp, dN.data_ptr(),
+              part.data_ptr(), st)
         dtile = 0
         part_rows = 0    # > 0: `part` comes from the fused data + weight gradient kernel (rows per segment block)
-        main, side = torch.cuda.current_stream(), _side_stream(dev)
-        keep = []        # buffers the side stream still reads: must outlive the join at the end
         seg_grads = [[None, None, None] for _ in range(nseg)]
         for l in range(L - 1, -1, -1):
             Cout, Cin = Ws[l].shape
@@ -847,7 +585,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                 coef[4].zero_()
             grads[3 * l + 1], grads[3 * l + 2] = coef[0, 0], coef[1, 0]      # summed over the segments by the kernel
             A = (coef[2].data_ptr(), coef[3].data_ptr(), coef[4].data_ptr())
-            if l == 0 and _DW0_FAST["on"] and C == 0 and nxyz == 3 and not (want_xyz or want_feats) and dN is not None:
+            if l == 0 and C == 0 and nxyz == 3 and not (want_xyz or want_feats):
                 # xyz-only layer 0, nobody wants the input gradient (SA level 0): dW0 straight from the columns, no list
                 # sums, no K = 3 GEMM, no centre term (csrc/compact.hip::dw0_xyz_kernel)
                 part0 = torch.empty((ldp // 256, Cout, 3), device=dev, dtype=f32)
@@ -855,7 +593,6 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                 _call("group_dw0", 0.0, lib.o3d_group_dw0_xyz, dN.data_ptr(), Ys[0].data_ptr(), ldp, A[0], A[1], A[2],
                       gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), X0n.data_ptr(), ldz, centers.data_ptr(), meta.data_ptr(),
                       start1, Cout, part0.data_ptr(), dW.data_ptr(), st)
-                keep += [dN, coef, part0]
                 grads[0] = dW
                 continue
             if l == 0:
@@ -864,51 +601,46 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                 spanmax = max(npoints) * ns
                 npo = lib.o3d_group_reduce_gather_scratch(B, nseg, npoints[0], Npads[0], npoints[-1], Npads[-1],
                                                           spanmax) if _REDUCE_GATHER["on"] else -1
-                if npo >= 0:     # experimental: gather through a transposed index, no float atomics
+                if npo >= 0:     # the cloud's columns through a transposed index: one LDS atomic per run of equal points
                     perm = torch.empty((ldp,), device=dev, dtype=torch.int32)
                     poff = torch.empty((npo,), device=dev, dtype=torch.int32)
                     _call("group_reduce", 0.0, lib.o3d_group_reduce_gather, dN.data_ptr(), Ys[0].data_ptr(), ldp, A[0], A[1],
                           A[2], gp.data_ptr(), cw.data_ptr(), ball_off.data_ptr(), ball_cnt.data_ptr(), B, nseg, npoints[0],
                           Npads[0], npoints[-1], Npads[-1], Cout, spanmax, perm.data_ptr(), poff.data_ptr(), S.data_ptr(),
                           _ptr(T), st)
-                else:
+                else:            # the index does not fit the LDS budget (o3d_group_reduce_gather_scratch < 0): one LDS atomic per column
                     _call("group_reduce", 0.0, lib.o3d_group_reduce_c, dN.data_ptr(), Ys[0].data_ptr(), ldp, A[0], A[1], A[2],
                           gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), ball_off.data_ptr(), ball_cnt.data_ptr(), B, nseg,
                           npoints[0], Npads[0], npoints[-1], Npads[-1], Cout, S.data_ptr(), _ptr(T), st)
                 one, zero = _const_vec(dev, Cout, 1.0), _const_vec(dev, Cout, 0.0)
                 Cinm = X0n.shape[0]                  # rows of the padded per-point operand
-                keep += [S, T, one, zero]
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    if Cinm % 64 == 0:       # aligned: the tile-matched MFMA weight-gradient kernel, X as stored
-                        wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cinm, Cout, ldz),), device=dev, dtype=f32)
-                        dWm = torch.empty((Cout, Cinm), device=dev, dtype=f32)
-                        _call("conv_wgrad_points", 2.0 * Cinm * Cout * ldz, lib.o3d_mlp_conv_wgrad2, S.data_ptr(), None, 4,
-                              S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(), None, None, 1,
-                              Cinm, Cout, ldz, wpart.data_ptr(), dWm.data_ptr(), side.cuda_stream, dims=(Cinm, Cout, True))
-                    else:
-                        tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
-                        total_chunks = ldz // 32
-                        nsl = max(1, min(total_chunks // 4 if total_chunks >= 4 else 1, 768 // tiles))
-                        wpart = torch.empty((nsl + 16, Cout, Cin), device=dev, dtype=f32)
-                        dWm = torch.empty((Cout, Cin), device=dev, dtype=f32)
-                        _call("conv_wgrad_points", 2.0 * Cin * Cout * ldz, lib.o3d_mlp_conv_wgrad, S.data_ptr(), None, None,
-                              None, 4, S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(), None,
-                              None, None, None, None, None, 0, 0, 0, 1.0, 1, Cin, Cout, ldz, nsl, wpart.data_ptr(),
-                              dWm.data_ptr(), side.cuda_stream)
-                    keep += [wpart, dWm]
-                    if nxyz and dWm.shape[1] != Cin:
-                        # the centre term of grouped_xyz = xyz[idx] - new_xyz and the compaction of the padded rows in one
-                        # launch (was: the term in place, then a strided torch copy of dWm[:, :Cin])
-                        dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
-                        _call("center_term", 0.0, lib.o3d_center_term_out, T.data_ptr(), centers.data_ptr(), Cout, nballs,
-                              dWm.shape[1], dWm.data_ptr(), Cin, dW.data_ptr(), side.cuda_stream)
-                        keep.append(dW)
-                    else:
-                        if nxyz:      # the centre term of grouped_xyz = xyz[idx] - new_xyz
-                            _call("center_term", 0.0, lib.o3d_center_term, T.data_ptr(), centers.data_ptr(), Cout, nballs,
-                                  dWm.shape[1], dWm.data_ptr(), side.cuda_stream)
-                        dW = dWm if dWm.shape[1] == Cin else dWm[:, :Cin].contiguous()
+                if Cinm % 64 == 0:       # aligned: the tile-matched MFMA weight-gradient kernel, X as stored
+                    wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cinm, Cout, ldz),), device=dev, dtype=f32)
+                    dWm = torch.empty((Cout, Cinm), device=dev, dtype=f32)
+                    _call("conv_wgrad_points", 2.0 * Cinm * Cout * ldz, lib.o3d_mlp_conv_wgrad2, S.data_ptr(), None, 4,
+                          S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(), None, None, 1,
+                          Cinm, Cout, ldz, wpart.data_ptr(), dWm.data_ptr(), st, dims=(Cinm, Cout, True))
+                else:
+                    tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
+                    total_chunks = ldz // 32
+                    nsl = max(1, min(total_chunks // 4 if total_chunks >= 4 else 1, 768 // tiles))
+                    wpart = torch.empty((nsl + 16, Cout, Cin), device=dev, dtype=f32)
+                    dWm = torch.empty((Cout, Cin), device=dev, dtype=f32)
+                    _call("conv_wgrad_points", 2.0 * Cin * Cout * ldz, lib.o3d_mlp_conv_wgrad, S.data_ptr(), None, None,
+                          None, 4, S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(), None,
+                          None, None, None, None, None, 0, 0, 0, 1.0, 1, Cin, Cout, ldz, nsl, wpart.data_ptr(),
+                          dWm.data_ptr(), st)
+                if nxyz and dWm.shape[1] != Cin:
+                    # the centre term of grouped_xyz = xyz[idx] - new_xyz and the compaction of the padded rows in one
+                    # launch (was: the term in place, then a strided torch copy of dWm[:, :Cin])
+                    dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
+                    _call("center_term", 0.0, lib.o3d_center_term_out, T.data_ptr(), centers.data_ptr(), Cout, nballs,
+                          dWm.shape[1], dWm.data_ptr(), Cin, dW.data_ptr(), st)
+                else:
+                    if nxyz:      # the centre term of grouped_xyz = xyz[idx] - new_xyz
+                        _call("center_term", 0.0, lib.o3d_center_term, T.data_ptr(), centers.data_ptr(), Cout, nballs,
+                              dWm.shape[1], dWm.data_ptr(), st)
+                    dW = dWm if dWm.shape[1] == Cin else dWm[:, :Cin].contiguous()
                 grads[0] = dW
                 if want_xyz or want_feats:
                     # dX = W0^T . S as a plain forward GEMM on the direct MFMA kernel: rows padded to a multiple of 64
@@ -917,12 +649,9 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                     dX = torch.empty((Cinm, ldz), device=dev, dtype=f32)
                     _call("conv_dgrad_points", 2.0 * Cinm * Cout * ldz, lib.o3d_mlp_conv_fwd, S.data_ptr(), W0t.data_ptr(),
                           None, None, 1, Cout, Cinm, ldz, dX.data_ptr(), None, None, st, dims=(Cout, Cinm))
-                    if not want_xyz:
-                        dnew_all = None
-                    elif _GLUE_TRIM["on"]:      # -inv_radius * W0[:, :3]^T . T as ONE GEMM call (beta = 0: T[:3] is only a shape)
+                    dnew_all = None
+                    if want_xyz:      # -inv_radius * W0[:, :3]^T . T as ONE GEMM call (beta = 0: T[:3] is only a shape)
                         dnew_all = torch.addmm(T[:3], Ws[0][:, :3].t(), T, beta=0.0, alpha=-float(cfg.inv_radius))
-                    else:
-                        dnew_all = ((-cfg.inv_radius) * Ws[0][:, :3]).t() @ T                        # (3, balls)
                     for s_ in range(nseg):
                         view = dX[:Cin, pt_bases[s_]:pt_bases[s_] + B * Npads[s_]].view(Cin, B, Npads[s_])
                         if want_feats:
@@ -933,8 +662,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                             seg_grads[s_][1] = dnew_all[:, ball_bases[s_]:ball_bases[s_] + nballs_s[s_]].reshape(
                                 3, B, npoints[s_]).permute(1, 2, 0)
                 continue
-            rows_fb = lib.o3d_mlp_conv_bwd_fused_rows(Cin, Cout, ldp) if (_FUSED_BWD["on"] and dN is not None and
-                                                                          Cout <= _FUSED_BWD["max_cout"]) else -1
+            rows_fb = lib.o3d_mlp_conv_bwd_fused_rows(Cin, Cout, ldp) if Cout <= FUSED_BWD_MAX_COUT else -1
             if rows_fb > 0:      # data + weight gradient in one launch (64-channel layers; csrc/mlp_wgrad.hip)
                 dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
                 wpart = torch.empty((lib.o3d_mlp_conv_bwd_fused_scratch(Cin, Cout, ldp),), device=dev, dtype=f32)
@@ -945,7 +673,6 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                       shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), ctx.Wts[l].data_ptr(), Cin, Cout, ldp, cw.data_ptr(),
                       meta.data_ptr(), start1, wpart.data_ptr(), dW.data_ptr(), part.data_ptr(), dNp.data_ptr(), st,
                       dims=(Cin, Cout))
-                keep += [dN, wpart, coef]
                 grads[3 * l] = dW
                 dN, part_rows = dNp, rows_fb
                 continue
@@ -953,37 +680,19 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             flops = (2.0 * Cin * Cout, meta, ldp)      # executed FLOPs = per live column (count read back when profiling)
             dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
             wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, ldp),), device=dev, dtype=f32)
-            keep += [dN, pkc, wpart, coef]
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                if dN is None:
-                    _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_cp, pkc.data_ptr(), cball.data_ptr(), nballs + 1,
-                          Ys[l].data_ptr(), A[0], A[1], A[2], Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(),
-                          shifts[l - 1].data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(),
-                          dW.data_ptr(), side.cuda_stream, dims=(Cin, Cout, True))
-                else:
-                    _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
-                          Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Cin, Cout, ldp,
-                          cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(), dW.data_ptr(), side.cuda_stream,
-                          dims=(Cin, Cout))
+            _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
+                  Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Cin, Cout, ldp,
+                  cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(), dW.data_ptr(), st, dims=(Cin, Cout))
             grads[3 * l] = dW
             Wt = ctx.Wts[l]
             dNp = torch.empty((Cin, ldp), device=dev, dtype=f32)
             dtile = _direct_tile(lib, ldp, Cin)
             part = torch.empty((ldp // dtile, 2, Cin), device=dev, dtype=f32)
-            if dN is None:
-                _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_cp, pkc.data_ptr(), cball.data_ptr(), nballs + 1,
-                      Ys[l].data_ptr(), A[0], A[1], A[2], Wt.data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1,
-                      dtile, Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(),
-                      means[l - 1].data_ptr(), dNp.data_ptr(), part.data_ptr(), st, dims=(Cin, Cout, True))
-            else:
-                _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
-                      Wt.data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1, dtile, Ys[l - 1].data_ptr(),
-                      scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),
-                      part.data_ptr(), st, dims=(Cin, Cout))
+            _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
+                  Wt.data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1, dtile, Ys[l - 1].data_ptr(),
+                  scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),
+                  part.data_ptr(), st, dims=(Cin, Cout))
             dN = dNp
-        main.wait_stream(side)       # join: every weight gradient is complete before autograd sees it
-        del keep
         gw = []
         for l in range(L):
             shape = (Ws[l].shape[0], Ws[l].shape[1], 1, 1)
@@ -995,32 +704,13 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         return (None, None, *gin, *gw)
 
 
-# layer-0 backward reduce as an LDS gather through a transposed index (csrc/compact.hip::reduce_gather_kernel) instead
-# of one LDS float atomic per column and channel.  Round-2 measurements on the MI355X (BAT, batch 48, same run A/B):
-# the first version (thread n walks point n's list) was 3x SLOWER than the atomics on real crops (1.96 vs 0.65 ms per
-# step: a point referenced by hundreds of balls serialised on one thread, and the per-list insertion sort was
-# quadratic); the balanced walk (equal shares of the sorted entries per thread, one atomic per run of equal points)
-# takes 0.50 ms including the index build.  ON by default; O3D_REDUCE_GATHER=0 selects the atomic kernel.
-# data + weight gradient of the 64 -> 64 and 64 -> 128 layers in one kernel (O3D_FUSED_BWD=0: the wgrad2 + direct-dgrad
-# pair).  The 64 -> 128 layer (SA level 0's pooled layer) joined at the end of round 3: same box, alternating, 5.878 -> 5.800
-# ms per BAT step (O3D_FUSED_BWD_MAX_COUT=64 restores the pair for it)
-_FUSED_BWD = {"on": _os.environ.get("O3D_FUSED_BWD", "1") != "0",
-              "max_cout": int(_os.environ.get("O3D_FUSED_BWD_MAX_COUT", "128"))}
-_REDUCE_GATHER = {"on": _os.environ.get("O3D_REDUCE_GATHER", "1") != "0"}
-
-
-# Pooled layer's gradient gathered from {gradient, arg-max column} pairs per (channel, ball) instead of a dense
-# (C, live columns) tensor (zero fill + scatter + two reads, ~1.5 GB of traffic per BAT step at batch 48).  Bitwise the
-# same gradients (tests/test_fused_gpu.py::test_pooled_pairs_match_dense_pooled_gradient), but measured on the MI355X
-# (BAT, batch 48, same run A/B) it LOSES: 7.73 vs 7.02 ms per step -- the pool backward drops from 0.29 to 0.11 ms, the
-# weight gradients pay +0.06 ms, and the five data-gradient launches of the pooled layers go from 1.13 to 1.96 ms: four
-# 8-byte gathers per k row and lane instead of one dwordx4 stream starve the barrier-free MFMA loop.  OFF by default
-# (O3D_POOLED_PK=1 enables it); a ball-aligned tile order would be needed to make the pooled read a broadcast.
-_POOLED_PK = {"on": _os.environ.get("O3D_POOLED_PK", "0") == "1"}
-
-
-def set_pooled_pk(enabled):
-    _POOLED_PK["on"] = bool(enabled)
+# data + weight gradient of a 64-input-channel inner layer in ONE kernel (csrc/mlp_wgrad.hip::fused_bwd_kernel: SA level 0's
+# 64 -> 64 and 64 -> 128 layers); wider outputs take the wgrad2 + direct-dgrad pair
+FUSED_BWD_MAX_COUT = 128
+# layer-0 backward reduce through a transposed index (csrc/compact.hip::reduce_gather_kernel) whenever its index fits the LDS
+# budget; the per-column LDS-atomic kernel (reduce_c_kernel) is the fallback for larger clouds.  `set_reduce_gather(False)`
+# forces the fallback: a TEST hook (tests/test_fused_gpu.py runs both), not a tuning switch.
+_REDUCE_GATHER = {"on": True}
 
 
 def set_reduce_gather(enabled):
@@ -1032,7 +722,7 @@ def reduce_gather_enabled():
 
 
 # ---- tracking inference: one kernel per set abstraction (csrc/sa_eval.hip) --------------------------------------
-_EVAL_FUSED = {"on": _os.environ.get("O3D_EVAL_FUSED", "1") != "0"}
+_EVAL_FUSED = {"on": True}      # (set_eval_fused(False): the layer-wise kernels, for the tests that compare the two)
 
 
 def set_eval_fused(enabled):
@@ -1132,9 +822,9 @@ def _run(mlp, xyz, new_xyz, feats, idx, nxyz, inv_radius):
     B, npoint, ns = idx.shape
     if _eval_fused_ok(mlp, layers, [(xyz, new_xyz, feats, idx)], nxyz):
         return _run_eval(mlp, layers, [(xyz, new_xyz, feats, idx)], nxyz, float(inv_radius))[0]
-    if _COMPACT["on"] and _compact_ok(layers, npoint, ns, B):
+    if _compact_ok(layers, npoint, ns, B):
         return FusedGroupedMLPCompact.apply(cfg, 1, xyz, new_xyz, feats, idx, *params)
-    return FusedGroupedMLP.apply(xyz, new_xyz, feats, idx, cfg, *params)
+    return None       # the caller runs the block operator by operator (nsample > 64, unaligned channel counts)
 
 
 def sa_group_mlp_pool(grouper, mlp, xyz, new_xyz, features):
@@ -1144,7 +834,8 @@ def sa_group_mlp_pool(grouper, mlp, xyz, new_xyz, features):
     if not _shape_ok(npoint, ns):
         return _composed(grouper, mlp, xyz, new_xyz, features, idx)
     inv_r = 1.0 / grouper.radius if grouper.normalize_xyz else 1.0
-    return _run(mlp, xyz, new_xyz, features, idx, 3, inv_r)
+    out = _run(mlp, xyz, new_xyz, features, idx, 3, inv_r)
+    return out if out is not None else _composed(grouper, mlp, xyz, new_xyz, features, idx)
 
 
 def sa_group_mlp_pool_pair(grouper, mlp, a, b):
@@ -1152,7 +843,7 @@ def sa_group_mlp_pool_pair(grouper, mlp, a, b):
     SharedMLP in ONE set of launches, numerically two consecutive calls (a first): separate BatchNorm
     batch statistics, running statistics updated twice.  Returns (pooled_a, pooled_b), or None when the
     joint layout does not apply (the caller then makes the two calls)."""
-    if not _COMPACT["on"] or a[0].shape[0] != b[0].shape[0] or (a[2] is None) != (b[2] is None):
+    if a[0].shape[0] != b[0].shape[0] or (a[2] is None) != (b[2] is None):
         return None
     if a[2] is not None and a[2].shape[1] != b[2].shape[1]:
         return None
@@ -1179,11 +870,11 @@ def sa_group_mlp_pool_pair(grouper, mlp, a, b):
 def group_mlp_pool(mlp, bundle, idx):
     """grouping_operation(bundle, idx) + SharedMLP + max over the last axis -> (B, C_last, idx.shape[1])."""
     _, npoint, ns = idx.shape
-    if not _shape_ok(npoint, ns):
+    out = _run(mlp, None, None, bundle, idx, 0, 1.0) if _shape_ok(npoint, ns) else None
+    if out is None:
         from . import ops
-        x = mlp(ops.grouping_operation(bundle, idx))
-        return x.max(dim=-1)[0]
-    return _run(mlp, None, None, bundle, idx, 0, 1.0)
+        out = mlp(ops.grouping_operation(bundle, idx)).max(dim=-1)[0]
+    return out
 
 
 def _composed(grouper, mlp, xyz, new_xyz, features, idx):

@@ -42,16 +42,15 @@ class _WgradJob(ctypes.Structure):        # o3d_wgrad_job of include/o3dsot.h
                 ("out_cols", _i)]
 
 
-# the weight gradients of a stack as ONE grouped launch (+ one reduction launch) at the end of its backward instead of a
-# launch + reduction per layer (csrc/mlp_wgrad.hip::wgrad2_group_kernel); O3D_WGRAD_GROUP=0: one launch per layer
-_GROUP = {"on": __import__("os").environ.get("O3D_WGRAD_GROUP", "1") != "0"}
+# the weight gradients of a stack are ONE grouped launch (+ one reduction launch) at the end of its backward instead of a
+# launch + reduction per layer (csrc/mlp_wgrad.hip::wgrad2_group_kernel)
 _MAXJOBS = 8                # WG_MAXJOBS of csrc/mlp_wgrad.hip
 # Deferred weight gradients: inside `defer_wgrads()` (the training step of open3dsot_amd/dist.py wraps loss.backward() in
 # it) the stacks do not launch their grouped weight gradients at the end of their own backward but queue the jobs; the
 # queue is flushed in groups of 8 when the scope ends -- the heads' 23 jobs of a BAT step in 3 launches + 3 reductions
 # instead of 7 + 7.  The gradient tensors autograd was handed are filled by the flush: the scope must end before anything
-# reads them (AccumulateGrad only stores them).  O3D_WGRAD_DEFER=0: every stack flushes for itself.
-_DEFER = {"on": __import__("os").environ.get("O3D_WGRAD_DEFER", "1") != "0", "queue": None, "keys": None}
+# reads them (AccumulateGrad only stores them; `_deferrable` lists what that requires of the parameters).
+_DEFER = {"queue": None, "keys": None}
 
 
 def _flush_jobs(jobs, st):
@@ -110,7 +109,7 @@ def _submit_jobs(jobs, keep, st, params):
 
 @contextlib.contextmanager
 def defer_wgrads():
-    if not _DEFER["on"] or _DEFER["queue"] is not None:
+    if _DEFER["queue"] is not None:          # nested scopes: the outer one flushes
         yield
         return
     _DEFER["queue"], _DEFER["keys"] = [], set()
@@ -120,23 +119,7 @@ def defer_wgrads():
         _flush_queue()
         _DEFER["queue"] = _DEFER["keys"] = None
 
-import os as _os
-
 _ON = {"on": True}
-# Weight gradients (and bias gradients) of a stack on a second HIP stream beside the data-gradient chain.  The heads'
-# launches are latency bound (15-18 us each on the MI355X whatever their size -- a 256x256x6144 GEMM is 8 us of MFMA
-# work, and neither 32-column tiles nor a 4-deep operand ring moved that) and the weight-gradient branch is off the
-# critical path, so overlap looked free.  Measured (BAT, batch 48, same run A/B): 7.39 ms per step with the side
-# stream against 6.98 without -- the fork / join edges inside the captured HIP graph cost more than the overlap
-# gains, as for the set-abstraction levels in round 1.  OFF by default; O3D_HEADS_SIDE_STREAM=1 enables it.
-_SIDE = {"on": _os.environ.get("O3D_HEADS_SIDE_STREAM", "0") == "1", "streams": {}}
-
-
-def _side_stream(dev):
-    key = (dev.type, dev.index)
-    if key not in _SIDE["streams"]:
-        _SIDE["streams"][key] = torch.cuda.Stream(device=dev)
-    return _SIDE["streams"][key]
 
 
 def set_fused_heads(enabled):
@@ -354,7 +337,6 @@ for _n in ("o3d_pw_fwd_pair", "o3d_pw_dgrad_pair", "o3d_bn_finalize_pair", "o3d_
 _PAIRABLE = {"o3d_pw_fwd": ("o3d_pw_fwd_pair", _PwFwdArgs, 1), "o3d_pw_dgrad": ("o3d_pw_dgrad_pair", _PwDgradArgs, 1),
              "o3d_bn_finalize": ("o3d_bn_finalize_pair", _BnFinArgs, 2),
              "o3d_bn_bwd_finalize": ("o3d_bn_bwd_finalize_pair", _BnBwdFinArgs, 2)}
-_PAIRS = {"on": _os.environ.get("O3D_HEAD_PAIRS", "1") != "0"}        # A/B switch
 
 
 def _drive(gens):
@@ -495,9 +477,7 @@ def _chain_backward(state, dOut, needs):
     one, zero = _const_vec(dev, Mp, 1.0), _const_vec(dev, Mp, 0.0)
     dX0 = None
 
-    main = torch.cuda.current_stream()
-    side = _side_stream(dev) if _SIDE["on"] else main
-    keep = []            # buffers the side stream reads or writes: alive until the join below
+    keep = []            # what the (possibly deferred) grouped launch reads or writes: alive until it has run
     jobs = []            # grouped weight gradients: launched together behind the data-gradient chain
 
     def wgrad(l, dN, Y, A, Cout_p, coef=None):
@@ -507,42 +487,23 @@ def _chain_backward(state, dOut, needs):
         sh = None if l == 0 else vecs[l - 1][3].data_ptr()
         Wl = Ws[l]
         Cout, Cin = Wl.shape[0], Wl.shape[1]
-        if _GROUP["on"] and side is main:
-            # the gradient in the parameter's OWN (Cout, Cin) shape, written compactly by the group's reduction: what
-            # autograd receives is contiguous (a slice of the padded buffer is cloned by AccumulateGrad -- one more launch,
-            # and with deferred launches a clone of a buffer that is not filled yet)
-            dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
-            scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Kp, Cout_p, P),), device=dev, dtype=f32)
-            jobs.append((2.0 * Kp * Cout_p * P, (dN.data_ptr(), Y.data_ptr(), A[0], A[1], A[2], Xs.data_ptr(), sc, sh, Kp,
-                                                 Cout_p, P, scratch.data_ptr(), dW.data_ptr(), Cout, Cin)))
-            # everything the (possibly deferred) launch reads: the layer input and its BatchNorm constants belong to the
-            # autograd node, which is released -- and its memory reused -- as soon as this backward returns
-            keep.extend((dN, Y, scratch, dW, coef, Xs, vecs[l - 1] if l > 0 else None))
-            return dW.view(Wl.shape)
-        if side is not main:
-            side.wait_stream(main)           # dN and the BatchNorm-backward constants of this layer are ready
-        with torch.cuda.stream(side):
-            dW = torch.empty((Cout_p, Kp), device=dev, dtype=f32)
-            scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Kp, Cout_p, P),), device=dev, dtype=f32)
-            _call("pw_conv_wgrad", 2.0 * Kp * Cout_p * P, lib.o3d_mlp_conv_wgrad2, dN.data_ptr(), None, 4, Y.data_ptr(),
-                  A[0], A[1], A[2], Xs.data_ptr(), sc, sh, 1, Kp, Cout_p, P, scratch.data_ptr(), dW.data_ptr(),
-                  side.cuda_stream, dims=(Kp, Cout_p, Y is dN))
-            out = (dW if (Cout, Cin) == (Cout_p, Kp) else dW[:Cout, :Cin]).reshape(Wl.shape)
-        keep.extend((dN, Y, scratch, dW, coef, out))
-        return out
+        # the gradient in the parameter's OWN (Cout, Cin) shape, written compactly by the group's reduction: what
+        # autograd receives is contiguous (a slice of the padded buffer is cloned by AccumulateGrad -- one more launch,
+        # and with deferred launches a clone of a buffer that is not filled yet)
+        dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
+        scratch = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Kp, Cout_p, P),), device=dev, dtype=f32)
+        jobs.append((2.0 * Kp * Cout_p * P, (dN.data_ptr(), Y.data_ptr(), A[0], A[1], A[2], Xs.data_ptr(), sc, sh, Kp,
+                                             Cout_p, P, scratch.data_ptr(), dW.data_ptr(), Cout, Cin)))
+        # everything the (possibly deferred) launch reads: the layer input and its BatchNorm constants belong to the
+        # autograd node, which is released -- and its memory reused -- as soon as this backward returns
+        keep.extend((dN, Y, scratch, dW, coef, Xs, vecs[l - 1] if l > 0 else None))
+        return dW.view(Wl.shape)
 
     # ---- last layer: plain conv (+ bias, + residual)
     l = L - 1
     if needs[cfg.nsrc + 4 * l + 1]:
-        if _GROUP["on"] and side is main:        # the bias gradient rides in the stack's grouped weight-gradient launch
-            db = torch.empty((Mp,), device=dev, dtype=f32)
-            jobs.append((0.0, (G.data_ptr(), None, None, None, None, None, None, None, 0, Mp, P, None, db.data_ptr(), 0, 0)))
-        else:
-            if side is not main:
-                side.wait_stream(main)
-            with torch.cuda.stream(side):
-                db = torch.empty((Mp,), device=dev, dtype=f32)
-                _call("row_sum", 0.0, lib.o3d_row_sum, G.data_ptr(), Mp, P, db.data_ptr(), side.cuda_stream)
+        db = torch.empty((Mp,), device=dev, dtype=f32)       # the bias gradient rides in the stack's grouped weight-gradient launch
+        jobs.append((0.0, (G.data_ptr(), None, None, None, None, None, None, None, 0, Mp, P, None, db.data_ptr(), 0, 0)))
         keep.extend((G, db))
         grads[4 * l + 1] = db[:Cl]
     grads[4 * l] = wgrad(l, G, G, (one.data_ptr(), zero.data_ptr(), zero.data_ptr()), Mp)
@@ -598,9 +559,6 @@ def _chain_backward(state, dOut, needs):
                                                                         G.data_ptr() if cfg.residual else None, dX0.data_ptr(),
                                                                         None, st], (K0p, Cp))
     _submit_jobs(jobs, keep, st, list(Ws) + [b_ for b_ in state.biases if b_ is not None])
-    keep = []
-    if side is not main:
-        main.wait_stream(side)       # join: every weight gradient is complete before autograd hands it on
     del keep
     gsrc, off = [], 0
     for i, C in enumerate(src_C):
@@ -685,7 +643,7 @@ def run_chain_pair(a, b):
     merged two by two where they match.  Caller has checked chain_supported for both."""
     cfg_a, pa = _chain_cfg(*a)
     cfg_b, pb = _chain_cfg(*b)
-    if not _PAIRS["on"] or a[0][0].shape[0] != b[0][0].shape[0] or a[0][0].shape[2] != b[0][0].shape[2]:
+    if a[0][0].shape[0] != b[0][0].shape[0] or a[0][0].shape[2] != b[0][0].shape[2]:
         return FlatChain.apply(cfg_a, *a[0], *pa), FlatChain.apply(cfg_b, *b[0], *pb)
     ta = (*a[0], *pa)
     return FlatChainPair.apply(cfg_a, cfg_b, len(ta), *ta, *b[0], *pb)
@@ -766,11 +724,8 @@ class SharedConvPair(torch.autograd.Function):
 
 
 def shared_conv_pair_supported(conv, xa, xb):
-    return (_ON["on"] and _SHARED["on"] and xa.is_cuda and xa.dtype == torch.float32 and xb.dtype == torch.float32 and
+    return (_ON["on"] and xa.is_cuda and xa.dtype == torch.float32 and xb.dtype == torch.float32 and
             xa.dim() == 3 and xb.dim() == 3 and xa.shape[0] == xb.shape[0] and xa.shape[1] == xb.shape[1] == conv.in_channels and
             conv.kernel_size == (1,) and conv.stride == (1,) and conv.padding == (0,) and conv.groups == 1 and
             conv.in_channels % 64 == 0 and conv.out_channels % 64 == 0 and
-            (xa.shape[0] * (xa.shape[2] + xb.shape[2])) % 128 == 0 and _GROUP["on"])
-
-
-_SHARED = {"on": _os.environ.get("O3D_SHARED_CONV", "1") != "0"}      # A/B switch
+            (xa.shape[0] * (xa.shape[2] + xb.shape[2])) % 128 == 0)

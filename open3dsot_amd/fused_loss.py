@@ -4,7 +4,6 @@ total w.r.t. the network outputs.  `MatchingBaseModel.compute_loss` (torch ops, 
 forward+backward) stays as the specification the kernel is tested against (tests/test_model_gpu.py).
 """
 import ctypes
-import os
 
 import torch
 
@@ -14,10 +13,8 @@ _vp, _i, _f = ctypes.c_void_p, ctypes.c_int, ctypes.c_float
 capi.register("o3d_track_loss", [_vp] * 8 + [_i] * 4 + [_f] * 5 + [_vp] * 7)
 
 _ON = {"on": True}
-# round 3, O3D_GLUE_TRIM=0 restores the previous forms (A/B): the total as its own 0-d output instead of `losses[0]`
-# (whose backward is a zero fill + a select copy), and no scaling launch when the upstream gradient is the constant 1
-# that DataParallelStep passes to `backward` -- together 4 launches of a 266-launch step
-_TRIM = {"on": os.environ.get("O3D_GLUE_TRIM", "1") != "0"}
+# (the total is its own 0-d output instead of `losses[0]`, whose backward would be a zero fill + a select copy; and there is no
+# scaling launch when the upstream gradient is the constant 1 that DataParallelStep passes to `backward`)
 _ONE = {}
 KEYS = ("loss_objective", "loss_box", "loss_seg", "loss_vote", "loss_bc")
 
@@ -80,11 +77,14 @@ class FusedTrackLoss(torch.autograd.Function):
     @staticmethod
     @capi.on_tensor_device
     def backward(ctx, g, _g_parts=None):
-        grads = ctx.grads            # kept: a second backward (retain_graph=True) scales the same tensors again
+        # kept: a second backward (retain_graph=True) scales the same tensors again.  NB the constant-1 path below hands out
+        # THESE tensors (no copy): a consumer that modified its incoming gradient in place would change what a second
+        # backward returns -- the fused stacks do not (they pack / read), and autograd's own accumulation is out of place here
+        grads = ctx.grads
         if g is None:
             return (None,) * 9
         known = _ONE.get(str(g.device))
-        if _TRIM["on"] and known is not None and g.data_ptr() == known.data_ptr() and g.dim() == 0:
+        if known is not None and g.data_ptr() == known.data_ptr() and g.dim() == 0:
             return (None, grads[0], grads[1], grads[2], grads[3], None, None, None, None)       # times the constant 1
         live = [t for t in grads if t is not None]
         scaled = iter(torch._foreach_mul(live, g))               # one launch; only the total carries gradient

@@ -14,7 +14,6 @@ import torch
 
 from . import capi
 from .fused import _call, _check_versions, _const_vec, _eval_consts, _ptr, _stream, _versions, count_batches, POOL_BWD_SPLIT, TILE
-from .fused import _GLUE_TRIM
 
 _vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
 capi.register("o3d_bn_relu_apply", [_vp, _vp, _vp, _i, _l, _vp, _vp])
@@ -79,12 +78,9 @@ class FusedPointwiseChain(torch.autograd.Function):
                       float(bn.momentum), float(bn.eps), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
                       vec[3].data_ptr(), fold.data_ptr(), st)
                 if b is not None:       # statistics were taken without the bias: mean(Y + b) = mean(Y) + b
-                    if _GLUE_TRIM["on"]:
-                        bias_fix.setdefault(float(bn.momentum), ([], []))
-                        bias_fix[float(bn.momentum)][0].append(bn.running_mean)
-                        bias_fix[float(bn.momentum)][1].append(b)
-                    else:
-                        bn.running_mean.add_(b, alpha=float(bn.momentum))
+                    bias_fix.setdefault(float(bn.momentum), ([], []))
+                    bias_fix[float(bn.momentum)][0].append(bn.running_mean)
+                    bias_fix[float(bn.momentum)][1].append(b)
             else:
                 _eval_consts(lib, bn, gammas[l], betas[l], vec, 1, st, conv_bias=b)
             Ys.append(Y)
@@ -111,7 +107,7 @@ class FusedPointwiseChain(torch.autograd.Function):
             # W^T of the inner layers for the data gradient: from the device's WeightPrep table (inside a tracker forward
             # all of them were refreshed by ONE launch) instead of one transposing copy per layer in the backward
             ctx.Wts = None
-            if _GLUE_TRIM["on"] and all(isinstance(params[4 * l], torch.nn.Parameter) for l in range(1, L)):
+            if all(isinstance(params[4 * l], torch.nn.Parameter) for l in range(1, L)):
                 from .fused_heads import prep_for
                 prep = prep_for(dev)
                 ctx.Wts = [None] + [prep.get(params[4 * l], Ws[l].shape[1], Ws[l].shape[0], transpose=True) for l in range(1, L)]
@@ -154,7 +150,7 @@ class FusedPointwiseChain(torch.autograd.Function):
         grads = [None] * (4 * L)
         dx = dcb = None
         zero_bias = None      # dL/db behind a training-mode BatchNorm is exactly zero: one fill for all layers of the stack
-        if _GLUE_TRIM["on"] and cfg.training and any(ctx.has_bias):
+        if cfg.training and any(ctx.has_bias):
             widths = [Ws[l].shape[0] if ctx.has_bias[l] else 0 for l in range(L)]
             flat0 = torch.zeros((sum(widths),), device=dev, dtype=f32)
             zero_bias, o = [], 0

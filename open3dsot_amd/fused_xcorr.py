@@ -7,7 +7,8 @@ Only the similarity channel depends on the search point, so layer 0 splits exact
 Y0[c, (j,i)] = Z[c, i] + W0[c, 0] * sim[j, i].  The M template points of one search point are a "ball" of M contiguous
 columns, so layers 1.. and the max-pool are the kernels of the set-abstraction levels (csrc/mlp_direct.hip,
 csrc/mlp_wgrad.hip, csrc/compact.hip) with every column live.  The cosine similarity itself (a (B,N,M) map from two
-small GEMM-shaped products) stays on torch ops; its gradient arrives from the layer-0 backward kernel.
+small GEMM-shaped products) is one kernel each way (`CosineSimMap`, round 4; torch.bmm + norms until then); its gradient
+arrives from the layer-0 backward kernel.
 """
 import ctypes
 
@@ -223,13 +224,65 @@ class FusedP2BXCorr(torch.autograd.Function):
         return (None, dsim, dxyz, dfeat, *gw)
 
 
+capi.register("o3d_cosine_sim_fwd", [_vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
+capi.register("o3d_cosine_sim_bwd", [_vp, _vp, _vp, _vp, _vp, _l, _l, _l, _vp, _l, _l, _l, _i, _i, _i, _i, _vp, _vp, _vp])
+
+
+class CosineSimMap(torch.autograd.Function):
+    """apply(t (B,f,M), s (B,f,N)) -> sim (B,N,M) = <t_i, s_j> / (max(|t_i|, eps) * max(|s_j|, eps)), eps = 1e-8:
+    nn.CosineSimilarity(dim=1) of models/head/xcorr.py:37-38 on the never-materialised (B,f,M,N) expansion, one kernel
+    each way (csrc/xcorr.hip); any strides (the features are (B,C,N) views of the flat conv_final output)."""
+
+    @staticmethod
+    @capi.on_tensor_device
+    def forward(ctx, t, s):
+        lib = capi.load()
+        B, f, M = t.shape
+        N = s.shape[2]
+        dev = t.device
+        td, sd = t.detach(), s.detach()
+        sim = torch.empty((B, N, M), device=dev, dtype=torch.float32)
+        tn = torch.empty((B, M), device=dev, dtype=torch.float32)
+        sn = torch.empty((B, N), device=dev, dtype=torch.float32)
+        _call("cosine_sim", 0.0, lib.o3d_cosine_sim_fwd, td.data_ptr(), *td.stride(), sd.data_ptr(), *sd.stride(), B, f, M, N,
+              sim.data_ptr(), tn.data_ptr(), sn.data_ptr(), _stream())
+        if any(ctx.needs_input_grad):
+            # NB: a detached alias, never `sim` itself: the returned tensor's grad_fn is this node, so storing it on ctx is a
+            # reference cycle that keeps the step's whole autograd graph alive until the GC runs (and the HIP-graph capture
+            # of the P2B step died in capture_end on exactly that)
+            ctx.saved = (td, sd, sim.detach(), tn, sn)
+        return sim
+
+    @staticmethod
+    @capi.on_tensor_device
+    def backward(ctx, dsim):
+        lib = capi.load()
+        td, sd, sim, tn, sn = ctx.saved
+        B, f, M = td.shape
+        N = sd.shape[2]
+        dsim = dsim.contiguous()
+        dt = torch.empty((B, f, M), device=td.device, dtype=torch.float32)
+        ds = torch.empty((B, f, N), device=td.device, dtype=torch.float32)
+        _call("cosine_sim_bwd", 0.0, lib.o3d_cosine_sim_bwd, dsim.data_ptr(), sim.data_ptr(), tn.data_ptr(), sn.data_ptr(),
+              td.data_ptr(), *td.stride(), sd.data_ptr(), *sd.stride(), B, f, M, N, dt.data_ptr(), ds.data_ptr(), _stream())
+        return (dt if ctx.needs_input_grad[0] else None), (ds if ctx.needs_input_grad[1] else None)
+
+
+def cosine_sim_supported(t, s):
+    return (t.is_cuda and t.dtype == torch.float32 and s.dtype == torch.float32 and t.shape[1] % 32 == 0 and
+            t.shape[2] <= 64 and t.shape[2] % 4 == 0 and s.shape[2] <= 128)
+
+
 def p2b_xcorr_mlp_pool(mlp, template_feature, search_feature, template_xyz):
     """(B,f,M), (B,f,N), (B,M,3) -> (B, h, N): SharedMLP over [sim ; xyz ; feat] + max over the template axis"""
     # cosine similarity as the (B,N,M) map the kernels index by column: <t,s> / (max(|t|,eps) * max(|s|,eps))
     # (nn.CosineSimilarity, eps = 1e-8, xcorr.py:37-38)
-    tn = template_feature.norm(dim=1).clamp_min(1e-8)                      # (B,M)
-    sn = search_feature.norm(dim=1).clamp_min(1e-8)                        # (B,N)
-    sim = torch.bmm(search_feature.transpose(1, 2), template_feature) / (sn.unsqueeze(2) * tn.unsqueeze(1))
+    if cosine_sim_supported(template_feature, search_feature):
+        sim = CosineSimMap.apply(template_feature, search_feature)
+    else:       # shapes outside the kernel's tile limits: the same map on torch ops
+        tn = template_feature.norm(dim=1).clamp_min(1e-8)                      # (B,M)
+        sn = search_feature.norm(dim=1).clamp_min(1e-8)                        # (B,N)
+        sim = torch.bmm(search_feature.transpose(1, 2), template_feature) / (sn.unsqueeze(2) * tn.unsqueeze(1))
     layers = _layers(mlp)
     cfg = _Cfg()
     cfg.training, cfg.bns = bool(mlp.training), [bn for _, bn in layers]

@@ -129,9 +129,6 @@ class M2TRACK(nn.Module):
         box, refined box, previous-frame box, motion -- are evaluated as ONE stacked smooth-L1 each and the weighted total
         as one dot product, about half the launches of the term-by-term form (`compute_loss_reference`, which it equals
         to fp32 rounding: tests/test_golden_m2track.py)."""
-        from . import fused
-        if not fused._GLUE_TRIM["on"]:
-            return self.compute_loss_reference(data, output)
         c = self.config
         aux, motion_pred, seg_logits = output["aux_estimation_boxes"], output["motion_pred"], output["seg_logits"]
         state = data["motion_state_label"]
@@ -178,7 +175,7 @@ class M2TRACK(nn.Module):
 
     def compute_loss_reference(self, data, output):
         """the loss term by term as models/m2track.py:153-231 writes it (~60 launches forward, ~120 backward): the
-        specification `compute_loss` is tested against, and what runs with O3D_GLUE_TRIM=0"""
+        specification `compute_loss` is tested against"""
         c = self.config
         total = 0.0
         ld = {}

@@ -88,7 +88,7 @@ class RowBatchNorm1d(nn.BatchNorm1d):
     def forward(self, x):
         if self.training and self.track_running_stats and self.momentum is not None and x.is_cuda:
             from . import fused
-            if fused._GLUE_TRIM["on"] and fused._COUNTERS["pending"] is not None:
+            if fused._COUNTERS["pending"] is not None:
                 self._check_input_dim(x)
                 out = nn.functional.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias, True,
                                                self.momentum, self.eps)

@@ -8,7 +8,6 @@ one ~10 us launch.  `state_dict()` has torch.optim.Adam's layout (`step`, `exp_a
 checkpoints are interchangeable with the reference's optimizer.
 """
 import ctypes
-import os
 
 import torch
 from torch.autograd.graph import increment_version
@@ -88,6 +87,15 @@ class FlatAdam(torch.optim.Optimizer):
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)
+        missing = [p for p in self._offsets if not self.state.get(p)]
+        if missing and len(missing) < len(self._offsets):
+            # torch.optim.Adam omits parameters that never received a gradient and would start them at step 0 on their first
+            # update; FlatAdam keeps ONE step counter for all parameters, so their bias correction continues at the
+            # checkpoint's step -- the updates of exactly those parameters differ from the reference optimizer's after resume
+            import warnings
+            warnings.warn("FlatAdam.load_state_dict: the checkpoint holds state for %d of %d parameters; the others get zero "
+                          "moments but share the checkpoint's step counter (torch.optim.Adam would restart them at step 0)"
+                          % (len(self._offsets) - len(missing), len(self._offsets)), RuntimeWarning, stacklevel=2)
         with torch.no_grad():                       # back into the flat buffers (the base class swapped in copies)
             step = None
             for p, (off, n) in self._offsets.items():
@@ -118,7 +126,7 @@ def make_adam(params, lr, weight_decay, betas=(0.5, 0.999), eps=1e-6):
                             fused=True if params and all(q.is_cuda for q in params) else None)
 
 
-_ON = {"on": os.environ.get("O3D_FLAT_ADAM", "1") != "0"}      # A/B switch
+_ON = {"on": True}      # set_flat_adam(False): torch.optim.Adam, for the tests that compare the two update rules
 
 
 def set_flat_adam(enabled):

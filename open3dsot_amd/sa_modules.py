@@ -15,7 +15,6 @@ Two execution paths produce the same numbers (tests/test_fused_gpu.py):
 Differences from the reference, by design: no `.cuda()` H2D copy for the non-FPS prefix
 indices (:56 builds them on the host) -- they are created on the device.
 """
-import os
 
 import torch
 import torch.nn as nn
@@ -24,11 +23,12 @@ import torch.nn.functional as F
 from . import nn_blocks as pt_utils
 from . import ops as pointnet2_utils
 
-_FUSED = {"enabled": True, "paired": os.environ.get("O3D_PAIRED", "1") != "0", "fps_streams": os.environ.get("O3D_FPS_STREAMS", "0") == "1"}
-_STREAMS = {}
+_FUSED = {"enabled": True, "paired": True}
 
 
 _PREFIX_IDX = {}
+_PREFIX_PINNED = set()        # keys whose tensor a captured HIP graph may hold the address of: never evicted
+_PREFIX_MAX = 64              # other entries (B * npoint int32 each): oldest first out beyond this many
 
 
 def _prefix_idx(B, npoint, dev):
@@ -37,19 +37,17 @@ def _prefix_idx(B, npoint, dev):
     READ-ONLY for the callers (tests/test_fused_gpu.py::test_prefix_indices_are_shared_and_intact)."""
     key = (B, npoint, str(dev))
     t = _PREFIX_IDX.get(key)
+    capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
     if t is None:
-        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+        if capturing:
             return torch.arange(npoint, dtype=torch.int32, device=dev).repeat(B, 1)      # not cached: graph-pool memory
-        # never evicted (an entry is B * npoint int32): a captured HIP graph may hold the tensor's address
         t = _PREFIX_IDX[key] = torch.arange(npoint, dtype=torch.int32, device=dev).repeat(B, 1)
+        if len(_PREFIX_IDX) > _PREFIX_MAX:       # bounded (inference with varying batch sizes would grow it for ever)
+            for old in [k for k in _PREFIX_IDX if k not in _PREFIX_PINNED and k != key][:len(_PREFIX_IDX) - _PREFIX_MAX]:
+                del _PREFIX_IDX[old]
+    elif capturing:
+        _PREFIX_PINNED.add(key)                  # the graph being captured reads this very tensor on every replay
     return t
-
-
-def _fps_stream(dev):
-    key = str(dev)
-    if key not in _STREAMS:
-        _STREAMS[key] = torch.cuda.Stream(device=dev)
-    return _STREAMS[key]
 
 
 def set_fused(enabled):
@@ -62,7 +60,8 @@ def fused_enabled():
 
 
 def set_paired(enabled):
-    """Run the template and the search branch of a shared backbone as one set of launches (default on)."""
+    """Run the template and the search branch of a shared backbone as one set of launches (default on; off = two module
+    calls, what tests/test_fused_gpu.py::test_paired_backbone_matches_sequential compares against)."""
     _FUSED["paired"] = bool(enabled)
 
 
@@ -127,18 +126,6 @@ class _PointnetSAModuleBase(nn.Module):
                     idx_a, idx_b = sample_idxs
                     new_a = pointnet2_utils.gather_xyz(xyz_a, idx_a)
                     new_b = pointnet2_utils.gather_xyz(xyz_b, idx_b)
-                elif self.use_fps and _FUSED["fps_streams"]:
-                    # the two farthest-point samplings are one workgroup per cloud each (48 of 256 CUs busy): b's on a
-                    # second stream beside a's.  OFF by default (O3D_FPS_STREAMS=1): measured on the MI355X the fork /
-                    # join inside the HIP graph costs more than the 0.09 ms overlap gains (8.54 vs 8.22 ms per step)
-                    main, side = torch.cuda.current_stream(), _fps_stream(xyz_b.device)
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
-                        idx_b, new_b = self._sample(xyz_b, npoint_b)
-                    idx_a, new_a = self._sample(xyz_a, npoint_a)
-                    main.wait_stream(side)
-                    idx_b.record_stream(main)
-                    new_b.record_stream(main)
                 elif self.use_fps:       # both farthest-point samplings in one launch (one wave per cloud each)
                     idx_a, idx_b = pointnet2_utils.furthest_point_sample_pair(xyz_a, npoint_a, xyz_b, npoint_b)
                     new_a = pointnet2_utils.gather_xyz(xyz_a, idx_a)

@@ -223,7 +223,7 @@ class BAT(MatchingBaseModel):
         template_feature, search_feature = pt_utils.pointwise_conv1d_pair(self.conv_final, template_feature, search_feature)
         pred_search_bc = pt_utils.seq_apply(self.mlp_bc, [search_xyz.transpose(1, 2), search_feature])
         pred_search_bc = pred_search_bc.transpose(1, 2)                                    # (B,N/8,9)
-        if fused._GLUE_TRIM["on"] and pred_search_bc.is_cuda:
+        if pred_search_bc.is_cuda:
             # its two consumers on the device (the kNN kernel and the fused loss) both want it point-major and dense: one
             # copy here instead of one in each
             pred_search_bc = pred_search_bc.contiguous()

@@ -581,22 +581,21 @@ def test_reduce_gather_matches_atomic_reduce_paired(kind, B, full):
         assert l2rel(a, b) < (1e-5 if B <= 4 else 5e-5), l2rel(a, b)
 
 
-def test_slotwise_fallback_path_matches_fp64():
-    """the slot-per-neighbour layout (used when the compact layout does not apply: nsample > 64 or more than
-    65536 balls) stays correct: same SA block, compact layout switched off"""
+def test_shapes_outside_the_compact_layout_run_operator_by_operator():
+    """what the distinct-neighbour layout does not take (here nsample = 128 > 64; likewise channel counts that are no
+    multiple of 64) runs the reference's own sequence -- ball query, grouping_operation, SharedMLP, max-pool -- on the
+    library's index operators and torch's convolutions (fused._composed): still correct against fp64, and NOT on a
+    fused kernel (round 4 retired the slot-per-neighbour fused path that used to sit in between)"""
     import copy
-    from open3dsot_amd import fused
+    from open3dsot_amd import fused, ops
     grouper, mlp, xyz, new_xyz, feats = make_case("sa2", train=True)
+    grouper = ops.QueryAndGroup(0.5, 128, use_xyz=True)
     mlp_ref = copy.deepcopy(mlp)
     f = feats.clone().requires_grad_(True)
     idx = grouper.query(xyz, new_xyz)
     ref64, l64, b64 = shadow64(mlp_ref, xyz, new_xyz, feats, idx, True)
-    fused.set_compact(False)
-    try:
-        out = fused.sa_group_mlp_pool(grouper, mlp, xyz, new_xyz, f)
-    finally:
-        fused.set_compact(True)
-    assert out.grad_fn.name().startswith("FusedGroupedMLPBackward")
+    out = fused.sa_group_mlp_pool(grouper, mlp, xyz, new_xyz, f)
+    assert "FusedGroupedMLP" not in out.grad_fn.name()
     assert rel(out, ref64) < 2e-5
     go = torch.randn(out.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
     out.backward(go)
@@ -651,69 +650,6 @@ def test_fused_full_size_layer_properties():
     out.backward(2 * g1)
     for a, p in zip(w, mlp.parameters()):
         assert rel(p.grad, 2 * a) < 1e-5
-
-
-@pytest.mark.parametrize("N,npoint,ns,C0,nxyz", [(256, 128, 32, 64, 3), (100, 64, 16, 40, 3), (64, 128, 4, 32, 0)])
-def test_group_layer0_kernels(lib, N, npoint, ns, C0, nxyz):
-    """csrc/group.hip against torch gathers/scatters: expand (Y0, statistics partials, per-ball sums),
-    list/ball reductions, the point counts / centre sums, and the affine recombination."""
-    g = torch.Generator(device="cuda").manual_seed(N + ns)
-    B, P, ld = 3, npoint * ns, -(-N // 128) * 128
-    idx = torch.randint(0, N, (B, npoint, ns), device="cuda", generator=g).int()
-    idx[:, :, ns // 2:] = idx[:, :, :1]                      # ball padding: repeated first hit
-    Z = torch.randn(B, C0, ld, device="cuda", generator=g)
-    W0 = torch.randn(C0, 5 + nxyz, device="cuda", generator=g)
-    new_xyz = torch.randn(B, npoint, 3, device="cuda", generator=g) if nxyz else None
-    c = torch.randn(C0, device="cuda", generator=g) * 0.1
-    Y0 = torch.empty(B, C0, P, device="cuda")
-    part = torch.empty(B * P // 256, 2, C0, device="cuda")
-    GY = torch.empty(B, C0, npoint, device="cuda")
-    ptr = lambda t: t.data_ptr() if t is not None else None
-    assert lib.o3d_group_expand_fwd(Z.data_ptr(), ld, idx.data_ptr(), ptr(new_xyz), W0.data_ptr(), W0.shape[1], B, C0,
-                                    npoint, ns, Y0.data_ptr(), part.data_ptr(), c.data_ptr(), GY.data_ptr(), st()) == 0
-    flat = idx.long().reshape(B, 1, P).expand(B, C0, P)
-    ref = Z.double().gather(2, flat)
-    if nxyz:
-        cc = torch.einsum("ck,bjk->bcj", W0[:, :3].double(), new_xyz.double())
-        ref = ref - cc.repeat_interleave(ns, dim=2)
-    assert rel(Y0, ref) < 1e-6
-    assert rel(GY, ref.reshape(B, C0, npoint, ns).sum(3)) < 1e-5
-    assert rel(part[:, 0].double().sum(0), ref.sum((0, 2))) < 1e-5
-    assert rel(part[:, 1].double().sum(0), ((ref - c.double()[None, :, None]) ** 2).sum((0, 2))) < 1e-5
-    # counts and centre sums
-    cnt = torch.empty(B, ld, device="cuda")
-    R = torch.empty(B, ld, 3, device="cuda") if nxyz else None
-    assert lib.o3d_group_meta(idx.data_ptr(), ptr(new_xyz), B, N, ld, npoint, ns, cnt.data_ptr(), ptr(R), st()) == 0
-    cnt_ref = torch.zeros(B, ld, device="cuda", dtype=torch.float64).scatter_add_(
-        1, idx.long().reshape(B, P), torch.ones(B, P, device="cuda", dtype=torch.float64))
-    assert torch.equal(cnt.double(), cnt_ref)
-    if nxyz:
-        R_ref = torch.zeros(B, ld, 3, device="cuda", dtype=torch.float64).scatter_add_(
-            1, idx.long().reshape(B, P, 1).expand(B, P, 3), new_xyz.double().repeat_interleave(ns, dim=1))
-        assert rel(R, R_ref) < 1e-5
-    # reductions of a dense gradient
-    dN = torch.randn(B, C0, P, device="cuda", generator=g)
-    S = torch.empty(B, C0, ld, device="cuda")
-    T = torch.empty(B, C0, npoint, device="cuda")
-    cnt2 = torch.empty(B, ld, device="cuda")
-    R2 = torch.empty(B, ld, 3, device="cuda") if nxyz else None
-    assert lib.o3d_group_reduce_bwd(dN.data_ptr(), idx.data_ptr(), B, C0, ld, npoint, ns, S.data_ptr(), T.data_ptr(),
-                                    ptr(new_xyz), cnt2.data_ptr(), ptr(R2), st()) == 0
-    assert torch.equal(cnt2, cnt)           # the same pass also yields the index-only quantities
-    if nxyz:
-        assert rel(R2, R_ref) < 1e-5
-    S_ref = torch.zeros(B, C0, ld, device="cuda", dtype=torch.float64).scatter_add_(2, flat, dN.double())
-    T_ref = dN.double().reshape(B, C0, npoint, ns).sum(3)
-    assert rel(S, S_ref) < 1e-5 and rel(T, T_ref) < 1e-5
-    # S = sum over lists of dY0, dY0 = A1*dN + A2*Y0 + A3
-    A1, A2, A3 = (torch.randn(C0, device="cuda", generator=g) for _ in range(3))
-    dY = A1.double()[None, :, None] * dN.double() + A2.double()[None, :, None] * ref + A3.double()[None, :, None]
-    assert lib.o3d_group_bwd_combine(S.data_ptr(), T.data_ptr() if nxyz else None, Z.data_ptr(), GY.data_ptr(), cnt.data_ptr(),
-                                     ptr(R), W0.data_ptr(), W0.shape[1], A1.data_ptr(), A2.data_ptr(), A3.data_ptr(), B, C0, ld,
-                                     npoint, ns, st()) == 0
-    assert rel(S, torch.zeros(B, C0, ld, device="cuda", dtype=torch.float64).scatter_add_(2, flat, dY)) < 2e-5
-    if nxyz:
-        assert rel(T, dY.reshape(B, C0, npoint, ns).sum(3)) < 2e-5
 
 
 @pytest.mark.parametrize("ns", [4, 16, 32])
@@ -821,47 +757,6 @@ def test_fused_path_on_a_non_current_device():
     assert torch.cuda.current_device() == 0
     got = fused.sa_group_mlp_pool(grouper, mlp1, xyz.to(dev1), new_xyz.to(dev1), feats.to(dev1))
     assert got.device == dev1 and rel(got, want) < 1e-6
-
-
-@pytest.mark.parametrize("kind,B,full", [("sa1", 3, False), ("sa2", 3, False), ("sa3", 3, False), ("rpn", 3, False),
-                                         ("sa1", 48, True), ("sa3", 48, True)])
-def test_pooled_pairs_match_dense_pooled_gradient(kind, B, full):
-    """the pooled layer's gradient gathered from {gradient, arg-max column} pairs per (channel, ball)
-    (o3d_pool_bwd_pk + o3d_mlp_conv_dgrad_cp / o3d_mlp_conv_wgrad2_cp) against the dense (C, live columns) tensor
-    (zero fill + scatter, o3d_pool_bwd_c): the same terms in the same order -> bitwise equal gradients, through the
-    two-segment (template + search) call"""
-    import copy
-    from open3dsot_amd import fused
-    grouper, mlp, xyz_s, new_s, feats_s = make_case(kind, B=B, full=full)
-    N, npoint = xyz_s.shape[1], new_s.shape[1]
-    xyz_t = (xyz_s[:, :N // 2, :] * 0.9 + 0.05).contiguous()
-    new_t = xyz_t[:, :npoint // 2, :].contiguous()
-    feats_t = torch.randn(feats_s.shape[0], feats_s.shape[1], N // 2, device="cuda") if feats_s is not None else None
-    grads = []
-    was, was_rg, was_fb = fused._POOLED_PK["on"], fused.reduce_gather_enabled(), fused._FUSED_BWD["max_cout"]
-    fused.set_reduce_gather(False)          # (the LDS-atomic orders of the layer-0 reduce differ run to run either way)
-    # the dense side on the unfused data / weight gradient pair, whose summation order the pair-gathering kernels share:
-    # the one-kernel backward that takes a dense 64 -> 128 pooled layer by default sums in its own order
-    fused._FUSED_BWD["max_cout"] = 64
-    try:
-        for pk in (False, True):
-            fused.set_pooled_pk(pk)
-            m = copy.deepcopy(mlp)
-            segs = [[t.clone().requires_grad_(True) if t is not None else None for t in sg]
-                    for sg in ((xyz_t, new_t, feats_t), (xyz_s, new_s, feats_s))]
-            outs = fused.sa_group_mlp_pool_pair(grouper, m, tuple(segs[0]), tuple(segs[1]))
-            gen = torch.Generator(device="cuda").manual_seed(4)
-            torch.autograd.backward(list(outs), [torch.randn(o.shape, device="cuda", generator=gen) for o in outs])
-            grads.append([(n1, p.grad) for n1, p in m.named_parameters()])
-    finally:
-        fused.set_pooled_pk(was)
-        fused.set_reduce_gather(was_rg)
-        fused._FUSED_BWD["max_cout"] = was_fb
-    for (n1, a), (_, b) in zip(*grads):
-        if n1.startswith("layer0"):        # behind the atomic layer-0 reduce: equal up to its summation order
-            assert l2rel(a, b) < 5e-5, (n1, l2rel(a, b))
-        else:
-            assert torch.equal(a, b), (n1, l2rel(a, b))
 
 
 @pytest.mark.parametrize("kind", ["sa1", "sa2", "sa3", "rpn"])

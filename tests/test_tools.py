@@ -83,7 +83,7 @@ def test_batch_counter_increments_are_merged_into_one_update():
     finally:
         torch._foreach_add_ = real
     assert [int(bn.num_batches_tracked) for bn in bns] == [1, 2, 2, 0]
-    assert calls == [3] or not fused._GLUE_TRIM["on"]
+    assert calls == [3]
     fused.count_batches(bns[3:], 1)                         # outside a scope: applied at once
     assert int(bns[3].num_batches_tracked) == 1
     fused.counters_end()                                    # nothing pending: a no-op

@@ -4,7 +4,7 @@ import re
 import sys
 
 # first match wins: (substring of the kernel name, family)
-FAMILIES = [("direct_gemm_pair", "GEMM pair launches (two stacks side by side)"), ("direct_gemm_kernel", "GEMM forward / data gradient (direct_gemm)"),
+FAMILIES = [("splitk_gemm", "GEMM forward / data gradient, split-K tile (small launches)"), ("direct_gemm_pair", "GEMM pair launches (two stacks side by side)"), ("direct_gemm_kernel", "GEMM forward / data gradient (direct_gemm)"),
             ("wgrad2_group", "weight gradients, grouped launches"), ("wgrad2_kernel", "weight gradients (wgrad2)"),
             ("fused_bwd", "data + weight gradient in one kernel (fused_bwd)"), ("wgrad_reduce", "weight-gradient slice reductions"),
             ("dw0", "SA level 0 dW0 from the columns"), ("conv_", "LDS-staged GEMMs (unaligned layers)"),
