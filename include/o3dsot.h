@@ -521,6 +521,23 @@ int o3d_cosine_sim_bwd(const float* dsim, const float* sim, const float* tn, con
                        long tsn, const float* s, long ssb, long ssc, long ssn, int B, int f, int M, int N, float* dt, float* ds,
                        void* stream);
 
+/* ---- Linear (+ BatchNorm1d over the rows) (+ ReLU) on R <= 64 rows: the heads of M2-Track (models/m2track.py:43-71) and
+ * the hidden rows of MiniPointNet (models/backbone/pointnet.py:118-126), one launch per layer each way (csrc/rowmlp.hip).
+ * Forward: Y (R, Cout) = act(bn(X (R, Cin; row stride ldx) . W^T (Cout, Cin) + bias)); gamma == NULL: no BatchNorm;
+ * training: batch statistics over the rows (biased variance), running statistics updated with `momentum` (unbiased
+ * variance), else the running statistics.  Z (R, Cout) = the pre-BatchNorm output, mean / invstd (Cout) = the constants the
+ * normalisation used: kept for the backward (any may be NULL).
+ * Backward of one layer: gradient of the layer's OUTPUT = dY (R, C; row stride lddy) or, dY == NULL, dZup (R, Cup) . Wup
+ * (Cup, C) (the layer above, computed on the spot); -> dZ (R, C) gradient of the pre-BatchNorm output, dW (C, Cin), db (C),
+ * dgamma / dbeta (C).  input_mode != 0: only the product, stored to dX (R, C; row stride lddx): the stack's input gradient. */
+int o3d_row_mlp_fwd(const float* X, int ldx, const float* W, const float* bias, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps, int training, int relu, int R, int Cin,
+                    int Cout, float* Z, float* Y, float* mean, float* invstd, void* stream);
+int o3d_row_mlp_bwd(const float* dY, int lddy, const float* dZup, const float* Wup, int Cup, int input_mode, float* dX, int lddx,
+                    const float* Z, const float* gamma, const float* beta, const float* mean, const float* invstd, int training,
+                    int relu, const float* X, int ldx, int R, int Cin, int C, float* dZ, float* dW, float* db, float* dgamma,
+                    float* dbeta, void* stream);
+
 /* ---- tracker losses (next row of SURVEY.md section 8f: the loss as one launch) ----------------------
  * MatchingBaseModel.compute_loss (models/base_model.py:122-164) + the BoxCloud term (models/bat.py:57-65)
  * + the weighted total (models/bat.py:131-137, models/p2b.py:69-74) and the gradients of the total.

@@ -163,8 +163,8 @@ class MiniPointNet(nn.Module):
         if nn_blocks._FLAT["on"]:
             mods = list(self.features)
             x = _pointwise_chain(x, _triples(mods[:self._n_point]), pool=True)
-            for m in mods[self._n_point + 2:]:
-                x = m(x)
+            from . import fused_rows
+            x = fused_rows.seq_rows(mods[self._n_point + 2:], x)     # Linear -> BatchNorm1d -> ReLU rows: one launch each
         else:
             x = self.features(x)
         return self.fc(x) if self.output_size > 0 else x

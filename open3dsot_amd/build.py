@@ -23,6 +23,7 @@ SOURCES = [
     ("compact.hip", []),
     ("pointwise.hip", []),
     ("heads.hip", []),
+    ("rowmlp.hip", []),
     ("xcorr.hip", []),
     ("sa_eval.hip", []),
     ("loss.hip", []),

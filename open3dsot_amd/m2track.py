@@ -96,16 +96,17 @@ class M2TRACK(nn.Module):
             mask_pred_bc = pred_bc * pred_cls
             mask_points = torch.cat([mask_points, mask_pred_bc], dim=1)
             out["pred_bc"] = pred_bc.transpose(1, 2)
+        from .fused_rows import seq_rows      # the heads' Linear -> BatchNorm1d -> ReLU rows: one launch per layer on the GPU
         point_feature = self.mini_pointnet(mask_points)
-        motion_pred = self.motion_mlp(point_feature)                               # (B,4)
+        motion_pred = seq_rows(self.motion_mlp, point_feature)                     # (B,4)
         if self.use_motion_cls:
-            logits = self.motion_state_mlp(point_feature)
+            logits = seq_rows(self.motion_state_mlp, point_feature)
             motion_pred_masked = motion_pred * torch.argmax(logits, dim=1, keepdim=True)
             out["motion_cls"] = logits
         else:
             motion_pred_masked = motion_pred
         if self.use_prev_refinement:
-            prev_boxes = self.final_mlp(point_feature)
+            prev_boxes = seq_rows(self.final_mlp, point_feature)
             out["estimation_boxes_prev"] = prev_boxes[:, :4] if prev_boxes.shape[1] != 4 else prev_boxes
         else:
             prev_boxes = torch.zeros_like(motion_pred)
@@ -117,7 +118,7 @@ class M2TRACK(nn.Module):
             merged = box_utils.remove_transform_points_tensor(merged.transpose(1, 2), aux_box).transpose(1, 2)
             if self.box_aware:
                 merged = torch.cat([merged, mask_pred_bc], dim=1)
-            offset = self.box_mlp(self.mini_pointnet2(merged))
+            offset = seq_rows(self.box_mlp, self.mini_pointnet2(merged))
             out["estimation_boxes"] = box_utils.get_offset_box_tensor(aux_box, offset)
         else:
             out["estimation_boxes"] = aux_box

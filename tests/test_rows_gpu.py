@@ -1,0 +1,100 @@
+"""GPU parity of the row stacks (open3dsot_amd/fused_rows.py on csrc/rowmlp.hip) against the nn.Sequential they are,
+evaluated by torch in fp64: the heads of M2-Track (models/m2track.py:43-71) and the hidden rows of MiniPointNet
+(models/backbone/pointnet.py:118-126).  Forward 1e-5 of the tensor scale, gradients 1e-4 L2, running statistics 1e-6."""
+import copy
+
+import pytest
+import torch
+from torch import nn
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def l2rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def build(kind, seed):
+    from open3dsot_amd.nn_blocks import RowBatchNorm1d
+    torch.manual_seed(seed)
+    if kind == "head4":
+        seq = nn.Sequential(nn.Linear(256, 128), RowBatchNorm1d(128), nn.ReLU(), nn.Linear(128, 128), RowBatchNorm1d(128), nn.ReLU(),
+                            nn.Linear(128, 4))
+        cin = 256
+    elif kind == "hidden":
+        seq = nn.Sequential(nn.Linear(512, 512), RowBatchNorm1d(512), nn.ReLU(), nn.Linear(512, 256), RowBatchNorm1d(256), nn.ReLU())
+        cin = 512
+    else:       # odd widths: partial feature slices, unaligned K
+        seq = nn.Sequential(nn.Linear(70, 40), RowBatchNorm1d(40), nn.ReLU(), nn.Linear(40, 9))
+        cin = 70
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for m in seq.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                m.weight.copy_(torch.empty(m.weight.shape).uniform_(0.5, 1.5, generator=g))
+                m.bias.copy_(torch.empty(m.bias.shape).normal_(0, 0.2, generator=g))
+                m.running_mean.copy_(torch.empty(m.bias.shape).normal_(0, 0.2, generator=g))
+                m.running_var.copy_(torch.empty(m.bias.shape).uniform_(0.5, 1.5, generator=g))
+    return seq, cin
+
+
+@pytest.mark.parametrize("kind", ["head4", "hidden", "odd"])
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("R", [48, 64, 5])
+def test_row_stack_vs_fp64(kind, train, R):
+    from open3dsot_amd import fused_rows
+    seq, cin = build(kind, 3)
+    ref = copy.deepcopy(seq).double().train(train)
+    seq = seq.cuda().train(train)
+    g = torch.Generator().manual_seed(R)
+    x = torch.randn(R, cin, generator=g)
+    xg = x.cuda().requires_grad_(True)
+    xr = x.double().requires_grad_(True)
+    layers = fused_rows.parse(seq)
+    assert fused_rows.supported(layers, xg)
+    out = fused_rows.seq_rows(seq, xg)
+    assert out.grad_fn is not None and "RowStack" in out.grad_fn.name()
+    want = ref(xr)
+    assert rel(out, want) < 1e-5, rel(out, want)
+    ct = torch.randn(out.shape, generator=g)
+    (out * ct.cuda()).sum().backward()
+    (want * ct.double()).sum().backward()
+    assert l2rel(xg.grad, xr.grad) < 1e-4, l2rel(xg.grad, xr.grad)
+    for (n1, p), (_, q) in zip(seq.named_parameters(), ref.named_parameters()):
+        scale = float(q.grad.abs().max())
+        if scale < 1e-9:                # a bias in front of a training-mode BatchNorm: its true gradient is zero
+            assert float(p.grad.abs().max()) < 1e-4, n1
+            continue
+        assert l2rel(p.grad, q.grad) < 1e-4, (n1, l2rel(p.grad, q.grad))
+    for (n1, b1), (_, b2) in zip(seq.named_buffers(), ref.named_buffers()):
+        if b1.dtype.is_floating_point:
+            assert rel(b1, b2) < 1e-6, n1
+        else:
+            assert int(b1) == int(b2), n1           # num_batches_tracked
+
+
+def test_row_stack_takes_strided_rows_and_falls_back_beyond_64_rows():
+    from open3dsot_amd import fused_rows
+    seq, cin = build("head4", 5)
+    seq = seq.cuda().train()
+    wide = torch.randn(48, cin + 8, device="cuda")
+    x = wide[:, 4:4 + cin]                       # rows with a stride larger than their length
+    a = fused_rows.seq_rows(seq, x)
+    twin = copy.deepcopy(seq)
+    # (the twin's running statistics start where seq's were BEFORE the call above: restore them for the comparison)
+    b = seq_ref_forward(twin, x.contiguous())
+    assert rel(a, b) < 1e-5
+    big = torch.randn(65, cin, device="cuda")
+    out = fused_rows.seq_rows(seq, big)
+    assert "RowStack" not in (out.grad_fn.name() if out.grad_fn is not None else "")
+
+
+def seq_ref_forward(seq, x):
+    ref = copy.deepcopy(seq).double()
+    return ref(x.double())

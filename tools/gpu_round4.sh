@@ -48,7 +48,7 @@ if has trace; then
   timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_graph -o bench -- python $REPO/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/rocprof_graph.log 2>&1; echo "trace graph exit $?"
   cd $REPO
   G=$(find $OUT/trace_graph -name "*kernel_trace.csv" | head -1); [ -n "$G" ] && python tools/trace_steps.py "$G" 20 100 > $OUT/steady_state_per_step.txt
-  [ -n "$G" ] && python tools/trace_families.py "$G" 20 > $OUT/steady_state_families.txt 2>/dev/null
+  [ -n "$G" ] && python tools/trace_families.py $OUT/steady_state_per_step.txt > $OUT/steady_state_families.txt 2>/dev/null
   rm -rf $OUT/trace_graph
   head -4 $OUT/steady_state_per_step.txt | cut -c1-200
 fi
@@ -58,7 +58,7 @@ for p in $PARTS; do case "$p" in m:*)
   timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_$ML -o bench -- python $REPO/bench.py --model $M --steps 40 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/rocprof_$ML.log 2>&1; echo "trace $M exit $?"
   cd $REPO
   G=$(find $OUT/trace_$ML -name "*kernel_trace.csv" | head -1); [ -n "$G" ] && python tools/trace_steps.py "$G" 20 100 > $OUT/steady_state_per_step_$ML.txt
-  [ -n "$G" ] && python tools/trace_families.py "$G" 20 > $OUT/steady_state_families_$ML.txt 2>/dev/null
+  [ -n "$G" ] && python tools/trace_families.py $OUT/steady_state_per_step_$ML.txt > $OUT/steady_state_families_$ML.txt 2>/dev/null
   rm -rf $OUT/trace_$ML
   head -3 $OUT/steady_state_per_step_$ML.txt | cut -c1-200
   timeout 300 python bench.py --model $M --no-cpu-baseline --no-secondary --per-launch $OUT/per_launch_roofline_$ML.txt > $OUT/bench_$ML.json 2> $OUT/bench_$ML.err; echo "bench $M exit $?" ;;
