@@ -418,7 +418,15 @@ def measure(args, rank, local_rank, world, full=True):
     barrier()
     elapsed = time.perf_counter() - t0
     log("timed %d steps: %.3f s" % (args.steps, elapsed))
+    multi = None
     if world > 1:
+        # self-checks of the multi-GPU run (the driver computes the scaling efficiency itself; these only say whether the
+        # run was the run it claims to be): every rank's own rate, and how far the replicas' parameters are apart after
+        # the timed steps -- identical gradients after the all-reduce and the same Adam update must leave them bitwise equal
+        try:
+            multi = D.replica_self_check(model, trainer, elapsed, args.batch * args.steps)
+        except Exception as e:       # a diagnostic must never take the bench line down
+            multi = {"self_check_error": "%s: %s" % (type(e).__name__, e)}
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -515,6 +523,8 @@ def measure(args, rank, local_rank, world, full=True):
         if full and not args.no_cpu_baseline and world == 1 and args.search_size == 1024:
             line["cpu_baseline"] = cpu_baseline(args.model, sd_cpu, args.batch, args.cpu_budget)
         line["config"]["rccl_world_size"] = dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1
+        if multi is not None:
+            line["config"].update(multi)
         return line
     return {}
 

@@ -336,3 +336,22 @@ class DataParallelStep:
         if self.world > 1:
             for b in self.model.buffers():
                 dist.broadcast(b.data, src=0)
+
+
+def replica_self_check(model, trainer, elapsed_s, pairs_per_rank):
+    """Collective (every rank must call it): what a multi-GPU bench run can say about itself -- each rank's own rate and how
+    far the replicas' parameters are apart after the timed steps (identical gradients after the all-reduce and the same Adam
+    update must leave them bitwise equal: anything else is a broken exchange).  -> dict for the bench line's `config`."""
+    world = dist.get_world_size()
+    first = next(model.parameters())
+    mine = torch.tensor([elapsed_s], device=first.device, dtype=torch.float64)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(every, mine)
+    flat = torch.cat([p.detach().reshape(-1).float() for p in model.parameters()])
+    hi, lo = flat.clone(), flat.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return {"per_rank_pairs_per_s": [round(pairs_per_rank / max(float(t.item()), 1e-12), 1) for t in every],
+            "max_parameter_divergence": float((hi - lo).abs().max().item()),
+            "gradient_exchange": "one flat %.2f MB all_reduce per step (%s), outside the captured graph" % (
+                trainer.grads.flat.numel() * trainer.grads.flat.element_size() / 1e6, dist.get_backend())}

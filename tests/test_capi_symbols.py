@@ -80,7 +80,7 @@ def header_prototypes():
 def test_ctypes_signatures_match_the_header():
     """every argtypes list registered by the Python binding has the arity and the argument kinds of its
     prototype in include/o3dsot.h (a silent ctypes mismatch corrupts arguments instead of failing)"""
-    from open3dsot_amd import capi, fused, fused_heads, fused_loss, fused_pointwise, points_utils  # noqa: F401  (they register)
+    from open3dsot_amd import capi, fused, fused_heads, fused_loss, fused_pointwise, fused_rows, fused_xcorr, optim, points_utils  # noqa: F401  (they register)
     protos = header_prototypes()
     kind = {ctypes.c_void_p: "p", ctypes.c_int: "i", ctypes.c_long: "l", ctypes.c_float: "f", ctypes.c_double: "d"}
     assert len(capi.SIGNATURES) >= 40

@@ -56,6 +56,12 @@ def _worker(rank, world, port, out):
         first, n = D.shard_indices(step, r, w, 8)
         trainer.step(_data(first, n))
     torch.save({k: v.clone() for k, v in model.state_dict().items()}, os.path.join(out, "rank%d.pt" % rank))
+    # bench.py's multi-GPU self-check (collective): replicas identical -> divergence exactly 0, one rate per rank
+    chk = D.replica_self_check(model, trainer, 0.5 + rank, 3 * 8)
+    with torch.no_grad():
+        next(model.parameters()).add_(0.25 * rank)          # ... and a broken exchange would show
+    chk2 = D.replica_self_check(model, trainer, 1.0, 24)
+    torch.save({"ok": chk, "broken": chk2}, os.path.join(out, "check%d.pt" % rank))
     torch.distributed.destroy_process_group()
 
 
@@ -64,6 +70,10 @@ def test_two_rank_gloo_matches_manual_average(tmp_path):
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     s0 = torch.load(tmp_path / "rank0.pt")
     s1 = torch.load(tmp_path / "rank1.pt")
+    for r in (0, 1):
+        c = torch.load(tmp_path / ("check%d.pt" % r))
+        assert c["ok"]["max_parameter_divergence"] == 0.0 and c["ok"]["per_rank_pairs_per_s"] == [48.0, 16.0], c["ok"]
+        assert abs(c["broken"]["max_parameter_divergence"] - 0.25) < 1e-6 and "all_reduce" in c["ok"]["gradient_exchange"]
     for k in s0:
         if "running" in k or "num_batches" in k:
             continue  # BatchNorm statistics are per-rank by design (no sync-BN in the reference)
