@@ -307,6 +307,10 @@ int o3d_center_term(const float* T, const float* centers, int C0, int nballs, in
 int o3d_center_term_out(const float* T, const float* centers, int C0, int nballs, int ldw, const float* dW, int ncols,
                         float* out, void* stream);
 
+/* Gradient of the ball centres: out (3, nballs)[k, ball] = scale * sum_c W0[c, k] * T[c, ball] (grouped_xyz = xyz[idx] -
+ * new_xyz, pointnet2_utils.py:319-320; live where the centres carry a gradient: the vote aggregation, rpn.py:55-60). */
+int o3d_center_grad(const float* T, const float* W0, int ldw, int C0, int nballs, float scale, float* out, void* stream);
+
 /* Layer-0 backward sums of dY = A1*dN + w*(A2*Y0 + A3): S (C0, point columns) per source point
  * (= group_points_grad, pointnet2_utils.py:237), T (C0, balls) per ball (may be NULL). */
 int o3d_group_reduce_c(const float* dN, const float* Y0, long ldp, const float* A1, const float* A2,

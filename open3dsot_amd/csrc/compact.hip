@@ -1223,6 +1223,36 @@ extern "C" int o3d_center_term_out(const float* T, const float* centers, int C0,
     return o3d_launch_status();
 }
 
+// Gradient of the ball centres (grouped_xyz = xyz[idx] - new_xyz, pointnet2_utils.py:319-320): out (3, nballs)[k, ball] =
+// scale * sum_c W0[c, k] * T[c, ball], T (C0, nballs) = per-ball sums of dY0, W0 (C0, ldw).  Was a torch.addmm (one rocBLAS
+// launch per level whose centres carry a gradient -- the vote aggregation, models/head/rpn.py:55-60 -- and the last vendor-BLAS
+// kernel of the BAT / P2B steps); thread per ball, T read coalesced, the three weight columns broadcast.
+namespace {
+__global__ __launch_bounds__(256) void center_grad_kernel(const float* __restrict__ T, const float* __restrict__ W0, int ldw, int C0,
+                                                          int nballs, float scale, float* __restrict__ out) {
+    const int ball = blockIdx.x * 256 + threadIdx.x;
+    if (ball >= nballs) return;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < C0; ++c) {
+        const float t = T[(long)c * nballs + ball];
+        s0 = fmaf(W0[(long)c * ldw + 0], t, s0);
+        s1 = fmaf(W0[(long)c * ldw + 1], t, s1);
+        s2 = fmaf(W0[(long)c * ldw + 2], t, s2);
+    }
+    out[ball] = scale * s0;
+    out[(long)nballs + ball] = scale * s1;
+    out[2L * nballs + ball] = scale * s2;
+}
+}  // namespace
+
+extern "C" int o3d_center_grad(const float* T, const float* W0, int ldw, int C0, int nballs, float scale, float* out, void* stream) {
+    if (!T || !W0 || !out || C0 <= 0 || nballs <= 0 || ldw < 3) return O3D_EINVAL;
+    hipLaunchKernelGGL(center_grad_kernel, dim3(o3d_cdiv(nballs, 256)), dim3(256), 0, o3d_stream(stream), T, W0, ldw, C0, nballs,
+                       scale, out);
+    return o3d_launch_status();
+}
+
 // X0 (rows, ldz), ldz = B*(ld0 + ld1): rows [0,nxyz) = xyz^T * inv_radius, [nxyz, nxyz+C) = feats, the rest zero;
 // columns of cloud b of segment s: [base_s + b*ld_s, +N_s) live, the padding up to ld_s zero.  xyz_s (B,N_s,3) (NULL
 // when nxyz == 0), feats_s (B,C,N_s) (NULL when C == 0); N1 = 0: one segment.

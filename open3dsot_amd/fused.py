@@ -55,6 +55,7 @@ capi.register("o3d_group_reduce_gather", [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _vp, _vp, _vp])
 capi.register("o3d_pack_points", [_vp, _vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp])
 capi.register("o3d_center_term", [_vp, _vp, _i, _i, _i, _vp, _vp])
+capi.register("o3d_center_grad", [_vp, _vp, _i, _i, _i, _f, _vp, _vp])
 capi.register("o3d_center_term_out", [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp])
 capi.register("o3d_pool_fwd_c", [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_fwd_ct", [_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
@@ -650,8 +651,10 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                     _call("conv_dgrad_points", 2.0 * Cinm * Cout * ldz, lib.o3d_mlp_conv_fwd, S.data_ptr(), W0t.data_ptr(),
                           None, None, 1, Cout, Cinm, ldz, dX.data_ptr(), None, None, st, dims=(Cout, Cinm))
                     dnew_all = None
-                    if want_xyz:      # -inv_radius * W0[:, :3]^T . T as ONE GEMM call (beta = 0: T[:3] is only a shape)
-                        dnew_all = torch.addmm(T[:3], Ws[0][:, :3].t(), T, beta=0.0, alpha=-float(cfg.inv_radius))
+                    if want_xyz:      # -inv_radius * W0[:, :3]^T . T (3, balls): one small launch (was a torch.addmm on rocBLAS)
+                        dnew_all = torch.empty((3, nballs), device=dev, dtype=f32)
+                        _call("center_grad", 0.0, lib.o3d_center_grad, T.data_ptr(), Ws[0].data_ptr(), Ws[0].shape[1], Cout, nballs,
+                              -float(cfg.inv_radius), dnew_all.data_ptr(), st)
                     for s_ in range(nseg):
                         view = dX[:Cin, pt_bases[s_]:pt_bases[s_] + B * Npads[s_]].view(Cin, B, Npads[s_])
                         if want_feats:
