@@ -185,3 +185,84 @@ class PointnetFPModule(nn.Module):
             interpolated = known_feats.expand(*(list(known_feats.size()[0:2]) + [unknown.size(1)]))
         x = interpolated if unknow_feats is None else torch.cat([interpolated, unknow_feats], dim=1)
         return self.mlp(x.unsqueeze(-1)).squeeze(-1)
+
+
+class FlowEmbedding(nn.Module):
+    """FlowNet3D flow embedding: for every point of cloud 1 its `nsample` neighbours in cloud 2, the position differences
+    and both features through a Conv2d-BN-ReLU stack, max over the neighbours.  Mirror of pointnet2_modules.py:215-269 (same
+    constructor, same `mlp_convs` / `mlp_bns` module lists, hence the same state_dict keys); no tracker instantiates it
+    (cold API).  Two defects of the reference are not reproduced: `corr_func is 'concat'` (:227, an
+    identity test on a string) is an equality test here, and with `knn=False` the reference unpacks `idx, cnt` from a
+    `ball_query` that returns ONE tensor (:254, a crash) -- here the ball query is simply used."""
+
+    def __init__(self, radius, nsample, in_channel, mlp, pooling='max', corr_func='concat', knn=True):
+        super().__init__()
+        if corr_func != 'concat':
+            raise ValueError("FlowEmbedding: only corr_func='concat' exists in the reference (pointnet2_modules.py:227,258)")
+        self.radius, self.nsample, self.knn, self.pooling, self.corr_func = radius, nsample, knn, pooling, corr_func
+        self.mlp_convs = nn.ModuleList()
+        self.mlp_bns = nn.ModuleList()
+        last_channel = in_channel * 2 + 3
+        for out_channel in mlp:
+            self.mlp_convs.append(nn.Conv2d(last_channel, out_channel, 1, bias=False))
+            self.mlp_bns.append(nn.BatchNorm2d(out_channel))
+            last_channel = out_channel
+
+    def forward(self, xyz1, xyz2, feature1, feature2):
+        """xyz1, xyz2 (B,N,3), feature1, feature2 (B,C,N) -> xyz1, (B, mlp[-1], N)"""
+        B, N, _ = xyz1.shape
+        xyz1_t = xyz1.permute(0, 2, 1).contiguous()
+        xyz2_t = xyz2.permute(0, 2, 1).contiguous()
+        if self.knn:
+            idx = pointnet2_utils.knn_point(self.nsample, xyz1, xyz2)
+        else:
+            idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz2.contiguous(), xyz1.contiguous())
+        pos_diff = pointnet2_utils.grouping_operation(xyz2_t, idx) - xyz1_t.view(B, -1, N, 1)
+        feat2_grouped = pointnet2_utils.grouping_operation(feature2.contiguous(), idx)
+        x = torch.cat([pos_diff, feat2_grouped, feature1.view(B, -1, N, 1).repeat(1, 1, 1, self.nsample)], dim=1)
+        for conv, bn in zip(self.mlp_convs, self.mlp_bns):
+            x = F.relu(bn(conv(x)))
+        return xyz1, torch.max(x, -1)[0]
+
+
+class PointNetSetUpConv(nn.Module):
+    """FlowNet3D set up-convolution: features of the sparser cloud 2 gathered around every point of cloud 1 (kNN or ball
+    query), a Conv2d-BN-ReLU stack over [feature2 ; position difference], max over the neighbours, the skip features of
+    cloud 1 concatenated, a Conv1d-BN-ReLU stack.  Mirror of pointnet2_modules.py:272-334 (same `mlp1_convs` / `mlp2_convs`
+    Sequentials, same state_dict keys); cold API.  `knn=False`: see FlowEmbedding (the reference's unpacking crash, :311)."""
+
+    def __init__(self, nsample, radius, f1_channel, f2_channel, mlp, mlp2, knn=True):
+        super().__init__()
+        self.nsample, self.radius, self.knn = nsample, radius, knn
+        self.mlp1_convs = nn.ModuleList()
+        self.mlp2_convs = nn.ModuleList()
+        last_channel = f2_channel + 3
+        for out_channel in mlp:
+            self.mlp1_convs.append(nn.Sequential(nn.Conv2d(last_channel, out_channel, 1, bias=False),
+                                                 nn.BatchNorm2d(out_channel), nn.ReLU(inplace=False)))
+            last_channel = out_channel
+        last_channel = (mlp[-1] if len(mlp) != 0 else last_channel) + f1_channel
+        for out_channel in mlp2:
+            self.mlp2_convs.append(nn.Sequential(nn.Conv1d(last_channel, out_channel, 1, bias=False),
+                                                 nn.BatchNorm1d(out_channel), nn.ReLU(inplace=False)))
+            last_channel = out_channel
+
+    def forward(self, xyz1, xyz2, feature1, feature2):
+        """xyz1 (B,N1,3) (more points), xyz2 (B,N2,3), feature1 (B,C1,N1) | None, feature2 (B,C2,N2) -> (B, C_out, N1)"""
+        xyz1_t = xyz1.permute(0, 2, 1).contiguous()
+        xyz2_t = xyz2.permute(0, 2, 1).contiguous()
+        B, _, N = xyz1_t.shape
+        if self.knn:
+            idx = pointnet2_utils.knn_point(self.nsample, xyz1, xyz2)
+        else:
+            idx = pointnet2_utils.ball_query(self.radius, self.nsample, xyz2.contiguous(), xyz1.contiguous())
+        pos_diff = pointnet2_utils.grouping_operation(xyz2_t, idx) - xyz1_t.view(B, -1, N, 1)
+        x = torch.cat([pointnet2_utils.grouping_operation(feature2.contiguous(), idx), pos_diff], dim=1)
+        for conv in self.mlp1_convs:
+            x = conv(x)
+        x = x.max(-1)[0]
+        if feature1 is not None:
+            x = torch.cat([x, feature1], dim=1)
+        for conv in self.mlp2_convs:
+            x = conv(x)
+        return x
