@@ -552,6 +552,20 @@ int o3d_track_loss(const float* cla, const float* seg, const float* vote, const 
                    int N, int P, int K, float w_obj, float w_box, float w_seg, float w_vote, float w_bc,
                    float* scratch, float* losses, float* g_cla, float* g_vote, float* g_boxes, float* g_bc, void* stream);
 
+/* M2-Track's loss (models/m2track.py:153-231) and the gradients of its weighted total: segmentation cross entropy with class
+ * weights (cw0, cw1) = (0.5, 2.0), motion-state cross entropy, (centre, angle) smooth-L1 pairs of the refined / previous /
+ * first-stage box and of the motion (the latter over the moving samples when `state` is given), BoxCloud smooth-L1 against
+ * the concatenation of bc_a and bc_b (B, N/2, K each).  NULL predictions switch their terms off: bc_pred (box_aware), motion_cls +
+ * state (use_motion_cls), est (use_second_stage), prev (use_prev_refinement).  losses[12] = {total, motion_cls, center, angle,
+ * center_prev, angle_prev, seg, center_aux, center_motion, angle_aux, angle_motion, bc}.  g_seg == NULL: losses only.
+ * scratch: 1024 floats. */
+int o3d_m2track_loss(const float* seg_logits, const int64_t* seg_label, const float* bc_pred, const float* bc_a, const float* bc_b,
+                     const float* motion_cls, const int64_t* state, const float* motion, const float* motion_lab, const float* aux,
+                     const float* est, const float* prev, const float* box_lab, const float* prev_lab, int B, int N, int K,
+                     float w_center, float w_angle, float w_seg, float w_bc, float w_mcls, float cw0, float cw1, float* scratch,
+                     float* losses, float* g_seg, float* g_bc, float* g_mcls, float* g_motion, float* g_aux, float* g_est,
+                     float* g_prev, void* stream);
+
 /* ---- BoxCloud (next row of SURVEY.md section 8f-2) -------------------------------------------------
  * get_point_to_box_distance (datasets/points_utils.py:127-143) with Box.corners (datasets/data_classes.py:
  * 226-250): out (B,N,9) = distance of every point to the box centre (channel 0) and to the 8 corners

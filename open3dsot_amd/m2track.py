@@ -132,6 +132,11 @@ class M2TRACK(nn.Module):
         to fp32 rounding: tests/test_golden_m2track.py)."""
         c = self.config
         aux, motion_pred, seg_logits = output["aux_estimation_boxes"], output["motion_pred"], output["seg_logits"]
+        if seg_logits.is_cuda and seg_logits.dtype == torch.float32:
+            from . import fused_loss
+            if fused_loss.enabled():      # the whole loss and its gradients as two launches (csrc/loss.hip, round 4)
+                return fused_loss.m2track_loss(c, data, output, self.use_motion_cls, self.use_second_stage,
+                                               self.use_prev_refinement, self.box_aware)
         state = data["motion_state_label"]
         dev = seg_logits.device
         # rows of the stacked problem: (name suffix, prediction (B,4), label (B,4)); the motion row last

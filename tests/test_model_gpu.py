@@ -435,6 +435,56 @@ def test_fused_track_loss_matches_compute_loss(with_bc, seed):
     assert og["center_xyz"].grad is None
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [(True, True, True, True), (False, False, False, False), (True, False, True, False)])
+@pytest.mark.parametrize("seed", [0, 1])
+def test_fused_m2_loss_matches_compute_loss_reference(flags, seed):
+    """csrc/loss.hip::o3d_m2track_loss (two launches: every term, the weighted total, all gradients) against the term-by-term
+    restatement of models/m2track.py:153-231 evaluated in fp64, for the reference's flag combinations (box_aware,
+    use_motion_cls, use_second_stage, use_prev_refinement); seed 1: no moving sample (the 1e-6 denominator)."""
+    from open3dsot_amd import fused_loss, m2track
+    box_aware, use_cls, second, prev_ref = flags
+    g = torch.Generator().manual_seed(100 + seed)
+    B, N, K = 48, 256, 9
+    model = m2track.M2TRACK(box_aware=box_aware, use_motion_cls=use_cls, use_second_stage=second, use_prev_refinement=prev_ref)
+    box = torch.randn(B, 4, generator=g)
+    out = {"seg_logits": torch.randn(B, 2, N, generator=g) * 2, "pred_bc": torch.randn(B, N, K, generator=g) * 1.5,
+           "motion_cls": torch.randn(B, 2, generator=g), "motion_pred": torch.randn(B, 4, generator=g) * 1.5,
+           "aux_estimation_boxes": box + torch.randn(B, 4, generator=g) * 0.8,
+           "estimation_boxes": box + torch.randn(B, 4, generator=g) * 1.5,
+           "estimation_boxes_prev": torch.randn(B, 4, generator=g) * 1.2}
+    data = {"seg_label": (torch.rand(B, N, generator=g) < 0.3).long(), "prev_bc": torch.randn(B, N // 2, K, generator=g),
+            "this_bc": torch.randn(B, N // 2, K, generator=g), "motion_state_label": (torch.rand(B, generator=g) < 0.5).long(),
+            "motion_label": torch.randn(B, 4, generator=g), "box_label": box, "box_label_prev": torch.randn(B, 4, generator=g)}
+    if seed == 1:
+        data["motion_state_label"].zero_()
+    names = ["seg_logits", "motion_pred", "aux_estimation_boxes"] + (["pred_bc"] if box_aware else []) + \
+        (["motion_cls"] if use_cls else []) + (["estimation_boxes"] if second else []) + (["estimation_boxes_prev"] if prev_ref else [])
+    o64 = {k: v.double().requires_grad_(k in names) for k, v in out.items()}
+    d64 = {k: (v.double() if v.is_floating_point() else v) for k, v in data.items()}
+    ref = model.compute_loss_reference(d64, o64)
+    (ref["loss_total"] * 0.7).backward()
+    og = {k: v.cuda().requires_grad_(k in names) for k, v in out.items()}
+    dg = {k: v.cuda() for k, v in data.items()}
+    assert fused_loss.enabled()
+    ld = model.compute_loss(dg, og)
+    assert set(ld) == set(ref), (sorted(ld), sorted(ref))
+    (ld["loss_total"] * 0.7).backward()
+    for k, v in ref.items():
+        assert ld[k].dim() == 0
+        assert abs(float(ld[k]) - float(v)) <= 3e-6 * (1 + abs(float(v))), (k, float(ld[k]), float(v))
+    for k in names:
+        r = o64[k].grad
+        err = float((og[k].grad.cpu().double() - r).abs().max())
+        assert err <= 3e-6 * float(r.abs().max()) + 1e-9, (k, err, float(r.abs().max()))
+    # the constant-1 seed DataParallelStep uses skips the scaling launch: same gradients as a plain backward
+    og2 = {k: v.cuda().requires_grad_(k in names) for k, v in out.items()}
+    tot = model.compute_loss(dg, og2)["loss_total"]
+    tot.backward(gradient=fused_loss.one(tot.device))
+    for k in names:
+        assert torch.allclose(og2[k].grad * 0.7, og[k].grad, rtol=1e-6, atol=1e-12), k
+
+
 def test_backward_seeded_with_the_constant_one_equals_plain_backward():
     """DataParallelStep seeds `loss.backward` with fused_loss.one(device): no `ones_like`, and the fused loss recognises the
     constant and skips its scaling launch.  Same gradients as the plain `loss.backward()` (to run-to-run rounding); any OTHER seed
