@@ -552,6 +552,16 @@ int o3d_track_loss(const float* cla, const float* seg, const float* vote, const 
                    int N, int P, int K, float w_obj, float w_box, float w_seg, float w_vote, float w_bc,
                    float* scratch, float* losses, float* g_cla, float* g_vote, float* g_boxes, float* g_bc, void* stream);
 
+/* M2-Track between its two stages (models/m2track.py:120-137 over datasets/points_utils.py:390-452): aux = the previous box
+ * `prev` (B,4 = x, y, z, yaw; NULL: zeros) moved by `motion` (B,4) [get_offset_box_tensor]; the first N/2 points carried along
+ * that motion [get_offset_points_tensor], then all N points expressed in the frame of aux [remove_transform_points_tensor].
+ * pts: channel c of point n of cloud b at pts[b*bstride + c*cstride + n] (channels 0..2 = xyz).  merged (B,3,N), aux (B,4).
+ * _bwd: g_merged (B,3,N), g_aux (B,4) | NULL -> g_prev (B,4) | NULL, g_motion (B,4); no gradient to the points. */
+int o3d_motion_merge_fwd(const float* pts, long bstride, long cstride, const float* prev, const float* motion, int B, int N,
+                         float* merged, float* aux, void* stream);
+int o3d_motion_merge_bwd(const float* pts, long bstride, long cstride, const float* prev, const float* motion, int B, int N,
+                         const float* g_merged, const float* g_aux, float* g_prev, float* g_motion, void* stream);
+
 /* M2-Track's loss (models/m2track.py:153-231) and the gradients of its weighted total: segmentation cross entropy with class
  * weights (cw0, cw1) = (0.5, 2.0), motion-state cross entropy, (centre, angle) smooth-L1 pairs of the refined / previous /
  * first-stage box and of the motion (the latter over the moving samples when `state` is given), BoxCloud smooth-L1 against

@@ -5,8 +5,15 @@ Mirror of the tensor helpers of datasets/points_utils.py: `rotz_batch_tensor` :3
 `remove_transform_points_tensor` :439-452.  Boxes are (B,4) = (x, y, z, yaw).  The reference mutates
 its `points` argument in place (`points -= ...`); these functions do not (same values returned).
 """
+import ctypes
+
 import torch
 
+from . import capi
+
+_vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
+capi.register("o3d_motion_merge_fwd", [_vp, _l, _l, _vp, _vp, _i, _i, _vp, _vp, _vp])
+capi.register("o3d_motion_merge_bwd", [_vp, _l, _l, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp])
 
 _ROTZ = {}        # device -> (basis (2, 9), constant part (9,)) of the z rotation as a linear map of (cos, sin)
 
@@ -74,3 +81,70 @@ def get_offset_points_tensor(points, ref_box, offset_box):
     p = torch.matmul(points - ref_c[:, None, :], rot.transpose(1, 2))             # into the box frame
     p = torch.matmul(p, rotz_batch_tensor(off_t).transpose(1, 2)) + off_c[:, None, :]
     return torch.matmul(p, rot) + ref_c[:, None, :]                                # back to the world
+
+
+class MotionMerge(torch.autograd.Function):
+    """M2-Track between its stages (models/m2track.py:120-137) as one launch each way (csrc/boxcloud.hip):
+    apply(points (B,C>=3,N) masked, channel-major, the first N/2 of the previous frame; prev (B,4) | None; motion (B,4))
+      -> merged (B,3,N) = both halves in the frame of the first-stage box, aux (B,4) = that box
+    i.e. aux = get_offset_box_tensor(prev, motion); merged = remove_transform_points_tensor(cat(get_offset_points_tensor(
+    first half, prev, motion), second half), aux) in the (B,3,N) layout.  No gradient to the points (they are data times a
+    hard mask in the model)."""
+
+    @staticmethod
+    @capi.on_tensor_device
+    def forward(ctx, points, prev, motion):
+        lib = capi.load()
+        B, C, N = points.shape
+        pts = points.detach()
+        if pts.stride(2) != 1:
+            pts = pts.contiguous()
+        pv = prev.detach().contiguous() if prev is not None else None
+        mo = motion.detach().contiguous()
+        merged = torch.empty((B, 3, N), device=pts.device, dtype=torch.float32)
+        aux = torch.empty((B, 4), device=pts.device, dtype=torch.float32)
+        st = torch.cuda.current_stream(pts.device).cuda_stream
+        capi.check(lib.o3d_motion_merge_fwd(pts.data_ptr(), pts.stride(0), pts.stride(1), pv.data_ptr() if pv is not None else None,
+                                            mo.data_ptr(), B, N, merged.data_ptr(), aux.data_ptr(), st), "motion_merge_fwd")
+        ctx.saved = (pts, pv, mo)
+        ctx.prev_grad = prev is not None and ctx.needs_input_grad[1]
+        ctx.set_materialize_grads(False)
+        return merged, aux
+
+    @staticmethod
+    @capi.on_tensor_device
+    def backward(ctx, g_merged, g_aux):
+        if ctx.needs_input_grad[0]:
+            raise RuntimeError("MotionMerge: no gradient with respect to the points")
+        lib = capi.load()
+        pts, pv, mo = ctx.saved
+        B, _, N = pts.shape
+        if g_merged is None:
+            g_merged = torch.zeros((B, 3, N), device=pts.device, dtype=torch.float32)
+        g_merged = g_merged.contiguous()
+        g_aux = g_aux.contiguous() if g_aux is not None else None
+        g_motion = torch.empty_like(mo)
+        g_prev = torch.empty_like(pv) if ctx.prev_grad else None
+        st = torch.cuda.current_stream(pts.device).cuda_stream
+        capi.check(lib.o3d_motion_merge_bwd(pts.data_ptr(), pts.stride(0), pts.stride(1), pv.data_ptr() if pv is not None else None,
+                                            mo.data_ptr(), B, N, g_merged.data_ptr(), g_aux.data_ptr() if g_aux is not None else None,
+                                            g_prev.data_ptr() if g_prev is not None else None, g_motion.data_ptr(), st),
+                   "motion_merge_bwd")
+        return None, g_prev, g_motion
+
+
+def motion_merge_supported(points, motion):
+    return (points.is_cuda and points.dtype == torch.float32 and motion.dtype == torch.float32 and points.dim() == 3 and
+            points.shape[1] >= 3 and points.shape[2] % 2 == 0 and not points.requires_grad)
+
+
+def motion_merge_reference(points, prev, motion):
+    """the same function from the reference's helpers (the specification of MotionMerge): -> merged (B,3,N), aux (B,4)"""
+    N = points.shape[2]
+    if prev is None:
+        prev = torch.zeros_like(motion)
+    xyz0, xyz1 = points[:, :3, :N // 2], points[:, :3, N // 2:]
+    aux = get_offset_box_tensor(prev, motion)
+    moved = get_offset_points_tensor(xyz0.transpose(1, 2), prev, motion).transpose(1, 2)
+    merged = torch.cat([moved, xyz1], dim=-1)
+    return remove_transform_points_tensor(merged.transpose(1, 2), aux).transpose(1, 2), aux

@@ -83,7 +83,6 @@ class M2TRACK(nn.Module):
         x = input_dict["points"].transpose(1, 2)
         if self.box_aware:
             x = torch.cat([x, input_dict["candidate_bc"].transpose(1, 2)], dim=1)
-        N = x.shape[2]
         seg_out = self.seg_pointnet(x)
         if self.box_aware:       # one split node instead of two slices (whose backward is 2 x (fill + copy) + an add)
             seg_logits, pred_bc = seg_out.split([2, seg_out.shape[1] - 2], dim=1)
@@ -91,7 +90,7 @@ class M2TRACK(nn.Module):
             seg_logits = seg_out[:, :2, :]
         pred_cls = torch.argmax(seg_logits, dim=1, keepdim=True)                  # (B,1,N) hard mask, no gradient
         mask_points = x[:, :4, :] * pred_cls
-        mask_xyz_t0, mask_xyz_t1 = mask_points[:, :3, :N // 2], mask_points[:, :3, N // 2:]
+        mask_xyz = mask_points                       # (B,4,N): data times the hard mask, no gradient; first N/2 = previous frame
         if self.box_aware:
             mask_pred_bc = pred_bc * pred_cls
             mask_points = torch.cat([mask_points, mask_pred_bc], dim=1)
@@ -110,12 +109,15 @@ class M2TRACK(nn.Module):
             out["estimation_boxes_prev"] = prev_boxes[:, :4] if prev_boxes.shape[1] != 4 else prev_boxes
         else:
             prev_boxes = torch.zeros_like(motion_pred)
-        aux_box = box_utils.get_offset_box_tensor(prev_boxes, motion_pred_masked)  # first-stage box
+        if self.use_second_stage and box_utils.motion_merge_supported(mask_xyz, motion_pred_masked):
+            # first-stage box + both halves of the points in its frame: one launch each way (csrc/boxcloud.hip)
+            merged, aux_box = box_utils.MotionMerge.apply(mask_xyz, prev_boxes if self.use_prev_refinement else None,
+                                                          motion_pred_masked)
+        else:
+            aux_box = box_utils.get_offset_box_tensor(prev_boxes, motion_pred_masked)  # first-stage box
+            if self.use_second_stage:
+                merged = box_utils.motion_merge_reference(mask_xyz, prev_boxes, motion_pred_masked)[0]
         if self.use_second_stage:
-            moved = box_utils.get_offset_points_tensor(mask_xyz_t0.transpose(1, 2), out.get("estimation_boxes_prev", prev_boxes[:, :4]),
-                                                       motion_pred_masked).transpose(1, 2)
-            merged = torch.cat([moved, mask_xyz_t1], dim=-1)                       # (B,3,N)
-            merged = box_utils.remove_transform_points_tensor(merged.transpose(1, 2), aux_box).transpose(1, 2)
             if self.box_aware:
                 merged = torch.cat([merged, mask_pred_bc], dim=1)
             offset = seq_rows(self.box_mlp, self.mini_pointnet2(merged))

@@ -98,3 +98,45 @@ def test_row_stack_takes_strided_rows_and_falls_back_beyond_64_rows():
 def seq_ref_forward(seq, x):
     ref = copy.deepcopy(seq).double()
     return ref(x.double())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_prev", [True, False])
+def test_motion_merge_matches_the_reference_helpers(with_prev):
+    """csrc/boxcloud.hip::motion_merge (M2-Track between its stages, one launch each way) against the chain of
+    datasets/points_utils.py's tensor helpers (box_utils.motion_merge_reference) evaluated in fp64: values and the gradients
+    with respect to the previous box and the motion, with gradient arriving through both outputs."""
+    from open3dsot_amd import box_utils
+    g = torch.Generator().manual_seed(5)
+    B, N = 48, 1024
+    pts = torch.randn(B, 4, N, generator=g) * 2.0
+    pts[:, :, ::7] = 0.0                                     # masked-out points sit at the origin
+    prev = torch.randn(B, 4, generator=g) * 0.7 if with_prev else None
+    motion = torch.randn(B, 4, generator=g) * 0.5
+    gm, ga = torch.randn(B, 3, N, generator=g), torch.randn(B, 4, generator=g)
+    p64 = prev.double().requires_grad_() if with_prev else None
+    m64 = motion.double().requires_grad_()
+    ref_m, ref_a = box_utils.motion_merge_reference(pts.double(), p64, m64)
+    ((ref_m * gm.double()).sum() + (ref_a * ga.double()).sum()).backward()
+    pg = prev.cuda().requires_grad_() if with_prev else None
+    mg = motion.cuda().requires_grad_()
+    big = torch.cat([pts, torch.zeros(B, 9, N)], 1).cuda()   # the model hands over a channel slice of a wider tensor
+    view = big[:, :4]
+    assert box_utils.motion_merge_supported(view, mg)
+    merged, aux = box_utils.MotionMerge.apply(view, pg, mg)
+    assert merged.shape == (B, 3, N) and aux.shape == (B, 4)
+    scale = float(ref_m.abs().max())
+    assert float((merged.cpu().double() - ref_m).abs().max()) <= 2e-6 * scale
+    assert float((aux.cpu().double() - ref_a).abs().max()) <= 2e-6 * float(ref_a.abs().max())
+    ((merged * gm.cuda()).sum() + (aux * ga.cuda()).sum()).backward()
+    pairs = [(mg, m64)] + ([(pg, p64)] if with_prev else [])
+    for got, ref in pairs:
+        err = float((got.grad.cpu().double() - ref.grad).abs().max())
+        assert err <= 1e-5 * float(ref.grad.abs().max()), (err, float(ref.grad.abs().max()))
+    # gradient through the first-stage box only (the second stage switched off upstream): the points' sums are zero
+    mg2 = motion.cuda().requires_grad_()
+    _, aux2 = box_utils.MotionMerge.apply(view, pg.detach() if with_prev else None, mg2)
+    (aux2 * ga.cuda()).sum().backward()
+    m3 = motion.double().requires_grad_()
+    (box_utils.get_offset_box_tensor(prev.double() if with_prev else torch.zeros(B, 4, dtype=torch.float64), m3) * ga.double()).sum().backward()
+    assert float((mg2.grad.cpu().double() - m3.grad).abs().max()) <= 1e-5 * float(m3.grad.abs().max())
