@@ -562,6 +562,11 @@ int o3d_motion_merge_fwd(const float* pts, long bstride, long cstride, const flo
 int o3d_motion_merge_bwd(const float* pts, long bstride, long cstride, const float* prev, const float* motion, int B, int N,
                          const float* g_merged, const float* g_aux, float* g_prev, float* g_motion, void* stream);
 
+/* get_offset_box_tensor (datasets/points_utils.py:420-436): box = `ref` (B,4) moved by `off` (B,4) given in ref's frame.
+ * g_box == NULL: forward, writes box; else backward: g_ref / g_off (either may be NULL) from g_box. */
+int o3d_offset_box(const float* ref, const float* off, int B, float* box, const float* g_box, float* g_ref, float* g_off,
+                   void* stream);
+
 /* M2-Track's loss (models/m2track.py:153-231) and the gradients of its weighted total: segmentation cross entropy with class
  * weights (cw0, cw1) = (0.5, 2.0), motion-state cross entropy, (centre, angle) smooth-L1 pairs of the refined / previous /
  * first-stage box and of the motion (the latter over the moving samples when `state` is given), BoxCloud smooth-L1 against

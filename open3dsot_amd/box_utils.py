@@ -13,6 +13,7 @@ from . import capi
 
 _vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
 capi.register("o3d_motion_merge_fwd", [_vp, _l, _l, _vp, _vp, _i, _i, _vp, _vp, _vp])
+capi.register("o3d_offset_box", [_vp, _vp, _i, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_motion_merge_bwd", [_vp, _l, _l, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp])
 
 _ROTZ = {}        # device -> (basis (2, 9), constant part (9,)) of the z rotation as a linear map of (cos, sin)
@@ -35,7 +36,8 @@ def rotz_batch_tensor_stacked(t):
     c, s = torch.cos(t), torch.sin(t)
     zero, one = torch.zeros_like(c), torch.ones_like(c)
     rows = [torch.stack([c, -s, zero], -1), torch.stack([s, c, zero], -1), torch.stack([zero, zero, one], -1)]
-    return torch.stack(rows, -2).to(torch.float32)
+    # float32 like the reference's; fp64 angles stay fp64 (the tests evaluate these helpers in fp64 as the specification)
+    return torch.stack(rows, -2).to(torch.float64 if t.dtype == torch.float64 else torch.float32)
 
 
 def rotz_batch_tensor(t):
@@ -57,8 +59,44 @@ def _parts(box):
     return center, yaw.squeeze(1)
 
 
+class OffsetBox(torch.autograd.Function):
+    """get_offset_box_tensor as one launch each way (csrc/boxcloud.hip::offset_box_kernel)"""
+
+    @staticmethod
+    @capi.on_tensor_device
+    def forward(ctx, ref, off):
+        lib = capi.load()
+        r, o = ref.detach().contiguous(), off.detach().contiguous()
+        box = torch.empty_like(r)
+        capi.check(lib.o3d_offset_box(r.data_ptr(), o.data_ptr(), r.shape[0], box.data_ptr(), None, None, None,
+                                      torch.cuda.current_stream(r.device).cuda_stream), "offset_box")
+        ctx.saved = (r, o)
+        return box
+
+    @staticmethod
+    @capi.on_tensor_device
+    def backward(ctx, g):
+        lib = capi.load()
+        r, o = ctx.saved
+        g = g.contiguous()
+        g_ref = torch.empty_like(r) if ctx.needs_input_grad[0] else None
+        g_off = torch.empty_like(o) if ctx.needs_input_grad[1] else None
+        capi.check(lib.o3d_offset_box(r.data_ptr(), o.data_ptr(), r.shape[0], None, g.data_ptr(),
+                                      g_ref.data_ptr() if g_ref is not None else None, g_off.data_ptr() if g_off is not None else None,
+                                      torch.cuda.current_stream(r.device).cuda_stream), "offset_box_bwd")
+        return g_ref, g_off
+
+
 def get_offset_box_tensor(ref_box, offset_box):
     """box `ref_box` moved by `offset_box` expressed in the ref box frame: (B,4),(B,4) -> (B,4)"""
+    if (ref_box.is_cuda and ref_box.dtype == torch.float32 and offset_box.dtype == torch.float32 and ref_box.dim() == 2 and
+            ref_box.shape == offset_box.shape and ref_box.shape[1] == 4 and ref_box.shape[0] > 0):
+        return OffsetBox.apply(ref_box, offset_box)
+    return get_offset_box_tensor_reference(ref_box, offset_box)
+
+
+def get_offset_box_tensor_reference(ref_box, offset_box):
+    """the torch-op form (the specification of OffsetBox; CPU and fp64 inputs)"""
     ref_c, ref_t = _parts(ref_box)
     off_c, off_t = _parts(offset_box)
     rot = rotz_batch_tensor(ref_t)
@@ -144,7 +182,7 @@ def motion_merge_reference(points, prev, motion):
     if prev is None:
         prev = torch.zeros_like(motion)
     xyz0, xyz1 = points[:, :3, :N // 2], points[:, :3, N // 2:]
-    aux = get_offset_box_tensor(prev, motion)
+    aux = get_offset_box_tensor_reference(prev, motion)
     moved = get_offset_points_tensor(xyz0.transpose(1, 2), prev, motion).transpose(1, 2)
     merged = torch.cat([moved, xyz1], dim=-1)
     return remove_transform_points_tensor(merged.transpose(1, 2), aux).transpose(1, 2), aux

@@ -167,7 +167,43 @@ __global__ __launch_bounds__(256) void motion_merge_bwd_kernel(MotionArgs a, con
     }
 }
 
+// get_offset_box_tensor (datasets/points_utils.py:420-436) on its own: box = ref moved by `off` given in ref's frame;
+// thread per box.  g_box == NULL: forward (box out), else backward (g_ref / g_off out, either may be NULL).
+__global__ __launch_bounds__(64) void offset_box_kernel(const float* __restrict__ ref, const float* __restrict__ off, int B,
+                                                        float* __restrict__ box, const float* __restrict__ g_box,
+                                                        float* __restrict__ g_ref, float* __restrict__ g_off) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= B) return;
+    const float rt = ref[4 * b + 3], ox = off[4 * b], oy = off[4 * b + 1];
+    const Rz r = rz(rt);
+    if (!g_box) {
+        float cx, cy;
+        rot2(r, ox, oy, cx, cy);
+        box[4 * b] = cx + ref[4 * b]; box[4 * b + 1] = cy + ref[4 * b + 1]; box[4 * b + 2] = off[4 * b + 2] + ref[4 * b + 2];
+        box[4 * b + 3] = rt + off[4 * b + 3];
+        return;
+    }
+    const float gx = g_box[4 * b], gy = g_box[4 * b + 1], gz = g_box[4 * b + 2], gt = g_box[4 * b + 3];
+    if (g_ref) {
+        g_ref[4 * b] = gx; g_ref[4 * b + 1] = gy; g_ref[4 * b + 2] = gz;
+        g_ref[4 * b + 3] = gt + gx * (-r.s * ox - r.c * oy) + gy * (r.c * ox - r.s * oy);
+    }
+    if (g_off) {
+        float mx, my;
+        rot2i(r, gx, gy, mx, my);
+        g_off[4 * b] = mx; g_off[4 * b + 1] = my; g_off[4 * b + 2] = gz; g_off[4 * b + 3] = gt;
+    }
+}
+
 }  // namespace
+
+// ref (B,4), off (B,4) -> box (B,4) [g_box == NULL]; or g_box (B,4) -> g_ref | NULL, g_off | NULL
+extern "C" int o3d_offset_box(const float* ref, const float* off, int B, float* box, const float* g_box, float* g_ref, float* g_off,
+                              void* stream) {
+    if (!ref || !off || B <= 0 || (!g_box && !box)) return O3D_EINVAL;
+    hipLaunchKernelGGL(offset_box_kernel, dim3(o3d_cdiv(B, 64)), dim3(64), 0, o3d_stream(stream), ref, off, B, box, g_box, g_ref, g_off);
+    return o3d_launch_status();
+}
 
 // pts: the masked points, channel-major per cloud (xyz = channels 0..2; the first N/2 points belong to the previous frame);
 // prev (B,4) | NULL (no previous-box refinement: zeros), motion (B,4) -> merged (B,3,N) in the frame of the first-stage box,

@@ -140,3 +140,26 @@ def test_motion_merge_matches_the_reference_helpers(with_prev):
     m3 = motion.double().requires_grad_()
     (box_utils.get_offset_box_tensor(prev.double() if with_prev else torch.zeros(B, 4, dtype=torch.float64), m3) * ga.double()).sum().backward()
     assert float((mg2.grad.cpu().double() - m3.grad).abs().max()) <= 1e-5 * float(m3.grad.abs().max())
+
+
+@pytest.mark.gpu
+def test_offset_box_kernel_matches_the_torch_form():
+    """box_utils.OffsetBox (one launch each way) against get_offset_box_tensor_reference (datasets/points_utils.py:420-436
+    restated with torch ops) in fp64; gradient to either operand alone as well"""
+    from open3dsot_amd import box_utils
+    g = torch.Generator().manual_seed(11)
+    for B in (1, 48, 100):
+        ref, off, gb = torch.randn(B, 4, generator=g) * 2, torch.randn(B, 4, generator=g), torch.randn(B, 4, generator=g)
+        r64, o64 = ref.double().requires_grad_(), off.double().requires_grad_()
+        want = box_utils.get_offset_box_tensor_reference(r64, o64)
+        (want * gb.double()).sum().backward()
+        rg, og = ref.cuda().requires_grad_(), off.cuda().requires_grad_()
+        got = box_utils.get_offset_box_tensor(rg, og)
+        assert got.grad_fn is not None and type(got.grad_fn).__name__.startswith("OffsetBox")
+        (got * gb.cuda()).sum().backward()
+        assert float((got.detach().cpu().double() - want.detach()).abs().max()) <= 2e-6 * float(want.abs().max())
+        for a, b in ((rg, r64), (og, o64)):
+            assert float((a.grad.cpu().double() - b.grad).abs().max()) <= 4e-6 * float(b.grad.abs().max())
+        og2 = off.cuda().requires_grad_()
+        (box_utils.get_offset_box_tensor(ref.cuda(), og2) * gb.cuda()).sum().backward()
+        assert torch.allclose(og2.grad, og.grad, rtol=0, atol=0)
