@@ -16,6 +16,9 @@ from . import capi
 from .fused import _call, _check_versions, _const_vec, _eval_consts, _ptr, _stream, _versions, count_batches, POOL_BWD_SPLIT, TILE
 
 _vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
+capi.register("o3d_pw_tile", [_l, _i])
+capi.register("o3d_pw_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp])
+capi.register("o3d_pw_dgrad", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
 capi.register("o3d_bn_relu_apply", [_vp, _vp, _vp, _i, _l, _vp, _vp])
 capi.register("o3d_act_bwd_partials", [_vp, _vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _vp])
 capi.register("o3d_gmax_fwd", [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp])
@@ -25,6 +28,12 @@ capi.register("o3d_cloud_sum_dy", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp
 
 class _Cfg:
     __slots__ = ("mode", "training", "bns")
+
+
+def _flat_ok(rows, k, P):
+    """the flat-layout entry points of csrc/mlp_direct.hip (o3d_pw_fwd / o3d_pw_dgrad): they pick the wave tile -- and with it
+    the number of statistics partial rows, P // o3d_pw_tile(P, rows) -- from the size of the launch"""
+    return rows % 64 == 0 and k % 16 == 0 and P % 128 == 0
 
 
 def supported(x, layers):
@@ -58,10 +67,16 @@ class FusedPointwiseChain(torch.autograd.Function):
             Cout, Cin = Ws[l].shape
             bn = cfg.bns[l]
             Y = torch.empty((Cout, P), device=dev, dtype=f32)
-            part = torch.empty((ntiles, 2, Cout), device=dev, dtype=f32) if cfg.training else None
+            flat = _flat_ok(Cout, Cin, P) and not (l == 0 and cbias is not None)
+            nrows = P // lib.o3d_pw_tile(P, Cout) if flat else ntiles
+            part = torch.empty((nrows, 2, Cout), device=dev, dtype=f32) if cfg.training else None
             stat_c = bn.running_mean if cfg.training else None
             src = X0 if l == 0 else Ys[-1]
-            if l == 0 and cbias is not None:
+            if flat:
+                _call("pw_conv_fwd", 2.0 * Cin * Cout * P, lib.o3d_pw_fwd, src.data_ptr(), Ws[l].data_ptr(),
+                      None if l == 0 else scales[-1].data_ptr(), None if l == 0 else shifts[-1].data_ptr(), None, None, Cin, Cout,
+                      P, Y.data_ptr(), _ptr(part), _ptr(stat_c), st, dims=(Cin, Cout))
+            elif l == 0 and cbias is not None:
                 cb = cbias.detach().contiguous()
                 _call("pw_conv_fwd", 2.0 * Cin * Cout * P, lib.o3d_pw_fwd_cloud, src.data_ptr(), Ws[0].data_ptr(), cb.data_ptr(),
                       B, N, Cin, Cout, Y.data_ptr(), _ptr(part), _ptr(stat_c), st, dims=(Cin, Cout))
@@ -73,7 +88,7 @@ class FusedPointwiseChain(torch.autograd.Function):
             b = biases[l].detach() if biases[l] is not None else None
             if cfg.training:
                 fold = torch.empty((64, Cout), device=dev, dtype=f32)
-                _call("bn_finalize", 0.0, lib.o3d_bn_finalize, part.data_ptr(), ntiles, Cout, float(P), stat_c.data_ptr(),
+                _call("bn_finalize", 0.0, lib.o3d_bn_finalize, part.data_ptr(), nrows, Cout, float(P), stat_c.data_ptr(),
                       gammas[l].data_ptr(), betas[l].data_ptr(), bn.running_mean.data_ptr(), bn.running_var.data_ptr(),
                       float(bn.momentum), float(bn.eps), vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
                       vec[3].data_ptr(), fold.data_ptr(), st)
@@ -199,16 +214,29 @@ class FusedPointwiseChain(torch.autograd.Function):
             if l >= 1:
                 Wt = ctx.Wts[l] if ctx.Wts is not None else Ws[l].t().contiguous()
                 dNp = torch.empty((Cin, P), device=dev, dtype=f32)
-                part = torch.empty((ntiles, 2, Cin), device=dev, dtype=f32)
-                _call("pw_conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_wt, dN.data_ptr(), None, None, None, 4,
-                      Ys[l].data_ptr(), A[0], A[1], A[2], Ws[l].data_ptr(), Wt.data_ptr(), None, 1, Cin, Cout, P,
-                      Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(),
-                      dNp.data_ptr(), part.data_ptr(), st, dims=(Cin, Cout))
-                dN, nparts = dNp, ntiles
+                if _flat_ok(Cin, Cout, P):
+                    nrows = P // lib.o3d_pw_tile(P, Cin)
+                    part = torch.empty((nrows, 2, Cin), device=dev, dtype=f32)
+                    _call("pw_conv_dgrad", flops, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
+                          Wt.data_ptr(), Cin, Cout, P, Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(),
+                          means[l - 1].data_ptr(), None, dNp.data_ptr(), part.data_ptr(), st, dims=(Cin, Cout))
+                else:
+                    nrows = ntiles
+                    part = torch.empty((ntiles, 2, Cin), device=dev, dtype=f32)
+                    _call("pw_conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_wt, dN.data_ptr(), None, None, None, 4,
+                          Ys[l].data_ptr(), A[0], A[1], A[2], Ws[l].data_ptr(), Wt.data_ptr(), None, 1, Cin, Cout, P,
+                          Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(),
+                          dNp.data_ptr(), part.data_ptr(), st, dims=(Cin, Cout))
+                dN, nparts = dNp, nrows
             elif ctx.needs_input_grad[0]:
                 dX = torch.empty((Cin, B, N), device=dev, dtype=f32)
-                _call("pw_conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_plain, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1],
-                      A[2], Ws[0].data_ptr(), 1, Cin, Cout, P, dX.data_ptr(), st, dims=(Cin, Cout))
+                if _flat_ok(Cin, Cout, P):
+                    Wt0 = Ws[0].t().contiguous()
+                    _call("pw_conv_dgrad", flops, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1], A[2],
+                          Wt0.data_ptr(), Cin, Cout, P, None, None, None, None, None, dX.data_ptr(), None, st, dims=(Cin, Cout))
+                else:
+                    _call("pw_conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_plain, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1],
+                          A[2], Ws[0].data_ptr(), 1, Cin, Cout, P, dX.data_ptr(), st, dims=(Cin, Cout))
                 dx = dX.permute(1, 0, 2)
         return (dx, dcb, None, *grads)
 

@@ -355,12 +355,15 @@ def test_m2track_step_is_captured_and_replays_like_the_eager_step():
 
 @pytest.mark.parametrize("mode", ["act", "gmax"])
 @pytest.mark.parametrize("train", [True, False])
-def test_fused_pointwise_chain_vs_fp64(mode, train):
+@pytest.mark.parametrize("shape", [(4, 256, [14, 64, 128, 64]), (48, 2048, [64, 64, 128, 256])])
+def test_fused_pointwise_chain_vs_fp64(mode, train, shape):
     """open3dsot_amd/fused_pointwise.py against an fp64 torch evaluation of Conv1d -> BatchNorm1d -> ReLU (x3)
-    [-> global max]: outputs, parameter / input gradients, running statistics"""
+    [-> global max]: outputs, parameter / input gradients, running statistics.  Second shape: M2-Track's 98 304 columns
+    (64- and 128-row layers on the 64-column / split-K tiles, the 256-row layer on 128-column tiles, aligned input: the
+    stack's input gradient on the flat entry point too)"""
     from open3dsot_amd import fused_pointwise
     torch.manual_seed(9)
-    B, N, widths = 4, 256, [14, 64, 128, 64]
+    B, N, widths = shape
     convs = [torch.nn.Conv1d(a, b, 1).cuda() for a, b in zip(widths[:-1], widths[1:])]
     bns = [torch.nn.BatchNorm1d(b).cuda().train(train) for b in widths[1:]]
     with torch.no_grad():
