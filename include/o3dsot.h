@@ -562,6 +562,14 @@ int o3d_motion_merge_fwd(const float* pts, long bstride, long cstride, const flo
 int o3d_motion_merge_bwd(const float* pts, long bstride, long cstride, const float* prev, const float* motion, int B, int N,
                          const float* g_merged, const float* g_aux, float* g_prev, float* g_motion, void* stream);
 
+/* Backward of a thin first layer of a per-point stack (models/backbone/pointnet.py:91-204 with 12-14 input channels) on the
+ * flat (C, P) layout, Cout == 64, Cin <= 16, P % 64 == 0: dY = A1*dN + A2*Y + A3 (per-row constants, the BatchNorm backward
+ * folded); dW (64, Cin) = dY . X^T; dX (Cin, P) = W^T . dY when dX != NULL.  One pass over dN and Y.
+ * scratch: o3d_thin_bwd_scratch() floats. */
+long o3d_thin_bwd_scratch(void);
+int o3d_thin_bwd(const float* dN, const float* Y, const float* A1, const float* A2, const float* A3, const float* X,
+                 const float* W, int Cin, int Cout, long P, float* scratch, float* dW, float* dX, void* stream);
+
 /* get_offset_box_tensor (datasets/points_utils.py:420-436): box = `ref` (B,4) moved by `off` (B,4) given in ref's frame.
  * g_box == NULL: forward, writes box; else backward: g_ref / g_off (either may be NULL) from g_box. */
 int o3d_offset_box(const float* ref, const float* off, int B, float* box, const float* g_box, float* g_ref, float* g_off,

@@ -594,17 +594,16 @@ bool o3d_direct_ok(int M, int K, int P) { return M % DT_M == 0 && K % 16 == 0 &&
 // M output rows: 64 while the expected number of waves (a quarter of the worst case is live after
 // compaction) does not fill the 256 CUs a few times over, else 128.
 extern "C" int o3d_direct_tile(long P, int M, int compact) {
-    (void)compact;
+    (void)M; (void)compact;
     // measured on the MI355X (batch 48, same run A/B): 64-column tiles for every launch lose 1.3 % (more loads
     // per MFMA); 64-column tiles only for the small launches (vote aggregation, BoxCloud xcorr: <= 64 K slots,
     // too few 128-column tiles for the 256 CUs) gain 0.8 % (7.705 -> 7.642 ms per step).  Round 4: with the split-K tile
     // behind the 64-column class, 300 K / 600 K slots (SA levels 2 / 1 on it) LOSE 0.15 / 0.57 ms per step
     // (profiles/r04_ab_splitk.txt)
-    // Above that, 128-column tiles unless they leave the chip under-filled: M2-Track's 64- and 128-row layers over 98 304
-    // columns were 768 / 1 536 one-wave-per-SIMD chains at 0.22 of their HBM roofline (profiles/r04_per_launch_roofline_m2track.txt);
-    // none of the BAT / P2B launches beyond 65 536 columns has fewer than 2 208 such waves
-    if (P <= 65536L) return 64;
-    return (P / 128) * (M > 64 ? M / 64 : 1) < 2048 ? 64 : 128;
+    // Also measured (round 4, profiles/r04_ab_m2track_narrow_tiles.txt): M2-Track's 64- / 128-row layers over 98 304 columns
+    // (768 / 1 536 waves of 128 columns) on the 64-column / split-K tiles instead: every data-gradient launch 20-120 % slower
+    // (the 128 <- 1024 one 0.32 -> 0.71 ms), the step 6.92 -> 7.60 ms; only the 64 -> 64 forward gained (29 -> 24 us)
+    return P <= 65536L ? 64 : 128;
 }
 
 // forward: Y = W . f(X), see o3d_mlp_conv_fwd

@@ -151,3 +151,128 @@ extern "C" int o3d_gmax_fwd(const float* Y, const float* scale, const float* shi
                        (long)B * N, out, argq, yarg);
     return o3d_launch_status();
 }
+
+// ---- backward of a THIN layer 0 (round 4) ---------------------------------------------------------------------------------
+// The per-point stacks of M2-Track start from 12-14 input channels (xyz + time flag + BoxCloud, models/m2track.py:45-56):
+// layer 0 is 64 x <= 16 x P.  Its weight gradient dW (64, Cin) = dY . X^T and the stack's input gradient dX (Cin, P) =
+// W^T . dY went through the LDS-staged MFMA kernels of mlp.hip built for wide layers: 58 + 25 us on 98 304 columns where the
+// 55 MB they read take 7 us (profiles/r04_per_launch_roofline_m2track.txt, pw_conv_wgrad / pw_conv_dgrad with Cin 12-14).
+// One pass over dN and Y instead, on the vector ALUs (2 x 16 FMAs per element of dY: 0.2 GFLOP in all): a workgroup of 16
+// waves owns 64 columns at a time, wave w the rows [4w, 4w + 4) of dY = A1*dN + A2*Y + A3; lane = column.  Each lane keeps
+// 4 x 16 sums of dW, reduced over the lanes once at the end (recursive halving: 63 shuffles) into one partial per workgroup;
+// the dX sums of the 16 waves meet in LDS.  A second small launch adds the partials in a fixed order.
+namespace {
+
+constexpr int TH_K = 64, TH_M = 16, TH_WV = 16, TH_KW = TH_K / TH_WV;
+constexpr int TH_GRID = 256;
+
+struct ThinBwd {
+    const float* dN; const float* Y; const float* A1; const float* A2; const float* A3;   // (64, P), per-row constants
+    const float* X;      // (Cin, P)
+    const float* W;      // (64, Cin)
+    int Cin; long P;
+    float* wpart;        // [gridDim.x][64][16]
+    float* dX;           // (Cin, P) or unused
+};
+
+template <bool DX>
+__global__ __launch_bounds__(TH_WV * 64) void thin_bwd_kernel(ThinBwd a) {
+    __shared__ float xs[2][TH_M][64];
+    __shared__ float red[DX ? TH_WV : 1][TH_M][64];
+    __shared__ float Ws[TH_K][TH_M];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (DX) {
+        const int k = tid >> 4, m = tid & 15;
+        Ws[k][m] = m < a.Cin ? a.W[k * a.Cin + m] : 0.f;
+    }
+    float c1[TH_KW], c2[TH_KW], c3[TH_KW];
+#pragma unroll
+    for (int j = 0; j < TH_KW; ++j) {
+        const int k = wave * TH_KW + j;
+        c1[j] = a.A1[k]; c2[j] = a.A2[k]; c3[j] = a.A3[k];
+    }
+    float acc[TH_KW * TH_M];
+#pragma unroll
+    for (int i = 0; i < TH_KW * TH_M; ++i) acc[i] = 0.f;
+    const long ngroups = a.P / 64;
+    int buf = 0;
+    for (long g = blockIdx.x; g < ngroups; g += gridDim.x, buf ^= 1) {
+        const long p = g * 64 + lane;
+        {   // the group's inputs: one value per thread (row = wave)
+            xs[buf][wave][lane] = wave < a.Cin ? a.X[(long)wave * a.P + p] : 0.f;
+        }
+        float dy[TH_KW];
+#pragma unroll
+        for (int j = 0; j < TH_KW; ++j) {
+            const long o = (long)(wave * TH_KW + j) * a.P + p;
+            dy[j] = fmaf(c1[j], a.dN[o], fmaf(c2[j], a.Y[o], c3[j]));
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < TH_M; ++m) {
+            const float x = xs[buf][m][lane];
+#pragma unroll
+            for (int j = 0; j < TH_KW; ++j) acc[j * TH_M + m] = fmaf(dy[j], x, acc[j * TH_M + m]);
+            if (DX) {
+                float d = 0.f;
+#pragma unroll
+                for (int j = 0; j < TH_KW; ++j) d = fmaf(Ws[wave * TH_KW + j][m], dy[j], d);
+                red[wave][m][lane] = d;
+            }
+        }
+        if (DX) {
+            __syncthreads();
+            if (wave < a.Cin) {          // thread (row = wave, column = lane) of the 16 x 64 outputs
+                float s = 0.f;
+#pragma unroll
+                for (int w = 0; w < TH_WV; ++w) s += red[w][wave][lane];
+                a.dX[(long)wave * a.P + p] = s;
+            }
+        }
+    }
+    // sums over the 64 lanes: recursive halving, afterwards lane l holds the total of acc index l (= row l / 16, input l % 16)
+#pragma unroll
+    for (int half = 32; half >= 1; half >>= 1) {
+        const bool up = (lane & half) != 0;
+#pragma unroll
+        for (int i = 0; i < half; ++i) {
+            const float keep = up ? acc[i + half] : acc[i];
+            const float send = up ? acc[i] : acc[i + half];
+            acc[i] = keep + __shfl_xor(send, half, 64);
+        }
+    }
+    a.wpart[((long)blockIdx.x * TH_K + wave * TH_KW + (lane >> 4)) * TH_M + (lane & 15)] = acc[0];
+}
+
+// dW (64, Cin) = sum over the workgroups' partials, fixed order: 64 threads per element, 4 elements per workgroup
+__global__ __launch_bounds__(256) void thin_reduce_kernel(const float* __restrict__ wpart, int nparts, int Cin,
+                                                          float* __restrict__ dW) {
+    const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;     // e over 64 x 16
+    float s = 0.f;
+    for (int g = lane; g < nparts; g += 64) s += wpart[(long)g * (TH_K * TH_M) + e];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    const int k = e >> 4, m = e & 15;
+    if (lane == 0 && m < Cin) dW[k * Cin + m] = s;
+}
+
+}  // namespace
+
+extern "C" long o3d_thin_bwd_scratch(void) { return (long)TH_GRID * TH_K * TH_M; }
+
+// Layer 0 of a per-point stack with Cout == 64 and Cin <= 16 on the flat (C, P) layout, P % 64 == 0:
+// dY = A1*dN + A2*Y + A3 (the BatchNorm backward folded, as o3d_mlp_conv_wgrad);  dW (64, Cin) = dY . X^T;
+// dX (Cin, P) = W^T . dY when dX != NULL.  scratch: o3d_thin_bwd_scratch() floats.
+extern "C" int o3d_thin_bwd(const float* dN, const float* Y, const float* A1, const float* A2, const float* A3, const float* X,
+                            const float* W, int Cin, int Cout, long P, float* scratch, float* dW, float* dX, void* stream) {
+    if (!dN || !Y || !A1 || !A2 || !A3 || !X || !W || !scratch || !dW || Cout != TH_K || Cin <= 0 || Cin > TH_M || P <= 0 ||
+        P % 64 != 0)
+        return O3D_EINVAL;
+    ThinBwd a{dN, Y, A1, A2, A3, X, W, Cin, P, scratch, dX};
+    const long ngroups = P / 64;
+    const int grid = (int)(ngroups < TH_GRID ? ngroups : TH_GRID);
+    if (dX) hipLaunchKernelGGL(thin_bwd_kernel<true>, dim3(grid), dim3(TH_WV * 64), 0, o3d_stream(stream), a);
+    else hipLaunchKernelGGL(thin_bwd_kernel<false>, dim3(grid), dim3(TH_WV * 64), 0, o3d_stream(stream), a);
+    hipLaunchKernelGGL(thin_reduce_kernel, dim3(TH_K * TH_M / 4), dim3(256), 0, o3d_stream(stream), scratch, grid, Cin, dW);
+    return o3d_launch_status();
+}

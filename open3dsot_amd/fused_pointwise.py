@@ -19,6 +19,8 @@ _vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
 capi.register("o3d_pw_tile", [_l, _i])
 capi.register("o3d_pw_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp])
 capi.register("o3d_pw_dgrad", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_thin_bwd_scratch", [])
+capi.register("o3d_thin_bwd", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp])
 capi.register("o3d_bn_relu_apply", [_vp, _vp, _vp, _i, _l, _vp, _vp])
 capi.register("o3d_act_bwd_partials", [_vp, _vp, _vp, _vp, _vp, _i, _l, _vp, _vp, _vp])
 capi.register("o3d_gmax_fwd", [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp])
@@ -195,7 +197,16 @@ class FusedPointwiseChain(torch.autograd.Function):
                 dcb = torch.empty((Cout, B), device=dev, dtype=f32)       # gradient of the per-cloud bias
                 _call("cloud_sum", 0.0, lib.o3d_cloud_sum_dy, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1], A[2], Cout, B, N,
                       dcb.data_ptr(), st)
-            if Cin % 64 == 0 and Cout % 64 == 0:
+            thin = l == 0 and Cout == 64 and Cin <= 16       # weight and input gradient in one pass (csrc/pointwise.hip)
+            if thin:
+                wpart = torch.empty((lib.o3d_thin_bwd_scratch(),), device=dev, dtype=f32)
+                dX = torch.empty((Cin, B, N), device=dev, dtype=f32) if ctx.needs_input_grad[0] else None
+                _call("pw_conv_wgrad", flops * (2 if dX is not None else 1), lib.o3d_thin_bwd, dN.data_ptr(), Ys[0].data_ptr(), A[0],
+                      A[1], A[2], X0.data_ptr(), Ws[0].data_ptr(), Cin, Cout, P, wpart.data_ptr(), dW.data_ptr(), _ptr(dX), st,
+                      dims=(Cin, Cout))
+                if dX is not None:
+                    dx = dX.permute(1, 0, 2)
+            elif Cin % 64 == 0 and Cout % 64 == 0:
                 wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, P),), device=dev, dtype=f32)
                 xs = (X0.data_ptr(), None, None) if l == 0 else \
                      (Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr())
@@ -228,7 +239,7 @@ class FusedPointwiseChain(torch.autograd.Function):
                           Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(),
                           dNp.data_ptr(), part.data_ptr(), st, dims=(Cin, Cout))
                 dN, nparts = dNp, nrows
-            elif ctx.needs_input_grad[0]:
+            elif ctx.needs_input_grad[0] and not thin:
                 dX = torch.empty((Cin, B, N), device=dev, dtype=f32)
                 if _flat_ok(Cin, Cout, P):
                     Wt0 = Ws[0].t().contiguous()
