@@ -542,6 +542,24 @@ int o3d_row_mlp_bwd(const float* dY, int lddy, const float* dZup, const float* W
                     int relu, const float* X, int ldx, int R, int Cin, int C, float* dZ, float* dW, float* db, float* dgamma,
                     float* dbeta, void* stream);
 
+/* Several independent layers in one launch (njobs <= 4; the heads of M2-Track that read the same feature, models/m2track.py:
+ * 60-71): job j is what o3d_row_mlp_fwd / o3d_row_mlp_bwd do with the same arguments (input_mode must be 0).
+ * o3d_row_mlp_input_grad: dX (R, C) = sum over the jobs of dZup_j (R, Cup_j) . Wup_j (Cup_j, C), fixed order; R, C, dX, lddx
+ * are taken from jobs[0], the other fields are ignored. */
+typedef struct {
+    const float* X; int ldx; const float* W; const float* bias; const float* gamma; const float* beta;
+    float* running_mean; float* running_var; float momentum, eps; int training, relu; int R, Cin, Cout;
+    float* Z; float* Y; float* mean; float* invstd;
+} o3d_row_fwd_args;
+typedef struct {
+    const float* dY; int lddy; const float* dZup; const float* Wup; int Cup; int input_mode; float* dX; int lddx;
+    const float* Z; const float* gamma; const float* beta; const float* mean; const float* invstd; int training, relu;
+    const float* X; int ldx; int R, Cin, C; float* dZ; float* dW; float* db; float* dgamma; float* dbeta;
+} o3d_row_bwd_args;
+int o3d_row_mlp_fwd_group(const o3d_row_fwd_args* jobs, int njobs, void* stream);
+int o3d_row_mlp_bwd_group(const o3d_row_bwd_args* jobs, int njobs, void* stream);
+int o3d_row_mlp_input_grad(const o3d_row_bwd_args* jobs, int njobs, void* stream);
+
 /* ---- tracker losses (next row of SURVEY.md section 8f: the loss as one launch) ----------------------
  * MatchingBaseModel.compute_loss (models/base_model.py:122-164) + the BoxCloud term (models/bat.py:57-65)
  * + the weighted total (models/bat.py:131-137, models/p2b.py:69-74) and the gradients of the total.

@@ -29,19 +29,7 @@ constexpr int RM_RMAX = 64;      // rows
 constexpr int RM_RPT = RM_RMAX / RM_RG;       // rows per thread: rg + RM_RG * i
 constexpr int RM_KMAX = 1024;    // input features (the weight slice of a workgroup lives in LDS: KMAX * FT floats)
 
-struct RowFwd {
-    const float* X; int ldx;     // (R, Cin), row stride ldx
-    const float* W;              // (Cout, Cin)
-    const float* bias;           // (Cout) or NULL
-    const float* gamma; const float* beta;     // BatchNorm affine or NULL (no BatchNorm)
-    float* running_mean; float* running_var;   // updated when training (may be NULL)
-    float momentum, eps;
-    int training, relu;
-    int R, Cin, Cout;
-    float* Z;                    // (R, Cout) pre-BatchNorm output, or NULL (not needed: no BatchNorm / no backward)
-    float* Y;                    // (R, Cout)
-    float* mean; float* invstd;  // (Cout) each: the constants the backward normalises with (batch or running statistics)
-};
+using RowFwd = o3d_row_fwd_args;      // include/o3dsot.h
 
 // acc[i] += sum_k A[row(i)][k] * Wt[k][fl] for this thread's rows; A (R, K) row-major (lda), Wt element (k, f) at
 // Wsrc[k * wk + f * wf] -- W[f][k] (wk = 1, wf = K) forward, W_up[k][f] (wk = ldw, wf = 1) backward.
@@ -104,9 +92,7 @@ __device__ __forceinline__ float rows_sum(float v, float* red) {
     return s;
 }
 
-__global__ __launch_bounds__(256) void row_mlp_fwd_kernel(RowFwd a) {
-    __shared__ __attribute__((aligned(16))) float Ws[RM_KMAX * RM_FT];
-    __shared__ float red[RM_RG * RM_FT];
+__device__ __forceinline__ void row_fwd_body(const RowFwd& a, float* Ws, float* red) {
     const int tid = threadIdx.x, fl = tid % RM_FT, rg = tid / RM_FT;
     const int f0 = blockIdx.x * RM_FT, f = f0 + fl;
     const int nf = a.Cout - f0 < RM_FT ? a.Cout - f0 : RM_FT;
@@ -161,27 +147,30 @@ __global__ __launch_bounds__(256) void row_mlp_fwd_kernel(RowFwd a) {
     }
 }
 
-struct RowBwd {
-    // incoming gradient of this layer's OUTPUT (R, C): given, or dZ_up (R, Cup) . W_up (Cup, C)
-    const float* dY; int lddy;
-    const float* dZup; const float* Wup; int Cup;
-    int input_mode;              // 1: the "layer" is the stack's input: store the incoming gradient as dX and stop
-    float* dX; int lddx;
-    // this layer
-    const float* Z;              // (R, C) pre-BatchNorm output (BatchNorm layers)
-    const float* gamma; const float* beta; const float* mean; const float* invstd;     // NULL: no BatchNorm
-    int training, relu;
-    const float* X; int ldx;     // (R, Cin) layer input
-    int R, Cin, C;
-    float* dZ;                   // (R, C) out: gradient of the pre-BatchNorm output (read by the layer below)
-    float* dW; float* db;        // (C, Cin), (C) or NULL
-    float* dgamma; float* dbeta; // (C) or NULL
-};
-
-__global__ __launch_bounds__(256) void row_mlp_bwd_kernel(RowBwd a) {
+__global__ __launch_bounds__(256) void row_mlp_fwd_kernel(RowFwd a) {
     __shared__ __attribute__((aligned(16))) float Ws[RM_KMAX * RM_FT];
     __shared__ float red[RM_RG * RM_FT];
-    __shared__ __attribute__((aligned(16))) float dZs[RM_RMAX * RM_FT];
+    row_fwd_body(a, Ws, red);
+}
+
+// up to RM_GROUP independent layers in one launch (blockIdx.y picks the job): the heads of M2-Track that read the same
+// feature advance side by side, 3 launches for 9
+constexpr int RM_GROUP = 4;
+struct RowFwdGroup { RowFwd a[RM_GROUP]; };
+__global__ __launch_bounds__(256) void row_mlp_fwd_group_kernel(RowFwdGroup g) {
+    __shared__ __attribute__((aligned(16))) float Ws[RM_KMAX * RM_FT];
+    __shared__ float red[RM_RG * RM_FT];
+    const RowFwd& a = g.a[blockIdx.y];
+    if ((int)blockIdx.x * RM_FT >= a.Cout) return;
+    row_fwd_body(a, Ws, red);
+}
+
+using RowBwd = o3d_row_bwd_args;      // include/o3dsot.h
+
+struct RowBwdGroup { RowBwd a[RM_GROUP]; int n; };
+
+// `more`: further gradient sources of the same output (input mode only): g += dZup_j . Wup_j for the jobs 1 .. n-1
+__device__ __forceinline__ void row_bwd_body(const RowBwd& a, float* Ws, float* red, float* dZs, const RowBwdGroup* more) {
     const int tid = threadIdx.x, fl = tid % RM_FT, rg = tid / RM_FT;
     const int f0 = blockIdx.x * RM_FT, f = f0 + fl;
     const int nf = a.C - f0 < RM_FT ? a.C - f0 : RM_FT;
@@ -198,6 +187,9 @@ __global__ __launch_bounds__(256) void row_mlp_bwd_kernel(RowBwd a) {
             if (live && rowok[i]) g[i] = a.dY[(long)(rg + RM_RG * i) * a.lddy + f];
     }
     if (a.input_mode) {
+        if (more)
+            for (int j = 1; j < more->n; ++j)
+                rows_times_slice(more->a[j].dZup, more->a[j].Cup, a.R, more->a[j].Cup, more->a[j].Wup, a.C, 1, f0, nf, Ws, g);
 #pragma unroll
         for (int i = 0; i < RM_RPT; ++i)
             if (live && rowok[i]) a.dX[(long)(rg + RM_RG * i) * a.lddx + f] = g[i];
@@ -267,7 +259,85 @@ __global__ __launch_bounds__(256) void row_mlp_bwd_kernel(RowBwd a) {
     }
 }
 
+__global__ __launch_bounds__(256) void row_mlp_bwd_kernel(RowBwd a) {
+    __shared__ __attribute__((aligned(16))) float Ws[RM_KMAX * RM_FT];
+    __shared__ float red[RM_RG * RM_FT];
+    __shared__ __attribute__((aligned(16))) float dZs[RM_RMAX * RM_FT];
+    row_bwd_body(a, Ws, red, dZs, nullptr);
+}
+
+__global__ __launch_bounds__(256) void row_mlp_bwd_group_kernel(RowBwdGroup g) {
+    __shared__ __attribute__((aligned(16))) float Ws[RM_KMAX * RM_FT];
+    __shared__ float red[RM_RG * RM_FT];
+    __shared__ __attribute__((aligned(16))) float dZs[RM_RMAX * RM_FT];
+    const RowBwd& a = g.a[blockIdx.y];
+    if ((int)blockIdx.x * RM_FT >= a.C) return;
+    row_bwd_body(a, Ws, red, dZs, nullptr);
+}
+
+// the gradient of rows that several stacks read: dX = sum over the jobs of dZup_j . Wup_j (fixed order)
+__global__ __launch_bounds__(256) void row_mlp_input_grad_kernel(RowBwdGroup g) {
+    __shared__ __attribute__((aligned(16))) float Ws[RM_KMAX * RM_FT];
+    row_bwd_body(g.a[0], Ws, nullptr, nullptr, &g);
+}
+
+static bool row_fwd_ok(const RowFwd& a) {
+    return a.X && a.W && a.Y && a.R > 0 && a.R <= RM_RMAX && a.Cin > 0 && a.Cin <= RM_KMAX && a.Cout > 0 && a.ldx >= a.Cin &&
+           !(a.gamma && !a.beta) && !(a.gamma && !a.training && (!a.running_mean || !a.running_var)) && !(a.mean && !a.invstd);
+}
+
+static bool row_bwd_ok(const RowBwd& a) {
+    if (a.R <= 0 || a.R > RM_RMAX || a.C <= 0 || (!a.dY && (!a.dZup || !a.Wup || a.Cup <= 0 || a.Cup > RM_KMAX)) ||
+        (a.dY && a.lddy < a.C))
+        return false;
+    if (a.input_mode) return a.dX && a.lddx >= a.C;
+    return !((a.gamma && (!a.beta || !a.mean || !a.invstd || !a.Z)) || (a.dW && (!a.X || a.Cin <= 0 || a.ldx < a.Cin)) ||
+             (a.relu && !a.gamma));
+}
+
 }  // namespace
+
+extern "C" int o3d_row_mlp_fwd_group(const o3d_row_fwd_args* jobs, int njobs, void* stream) {
+    if (!jobs || njobs <= 0 || njobs > RM_GROUP) return O3D_EINVAL;
+    RowFwdGroup g = {};
+    int cmax = 0;
+    for (int j = 0; j < njobs; ++j) {
+        if (!row_fwd_ok(jobs[j])) return O3D_EINVAL;
+        g.a[j] = jobs[j];
+        cmax = jobs[j].Cout > cmax ? jobs[j].Cout : cmax;
+    }
+    hipLaunchKernelGGL(row_mlp_fwd_group_kernel, dim3(o3d_cdiv(cmax, RM_FT), njobs), dim3(256), 0, o3d_stream(stream), g);
+    return o3d_launch_status();
+}
+
+extern "C" int o3d_row_mlp_bwd_group(const o3d_row_bwd_args* jobs, int njobs, void* stream) {
+    if (!jobs || njobs <= 0 || njobs > RM_GROUP) return O3D_EINVAL;
+    RowBwdGroup g = {};
+    int cmax = 0;
+    for (int j = 0; j < njobs; ++j) {
+        if (!row_bwd_ok(jobs[j]) || jobs[j].input_mode) return O3D_EINVAL;
+        g.a[j] = jobs[j];
+        cmax = jobs[j].C > cmax ? jobs[j].C : cmax;
+    }
+    g.n = njobs;
+    hipLaunchKernelGGL(row_mlp_bwd_group_kernel, dim3(o3d_cdiv(cmax, RM_FT), njobs), dim3(256), 0, o3d_stream(stream), g);
+    return o3d_launch_status();
+}
+
+// dX (R, C) = sum_j dZup_j (R, Cup_j) . Wup_j (Cup_j, C); R, C, dX, lddx from jobs[0]
+extern "C" int o3d_row_mlp_input_grad(const o3d_row_bwd_args* jobs, int njobs, void* stream) {
+    if (!jobs || njobs <= 0 || njobs > RM_GROUP) return O3D_EINVAL;
+    RowBwdGroup g = {};
+    for (int j = 0; j < njobs; ++j) {
+        RowBwd a = jobs[j];
+        a.dY = nullptr; a.input_mode = 1; a.R = jobs[0].R; a.C = jobs[0].C; a.dX = jobs[0].dX; a.lddx = jobs[0].lddx;
+        if (!row_bwd_ok(a)) return O3D_EINVAL;
+        g.a[j] = a;
+    }
+    g.n = njobs;
+    hipLaunchKernelGGL(row_mlp_input_grad_kernel, dim3(o3d_cdiv(jobs[0].C, RM_FT)), dim3(256), 0, o3d_stream(stream), g);
+    return o3d_launch_status();
+}
 
 extern "C" int o3d_row_mlp_fwd(const float* X, int ldx, const float* W, const float* bias, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps, int training, int relu,

@@ -241,13 +241,10 @@ class FusedPointwiseChain(torch.autograd.Function):
                 dN, nparts = dNp, nrows
             elif ctx.needs_input_grad[0] and not thin:
                 dX = torch.empty((Cin, B, N), device=dev, dtype=f32)
-                if _flat_ok(Cin, Cout, P):
-                    Wt0 = Ws[0].t().contiguous()
-                    _call("pw_conv_dgrad", flops, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1], A[2],
-                          Wt0.data_ptr(), Cin, Cout, P, None, None, None, None, None, dX.data_ptr(), None, st, dims=(Cin, Cout))
-                else:
-                    _call("pw_conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_plain, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1],
-                          A[2], Ws[0].data_ptr(), 1, Cin, Cout, P, dX.data_ptr(), st, dims=(Cin, Cout))
+                # (the LDS-staged kernel: on 64 <- 512 x 98 304 columns it takes 0.113 ms, the direct 128-column tile 0.150 ms --
+                # 768 one-wave chains of 512 MFMAs -- and the split-K tile 0.183 ms; profiles/r04_ab_m2track_narrow_tiles.txt)
+                _call("pw_conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_plain, dN.data_ptr(), Ys[0].data_ptr(), A[0], A[1],
+                      A[2], Ws[0].data_ptr(), 1, Cin, Cout, P, dX.data_ptr(), st, dims=(Cin, Cout))
                 dx = dX.permute(1, 0, 2)
         return (dx, dcb, None, *grads)
 

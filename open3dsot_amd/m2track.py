@@ -95,17 +95,20 @@ class M2TRACK(nn.Module):
             mask_pred_bc = pred_bc * pred_cls
             mask_points = torch.cat([mask_points, mask_pred_bc], dim=1)
             out["pred_bc"] = pred_bc.transpose(1, 2)
-        from .fused_rows import seq_rows      # the heads' Linear -> BatchNorm1d -> ReLU rows: one launch per layer on the GPU
-        point_feature = self.mini_pointnet(mask_points)
-        motion_pred = seq_rows(self.motion_mlp, point_feature)                     # (B,4)
+        from .fused_rows import seq_rows, seq_rows_group   # the heads' Linear -> BatchNorm1d -> ReLU rows on the GPU: one launch
+        point_feature = self.mini_pointnet(mask_points)    # per layer, and the heads that read the same feature side by side
+        heads = [self.motion_mlp] + ([self.motion_state_mlp] if self.use_motion_cls else []) + \
+            ([self.final_mlp] if self.use_prev_refinement else [])
+        head_out = seq_rows_group(heads, point_feature)
+        motion_pred = head_out[0]                                                  # (B,4)
         if self.use_motion_cls:
-            logits = seq_rows(self.motion_state_mlp, point_feature)
+            logits = head_out[1]
             motion_pred_masked = motion_pred * torch.argmax(logits, dim=1, keepdim=True)
             out["motion_cls"] = logits
         else:
             motion_pred_masked = motion_pred
         if self.use_prev_refinement:
-            prev_boxes = seq_rows(self.final_mlp, point_feature)
+            prev_boxes = head_out[-1]
             out["estimation_boxes_prev"] = prev_boxes[:, :4] if prev_boxes.shape[1] != 4 else prev_boxes
         else:
             prev_boxes = torch.zeros_like(motion_pred)

@@ -163,3 +163,56 @@ def test_offset_box_kernel_matches_the_torch_form():
         og2 = off.cuda().requires_grad_()
         (box_utils.get_offset_box_tensor(ref.cuda(), og2) * gb.cuda()).sum().backward()
         assert torch.allclose(og2.grad, og.grad, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("unused_head", [False, True])
+def test_row_stack_group_equals_the_single_stacks(train, unused_head):
+    """fused_rows.seq_rows_group (three heads of different output widths on the same rows, one launch per layer) against
+    the same heads one at a time and against fp64: outputs, every parameter gradient, the summed input gradient, running
+    statistics; a head whose output nothing reads contributes exactly zero."""
+    from open3dsot_amd import fused_rows
+    from open3dsot_amd.nn_blocks import RowBatchNorm1d
+
+    def head(out, seed):
+        torch.manual_seed(seed)
+        seq = nn.Sequential(nn.Linear(256, 128), RowBatchNorm1d(128), nn.ReLU(), nn.Linear(128, 128), RowBatchNorm1d(128), nn.ReLU(),
+                            nn.Linear(128, out))
+        with torch.no_grad():
+            for m in seq.modules():
+                if isinstance(m, nn.BatchNorm1d):
+                    m.weight.uniform_(0.5, 1.5); m.bias.normal_(0, 0.2); m.running_mean.normal_(0, 0.2); m.running_var.uniform_(0.5, 1.5)
+        return seq
+    heads = [head(4, 1), head(2, 2), head(4, 3)]
+    refs = [copy.deepcopy(h).double().train(train) for h in heads]
+    singles = [copy.deepcopy(h).cuda().train(train) for h in heads]
+    heads = [h.cuda().train(train) for h in heads]
+    R = 48
+    x = torch.randn(R, 256, generator=torch.Generator().manual_seed(7))
+    xg, xs, xr = x.cuda().requires_grad_(True), x.cuda().requires_grad_(True), x.double().requires_grad_(True)
+    outs = fused_rows.seq_rows_group(heads, xg)
+    assert type(outs[0].grad_fn).__name__.startswith("RowStackGroup")
+    souts = [fused_rows.seq_rows(h, xs) for h in singles]
+    routs = [h(xr) for h in refs]
+    gos = [torch.randn(R, o.shape[1], generator=torch.Generator().manual_seed(20 + i)) for i, o in enumerate(outs)]
+    live = [0, 2] if unused_head else [0, 1, 2]
+    sum((outs[i] * gos[i].cuda()).sum() for i in live).backward()
+    sum((souts[i] * gos[i].cuda()).sum() for i in live).backward()
+    sum((routs[i] * gos[i].double()).sum() for i in live).backward()
+    for o, s, r in zip(outs, souts, routs):
+        assert torch.equal(o, s)                       # the same kernel body: bit-identical
+        assert rel(o, r) < 1e-5
+    assert l2rel(xg.grad, xr.grad) < 1e-4 and l2rel(xg.grad, xs.grad) < 1e-6
+    for i, (h, s, r) in enumerate(zip(heads, singles, refs)):
+        for (n, p), (_, q), (_, t) in zip(h.named_parameters(), s.named_parameters(), r.named_parameters()):
+            if i not in live:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
+                continue
+            assert torch.equal(p.grad, q.grad), n
+            assert l2rel(p.grad, t.grad) < 2e-4, (n, l2rel(p.grad, t.grad))
+        if train:
+            for (n, b), (_, c) in zip(h.named_buffers(), r.named_buffers()):
+                if b.dtype.is_floating_point:
+                    assert rel(b, c) < 1e-6, n
+                else:
+                    assert int(b) == int(c), n
