@@ -209,7 +209,9 @@ def test_row_stack_group_equals_the_single_stacks(train, unused_head):
                 assert p.grad is None or float(p.grad.abs().max()) == 0.0, n
                 continue
             assert torch.equal(p.grad, q.grad), n
-            assert l2rel(p.grad, t.grad) < 2e-4, (n, l2rel(p.grad, t.grad))
+            # (a Linear bias in front of a training-mode BatchNorm has an exactly zero gradient: judged on the head's scale)
+            scale = max(float(u.grad.abs().max()) for u in r.parameters())
+            assert float((p.grad.cpu().double() - t.grad).abs().max()) < 1e-4 * scale, n
         if train:
             for (n, b), (_, c) in zip(h.named_buffers(), r.named_buffers()):
                 if b.dtype.is_floating_point:
