@@ -580,6 +580,12 @@ int o3d_motion_merge_fwd(const float* pts, long bstride, long cstride, const flo
 int o3d_motion_merge_bwd(const float* pts, long bstride, long cstride, const float* prev, const float* motion, int B, int N,
                          const float* g_merged, const float* g_aux, float* g_prev, float* g_motion, void* stream);
 
+/* Backward of o3d_gmax_fwd without the dense gradient: pk (C, B) float2 = {dOut where out > 0 else 0, bits(column of the
+ * maximum relative to its cloud)} -- the pooled operand of o3d_mlp_conv_dgrad_wt / o3d_mlp_conv_wgrad2 with one ball of
+ * ns = N columns per cloud -- and the BatchNorm-backward sums part[0][0][c] = sum g, part[0][1][c] = sum g * (yarg - mean). */
+int o3d_gmax_bwd_pk(const float* dOut, const float* out, const int32_t* argq, const float* yarg, const float* mean, int B, int C,
+                    int N, float* pk, float* part, void* stream);
+
 /* Backward of a thin first layer of a per-point stack (models/backbone/pointnet.py:91-204 with 12-14 input channels) on the
  * flat (C, P) layout, Cout == 64, Cin <= 16, P % 64 == 0: dY = A1*dN + A2*Y + A3 (per-row constants, the BatchNorm backward
  * folded); dW (64, Cin) = dY . X^T; dX (Cin, P) = W^T . dY when dX != NULL.  One pass over dN and Y.

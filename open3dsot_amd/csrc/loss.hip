@@ -265,26 +265,28 @@ __device__ __forceinline__ float nll2(float x0, float x1, int y, float& p1) {
 // 5 motion angle (moving), 6/7 refined centre / angle, 8/9 previous, 10/11 first stage, 12 motion-state NLL
 __global__ __launch_bounds__(LT) void m2_loss_sums_kernel(M2LossArgs a) {
     __shared__ float red[LT / 64][MS];
-    const int tid = threadIdx.x, gtid = blockIdx.x * LT + threadIdx.x, gstride = LG * LT;
+    const int tid = threadIdx.x;
     float s[MS];
 #pragma unroll
     for (int k = 0; k < MS; ++k) s[k] = 0.f;
-    const long npts = (long)a.B * a.N;
-    for (long i = gtid; i < npts; i += gstride) {
-        const long b = i / a.N, n = i - b * a.N;
-        const int y = a.seg_label[i] != 0;
-        float p1;
-        const float nll = nll2(a.seg_logits[(b * 2 + 0) * a.N + n], a.seg_logits[(b * 2 + 1) * a.N + n], y, p1);
-        const float w = y ? a.cw1 : a.cw0;
-        s[0] += w;
-        s[1] += w * nll;
-    }
-    if (a.bc_pred) {
-        const long half = (long)(a.N / 2) * a.K, per = (long)a.N * a.K, nel = (long)a.B * per;
-        for (long e = gtid; e < nel; e += gstride) {
-            const long b = e / per, r = e - b * per;
-            const float lab = r < half ? a.bc_a[b * half + r] : a.bc_b[b * half + (r - half)];
-            s[2] += smooth_l1(a.bc_pred[e] - lab);
+    // a cloud per workgroup (no per-element division: as a flat grid-stride loop with b = i / N this kernel took 40 us)
+    const int half = (a.N / 2) * a.K, per = a.N * a.K;
+    for (int b = blockIdx.x; b < a.B; b += LG) {
+        const float* l0 = a.seg_logits + (long)b * 2 * a.N;
+        const int64_t* lab = a.seg_label + (long)b * a.N;
+        for (int n = tid; n < a.N; n += LT) {
+            const int y = lab[n] != 0;
+            float p1;
+            const float nll = nll2(l0[n], l0[a.N + n], y, p1);
+            const float w = y ? a.cw1 : a.cw0;
+            s[0] += w;
+            s[1] += w * nll;
+        }
+        if (a.bc_pred) {
+            const float* pr = a.bc_pred + (long)b * per;
+            const float* la = a.bc_a + (long)b * half;
+            const float* lb = a.bc_b + (long)b * half - half;
+            for (int r = tid; r < per; r += LT) s[2] += smooth_l1(pr[r] - (r < half ? la[r] : lb[r]));
         }
     }
     if (blockIdx.x == 0) {
@@ -324,7 +326,7 @@ __global__ __launch_bounds__(LT) void m2_loss_sums_kernel(M2LossArgs a) {
 
 __global__ __launch_bounds__(LT) void m2_loss_grads_kernel(M2LossArgs a) {
     __shared__ float tot[MS];
-    const int tid = threadIdx.x, gtid = blockIdx.x * LT + threadIdx.x, gstride = LG * LT;
+    const int tid = threadIdx.x, gtid = blockIdx.x * LT + threadIdx.x;
     if (tid < MS) {
         float t = 0.f;
         for (int g = 0; g < LG; ++g) t += a.partial[g * MS + tid];
@@ -351,24 +353,27 @@ __global__ __launch_bounds__(LT) void m2_loss_grads_kernel(M2LossArgs a) {
         a.losses[7] = l_cx; a.losses[8] = l_cm; a.losses[9] = l_ax; a.losses[10] = l_am; a.losses[11] = l_bc;
     }
     if (!a.g_seg) return;
-    const long npts = (long)a.B * a.N;
     const float c_seg = a.w_seg / s[0];
-    for (long i = gtid; i < npts; i += gstride) {
-        const long b = i / a.N, n = i - b * a.N;
-        const int y = a.seg_label[i] != 0;
-        float p1;
-        nll2(a.seg_logits[(b * 2 + 0) * a.N + n], a.seg_logits[(b * 2 + 1) * a.N + n], y, p1);
-        const float w = (y ? a.cw1 : a.cw0) * c_seg;
-        a.g_seg[(b * 2 + 0) * a.N + n] = w * ((1.f - p1) - (y ? 0.f : 1.f));
-        a.g_seg[(b * 2 + 1) * a.N + n] = w * (p1 - (y ? 1.f : 0.f));
-    }
-    if (a.bc_pred) {
-        const long half = (long)(a.N / 2) * a.K, per = (long)a.N * a.K, nel = (long)a.B * per;
-        const float c_bc = a.w_bc / ((float)a.B * a.N * a.K);
-        for (long e = gtid; e < nel; e += gstride) {
-            const long b = e / per, r = e - b * per;
-            const float lab = r < half ? a.bc_a[b * half + r] : a.bc_b[b * half + (r - half)];
-            a.g_bc[e] = c_bc * fminf(fmaxf(a.bc_pred[e] - lab, -1.f), 1.f);
+    const int half = (a.N / 2) * a.K, per = a.N * a.K;
+    const float c_bc = a.w_bc / ((float)a.B * a.N * a.K);
+    for (int b = blockIdx.x; b < a.B; b += LG) {
+        const float* l0 = a.seg_logits + (long)b * 2 * a.N;
+        const int64_t* lab = a.seg_label + (long)b * a.N;
+        float* g0 = a.g_seg + (long)b * 2 * a.N;
+        for (int n = tid; n < a.N; n += LT) {
+            const int y = lab[n] != 0;
+            float p1;
+            nll2(l0[n], l0[a.N + n], y, p1);
+            const float w = (y ? a.cw1 : a.cw0) * c_seg;
+            g0[n] = w * ((1.f - p1) - (y ? 0.f : 1.f));
+            g0[a.N + n] = w * (p1 - (y ? 1.f : 0.f));
+        }
+        if (a.bc_pred) {
+            const float* pr = a.bc_pred + (long)b * per;
+            const float* la = a.bc_a + (long)b * half;
+            const float* lb = a.bc_b + (long)b * half - half;
+            float* g = a.g_bc + (long)b * per;
+            for (int r = tid; r < per; r += LT) g[r] = c_bc * fminf(fmaxf(pr[r] - (r < half ? la[r] : lb[r]), -1.f), 1.f);
         }
     }
     if (blockIdx.x == 0) {

@@ -276,3 +276,39 @@ extern "C" int o3d_thin_bwd(const float* dN, const float* Y, const float* A1, co
     hipLaunchKernelGGL(thin_reduce_kernel, dim3(TH_K * TH_M / 4), dim3(256), 0, o3d_stream(stream), scratch, grid, Cin, dW);
     return o3d_launch_status();
 }
+
+// ---- backward of the global max without the dense gradient (round 4) ---------------------------------------------------------
+// dN of a "gmax" stack's last layer is zero except at one column per (cloud, channel): materialising it cost a zero fill of
+// (C, P) -- 400 MB for M2-Track's 1024-channel layer -- a scatter, and a dense read in each of the two GEMMs behind it.  The
+// GEMM kernels can build that operand on the fly from pk (C, B) = {dOut where out > 0, bits(arg - first column of the cloud)}
+// (the pooled-source modes of mlp_direct.hip / mlp_wgrad.hip: one "ball" of N columns per cloud): this kernel writes pk and
+// the BatchNorm-backward sums {sum g, sum g * (yarg - mean)} (one partial row), thread per channel, fixed order.
+namespace {
+__global__ __launch_bounds__(64) void gmax_bwd_pk_kernel(const float* __restrict__ dOut, const float* __restrict__ out,
+                                                         const int32_t* __restrict__ argq, const float* __restrict__ yarg,
+                                                         const float* __restrict__ mean, int B, int C, int N,
+                                                         float2* __restrict__ pk, float* __restrict__ part) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= C) return;
+    const float mu = mean[c];
+    float s = 0.f, q = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const long o = (long)b * C + c;
+        const float g = out[o] > 0.f ? dOut[o] : 0.f;
+        pk[(long)c * B + b] = make_float2(g, __int_as_float(argq[o] - b * N));
+        s += g;
+        q = fmaf(g, yarg[o] - mu, q);
+    }
+    part[c] = s;
+    part[C + c] = q;
+}
+}  // namespace
+
+// dOut, out, yarg (B, C), argq (B, C) as o3d_gmax_fwd wrote them -> pk (C, B, 2), part [1][2][C]
+extern "C" int o3d_gmax_bwd_pk(const float* dOut, const float* out, const int32_t* argq, const float* yarg, const float* mean,
+                               int B, int C, int N, float* pk, float* part, void* stream) {
+    if (!dOut || !out || !argq || !yarg || !mean || !pk || !part || B <= 0 || C <= 0 || N <= 0) return O3D_EINVAL;
+    hipLaunchKernelGGL(gmax_bwd_pk_kernel, dim3(o3d_cdiv(C, 64)), dim3(64), 0, o3d_stream(stream), dOut, out, argq, yarg, mean,
+                       B, C, N, reinterpret_cast<float2*>(pk), part);
+    return o3d_launch_status();
+}

@@ -19,6 +19,7 @@ _vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
 capi.register("o3d_pw_tile", [_l, _i])
 capi.register("o3d_pw_fwd", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp])
 capi.register("o3d_pw_dgrad", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp])
+capi.register("o3d_gmax_bwd_pk", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp])
 capi.register("o3d_thin_bwd_scratch", [])
 capi.register("o3d_thin_bwd", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _vp, _vp])
 capi.register("o3d_bn_relu_apply", [_vp, _vp, _vp, _i, _l, _vp, _vp])
@@ -30,6 +31,9 @@ capi.register("o3d_cloud_sum_dy", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp
 
 class _Cfg:
     __slots__ = ("mode", "training", "bns")
+
+
+_POOLED_GMAX = {"on": True}      # test hook: the dense-gradient backward of a "gmax" stack (the path it replaced)
 
 
 def _flat_ok(rows, k, P):
@@ -150,13 +154,24 @@ class FusedPointwiseChain(torch.autograd.Function):
         st = _stream()
         ntiles = P // TILE
         Cl = Ws[-1].shape[0]
-        dN = torch.empty((Cl, P), device=dev, dtype=f32)
+        dN = torch.empty((Cl, P), device=dev, dtype=f32) if not (cfg.mode != "act" and L >= 2 and Cl % 64 == 0 and
+                                                                   Ws[-1].shape[1] % 64 == 0 and N % 128 == 0 and
+                                                                   _POOLED_GMAX["on"]) else None
+        pk = None
         if cfg.mode == "act":
             g = dOut.permute(1, 0, 2).reshape(Cl, P).contiguous()
             part = torch.empty((ntiles, 2, Cl), device=dev, dtype=f32)
             _call("pw_act_bwd", 0.0, lib.o3d_act_bwd_partials, g.data_ptr(), Ys[-1].data_ptr(), scales[-1].data_ptr(),
                   shifts[-1].data_ptr(), means[-1].data_ptr(), Cl, P, dN.data_ptr(), part.data_ptr(), st)
             nparts = ntiles
+        elif L >= 2 and Cl % 64 == 0 and Ws[-1].shape[1] % 64 == 0 and N % 128 == 0 and _POOLED_GMAX["on"]:
+            # the last layer's GEMMs build the one-hot gradient of the max on the fly (csrc/pointwise.hip::gmax_bwd_pk_kernel)
+            dOut = dOut.contiguous()
+            pk = torch.empty((Cl, B, 2), device=dev, dtype=f32)
+            part = torch.empty((1, 2, Cl), device=dev, dtype=f32)
+            _call("pool_bwd", 0.0, lib.o3d_gmax_bwd_pk, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
+                  means[-1].data_ptr(), B, Cl, N, pk.data_ptr(), part.data_ptr(), st)
+            nparts, dN = 1, None
         else:
             dOut = dOut.contiguous()
             part = torch.empty((POOL_BWD_SPLIT, 2, Cl), device=dev, dtype=f32)
@@ -210,7 +225,8 @@ class FusedPointwiseChain(torch.autograd.Function):
                 wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, P),), device=dev, dtype=f32)
                 xs = (X0.data_ptr(), None, None) if l == 0 else \
                      (Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr())
-                _call("pw_conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2, dN.data_ptr(), None, 4, Ys[l].data_ptr(), A[0], A[1],
+                _call("pw_conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2, _ptr(dN), _ptr(pk) if dN is None else None,
+                      N if dN is None else 4, Ys[l].data_ptr(), A[0], A[1],
                       A[2], xs[0], xs[1], xs[2], 1, Cin, Cout, P, wpart.data_ptr(), dW.data_ptr(), st, dims=(Cin, Cout))
             else:
                 tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
@@ -225,7 +241,14 @@ class FusedPointwiseChain(torch.autograd.Function):
             if l >= 1:
                 Wt = ctx.Wts[l] if ctx.Wts is not None else Ws[l].t().contiguous()
                 dNp = torch.empty((Cin, P), device=dev, dtype=f32)
-                if _flat_ok(Cin, Cout, P):
+                if dN is None:           # pooled source: 128-column tiles, one ball of N columns per cloud
+                    nrows = ntiles
+                    part = torch.empty((ntiles, 2, Cin), device=dev, dtype=f32)
+                    _call("pw_conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_wt, None, None, None, None, N,
+                          Ys[l].data_ptr(), A[0], A[1], A[2], Ws[l].data_ptr(), Wt.data_ptr(), pk.data_ptr(), 1, Cin, Cout, P,
+                          Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(),
+                          dNp.data_ptr(), part.data_ptr(), st, dims=(Cin, Cout))
+                elif _flat_ok(Cin, Cout, P):
                     nrows = P // lib.o3d_pw_tile(P, Cin)
                     part = torch.empty((nrows, 2, Cin), device=dev, dtype=f32)
                     _call("pw_conv_dgrad", flops, lib.o3d_pw_dgrad, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
