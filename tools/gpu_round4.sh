@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU call (gpurun).  usage: gpu_round4.sh <tag> [parts]   parts = any of: smoke tests ref bench qbench trace pmc sq probe:<name> ab:<env> k:<name+name+...> m:<MODEL>
+# One GPU call (gpurun).  usage: gpu_round4.sh <tag> [parts]   parts = any of: smoke tests ref bench qbench trace pmc sq probe:<name> ab:<env> hook:<module.dict.key>[:MODEL] k:<name+name+...> m:<MODEL>
 # (default: smoke tests ref bench trace).  Everything lands in gpurun_out/<tag>/.
 TAG=${1:-r4}; shift
 PARTS="${*:-smoke tests ref bench trace}"
@@ -40,6 +40,10 @@ if has qbench; then
   timeout 600 python bench.py --no-cpu-baseline --no-secondary --per-launch $OUT/per_launch_roofline_bat.txt > $OUT/bench.json 2> $OUT/bench.err; echo "qbench exit $?"
   tail -2 $OUT/bench.err | cut -c1-300
 fi
+for p in $PARTS; do case "$p" in hook:*)     # hook:<module>.<dict>.<key>[:MODEL] -> same-box A/B of a test hook (tools/ab_hook.py)
+  H=${p#hook:}; HM=${H#*:}; [ "$HM" = "$H" ] && HM=BAT; H=${H%%:*}
+  timeout 1200 python tools/ab_hook.py $H 3 --model $HM > $OUT/ab_hook_${H}_$HM.txt 2>&1; cat $OUT/ab_hook_${H}_$HM.txt | tail -4 ;;
+esac; done
 for p in $PARTS; do case "$p" in ab:*)
   bash tools/ab.sh "$(echo "${p#ab:}" | tr '+' ' ')" 2 > $OUT/ab_$(echo "${p#ab:}" | tr -c 'A-Za-z0-9_=' '_').txt 2>&1; cat $OUT/ab_$(echo "${p#ab:}" | tr -c 'A-Za-z0-9_=' '_').txt | tail -3 ;;
 esac; done
