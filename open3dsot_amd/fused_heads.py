@@ -107,11 +107,8 @@ def _submit_jobs(jobs, keep, st, params):
         _DEFER["keys"] |= keys
 
 
-_DEFER_REDUCE = {"on": True}       # test / A-B hook (tools/ab_hook.py): the stacks' slice reductions as launches of their own
-
-
 def deferring():
-    return _DEFER["queue"] is not None and _DEFER_REDUCE["on"]
+    return _DEFER["queue"] is not None
 
 
 def submit_reduce(Cin, Cout, P, scratch, dW, st, param):
