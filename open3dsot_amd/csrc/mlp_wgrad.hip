@@ -620,7 +620,7 @@ static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y,
                        int Cout, int P, const float* w, const int32_t* meta, long start1, float* scratch, float* dW,
                        void* stream) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || P <= 0 || P % 64 || !Y || !A1 || !A2 || !A3 ||
-        !X || (in_scale == nullptr) != (in_shift == nullptr) || !scratch || (!dN && (!pk || ns < 4 || ns % 4)))
+        !X || (in_scale == nullptr) != (in_shift == nullptr) || !scratch || !dW || (!dN && (!pk || ns < 4 || ns % 4)))
         return O3D_EINVAL;
     int TM, TN, WK, CP, nsl;
     wgrad2_plan(Cin, Cout, B, P, TM, TN, WK, CP, nsl);
@@ -640,7 +640,6 @@ static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y,
     else if (TN == 128)         rc = launch_wgrad2<64, 128>(a, s);
     else                        rc = launch_wgrad2<64, 64>(a, s);
     if (rc != O3D_OK) return rc;
-    if (!dW) return o3d_launch_status();       // partial tiles only: the caller reduces them later (a REDUCE job of a group)
     const long n = (long)Cout * Cin;
     o3d_wgrad_reduce(scratch, nsl * WK, n, scratch + (long)nsl * WK * n, dW, s);
     return o3d_launch_status();
@@ -669,20 +668,6 @@ extern "C" int o3d_mlp_conv_wgrad2_group(const o3d_wgrad_job* jobs, int njobs, v
             nblk += q.Cout;
             r.part[i] = q.dW; r.out[i] = q.dW; r.n[i] = 0; r.nslices[i] = 0; r.ld[i] = 1; r.orows[i] = r.ocols[i] = 0;
             r.first[i] = rblk;
-            continue;
-        }
-        if (!q.dN && !q.X && !q.Y && q.scratch && q.dW && q.Cin > 0 && q.Cout > 0 && q.Cin % 64 == 0 && q.Cout % 64 == 0 &&
-            q.P > 0 && q.P % 64 == 0 && q.P <= 0x7fffffff) {
-            // a REDUCE job: the partial tiles are in scratch already (o3d_mlp_conv_wgrad2 / _c called with dW == NULL for
-            // the same Cin, Cout, P): no workgroup of the first launch, one entry of the reduction launch
-            int TM, TN, WK, CP, nsl;
-            wgrad2_plan(q.Cin, q.Cout, 1, (int)q.P, TM, TN, WK, CP, nsl);
-            g.kind[i] = 0;
-            g.first[i] = nblk;
-            r.part[i] = q.scratch; r.out[i] = q.dW; r.n[i] = (long)q.Cout * q.Cin; r.nslices[i] = nsl * WK;
-            r.ld[i] = q.Cin; r.orows[i] = q.Cout; r.ocols[i] = q.Cin;
-            r.first[i] = rblk;
-            rblk += o3d_cdiv(r.n[i], 32);
             continue;
         }
         if (!q.dN || !q.Y || !q.A1 || !q.A2 || !q.A3 || !q.X || (q.in_scale == nullptr) != (q.in_shift == nullptr) ||
@@ -716,7 +701,7 @@ extern "C" int o3d_mlp_conv_wgrad2_group(const o3d_wgrad_job* jobs, int njobs, v
     if (!attr_ok || lds > 80 * 1024) return O3D_ELAUNCH;
     hipStream_t s = o3d_stream(stream);
     if (lds < 16) lds = 16;            // (row-sum jobs only: four floats of staging)
-    if (nblk > 0) hipLaunchKernelGGL(wgrad2_group_kernel, dim3(nblk), dim3(256), lds, s, g);
+    hipLaunchKernelGGL(wgrad2_group_kernel, dim3(nblk), dim3(256), lds, s, g);
     if (rblk > 0) hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3(rblk), dim3(256), 0, s, r);
     return o3d_launch_status();
 }

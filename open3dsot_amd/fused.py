@@ -683,17 +683,9 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             flops = (2.0 * Cin * Cout, meta, ldp)      # executed FLOPs = per live column (count read back when profiling)
             dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
             wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, ldp),), device=dev, dtype=f32)
-            # inside the training step's deferral scope (fused_heads.defer_wgrads) the slice reduction of this gradient is
-            # queued into the grouped reduction launches at the end of the backward instead of being a launch of its own
-            from . import fused_heads as _fh
-            Wp = ctx.versions[3 * l][0] if len(ctx.versions) == 3 * L else None
-            later = isinstance(Wp, torch.nn.Parameter) and Wp.is_leaf and _fh.deferring()
             _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
                   Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Cin, Cout, ldp,
-                  cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(), None if later else dW.data_ptr(), st,
-                  dims=(Cin, Cout))
-            if later:
-                _fh.submit_reduce(Cin, Cout, ldp, wpart, dW, st, Wp)
+                  cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(), dW.data_ptr(), st, dims=(Cin, Cout))
             grads[3 * l] = dW
             Wt = ctx.Wts[l]
             dNp = torch.empty((Cin, ldp), device=dev, dtype=f32)

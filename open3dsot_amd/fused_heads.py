@@ -107,18 +107,6 @@ def _submit_jobs(jobs, keep, st, params):
         _DEFER["keys"] |= keys
 
 
-def deferring():
-    return _DEFER["queue"] is not None
-
-
-def submit_reduce(Cin, Cout, P, scratch, dW, st, param):
-    """The slice reduction of ONE weight gradient whose partial tiles are in `scratch` already (o3d_mlp_conv_wgrad2 / _c
-    called with dW = NULL): queued as a REDUCE job of the grouped launch -- the set-abstraction and per-point stacks' eight
-    to fourteen 8-us reductions per step ride in the heads' reduction launches.  Same contract as `_submit_jobs`."""
-    job = (0.0, (None, None, None, None, None, None, None, None, Cin, Cout, P, scratch.data_ptr(), dW.data_ptr(), 0, 0))
-    _submit_jobs([job], (scratch, dW), st, [param])
-
-
 @contextlib.contextmanager
 def defer_wgrads():
     if _DEFER["queue"] is not None:          # nested scopes: the outer one flushes

@@ -134,7 +134,6 @@ class FusedPointwiseChain(torch.autograd.Function):
                 ctx.Wts = [None] + [prep.get(params[4 * l], Ws[l].shape[1], Ws[l].shape[0], transpose=True) for l in range(1, L)]
             ctx.cfg = cfg
             ctx.versions = _versions(params)
-            ctx.wparams = [params[4 * l] for l in range(L)]
             ctx.dims = (B, N, L)
             ctx.has_bias = [b is not None for b in biases]
             ctx.has_cbias = cbias is not None
@@ -226,16 +225,9 @@ class FusedPointwiseChain(torch.autograd.Function):
                 wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, P),), device=dev, dtype=f32)
                 xs = (X0.data_ptr(), None, None) if l == 0 else \
                      (Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr())
-                from . import fused_heads as _fh
-                Wp = ctx.wparams[l]       # (a leaf only: the gradient of a VIEW of a parameter is read by autograd at once)
-                later = isinstance(Wp, torch.nn.Parameter) and Wp.is_leaf and _fh.deferring()   # the slice reduction rides in
-                #                                                                   the grouped launches (fused.py)
                 _call("pw_conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2, _ptr(dN), _ptr(pk) if dN is None else None,
                       N if dN is None else 4, Ys[l].data_ptr(), A[0], A[1],
-                      A[2], xs[0], xs[1], xs[2], 1, Cin, Cout, P, wpart.data_ptr(), None if later else dW.data_ptr(), st,
-                      dims=(Cin, Cout))
-                if later:
-                    _fh.submit_reduce(Cin, Cout, P, wpart, dW, st, Wp)
+                      A[2], xs[0], xs[1], xs[2], 1, Cin, Cout, P, wpart.data_ptr(), dW.data_ptr(), st, dims=(Cin, Cout))
             else:
                 tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
                 nsl = max(1, min(P // 32 // 4, 768 // tiles))

@@ -1059,43 +1059,3 @@ def test_flat_batch_single_copy_step_equals_per_field_step():
     pool[0]["fps_idx_s"].zero_()
     l_eager = float(tb._forward_backward(pool[0]))
     assert abs(l_eager - float(ta.step(raw[0]))) <= 1e-5 * (1 + abs(l_eager))
-
-
-@pytest.mark.parametrize("name", ["BAT", "M2TRACK"])
-def test_whole_step_deferred_reductions_equal_the_immediate_ones(name):
-    """inside fused_heads.defer_wgrads() the set-abstraction / per-point stacks leave their weight-gradient partial tiles in
-    scratch and queue the slice REDUCTION into the grouped launches at the end of the backward (fused.py, fused_pointwise.py):
-    every parameter gradient of a whole step, deferred == immediate, bitwise (same partial tiles, same order of summation);
-    the gradient buffers are NaN-poisoned before the backward so that a tensor read before its flush shows."""
-    from open3dsot_amd import fused_heads, synth
-    dev = torch.device("cuda", 0)
-    if name == "M2TRACK":
-        from open3dsot_amd import m2track
-        torch.manual_seed(21)
-        model = m2track.M2TRACK().cuda().train()
-        batch = synth.to_torch(synth.make_motion_batch(5, 8, 512), dev)
-    else:
-        model = make_model(name, 21)
-        batch = synth.to_torch(synth.make_batch(5, 8, 512, 1024), dev)
-    saved = {k: v.clone() for k, v in model.state_dict().items()}
-
-    def grads(deferred):
-        model.load_state_dict(saved)
-        model.zero_grad(set_to_none=True)
-        loss, _ = model.training_loss(batch)
-        for n in (256 * 256, 128 * 128, 256 * 128, 512 * 256, 64 * 64, 1024 * 128):
-            t = torch.full((n,), float("nan"), device=dev)
-            del t
-        if deferred:
-            with fused_heads.defer_wgrads():
-                loss.backward()
-        else:
-            loss.backward()
-        torch.cuda.synchronize()
-        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
-
-    now, later = grads(False), grads(True)
-    assert set(now) == set(later) and len(now) > 20
-    for k in now:
-        assert torch.isfinite(later[k]).all(), k
-        assert torch.equal(now[k], later[k]), (k, float((now[k] - later[k]).abs().max()))
