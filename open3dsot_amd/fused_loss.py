@@ -157,7 +157,7 @@ class FusedM2Loss(torch.autograd.Function):
     @staticmethod
     @capi.on_tensor_device
     def backward(ctx, g, _g_parts=None):
-        grads = ctx.grads
+        grads = ctx.grads          # (kept for a second backward; handed out uncopied under the constant-1 seed: see FusedTrackLoss)
         if g is None:
             return (None,) * 15
         known = _ONE.get(str(g.device))
