@@ -331,7 +331,7 @@ __device__ __forceinline__ void direct_gemm_body(DirectArgs& a, const int bx, co
 
 
 template <int WAVES, int MODE, int EPI, int NT, int MT = 2>
-__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, NT == 4 ? 2 : 4)))
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, (NT == 4 && MT == 2) ? 2 : 4)))
 void direct_gemm_kernel(DirectArgs a) {
     direct_gemm_body<WAVES, MODE, EPI, NT, MT>(a, blockIdx.x, blockIdx.y);
 }
@@ -574,6 +574,13 @@ template <int MODE, int EPI>
 int launch_direct_small(const DirectArgs& a, int tile, hipStream_t st) {
     if constexpr (MODE <= B_DY && EPI <= 2) {
         if (splitk_ok(a, tile)) return launch_splitk<MODE, EPI>(a, st);
+    }
+    // Narrow outputs (64 / 128 rows) over many columns -- M2-Track's per-point layers, 98 304 columns: HBM-bound, and as 64-row
+    // waves only 768 / 1 536 of them, one per SIMD (0.22-0.53 of the HBM roof).  32-row waves of the same 128 columns: twice the
+    // waves, 64 accumulator registers (four per SIMD fit), the second reader of a B panel hits L1/L2.  Same box, M2-Track step:
+    // 6.487 -> 6.439 ms; on the compact launches of BAT (launch_direct below) the same rule measured +0.02 / 0.00 ms: not there.
+    if constexpr (MODE != B_DYPOOL) {
+        if (tile == 128 && a.M <= 128) return launch_direct_nt<MODE, EPI, 4, 1>(a, st);
     }
     return tile == 64 ? launch_direct_nt<MODE, EPI, 2>(a, st) : launch_direct_nt<MODE, EPI, 4>(a, st);
 }

@@ -32,6 +32,18 @@ if has ref && [ -d $REPO/.refscratch ]; then
   echo "reference-modules pytest exit $?" | tee -a $OUT/reference_modules_over_hip_ext.log
   grep -E "PASSED|FAILED|SKIPPED|passed|failed|^E  |reference .* class over" $OUT/reference_modules_over_hip_ext.log | cut -c1-400 | head -30
 fi
+if has pmc; then
+  cd /tmp
+  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python $REPO/bench.py --steps 2 --warmup 3 --no-graph --no-cpu-baseline --no-secondary > $OUT/rocprof_fetch.log 2>&1; echo "pmc fetch exit $?"
+  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- python $REPO/bench.py --steps 2 --warmup 3 --no-graph --no-cpu-baseline --no-secondary > $OUT/rocprof_write.log 2>&1; echo "pmc write exit $?"
+  cd $REPO
+  mkdir -p $OUT/pmc; find $OUT/pmc_fetch $OUT/pmc_write -name "*counter_collection.csv" | while read f; do cp "$f" $OUT/pmc/$(echo $f | grep -o "pmc_[a-z]*")_$(basename $f); done
+  python tools/pmc_summary.py $OUT/pmc $OUT/fabric_pmc_per_kernel.csv
+  python tools/hbm_traffic.py $OUT/fabric_pmc_per_kernel.csv $OUT/hbm_traffic.json BAT 48 8   # 3 warm-up + 2 timed + 3 roofline-profile eager steps
+  rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc
+  # (on the box only: the bench part below then reports `traffic` from counters of exactly this library)
+  [ -f $OUT/hbm_traffic.json ] && cp $OUT/hbm_traffic.json $REPO/profiles/hbm_traffic.json
+fi
 if has bench; then
   timeout 1200 python bench.py --per-launch $OUT/per_launch_roofline_bat.txt > $OUT/bench.json 2> $OUT/bench.err; echo "bench exit $?"
   tail -3 $OUT/bench.err | cut -c1-300
@@ -67,16 +79,6 @@ for p in $PARTS; do case "$p" in m:*)
   head -3 $OUT/steady_state_per_step_$ML.txt | cut -c1-200
   timeout 300 python bench.py --model $M --no-cpu-baseline --no-secondary --per-launch $OUT/per_launch_roofline_$ML.txt > $OUT/bench_$ML.json 2> $OUT/bench_$ML.err; echo "bench $M exit $?" ;;
 esac; done
-if has pmc; then
-  cd /tmp
-  timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o bench -- python $REPO/bench.py --steps 2 --warmup 3 --no-graph --no-cpu-baseline --no-secondary > $OUT/rocprof_fetch.log 2>&1; echo "pmc fetch exit $?"
-  timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o bench -- python $REPO/bench.py --steps 2 --warmup 3 --no-graph --no-cpu-baseline --no-secondary > $OUT/rocprof_write.log 2>&1; echo "pmc write exit $?"
-  cd $REPO
-  mkdir -p $OUT/pmc; find $OUT/pmc_fetch $OUT/pmc_write -name "*counter_collection.csv" | while read f; do cp "$f" $OUT/pmc/$(echo $f | grep -o "pmc_[a-z]*")_$(basename $f); done
-  python tools/pmc_summary.py $OUT/pmc $OUT/fabric_pmc_per_kernel.csv
-  python tools/hbm_traffic.py $OUT/fabric_pmc_per_kernel.csv $OUT/hbm_traffic.json BAT 48 8   # 3 warm-up + 2 timed + 3 roofline-profile eager steps
-  rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/pmc
-fi
 if has sq; then
   cd /tmp
   timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc_sq1 -o bench -- python $REPO/bench.py --steps 2 --warmup 2 --no-graph --no-cpu-baseline --no-secondary > $OUT/rocprof_sq1.log 2>&1; echo "pmc sq1 exit $?"
