@@ -139,3 +139,54 @@ def test_fused_backward_entry_validates_shapes_without_a_device():
     assert lib.o3d_compact_build2(None, 8, 8, None, 8, 8, 1, 4, 0, 8, 16, *([None] * 7)) == EINVAL
     assert lib.o3d_best_proposal(None, 1, 64, p, None, None) == EINVAL and lib.o3d_best_proposal(p, 0, 64, p, None, None) == EINVAL
     assert lib.o3d_adam_step(p, 1, p, p, p, 1e-3, 0.5, 0.999, 1e-6, 0.0, 0.0, 1e-3, None) == EINVAL             # bc1 = 0: step 0
+
+
+def test_round4_entry_points_validate_before_any_launch():
+    """the entry points added in round 4 (M2-Track loss, the transforms between its stages, row-stack groups, the thin
+    first-layer backward, the pooled global-max backward, P2B's similarity map) refuse NULL operands / unsupported shapes with
+    O3D_EINVAL before touching the device"""
+    from open3dsot_amd import box_utils, capi, fused_loss, fused_pointwise, fused_rows, fused_xcorr  # noqa: F401  (they register)
+    lib = capi.load()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    EINVAL = -1
+    assert lib.o3d_m2track_loss(*([None] * 14), 2, 8, 9, 1.0, 1.0, 1.0, 1.0, 1.0, 0.5, 2.0, *([None] * 10)) == EINVAL
+    # BoxCloud term switched on needs both label halves and an even number of points
+    assert lib.o3d_m2track_loss(p, p, p, None, None, None, None, p, p, p, None, None, p, None, 2, 8, 9, 1.0, 1.0, 1.0, 1.0, 1.0, 0.5,
+                                2.0, p, p, *([None] * 8)) == EINVAL
+    assert lib.o3d_m2track_loss(p, p, p, p, p, None, None, p, p, p, None, None, p, None, 2, 7, 9, 1.0, 1.0, 1.0, 1.0, 1.0, 0.5,
+                                2.0, p, p, *([None] * 8)) == EINVAL
+    assert lib.o3d_motion_merge_fwd(None, 8, 8, None, None, 1, 8, None, None, None) == EINVAL
+    assert lib.o3d_motion_merge_fwd(p, 32, 8, None, p, 1, 7, p, p, None) == EINVAL               # odd N: no two halves
+    assert lib.o3d_motion_merge_bwd(p, 32, 8, None, p, 1, 8, None, None, None, None, None) == EINVAL
+    assert lib.o3d_offset_box(None, None, 1, None, None, None, None, None) == EINVAL
+    assert lib.o3d_offset_box(p, p, 1, None, None, None, None, None) == EINVAL                    # forward without an output
+    assert lib.o3d_thin_bwd_scratch() == 256 * 64 * 16
+    assert lib.o3d_thin_bwd(p, p, p, p, p, p, p, 17, 64, 64, p, p, None, None) == EINVAL          # Cin > 16
+    assert lib.o3d_thin_bwd(p, p, p, p, p, p, p, 12, 128, 64, p, p, None, None) == EINVAL         # Cout != 64
+    assert lib.o3d_thin_bwd(p, p, p, p, p, p, p, 12, 64, 100, p, p, None, None) == EINVAL         # P % 64
+    assert lib.o3d_gmax_bwd_pk(None, None, None, None, None, 1, 8, 8, None, None, None) == EINVAL
+    assert lib.o3d_row_mlp_fwd_group(None, 1, None) == EINVAL and lib.o3d_row_mlp_fwd_group(p, 5, None) == EINVAL
+    assert lib.o3d_row_mlp_bwd_group(None, 1, None) == EINVAL and lib.o3d_row_mlp_input_grad(p, 0, None) == EINVAL
+    jobs = (fused_rows._RowFwdArgs * 1)()                   # a zeroed job: NULL operands
+    assert lib.o3d_row_mlp_fwd_group(ctypes.addressof(jobs), 1, None) == EINVAL
+    bjobs = (fused_rows._RowBwdArgs * 1)()
+    assert lib.o3d_row_mlp_bwd_group(ctypes.addressof(bjobs), 1, None) == EINVAL
+    assert lib.o3d_cosine_sim_fwd(None, 1, 1, 1, None, 1, 1, 1, 1, 32, 4, 8, None, None, None, None) == EINVAL
+    assert lib.o3d_cosine_sim_fwd(p, 1, 1, 1, p, 1, 1, 1, 1, 33, 4, 8, p, p, p, None) == EINVAL      # channels % 32
+
+
+def test_row_group_structs_match_the_header_layout():
+    """ctypes mirrors of o3d_row_fwd_args / o3d_row_bwd_args: same field names, in the header's order"""
+    from open3dsot_amd import fused_rows
+    src = open(os.path.join(ROOT, "include", "o3dsot.h")).read()
+    for name, cls in (("o3d_row_fwd_args", fused_rows._RowFwdArgs), ("o3d_row_bwd_args", fused_rows._RowBwdArgs)):
+        body = re.search(r"typedef struct \{([^}]*)\}\s*%s;" % name, src).group(1)
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            base, names = re.match(r"((?:const\s+)?\w+\s*\**)\s*(.*)", decl).groups()
+            fields += [n.strip().lstrip("*").strip() for n in names.split(",")]
+        assert fields == [f[0] for f in cls._fields_], (name, fields, [f[0] for f in cls._fields_])
