@@ -233,13 +233,29 @@ def run_infer(args):
     capi.load()
     dev = torch.device("cuda", 0)
     torch.manual_seed(1234)
-    model = trackers.get_model(args.model if args.model != "M2TRACK" else "BAT")().to(dev).eval()
     B = args.infer_batch
-    frames = [synth.to_torch(synth.make_batch(100 + i * B, B), dev) for i in range(max(2, args.pool))]
+    if args.model == "M2TRACK":
+        # the network half of BaseModel.evaluate_one_sample for the motion tracker (models/base_model.py:44-57 on the input
+        # of MotionBaseModel.build_input_dict, :255-304): the two-stage forward on the stacked previous / current crops ->
+        # the refined box (x, y, z, theta)
+        from open3dsot_amd import m2track
+        model = m2track.M2TRACK().to(dev).eval()
+        keep = ("points", "candidate_bc")
+        frames = [{k: v for k, v in synth.to_torch(synth.make_motion_batch(100 + i * B, B, 1024), dev).items() if k in keep}
+                  for i in range(max(2, args.pool))]
+        shapes = "2 x 1024 pts"
 
-    def fwd(b):      # the network half of evaluate_one_sample (models/base_model.py:44-57): forward + the best proposal's
-        with torch.no_grad():      # (x, y, z, theta), selected on the device (no (64,5) copy to the host)
-            return model.evaluate_one_sample(b)
+        def fwd(b):
+            with torch.no_grad():
+                return (model(b)["estimation_boxes"],)
+    else:
+        model = trackers.get_model(args.model)().to(dev).eval()
+        frames = [synth.to_torch(synth.make_batch(100 + i * B, B), dev) for i in range(max(2, args.pool))]
+        shapes = "512/1024 pts"
+
+        def fwd(b):      # the network half of evaluate_one_sample (models/base_model.py:44-57): forward + the best proposal's
+            with torch.no_grad():      # (x, y, z, theta), selected on the device (no (64,5) copy to the host)
+                return model.evaluate_one_sample(b)
 
     for i in range(max(args.warmup, 3)):
         fwd(frames[i % len(frames)])
@@ -278,13 +294,13 @@ def run_infer(args):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
     return {
-        "metric": "tracked frames/sec (eval forward, %s KITTI-Car 512/1024 pts, batch %d)" % (model.__class__.__name__, B),
+        "metric": "tracked frames/sec (eval forward, %s KITTI-Car %s, batch %d)" % (model.__class__.__name__, shapes, B),
         "value": round(B / ms * 1e3, 1), "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
         "data": "synthetic KITTI-Car-like pairs (open3dsot_amd/synth.py), random-init weights, BatchNorm on running statistics",
-        "config": {"workload": "%s_Car.yaml tracking inference, template 512 / search 1024 pts, batch %d, eval forward only, "
-                               "fp32" % (model.__class__.__name__, B), "hip_graph": True, "eager_ms_per_frame": round(eager_ms, 4),
-                   "best_proposal_on_device": True, "graph_replay_matches_eager": bool(same)}}
+        "config": {"workload": "%s tracking inference, KITTI-Car %s, batch %d, eval forward only, fp32"
+                               % (model.__class__.__name__, shapes, B), "hip_graph": True, "eager_ms_per_frame": round(eager_ms, 4),
+                   "best_proposal_on_device": args.model != "M2TRACK", "graph_replay_matches_eager": bool(same)}}
 
 
 def run(args):
@@ -357,6 +373,7 @@ def secondary_lines(args):
     one("bat_dense_worst_case", dense=True)
     one("bat_infer_batch1", infer=True)
     one("p2b_infer_batch1", infer=True, model="P2B")
+    one("m2track_infer_batch1", infer=True, model="M2TRACK")     # (last: a fault while capturing it cannot touch the lines above)
     return out
 
 
