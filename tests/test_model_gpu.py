@@ -1059,3 +1059,65 @@ def test_flat_batch_single_copy_step_equals_per_field_step():
     pool[0]["fps_idx_s"].zero_()
     l_eager = float(tb._forward_backward(pool[0]))
     assert abs(l_eager - float(ta.step(raw[0]))) <= 1e-5 * (1 + abs(l_eager))
+
+
+def test_m2track_inference_graph_replay_matches_eager_and_cpu_mirror():
+    """M2-Track's tracking-inference forward (SURVEY.md section 8f-4 for config 4): eval mode, batch 1, the stacked 2 x 1024-point
+    crops, no autograd, captured as ONE HIP graph and replayed on new frames: replay == eager (bitwise) == the golden-pinned
+    CPU mirror of the model (1e-4 of the box scale; the hard masks -- argmax of the segmentation / motion-state logits --
+    equal); eval mode leaves every buffer untouched."""
+    from open3dsot_amd import m2track, synth
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(31)
+    cpu = m2track.M2TRACK().eval()
+    g = torch.Generator().manual_seed(32)
+    with torch.no_grad():
+        for m in cpu.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.weight.copy_(torch.empty(m.weight.shape).uniform_(0.5, 1.5, generator=g))
+                m.bias.copy_(torch.empty(m.bias.shape).normal_(0, 0.1, generator=g))
+                m.running_mean.copy_(torch.empty(m.bias.shape).normal_(0, 0.1, generator=g))
+                m.running_var.copy_(torch.empty(m.bias.shape).uniform_(0.5, 1.5, generator=g))
+    gpu = m2track.M2TRACK().eval()
+    gpu.load_state_dict(cpu.state_dict())
+    gpu = gpu.to(dev)
+    sd = {k: v.detach().cpu().clone() for k, v in gpu.state_dict().items()}
+    keep = ("points", "candidate_bc")
+    hosts = [{k: v for k, v in synth.to_torch(synth.make_motion_batch(900 + i, 1, 1024)).items() if k in keep} for i in range(3)]
+    frames = [{k: v.to(dev) for k, v in h.items()} for h in hosts]
+    keys = ("estimation_boxes", "aux_estimation_boxes", "motion_pred", "seg_logits", "motion_cls", "estimation_boxes_prev")
+
+    def fwd(b):
+        with torch.no_grad():
+            out = gpu(b)
+        return [out[k] for k in keys]
+
+    eager = [[t.clone() for t in fwd(f)] for f in frames]
+    static = {k: v.clone() for k, v in frames[0].items()}
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fwd(static)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        outs = fwd(static)
+    for h, f, e in zip(hosts, frames, eager):
+        for k, v in f.items():
+            static[k].copy_(v)
+        graph.replay()
+        torch.cuda.synchronize()
+        for a, b in zip(outs, e):
+            assert torch.equal(a, b)
+        with torch.no_grad():
+            ref = cpu(h)
+        got = dict(zip(keys, outs))
+        same_mask = bool((got["seg_logits"].argmax(1).cpu() == ref["seg_logits"].argmax(1)).all()) and \
+            bool((got["motion_cls"].argmax(1).cpu() == ref["motion_cls"].argmax(1)).all())
+        if not same_mask:
+            continue               # a logit pair within rounding of a tie flips the hard mask: not comparable downstream
+        for k in keys:
+            assert rel(got[k], ref[k]) < 1e-4, (k, rel(got[k], ref[k]))
+    for k, v in gpu.state_dict().items():
+        assert torch.equal(v.cpu(), sd[k]), k
