@@ -190,3 +190,19 @@ def test_row_group_structs_match_the_header_layout():
             base, names = re.match(r"((?:const\s+)?\w+\s*\**)\s*(.*)", decl).groups()
             fields += [n.strip().lstrip("*").strip() for n in names.split(",")]
         assert fields == [f[0] for f in cls._fields_], (name, fields, [f[0] for f in cls._fields_])
+
+
+def test_no_tuning_switches_in_the_product():
+    """one product path: the kernels read no environment variable, and the Python package knows exactly two `O3D_*`
+    variables -- O3D_LIB_VARIANT (load an A/B build of the library, tools/build_variant.sh) and O3D_REQUIRE_GRAPH (fail
+    instead of falling back to the eager step when the HIP-graph capture fails); experiments use tools/ab.sh on a scratch
+    edit or the module-level test hooks (tools/ab_hook.py), and leave nothing behind"""
+    import glob
+    csrc = glob.glob(os.path.join(ROOT, "open3dsot_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "open3dsot_amd", "csrc", "*.hpp"))
+    assert len(csrc) >= 15
+    for f in csrc:
+        assert "getenv" not in open(f).read(), f
+    names = set()
+    for f in glob.glob(os.path.join(ROOT, "open3dsot_amd", "*.py")) + glob.glob(os.path.join(ROOT, "pointnet2_ops", "*.py")):
+        names |= set(re.findall(r"[\"'](O3D_[A-Z0-9_]+)[\"']", open(f).read()))
+    assert names <= {"O3D_LIB_VARIANT", "O3D_REQUIRE_GRAPH"}, names

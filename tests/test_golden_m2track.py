@@ -140,3 +140,55 @@ def test_m2track_matches_reference_at_batch48(gold, gold48, mode):
         for k, v in net.state_dict().items():
             if "running" in k:
                 np.testing.assert_allclose(v.numpy(), gold48["train.sd_after." + k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+def test_motion_merge_closed_form_backward_equals_autograd_of_the_reference_chain():
+    """csrc/boxcloud.hip::motion_merge_bwd_kernel does not differentiate the reference's chain step by step: z rotations commute,
+    so the previous frame's half collapses to Rz(-prev_t)(x - prev_c) and the current half is Rz(-aux_t)(x - aux_c); four
+    per-cloud sums and the chain through aux = prev (+) motion give both gradients.  The same closed form in torch (fp64, CPU)
+    against autograd of get_offset_box_tensor / get_offset_points_tensor / remove_transform_points_tensor
+    (datasets/points_utils.py:390-452 as mirrored in open3dsot_amd/box_utils.py): 1e-12."""
+    from open3dsot_amd import box_utils
+    g = torch.Generator().manual_seed(3)
+    B, N = 6, 64
+    pts = torch.randn(B, 4, N, generator=g, dtype=torch.float64) * 2
+    prev = (torch.randn(B, 4, generator=g, dtype=torch.float64) * 0.7).requires_grad_()
+    mo = (torch.randn(B, 4, generator=g, dtype=torch.float64) * 0.5).requires_grad_()
+    gm = torch.randn(B, 3, N, generator=g, dtype=torch.float64)
+    ga = torch.randn(B, 4, generator=g, dtype=torch.float64)
+    merged, aux = box_utils.motion_merge_reference(pts, prev, mo)
+    ((merged * gm).sum() + (aux * ga).sum()).backward()
+
+    def rot(t, x, y):                 # Rz(t) (x, y)
+        c, s = torch.cos(t), torch.sin(t)
+        return c * x - s * y, s * x + c * y
+
+    with torch.no_grad():
+        pc, pt, mc, mt = prev[:, :3], prev[:, 3], mo[:, :3], mo[:, 3]
+        ax, ay = rot(pt, mc[:, 0], mc[:, 1])
+        ac = torch.stack([ax + pc[:, 0], ay + pc[:, 1], mc[:, 2] + pc[:, 2]], 1)
+        at = pt + mt
+        # forward identity: the previous half never sees the motion
+        h = N // 2
+        y0 = rot(-pt[:, None], pts[:, 0, :h] - pc[:, 0:1], pts[:, 1, :h] - pc[:, 1:2])
+        assert float((merged[:, 0, :h] - y0[0]).abs().max()) < 1e-12 and float((merged[:, 1, :h] - y0[1]).abs().max()) < 1e-12
+        sums = []
+        for (c, t, sl) in ((pc, pt, slice(0, h)), (ac, at, slice(h, N))):
+            dx, dy = pts[:, 0, sl] - c[:, 0:1], pts[:, 1, sl] - c[:, 1:2]
+            cs, sn = torch.cos(t)[:, None], torch.sin(t)[:, None]
+            tx, ty = -sn * dx + cs * dy, -cs * dx - sn * dy          # d/dtheta of Rz(-theta)(d)
+            S = gm[:, :, sl].sum(2)
+            T = (gm[:, 0, sl] * tx + gm[:, 1, sl] * ty).sum(1)
+            sums.append((S, T))
+        (S0, T0), (S1, T1) = sums
+        gpx, gpy = rot(pt, -S0[:, 0], -S0[:, 1])
+        gax, gay = rot(at, -S1[:, 0], -S1[:, 1])
+        gac = torch.stack([gax, gay, -S1[:, 2]], 1) + ga[:, :3]
+        gat = T1 + ga[:, 3]
+        gmx, gmy = rot(-pt, gac[:, 0], gac[:, 1])
+        g_motion = torch.stack([gmx, gmy, gac[:, 2], gat], 1)
+        dax = -torch.sin(pt) * mc[:, 0] - torch.cos(pt) * mc[:, 1]
+        day = torch.cos(pt) * mc[:, 0] - torch.sin(pt) * mc[:, 1]
+        g_prev = torch.stack([gpx + gac[:, 0], gpy + gac[:, 1], -S0[:, 2] + gac[:, 2], T0 + gat + gac[:, 0] * dax + gac[:, 1] * day], 1)
+    assert float((g_motion - mo.grad).abs().max()) < 1e-12 * (1 + float(mo.grad.abs().max()))
+    assert float((g_prev - prev.grad).abs().max()) < 1e-12 * (1 + float(prev.grad.abs().max()))
