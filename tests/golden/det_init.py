@@ -63,3 +63,30 @@ def fill_state_dict_random(module, seed=0):
         new[key] = torch.from_numpy(np.asarray(v)).to(t.dtype)
     module.load_state_dict(new, strict=True)
     return module
+
+
+def fill_by_module_type(module, seed=0):
+    """Storage-free like `fill_state_dict_random`, for trees whose BatchNorm keys carry no `bn.` marker (M2-Track's
+    nn.Sequential stacks): what a tensor is comes from the TYPE of the module that owns it, the values from a PCG64 stream
+    seeded by (crc32(state-dict key), seed) -- so the reference's class and the mirror (same keys) get the same numbers."""
+    import numpy as np
+    from torch import nn
+    with torch.no_grad():
+        for mname, m in module.named_modules():
+            for pname, t in list(m.named_parameters(recurse=False)) + list(m.named_buffers(recurse=False)):
+                key = (mname + "." if mname else "") + pname
+                if not t.dtype.is_floating_point:
+                    t.zero_()
+                    continue
+                rng = np.random.default_rng([zlib.crc32(key.encode()), seed])
+                shape = tuple(t.shape)
+                if isinstance(m, nn.modules.batchnorm._BatchNorm):
+                    v = {"weight": rng.uniform(0.7, 1.3, shape), "bias": rng.normal(0.0, 0.05, shape),
+                         "running_mean": rng.normal(0.0, 0.1, shape), "running_var": rng.uniform(0.6, 1.4, shape)}[pname]
+                elif pname == "bias":
+                    v = rng.normal(0.0, 0.05, shape)
+                else:
+                    fan_in = max(1, t.numel() // t.shape[0])
+                    v = rng.normal(0.0, (2.0 / fan_in) ** 0.5, shape)
+                t.copy_(torch.from_numpy(np.asarray(v)).to(t.dtype))
+    return module

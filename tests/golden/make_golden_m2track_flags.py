@@ -1,0 +1,55 @@
+"""Generate tests/golden/ref_m2track_flags.npz: the REFERENCE'S OWN M2TRACK class with its configuration flags switched
+(box_aware, use_motion_cls, use_second_stage, use_prev_refinement -- models/m2track.py:22-71,73-151,153-231), forward
+and compute_loss, train and eval.  The default configuration is ref_m2track.npz; this fixture pins the branches.
+
+Run from the repo root, only where /root/reference exists:  python tests/golden/make_golden_m2track_flags.py
+Stubs and loading exactly as tests/golden/make_golden_m2track.py (imported for them).  No weights are stored: both sides
+fill their modules with tests/golden/det_init.py::fill_by_module_type (same state-dict keys -> same values)."""
+import copy
+import os
+import sys
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import make_golden_m2track as base  # noqa: E402  (installs the stubs, loads the reference modules)
+from det_init import fill_by_module_type  # noqa: E402
+
+VARIANTS = {
+    "plain": dict(box_aware=False, use_motion_cls=False, use_second_stage=False, use_prev_refinement=False),
+    "no_bc": dict(box_aware=False, use_motion_cls=True, use_second_stage=True, use_prev_refinement=True),
+    "no_cls_no_prev": dict(box_aware=True, use_motion_cls=False, use_second_stage=True, use_prev_refinement=False),
+    "one_stage": dict(box_aware=True, use_motion_cls=True, use_second_stage=False, use_prev_refinement=True),
+}
+
+
+def main():
+    fix = {}
+    batch = base.synth.make_motion_batch(31, 8, point_sample_size=128)
+    for k, v in batch.items():
+        fix["in." + k] = v
+    tb = base.synth.to_torch(batch)
+    for name, flags in VARIANTS.items():
+        cfg = dict(base.ours.M2_KITTI)
+        cfg.update(flags)
+        torch.manual_seed(5)
+        net = fill_by_module_type(base.ref_m2.M2TRACK(SimpleNamespace(**cfg)), seed=17)
+        fix["%s.nparams" % name] = np.int64(sum(p.numel() for p in net.parameters()))
+        for mode in ("train", "eval"):
+            n2 = copy.deepcopy(net).train(mode == "train")
+            out = n2({k: v.clone() for k, v in tb.items()})
+            for k, v in out.items():
+                fix["%s.%s.out.%s" % (name, mode, k)] = v.detach().numpy()
+            ld = n2.compute_loss(tb, out)
+            for k, v in ld.items():
+                fix["%s.%s.loss.%s" % (name, mode, k)] = np.float32(float(v))
+    path = os.path.join(HERE, "ref_m2track_flags.npz")
+    np.savez_compressed(path, **fix)
+    print("wrote", path, "%.2f MB" % (os.path.getsize(path) / 1e6), len(fix), "arrays")
+
+
+if __name__ == "__main__":
+    main()

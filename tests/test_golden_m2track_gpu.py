@@ -66,3 +66,36 @@ def test_gpu_m2track_matches_reference_at_batch48_losses_1e4(gold, gold48, mode)
         for k, v in net.state_dict().items():
             if "running" in k:
                 np.testing.assert_allclose(v.cpu().numpy(), gold48["train.sd_after." + k], rtol=1e-4, atol=1e-5, err_msg=k)
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+@pytest.mark.parametrize("name", ["plain", "no_bc", "no_cls_no_prev", "one_stage"])
+def test_gpu_m2track_flag_variants_match_the_reference_class(name, mode):
+    """the reference's own M2TRACK with its configuration flags switched (tests/golden/ref_m2track_flags.npz, generator
+    tests/golden/make_golden_m2track_flags.py): the GPU path -- per-point stacks, row kernels, motion_merge with / without
+    the previous-box refinement, the loss operator with terms switched off -- gives the same output keys, outputs and loss
+    terms (batch 8: the BatchNorm1d rows' amplification bounds of the default-configuration test), and its backward runs"""
+    from test_golden_m2track import FLAG_VARIANTS, build_variant
+    gold = np.load(os.path.join(ROOT, "tests", "golden", "ref_m2track_flags.npz"))
+    net = build_variant(name).cuda().train(mode == "train")
+    b = {k[3:]: torch.from_numpy(gold[k]).cuda() for k in gold.files if k.startswith("in.")}
+    with torch.set_grad_enabled(mode == "train"):
+        out = net(b)
+        ld = net.compute_loss(b, out)
+    pre = "%s.%s." % (name, mode)
+    assert set(out) == {k[len(pre) + 4:] for k in gold.files if k.startswith(pre + "out.")}
+    assert set(ld) == {k[len(pre) + 5:] for k in gold.files if k.startswith(pre + "loss.")}
+    # hard masks (argmax of the segmentation / motion-state logits) must agree for anything downstream to be comparable
+    seg_same = bool((out["seg_logits"].argmax(1).cpu().numpy() == gold[pre + "out.seg_logits"].argmax(1)).all())
+    cls_same = "motion_cls" not in out or bool((out["motion_cls"].argmax(1).cpu().numpy() == gold[pre + "out.motion_cls"].argmax(1)).all())
+    assert seg_same and cls_same, (name, mode, seg_same, cls_same)
+    for k in out:
+        np.testing.assert_allclose(out[k].detach().cpu().numpy(), gold[pre + "out." + k], err_msg=k, rtol=2e-3, atol=5e-4)
+    for k in ld:
+        assert abs(float(ld[k]) - float(gold[pre + "loss." + k])) < 1e-3 * (1 + abs(float(ld[k]))), (k, float(ld[k]))
+    if mode == "train":
+        ld["loss_total"].backward()
+        used = FLAG_VARIANTS[name]
+        for pname, p in net.named_parameters():
+            assert p.grad is not None and torch.isfinite(p.grad).all(), pname
+        assert used["use_second_stage"] == any(n.startswith("box_mlp") for n, _ in net.named_parameters())
