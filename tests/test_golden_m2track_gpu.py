@@ -85,10 +85,21 @@ def test_gpu_m2track_flag_variants_match_the_reference_class(name, mode):
     pre = "%s.%s." % (name, mode)
     assert set(out) == {k[len(pre) + 4:] for k in gold.files if k.startswith(pre + "out.")}
     assert set(ld) == {k[len(pre) + 5:] for k in gold.files if k.startswith(pre + "loss.")}
-    # hard masks (argmax of the segmentation / motion-state logits) must agree for anything downstream to be comparable
-    seg_same = bool((out["seg_logits"].argmax(1).cpu().numpy() == gold[pre + "out.seg_logits"].argmax(1)).all())
-    cls_same = "motion_cls" not in out or bool((out["motion_cls"].argmax(1).cpu().numpy() == gold[pre + "out.motion_cls"].argmax(1)).all())
-    assert seg_same and cls_same, (name, mode, seg_same, cls_same)
+    # hard masks (argmax of the segmentation / motion-state logits) gate everything downstream: a flip is only acceptable
+    # where the reference's own two logits are within rounding of a tie, and then nothing behind the mask is comparable
+    flips = 0
+    for key in ("seg_logits", "motion_cls"):
+        if key not in out:
+            continue
+        ref = gold[pre + "out." + key]
+        np.testing.assert_allclose(out[key].detach().cpu().numpy(), ref, err_msg=key, rtol=2e-3, atol=5e-4)
+        differ = out[key].argmax(1).cpu().numpy() != ref.argmax(1)
+        if differ.any():
+            margin = np.abs(ref[:, 0] - ref[:, 1])[differ]
+            assert float(margin.max()) < 2e-3, (name, mode, key, int(differ.sum()), float(margin.max()))
+            flips += int(differ.sum())
+    if flips:
+        pytest.skip("%d hard-mask decision(s) within 2e-3 of a tie flipped: outputs behind the mask are not comparable" % flips)
     for k in out:
         np.testing.assert_allclose(out[k].detach().cpu().numpy(), gold[pre + "out." + k], err_msg=k, rtol=2e-3, atol=5e-4)
     for k in ld:
