@@ -26,9 +26,44 @@ VARIANTS = {
 }
 
 
+def nets():
+    out = {}
+    for name, flags in VARIANTS.items():
+        cfg = dict(base.ours.M2_KITTI)
+        cfg.update(flags)
+        torch.manual_seed(5)
+        out[name] = fill_by_module_type(base.ref_m2.M2TRACK(SimpleNamespace(**cfg)), seed=17)
+    return out
+
+
+def min_margin(models, tb):
+    """smallest |logit0 - logit1| over every hard-mask decision (segmentation, motion state) of every variant and mode: a fixture
+    whose decisions all sit clear of a tie stays comparable behind the masks on any arithmetic"""
+    worst = 1e9
+    for name, net in models.items():
+        for train in (True, False):
+            with torch.no_grad():
+                out = copy.deepcopy(net).train(train)({k: v.clone() for k, v in tb.items()})
+            for key in ("seg_logits", "motion_cls"):
+                if key in out:
+                    worst = min(worst, float((out[key][:, 0] - out[key][:, 1]).abs().min()))
+    return worst
+
+
 def main():
     fix = {}
-    batch = base.synth.make_motion_batch(31, 8, point_sample_size=128)
+    models = nets()
+    best = (-1.0, None)
+    for first in range(31, 31 + 40 * 8, 8):          # pick the synthetic batch whose closest decision is furthest from a tie
+        cand = base.synth.make_motion_batch(first, 8, point_sample_size=128)
+        m = min_margin(models, base.synth.to_torch(cand))
+        if m > best[0]:
+            best = (m, first)
+        if m >= 5e-3:
+            break
+    print("batch first_index %d: closest hard-mask decision %.2e from a tie" % (best[1], best[0]))
+    batch = base.synth.make_motion_batch(best[1], 8, point_sample_size=128)
+    fix["min_margin"] = np.float32(best[0])
     for k, v in batch.items():
         fix["in." + k] = v
     tb = base.synth.to_torch(batch)
