@@ -205,6 +205,19 @@ class FC(nn.Sequential):
             self.add_module(name + key, mod)
 
 
+def feature_dropout_no_scaling(x, p, train=False, inplace=False):
+    """Whole-channel dropout WITHOUT the 1/(1-p) rescaling: a Bernoulli(1 - p) keep mask per (sample, channel), broadcast
+    over the remaining dimensions.  `pointnet2_utils.RandomDropout` (pointnet2/utils/pointnet2_utils.py:24-32) calls
+    `pt_utils.feature_dropout_no_scaling`, which the reference's own pytorch_utils.py does not define (the class cannot run
+    there; no tracker uses it): this is the upstream `pointnet2_ops` function of that name, restated with torch ops."""
+    if p < 0 or p > 1:
+        raise ValueError("dropout probability has to be between 0 and 1, but got {}".format(p))
+    if not train or float(p) == 0.0:
+        return x
+    keep = torch.empty(x.shape[:2] + (1,) * (x.dim() - 2), device=x.device, dtype=x.dtype).bernoulli_(1.0 - float(p))
+    return x.mul_(keep) if inplace else x * keep
+
+
 def set_bn_momentum_default(bn_momentum):
     def fn(m):
         if isinstance(m, (nn.BatchNorm1d, nn.BatchNorm2d, nn.BatchNorm3d)):

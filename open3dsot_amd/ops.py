@@ -1,7 +1,7 @@
 """Autograd operators and grouping modules -- the Python operator boundary of the hot path.
 
 Mirrors the public names, argument order, return arity and dtypes of the reference's
-pointnet2/utils/pointnet2_utils.py (FurthestPointSampling :35, GatherOperation :68,
+pointnet2/utils/pointnet2_utils.py (RandomDropout :24, FurthestPointSampling :35, GatherOperation :68,
 ThreeNN :105, ThreeInterpolate :137, GroupingOperation :194, BallQuery :245,
 QueryAndGroup :280, GroupAll :342, knn_point :388) so models written against that module
 run unchanged.  The arithmetic is in libo3dsot_hip.so (open3dsot_amd.ext); nothing here
@@ -12,6 +12,22 @@ from torch import nn
 from torch.autograd import Function
 
 from . import ext as _ext
+
+
+class RandomDropout(nn.Module):
+    """pointnet2_utils.py:24-32: feature dropout with a drop probability drawn from U(0, p) per call.  (The reference passes
+    the bound method `self.train` as the training flag -- always true -- and calls a function its pytorch_utils.py lacks;
+    here the flag is `self.training` and the function is nn_blocks.feature_dropout_no_scaling.)"""
+
+    def __init__(self, p=0.5, inplace=False):
+        super().__init__()
+        self.p = p
+        self.inplace = inplace
+
+    def forward(self, X):
+        from .nn_blocks import feature_dropout_no_scaling
+        theta = torch.Tensor(1).uniform_(0, self.p)[0]
+        return feature_dropout_no_scaling(X, theta, self.training, self.inplace)
 
 
 class FurthestPointSampling(Function):
