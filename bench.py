@@ -440,13 +440,13 @@ def measure(args, rank, local_rank, world, full=True):
         # self-checks of the multi-GPU run (the driver computes the scaling efficiency itself; these only say whether the
         # run was the run it claims to be): every rank's own rate, and how far the replicas' parameters are apart after
         # the timed steps -- identical gradients after the all-reduce and the same Adam update must leave them bitwise equal
-        try:
-            multi = D.replica_self_check(model, trainer, elapsed, args.batch * args.steps)
-        except Exception as e:       # a diagnostic must never take the bench line down
-            multi = {"self_check_error": "%s: %s" % (type(e).__name__, e)}
+        # The timing exchange first; the self-check is a fixed sequence of collectives on every rank (its fallible local
+        # work happens before them and the ranks agree on an ok flag: dist.replica_self_check) -- no per-rank try/except
+        # around collectives, which would leave the other ranks blocked in them
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        own_elapsed, elapsed = elapsed, float(t.item())
+        multi = D.replica_self_check(model, trainer, own_elapsed, args.batch * args.steps)
 
     # ---- roofline of the dominant kernel family, measured live with HIP events ------------
     roofline = None

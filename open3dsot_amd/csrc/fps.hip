@@ -106,7 +106,7 @@ __global__ __launch_bounds__(64 * NW) void fps_reg_kernel(const float* __restric
         const float y = in ? s_xyz[3 * k + 1] : 0.f;
         const float z = in ? s_xyz[3 * k + 2] : 0.f;
         const float mag = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
-        const bool valid = in && !(mag <= 1e-3f);
+        const bool valid = in && !o3d_fps_near_origin(mag);
         // skipped / padded slots: min-distance pinned at +0 and key 0 => never a winner
         px[i] = x; py[i] = y; pz[i] = z;
         tmp[i] = valid ? 1e10f : 0.f;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(1024) void fps_generic_kernel(const float* __restri
         for (int k = tid; k < N; k += 1024) {
             const float x = p[3 * k], y = p[3 * k + 1], z = p[3 * k + 2];
             const float mag = __fmaf_rn(z, z, __fmaf_rn(y, y, __fmul_rn(x, x)));
-            if (mag <= 1e-3f) continue;
+            if (o3d_fps_near_origin(mag)) continue;
             const float d2 = fminf(o3d_sqdist3(x, y, z, x1, y1, z1), tmp[k]);
             tmp[k] = d2;
             // key: distance bits, then inverted rank (rank < 2^31 so the low word is never 0)

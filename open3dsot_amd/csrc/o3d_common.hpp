@@ -21,6 +21,11 @@ __device__ __forceinline__ float o3d_sqdist3(float ax, float ay, float az, float
     return __fmaf_rn(dz, dz, __fmaf_rn(dy, dy, __fmul_rn(dx, dx)));
 }
 
+// Farthest-point sampling's near-origin rule (Appendix A.1): upstream writes `if (mag <= 1e-3) continue;` -- the float
+// magnitude against the DOUBLE literal.  (float)1e-3 = 0x3A83126F lies above the double 0.001, so that one float is kept
+// (`mag <= 1e-3f` would skip it).  The compare is spelled as upstream spells it; one cvt + one fp64 compare per point.
+__device__ __forceinline__ bool o3d_fps_near_origin(float mag) { return (double)mag <= 1e-3; }
+
 static inline int o3d_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- cross-lane moves on the DPP path (no LDS round trip like ds_bpermute / __shfl_xor) ---------------------------

@@ -133,7 +133,7 @@ __device__ __forceinline__ void row_fwd_body(const RowFwd& a, float* Ws, float* 
         }
         if (live && rg == 0 && a.mean) { a.mean[f] = mu; a.invstd[f] = istd; }
         sc = (live ? a.gamma[f] : 1.f) * istd;
-        sh = (live ? a.beta[f] : 0.f) - mu * sc;
+        sh = fmaf(-mu, sc, live ? a.beta[f] : 0.f);        // (spelled out: the backward recomputes y with this very expression)
     }
     if (!live) return;
 #pragma unroll
@@ -204,7 +204,10 @@ __device__ __forceinline__ void row_bwd_body(const RowBwd& a, float* Ws, float* 
         for (int i = 0; i < RM_RPT; ++i) {
             const float zz = (live && rowok[i]) ? a.Z[(long)(rg + RM_RG * i) * a.C + f] : mu;
             xh[i] = (zz - mu) * istd;
-            if (a.relu && !(fmaf(xh[i], gm, bt) > 0.f)) g[i] = 0.f;
+            // ReLU mask from y recomputed EXACTLY as the forward computed it (sc = gamma * istd, sh = fma(-mu, sc, beta),
+            // y = fma(z, sc, sh)): another association rounds differently and an output within rounding of 0 would get
+            // its gradient passed where the forward clamped it (torch masks on the stored output)
+            if (a.relu && !(fmaf(zz, gm * istd, fmaf(-mu, gm * istd, bt)) > 0.f)) g[i] = 0.f;
             if (!rowok[i]) g[i] = 0.f;
             s1 += g[i];
             s2 = fmaf(g[i], xh[i], s2);

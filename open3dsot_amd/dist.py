@@ -22,13 +22,15 @@ def env_rank():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init_distributed(backend=None):
-    """Initialise torch.distributed from the torchrun environment; returns (rank, local_rank, world)."""
+def init_distributed(backend=None, force=False):
+    """Initialise torch.distributed from the torchrun environment; returns (rank, local_rank, world).
+    force: create the process group at world size 1 as well (a one-rank RCCL communicator: what
+    tests/test_model_gpu.py::test_world_size_one_rccl_* drives the multi-GPU code path with on a one-GPU box)."""
     rank, local_rank, world = env_rank()
     use_cuda = torch.cuda.is_available()
     if use_cuda:
         torch.cuda.set_device(local_rank)
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         kw = {}
@@ -126,10 +128,17 @@ class DataParallelStep:
     outside the graph (eagerly enqueued while the graph runs)."""
 
     def __init__(self, model, optimizer=None, world=None, graph=False, graph_warmup=3, prefetch_sampling=True,
-                 require_graph=None):
+                 require_graph=None, exchange=None):
         self.model = model
         self.world = world if world is not None else (dist.get_world_size() if dist.is_initialized() else 1)
-        if self.world > 1:  # identical replicas: rank 0's parameters and buffers everywhere
+        # exchange: run the multi-rank path -- parameter broadcast, gradient pack inside the captured step, the one flat
+        # all-reduce, p.grad = views of the exchange buffer.  Default: whenever there is more than one rank; True forces
+        # it at world size 1 (needs an initialised process group), so that the very code an 8-GPU run executes can be
+        # exercised on one GPU
+        self.exchange = (self.world > 1) if exchange is None else bool(exchange)
+        if self.exchange and not dist.is_initialized():
+            raise RuntimeError("DataParallelStep(exchange=True) needs an initialised torch.distributed process group")
+        if self.exchange:  # identical replicas: rank 0's parameters and buffers everywhere
             for t in list(model.parameters()) + list(model.buffers()):
                 dist.broadcast(t.data, src=0)
         self.grads = FlatGrads(model.parameters())
@@ -169,7 +178,7 @@ class DataParallelStep:
         """flat exchange buffer (packed by `_forward_backward`) -> mean over ranks, p.grad = its views.  One collective on
         one contiguous 5.9 MB message; RCCL averages in the collective itself (ReduceOp.AVG: no separate division
         launch), gloo (CPU tests) sums and divides."""
-        if self.world > 1:
+        if self.exchange:
             if dist.get_backend() == "nccl":
                 dist.all_reduce(self.grads.flat, op=dist.ReduceOp.AVG)
             else:
@@ -178,7 +187,10 @@ class DataParallelStep:
             # p.grad = the views of the exchange buffer.  An eager step cleared them (autograd ASSIGNS fresh tensors, which
             # `_forward_backward` packs into the buffer), so they are bound again; a replayed graph never touches p.grad,
             # so once bound they stay bound: no per-step host loop over the 76 parameters (round-3 review)
-            if self.graph is None or not self._views_bound or self.grads.params[0].grad is not self.grads.views[0]:
+            # (p.grad is OWNED by this class once a graph is captured; the check walks every parameter -- a caller that
+            # cleared or replaced some of them, e.g. zero_grad on a subset, gets them bound again: ~10 us of host time)
+            if self.graph is None or not self._views_bound or \
+                    any(p.grad is not v for p, v in zip(self.grads.params, self.grads.views)):
                 self.grads.bind_views()
                 self._views_bound = self.graph is not None
 
@@ -192,7 +204,7 @@ class DataParallelStep:
                 loss.backward(gradient=self._one)      # no ones_like launch; the fused loss skips its scaling launch
             else:
                 loss.backward()
-        if self.world > 1:
+        if self.exchange:
             # pack the gradients autograd produced into the exchange buffer: one multi-tensor copy, part of the captured
             # HIP graph when there is one (so a replayed step ends with the message ready to be reduced)
             self.grads.gather([p.grad for p in self.grads.params])
@@ -295,8 +307,9 @@ class DataParallelStep:
             # the replayed finalize kernels rewrote the BatchNorm running statistics through raw pointers: bump their
             # version counters (host only) so version-keyed caches -- eval-mode constants -- see a training step
             increment_version(self._buffers)
-            if self.world == 1 and (not self._views_bound or self.grads.params[0].grad is not self._static_grads[0]):
-                # (world > 1: the replay packed them into the exchange buffer, reduce_gradients binds its views)
+            if not self.exchange and (not self._views_bound or
+                                      any(p.grad is not g for p, g in zip(self.grads.params, self._static_grads))):
+                # (with an exchange the replay packed them into the exchange buffer, reduce_gradients binds its views)
                 for p, g in zip(self.grads.params, self._static_grads):   # the replay rewrites these very buffers: bound once
                     p.grad = g
                 self._views_bound = True
@@ -333,7 +346,7 @@ class DataParallelStep:
     def sync_buffers(self):
         """BatchNorm statistics are per rank during training (no sync-BN in the reference; its DDP wrapper
         re-broadcasts rank 0's buffers every forward): call before checkpointing so every rank holds rank 0's"""
-        if self.world > 1:
+        if self.exchange:
             for b in self.model.buffers():
                 dist.broadcast(b.data, src=0)
 
@@ -344,11 +357,21 @@ def replica_self_check(model, trainer, elapsed_s, pairs_per_rank):
     update must leave them bitwise equal: anything else is a broken exchange).  -> dict for the bench line's `config`."""
     world = dist.get_world_size()
     first = next(model.parameters())
-    mine = torch.tensor([elapsed_s], device=first.device, dtype=torch.float64)
-    every = [torch.zeros_like(mine) for _ in range(world)]
+    # every fallible LOCAL step (allocations: the flat parameter copy is 3 x 5.9 MB) comes before the first collective, and
+    # the ranks agree on an ok flag first: a rank that failed alone would otherwise skip collectives the others block in
+    err = None
+    try:
+        mine = torch.tensor([elapsed_s], device=first.device, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        flat = torch.cat([p.detach().reshape(-1).float() for p in model.parameters()])
+        hi, lo = flat.clone(), flat.clone()
+    except Exception as e:
+        err = "%s: %s" % (type(e).__name__, e)
+    ok = torch.tensor([0 if err else 1], device=first.device, dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) == 0:
+        return {"self_check_error": err or "another rank could not allocate the self-check buffers"}
     dist.all_gather(every, mine)
-    flat = torch.cat([p.detach().reshape(-1).float() for p in model.parameters()])
-    hi, lo = flat.clone(), flat.clone()
     dist.all_reduce(hi, op=dist.ReduceOp.MAX)
     dist.all_reduce(lo, op=dist.ReduceOp.MIN)
     return {"per_rank_pairs_per_s": [round(pairs_per_rank / max(float(t.item()), 1e-12), 1) for t in every],

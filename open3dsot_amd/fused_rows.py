@@ -54,9 +54,21 @@ def parse(seq):
     return layers or None
 
 
+FMAX = 1024        # csrc/rowmlp.hip::RM_KMAX: a workgroup's weight slice lives in LDS; wider layers return EINVAL there
+
+
 def supported(layers, x):
-    return (_ON["on"] and layers is not None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and
-            0 < x.shape[0] <= RMAX and x.shape[1] == layers[0][0].in_features)
+    """the kernel's own limits, so that anything outside them takes the nn.Sequential path instead of a RuntimeError from
+    the library: <= RMAX rows, every Linear <= FMAX features wide (in and out: the backward stages the layer above), and
+    no training-mode BatchNorm over a single row (torch raises there; the kernel would normalise with var = 0)"""
+    if not (_ON["on"] and layers is not None and x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and
+            0 < x.shape[0] <= RMAX and x.shape[1] == layers[0][0].in_features):
+        return False
+    if any(lin.in_features > FMAX or lin.out_features > FMAX for lin, _, _ in layers):
+        return False
+    if x.shape[0] == 1 and any(bn is not None and bn.training for _, bn, _ in layers):
+        return False
+    return True
 
 
 class _Cfg:

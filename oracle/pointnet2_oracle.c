@@ -70,7 +70,11 @@ int o3d_oracle_furthest_point_sampling(const float* xyz, int B, int N, int npoin
                 for (int k = tid; k < N; k += bs) {
                     const float x2 = p[k * 3 + 0], y2 = p[k * 3 + 1], z2 = p[k * 3 + 2];
                     const float mag = fmaf(z2, z2, fmaf(y2, y2, x2 * x2));
-                    if (mag <= 1e-3f) continue; /* near-origin points: never selected, temp untouched */
+                    /* near-origin points: never selected, temp untouched.  Upstream's source compares the float against the
+                     * DOUBLE literal 1e-3 (`if (mag <= 1e-3) continue;`): 0x3A83126F = (float)1e-3 = 0.00100000004749... is
+                     * ABOVE the double 0.001, so a point of exactly that magnitude is kept (with `1e-3f` it would be skipped;
+                     * the two differ for this one float only; tests/test_oracle_kat.py::test_fps_near_origin_literal_is_double) */
+                    if ((double)mag <= 1e-3) continue;
                     const float d = sqdist3(x2, y2, z2, x1, y1, z1);
                     const float d2 = fminf(d, temp[k]);
                     temp[k] = d2;

@@ -69,6 +69,14 @@ ref_m2 = load("models.m2track", "models/m2track.py")
 from open3dsot_amd import m2track as ours, synth  # noqa: E402
 
 
+def rotz_like_input(t):
+    """datasets/points_utils.py:377-387 with the matrix in the angle's dtype (the reference writes float32 there)"""
+    out = torch.zeros(tuple(list(t.shape) + [3, 3]), dtype=t.dtype, device=t.device)
+    c, s = torch.cos(t), torch.sin(t)
+    out[..., 0, 0], out[..., 0, 1], out[..., 1, 0], out[..., 1, 1], out[..., 2, 2] = c, -s, s, c, 1
+    return out
+
+
 def main():
     from types import SimpleNamespace
     import copy
@@ -135,6 +143,61 @@ def main():
     path2 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_m2track_b48.npz")
     np.savez_compressed(path2, **fix2)
     print("wrote", path2, "%.1f MB" % (os.path.getsize(path2) / 1e6), len(fix2), "arrays")
+    # ---- round 5: the fp64 YARDSTICK of both fixtures (third file; the two above stay byte-identical).  The same reference
+    # model evaluated in double precision on the same inputs, with its two hard-mask decisions (`torch.argmax` of the
+    # segmentation logits per point and of the motion-state logits per cloud, models/m2track.py:95,113) REPLAYED from the
+    # fp32 run, so that the fp64 values are the exact evaluation of the graph the fp32 run executed (a near-tie that fp64
+    # would decide differently gates everything downstream and is not a rounding question).  Tests then hold the GPU run to
+    # max(1e-4, 3 x the reference's own fp32 distance to this) per output instead of a bare tolerance.
+    fix3 = {}
+    for tag, bt in (("b8", synth.make_motion_batch(11, 8, point_sample_size=128)),
+                    ("b48", synth.make_motion_batch(111, 48, point_sample_size=256))):
+        tb = synth.to_torch(bt)
+        tb64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in tb.items()}
+        for mode in ("train", "eval"):
+            tape = []
+            real_argmax = torch.argmax
+            n32 = copy.deepcopy(net).train(mode == "train")
+            torch.argmax = lambda *a, **k: (tape.append(real_argmax(*a, **k)), tape[-1])[1]
+            try:
+                out32 = n32({k: v.clone() for k, v in tb.items()})
+            finally:
+                torch.argmax = real_argmax
+            n_dec = len(tape)
+            n64 = copy.deepcopy(net).double().train(mode == "train")
+            flips = []
+
+            def replay(*a, **k):
+                mine, theirs = real_argmax(*a, **k), tape.pop(0)
+                flips.append(int((mine != theirs).sum()))
+                return theirs
+            torch.argmax = replay
+            torch.set_default_dtype(torch.float64)        # m2track.py:171 builds the class weights with torch.tensor([...])
+            real_rotz = points_utils.rotz_batch_tensor    # datasets/points_utils.py:379 hard-codes float32: same entries,
+            points_utils.rotz_batch_tensor = rotz_like_input   # the angle's dtype
+            try:
+                out64 = n64({k: v.clone() for k, v in tb64.items()})
+                ld64 = n64.compute_loss(tb64, out64)
+            finally:
+                torch.argmax = real_argmax
+                torch.set_default_dtype(torch.float32)
+                points_utils.rotz_batch_tensor = real_rotz
+            assert not tape and len(flips) == n_dec
+            for k, v in out64.items():
+                assert v.dtype == torch.float64, k
+                fix3["%s.%s.out.%s" % (tag, mode, k)] = v.detach().numpy()
+                print("  %s %s %-22s reference fp32 vs fp64: %.2e of the scale" % (
+                    tag, mode, k, float((out32[k].double() - v).abs().max() / (v.abs().max() + 1e-12))))
+            for k, v in ld64.items():
+                fix3["%s.%s.loss.%s" % (tag, mode, k)] = np.float64(float(v))
+            fix3["%s.%s.fp64_would_flip" % (tag, mode)] = np.array(flips, np.int64)
+            if mode == "train":
+                for k, v in n64.state_dict().items():
+                    if "running" in k:
+                        fix3["%s.train.sd_after.%s" % (tag, k)] = v.detach().numpy().copy()
+    path3 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ref_m2track_f64.npz")
+    np.savez_compressed(path3, **fix3)
+    print("wrote", path3, "%.1f MB" % (os.path.getsize(path3) / 1e6), len(fix3), "arrays")
 
 
 if __name__ == "__main__":

@@ -99,6 +99,39 @@ def test_two_rank_gloo_matches_manual_average(tmp_path):
         assert torch.allclose(v, p.detach(), rtol=1e-5, atol=1e-6), k
 
 
+def _world1_worker(rank, port, out):
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    from open3dsot_amd import dist as D
+    D.init_distributed("gloo", force=True)
+    model, twin = Toy(), Toy()
+    forced = D.DataParallelStep(model, exchange=True)          # the multi-rank path on one rank
+    plain = D.DataParallelStep(twin, world=1)
+    assert forced.exchange and not plain.exchange and forced.world == 1
+    for step in range(3):
+        forced.step(_data(step * 8, 8))
+        plain.step(_data(step * 8, 8))
+    res = {"views": all(p.grad is v for p, v in zip(forced.grads.params, forced.grads.views)),
+           "plain_views": any(p.grad is v for p, v in zip(plain.grads.params, plain.grads.views)),
+           "equal": all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), twin.state_dict().values())),
+           "check": D.replica_self_check(model, forced, 1.0, 24)}
+    torch.save(res, os.path.join(out, "w1.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_forced_exchange_at_world_size_one_equals_the_plain_step(tmp_path):
+    """DataParallelStep(exchange=True) on a one-rank process group runs the multi-rank code (pack, all-reduce, views of the
+    exchange buffer as p.grad) and must leave exactly the plain single-process parameters; the GPU twin
+    (tests/test_model_gpu.py::test_world_size_one_rccl_drives_the_multi_gpu_step) does it over RCCL with the HIP graph"""
+    mp.spawn(_world1_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / "w1.pt")
+    assert r["views"] and not r["plain_views"] and r["equal"], r
+    assert r["check"]["max_parameter_divergence"] == 0.0 and r["check"]["per_rank_pairs_per_s"] == [24.0]
+    import pytest
+    from open3dsot_amd import dist as D
+    with pytest.raises(RuntimeError):
+        D.DataParallelStep(Toy(), exchange=True)               # no process group in this process
+
+
 def test_shards_are_disjoint():
     from open3dsot_amd import dist as D
     seen = set()

@@ -119,6 +119,64 @@ def test_rotz_as_one_gemm_is_the_stacked_matrix_bit_for_bit():
 
 
 @pytest.fixture(scope="module")
+def gold64():
+    return np.load(os.path.join(ROOT, "tests", "golden", "ref_m2track_f64.npz"))
+
+
+def scale_err(a, b):
+    """max |a - b| relative to the scale of b (b: the fp64 truth)"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def assert_within_fp64_yardstick(out, ld, sd_after, ref32, gold64, tag, mode, report=None):
+    """The reference's own M2TRACK evaluated in DOUBLE precision (hard-mask decisions replayed from its fp32 run:
+    tests/golden/make_golden_m2track.py, third fixture) is the truth; the reference's own fp32 run's distance to it is the
+    yardstick.  Every output / loss term / running statistic of the run under test must be within
+    max(1e-4 (1e-5 for the running statistics), 3 x yardstick) of the truth, relative to the tensor's scale -- the rule
+    tests/test_golden_trackers_b8.py holds BAT / P2B to, instead of a bare tolerance."""
+    pre = "%s.%s." % (tag, mode)
+    rows = []
+    for k, v in out.items():
+        truth = gold64[pre + "out." + k]
+        err, yard = scale_err(v.detach().cpu().numpy(), truth), scale_err(ref32["%s.out.%s" % (mode, k)], truth)
+        rows.append(("out." + k, err, yard, max(1e-4, 3 * yard)))
+    for k, v in ld.items():
+        truth = float(gold64[pre + "loss." + k])
+        err = abs(float(v) - truth) / (1 + abs(truth))
+        yard = abs(float(ref32["%s.loss.%s" % (mode, k)]) - truth) / (1 + abs(truth))
+        rows.append(("loss." + k, err, yard, max(1e-4, 3 * yard)))
+    for k, v in (sd_after or {}).items():
+        if "running" in k:
+            truth = gold64["%s.train.sd_after.%s" % (tag, k)]
+            err, yard = scale_err(v.cpu().numpy(), truth), scale_err(ref32["train.sd_after." + k], truth)
+            rows.append(("sd." + k, err, yard, max(1e-5, 3 * yard)))
+    if report is not None:
+        report.extend(rows)
+    bad = [r for r in rows if not r[1] <= r[3]]
+    assert not bad, ["%s: err %.2e, reference fp32 vs fp64 %.2e, bound %.2e" % r for r in bad]
+    return rows
+
+
+@pytest.mark.parametrize("mode", ["train", "eval"])
+@pytest.mark.parametrize("tag", ["b8", "b48"])
+def test_m2track_flat_path_within_the_references_fp64_yardstick(gold, gold48, gold64, tag, mode):
+    """CPU twin of tests/test_golden_m2track_gpu.py::test_gpu_m2track_within_the_references_fp64_yardstick: the flat-GEMM
+    host path (torch ops) against the double-precision evaluation of the reference's own model"""
+    assert int(gold64["%s.%s.fp64_would_flip" % (tag, mode)].sum()) == 0      # no hard-mask decision near a tie in the fixtures
+    net = build(gold, mode == "train")
+    ref32 = gold if tag == "b8" else gold48
+    b = batch(ref32)
+    out = net(b)
+    ld = net.compute_loss(b, out)
+    if tag == "b48" and mode == "eval":        # the batch-48 fixture keeps three eval outputs only
+        out = {k: v for k, v in out.items() if "eval.out." + k in ref32.files}
+    rows = assert_within_fp64_yardstick(out, ld, net.state_dict() if mode == "train" else None, ref32, gold64, tag, mode)
+    worst = max(rows, key=lambda r: r[1] / r[3])
+    print("%s %s worst: %s err %.2e (reference fp32: %.2e, bound %.2e)" % ((tag, mode) + worst))
+
+
+@pytest.fixture(scope="module")
 def gold48():
     return np.load(os.path.join(ROOT, "tests", "golden", "ref_m2track_b48.npz"))
 

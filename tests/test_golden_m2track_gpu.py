@@ -16,56 +16,50 @@ def gold():
     return np.load(os.path.join(ROOT, "tests", "golden", "ref_m2track.npz"))
 
 
-@pytest.mark.parametrize("mode", ["train", "eval"])
-def test_gpu_m2track_matches_reference(gold, mode):
-    from open3dsot_amd import m2track, nn_blocks
-    assert nn_blocks._FLAT["on"]
-    net = m2track.M2TRACK()
-    net.load_state_dict({k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("sd.")}, strict=True)
-    net = net.cuda().train(mode == "train")
-    b = {k[3:]: torch.from_numpy(gold[k]).cuda() for k in gold.files if k.startswith("in.")}
-    with torch.set_grad_enabled(mode == "train"):
-        out = net(b)
-        ld = net.compute_loss(b, out)
-    # the heads run BatchNorm1d over the fixture's batch of 8 clouds: a 1e-7 change of the pooled features (the GEMM
-    # kernels sum in their own order) moves a normalised value by 1e-4 -- the bound of the CPU twin's flat path
-    for k in out:
-        np.testing.assert_allclose(out[k].detach().cpu().numpy(), gold["%s.out.%s" % (mode, k)], err_msg=k, rtol=2e-3, atol=5e-4)
-    for k in ld:
-        assert abs(float(ld[k]) - float(gold["%s.loss.%s" % (mode, k)])) < 1e-3 * (1 + abs(float(ld[k]))), k
-    if mode == "train":
-        for k, v in net.state_dict().items():
-            if "running" in k:
-                np.testing.assert_allclose(v.cpu().numpy(), gold["train.sd_after." + k], rtol=1e-4, atol=1e-5, err_msg=k)
-
-
 @pytest.fixture(scope="module")
 def gold48():
     return np.load(os.path.join(ROOT, "tests", "golden", "ref_m2track_b48.npz"))
 
 
+@pytest.fixture(scope="module")
+def gold64():
+    return np.load(os.path.join(ROOT, "tests", "golden", "ref_m2track_f64.npz"))
+
+
 @pytest.mark.parametrize("mode", ["train", "eval"])
-def test_gpu_m2track_matches_reference_at_batch48_losses_1e4(gold, gold48, mode):
-    """the reference's own M2TRACK on the benchmarked batch of 48 frame pairs (tests/golden/make_golden_m2track.py, second
-    fixture): every loss term of the GPU run within 1e-4 (round 3 held 1e-3 on the 8-cloud fixture, whose BatchNorm1d rows
-    over 8 samples amplify 1e-7 to 1e-4), end points 1e-3, running statistics 1e-4"""
-    from open3dsot_amd import m2track
+@pytest.mark.parametrize("tag", ["b8", "b48"])
+def test_gpu_m2track_within_the_references_fp64_yardstick(gold, gold48, gold64, tag, mode):
+    """The reference's own M2TRACK on the 8-cloud fixture and on the benchmarked batch of 48 frame pairs, judged against
+    its DOUBLE-precision evaluation (tests/golden/make_golden_m2track.py, third fixture: hard-mask decisions replayed from
+    the fp32 run) with the reference's own fp32 run as the yardstick: every output, every loss term within
+    max(1e-4, 3 x the reference's fp32-vs-fp64 distance) of the truth relative to the tensor's scale, running statistics
+    max(1e-5, 3 x).  Round 4 held the outputs to a bare rtol 2e-3 / atol 5e-4 (batch 8) and 1e-3 / 2e-4 (batch 48) against
+    the fp32 values: a BatchNorm1d over 8 rows amplifies 1e-7 to 1e-4, but nothing said how much of the bound was used."""
+    from open3dsot_amd import m2track, nn_blocks
+    from test_golden_m2track import assert_within_fp64_yardstick
+    assert nn_blocks._FLAT["on"]
     net = m2track.M2TRACK()
     net.load_state_dict({k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("sd.")}, strict=True)
     net = net.cuda().train(mode == "train")
-    b = {k[3:]: torch.from_numpy(gold48[k]).cuda() for k in gold48.files if k.startswith("in.")}
+    ref32 = gold if tag == "b8" else gold48
+    b = {k[3:]: torch.from_numpy(ref32[k]).cuda() for k in ref32.files if k.startswith("in.")}
     with torch.set_grad_enabled(mode == "train"):
         out = net(b)
         ld = net.compute_loss(b, out)
+    if tag == "b48" and mode == "eval":        # the batch-48 fixture keeps three eval outputs only
+        out = {k: v for k, v in out.items() if "eval.out." + k in ref32.files}
+    report = []
+    try:
+        assert_within_fp64_yardstick(out, {k: v.detach() for k, v in ld.items()}, net.state_dict() if mode == "train" else None,
+                                     ref32, gold64, tag, mode, report)
+    finally:
+        worst = max(report, key=lambda r: r[1] / r[3])
+        print("M2-Track %s %s vs fp64, worst of %d quantities: %s err %.2e (reference fp32: %.2e, bound %.2e)"
+              % ((tag, mode, len(report)) + worst))
+    # and the fp32 fixture's own loss values: 1e-4 at the benchmarked batch (round 4's bound), 1e-3 on the 8-cloud one
     for k in ld:
-        want = float(gold48["%s.loss.%s" % (mode, k)])
-        assert abs(float(ld[k]) - want) <= 1e-4 * (1 + abs(want)), (k, float(ld[k]), want)
-    for k in ("estimation_boxes", "motion_cls", "estimation_boxes_prev"):
-        np.testing.assert_allclose(out[k].detach().cpu().numpy(), gold48["%s.out.%s" % (mode, k)], err_msg=k, rtol=1e-3, atol=2e-4)
-    if mode == "train":
-        for k, v in net.state_dict().items():
-            if "running" in k:
-                np.testing.assert_allclose(v.cpu().numpy(), gold48["train.sd_after." + k], rtol=1e-4, atol=1e-5, err_msg=k)
+        want = float(ref32["%s.loss.%s" % (mode, k)])
+        assert abs(float(ld[k]) - want) <= (1e-4 if tag == "b48" else 1e-3) * (1 + abs(want)), (k, float(ld[k]), want)
 
 
 @pytest.mark.parametrize("mode", ["train", "eval"])

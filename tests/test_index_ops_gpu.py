@@ -71,6 +71,19 @@ def test_fps_sizes_and_ties(ext, variant, N, npoint):
         assert np.array_equal(got, exp), explain(got, exp, "fps N=%d %s %s" % (N, kind, variant))
 
 
+@pytest.mark.parametrize("variant", ["dpp", "shfl"])
+def test_fps_near_origin_literal_is_double(ext, variant):
+    """|p|^2 == (float)1e-3 exactly: kept, as upstream's double literal keeps it (tests/test_oracle_kat.py holds the
+    hand-checked case); the register kernels (N <= 2048) and the LDS fallback (N > 2048) against the oracle"""
+    from test_oracle_kat import near_origin_literal_case
+    xyz, want = near_origin_literal_case()
+    assert ext.fps_variant(dev(xyz), 3, _variant=variant).cpu().numpy().tolist() == want
+    for n_fill in (296, 2500):
+        big = np.concatenate([xyz, np.tile(np.array([[[0.75, 0, 0]]], f32), (1, n_fill, 1))], 1)
+        got = ext.fps_variant(dev(big), 3, _variant=variant).cpu().numpy()
+        assert np.array_equal(got, O.furthest_point_sampling(big, 3)) and got[0, 1] == 1, got
+
+
 def test_fps_full_size_batch48(ext):
     from open3dsot_amd import synth
     b = synth.make_batch(100, 48)

@@ -251,9 +251,12 @@ def test_full_size_batch48_gradients_vs_fp64(model_name):
     batch.  Keys whose true gradient is zero (a bias in front of a training-mode BatchNorm) must be rounding noise.  The
     module docstring explains why end-to-end gradients are not a 1e-4 quantity."""
     from open3dsot_amd import synth
-    model = make_model(model_name, 4)
+    _batch48_gradients_vs_fp64(model_name, synth.make_batch(148, 48), "B=48")
+
+
+def _batch48_gradients_vs_fp64(model_name, host, tag, seed=4):
+    model = make_model(model_name, seed)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    host = synth.make_batch(148, 48)
     loss, ld, g = gpu_run(model, sd, host, True, "loss")
     l64, _, g64, _ = oracle_run(model_name, sd, host, torch.float64, "loss")
     _, _, g32, _ = oracle_run(model_name, sd, host, torch.float32, "loss")
@@ -276,10 +279,48 @@ def test_full_size_batch48_gradients_vs_fp64(model_name):
         assert err <= max(2e-2, 3.0 * yard), (k, err, "fp32 CPU oracle vs fp64 on this key:", yard)
     whole, whole32 = (num / den) ** 0.5, (num32 / den) ** 0.5
     cos, ratio = flat_cos(g, g64)
-    print("%s B=48 gradient vs fp64: whole-gradient L2 error %.2e (fp32 CPU oracle: %.2e), cos %.6f, norm ratio %.4f; worst "
+    print("%s " + tag + " gradient vs fp64: whole-gradient L2 error %.2e (fp32 CPU oracle: %.2e), cos %.6f, norm ratio %.4f; worst "
           "key %s %.2e (fp32 CPU oracle on it: %.2e)" % (model_name, whole, whole32, cos, ratio, *worst))
     assert whole <= max(2e-2, 1.5 * whole32), (whole, whole32)
     assert cos > 0.995 and abs(ratio - 1) < 0.03, (cos, ratio)
+
+
+def test_bat_dense_worst_case_batch48():
+    """The worst case of the data-dependent work -- `synth.make_dense_batch`, the clouds `bench.py --dense` and the
+    `bat_dense_worst_case` secondary line time: every ball of every set-abstraction level full of DISTINCT neighbours,
+    so the distinct-neighbour layout compacts nothing (live fraction 1.0: 1.18 M-column launches at level 0, the
+    tile / slice plans and the segment offset `start1` of that size).  48 pairs, 512 / 1024 points, through the fused
+    path: sampling indices bit-exact, every end point / loss term / running statistic within 1e-4 of the fp32 CPU
+    oracle, every parameter gradient against the oracle's fp64 evaluation under the rule of
+    `test_full_size_batch48_gradients_vs_fp64` (max(2e-2, 3 x the fp32 oracle's own distance to fp64 on that key))."""
+    from open3dsot_amd import fused, fused_loss, synth
+    dev = torch.device("cuda", 0)
+    host = synth.make_dense_batch(100, 48)
+    model = make_model("BAT", 3)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    batch = synth.to_torch(host, dev)
+    out = model(batch)
+    data = dict(batch)
+    sidx = out["sample_idxs"][:, :out["estimation_cla"].shape[1]].long()
+    data["seg_label"] = batch["seg_label"].gather(1, sidx)
+    data["points2cc_dist_s"] = batch["points2cc_dist_s"].gather(1, sidx[:, :, None].expand(-1, -1, 9))
+    total, ld_fused = fused_loss.track_loss(model.config, data, out, with_bc=True)
+    torch.cuda.synchronize()
+    ref, ref_ld, sd_after = oracle_forward_loss("BAT", sd, host)
+    assert np.array_equal(out["sample_idxs"].cpu().numpy(), ref["sample_idxs"].numpy())
+    for k in OUT_KEYS:
+        assert rel(out[k], ref[k]) < 1e-4, (k, rel(out[k], ref[k]))
+    for k, v in ref_ld.items():
+        got = float(total) if k == "total" else float(ld_fused[k])
+        assert abs(got - v) <= 1e-4 * (1 + abs(v)), (k, got, v)
+    for k, v in model.state_dict().items():
+        if "running" in k:
+            assert rel(v, sd_after[k]) < 1e-4, (k, rel(v, sd_after[k]))
+    # nothing compacts: the backbone's paired levels computed every ball slot
+    model.load_state_dict(sd)
+    prof = fused.profile_step(lambda: model.training_loss(batch)[0].backward(), 157.3, repeats=1)
+    assert prof is not None and prof["live_fraction"] is not None and prof["live_fraction"] > 0.999, prof and prof["live_fraction"]
+    _batch48_gradients_vs_fp64("BAT", host, "DENSE B=48")
 
 
 def test_bat_nuscenes_search_2048():
@@ -520,6 +561,40 @@ def test_backward_seeded_with_the_constant_one_equals_plain_backward():
         tol = 4e-6 * float(a.abs().max()) + 1e-6 * gmax
         assert float((b - a).abs().max()) <= tol and float((c - a).abs().max()) <= tol
         assert float((d * 2 - a).abs().max()) <= tol
+
+
+@pytest.mark.parametrize("model_name", ["BAT", "M2TRACK"])
+def test_second_backward_under_the_constant_one_seed_returns_the_same_gradients(model_name):
+    """Under the constant-1 seed FusedTrackLoss / FusedM2Loss hand their stored gradient tensors to autograd UNCOPIED and
+    keep them for a second backward (retain_graph=True).  That is sound only while no consumer modifies its incoming
+    gradient in place (round-4 advisor): this test enforces it -- two backward passes over one retained graph must give
+    the same parameter gradients (to the run-to-run rounding of the LDS-atomic list sums), and the loss functions' stored
+    tensors must be bitwise what they were before either pass."""
+    from open3dsot_amd import fused_loss, m2track, synth
+    dev = torch.device("cuda", 0)
+    if model_name == "BAT":
+        model = make_model("BAT", 12)
+        batch = synth.to_torch(synth.make_batch(77, 4, 512, 1024), dev)
+    else:
+        torch.manual_seed(3)
+        model = m2track.M2TRACK().to(dev).train()
+        batch = synth.to_torch(synth.make_motion_batch(5, 8, 256), dev)
+    one = fused_loss.one(dev)
+    loss, _ = model.training_loss(batch)
+    fn = loss.grad_fn
+    assert type(fn).__name__.startswith(("FusedTrackLoss", "FusedM2Loss")), type(fn).__name__
+    before = [t.clone() if t is not None else None for t in fn.grads]
+    model.zero_grad(set_to_none=True)
+    loss.backward(gradient=one, retain_graph=True)
+    first = [p.grad.clone() for p in model.parameters()]
+    for t, b in zip(fn.grads, before):
+        assert t is None or torch.equal(t, b)          # nobody wrote into the handed-out tensors
+    model.zero_grad(set_to_none=True)
+    loss.backward(gradient=one)
+    second = [p.grad.clone() for p in model.parameters()]
+    gmax = max(float(a.abs().max()) for a in first)
+    for a, b in zip(first, second):
+        assert float((b - a).abs().max()) <= 4e-6 * float(a.abs().max()) + 1e-6 * gmax
 
 
 @pytest.mark.parametrize("model_name", ["BAT", "P2B"])
@@ -936,6 +1011,80 @@ def test_two_rank_rccl_step_keeps_replicas_identical(tmp_path):
         assert torch.equal(r0["sd"][k], r1["sd"][k]), k
     assert diff > 0                          # per-rank statistics really differ (disjoint shards)
     assert all(np.isfinite(v) for v in r0["losses"] + r1["losses"])
+
+
+def _rccl_world1_worker(rank, port, out):
+    import os
+    os.environ.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    from open3dsot_amd import dist as D, synth, trackers
+    r, lr, w = D.init_distributed(force=True)           # a one-rank RCCL communicator (watchdog thread and all)
+    dev = torch.device("cuda", lr)
+    res = {"backend": torch.distributed.get_backend(), "world": torch.distributed.get_world_size()}
+    torch.manual_seed(100)
+    model = trackers.BAT().to(dev).train()
+    twin = trackers.BAT().to(dev).train()
+    twin.load_state_dict(model.state_dict())
+    # exchange=True: the code path of a multi-GPU run -- broadcast, gradient pack INSIDE the captured graph (captured while
+    # the process group's watchdog thread is alive: capture_error_mode="thread_local"), all_reduce(AVG) on the flat
+    # buffer, p.grad = views of that buffer, FlatAdam on them, the replicas' self-check
+    trainer = D.DataParallelStep(model, graph=True, graph_warmup=1, exchange=True, require_graph=True)
+    plain = D.DataParallelStep(twin, world=1, graph=True, graph_warmup=1, exchange=False, require_graph=True)
+    assert trainer.exchange and not plain.exchange
+    batches = [synth.to_torch(synth.make_batch(40 + 4 * i, 4, 256, 512), dev) for i in range(4)]
+    losses, plain_losses = [], []
+    for i, b in enumerate(batches):                     # 1 eager step, the capture, 2 replays
+        nxt = batches[i + 1] if i + 1 < len(batches) else None
+        losses.append(float(trainer.step(b, next_batch=nxt)))
+        plain_losses.append(float(plain.step(b, next_batch=nxt)))
+    torch.cuda.synchronize()
+    res["graph"], res["err"] = trainer.graph is not None, trainer.graph_error
+    res["losses"], res["plain_losses"] = losses, plain_losses
+    # after a replayed step: the exchange buffer holds what the captured backward wrote (world size 1: AVG is the identity)
+    res["flat_equals_graph_grads"] = all(
+        torch.allclose(v, g, rtol=1e-6, atol=0) for v, g in zip(trainer.grads.views, trainer._static_grads))
+    res["grads_are_views"] = all(p.grad is v for p, v in zip(trainer.grads.params, trainer.grads.views))
+    res["views_bound_once"] = bool(trainer._views_bound)
+    # a caller clearing a SUBSET of the gradients gets them bound again at the next step (round-4 advisor)
+    some = trainer.grads.params[5]
+    some.grad = None
+    trainer.step(batches[0])
+    res["rebound_after_partial_clear"] = some.grad is trainer.grads.views[5]
+    plain.step(batches[0])
+    torch.cuda.synchronize()
+    res["self_check"] = D.replica_self_check(model, trainer, 1.0, 4)
+    res["param_gap"] = max(float((a.detach() - b.detach()).abs().max()) for a, b in zip(model.parameters(), twin.parameters()))
+    res["finite"] = all(bool(torch.isfinite(p).all()) for p in model.parameters())
+    torch.save(res, os.path.join(out, "world1.pt"))
+    torch.distributed.destroy_process_group()
+
+
+def test_world_size_one_rccl_drives_the_multi_gpu_step(tmp_path):
+    """The sequence a multi-GPU run executes -- HIP-graph replay with the gradient pack inside, one RCCL
+    `all_reduce(AVG)` on the flat 5.9 MB buffer, `FlatAdam` on its views, `replica_self_check` -- on ONE GPU: an NCCL (=RCCL)
+    process group of world size 1 and `DataParallelStep(exchange=True)`.  Everything but the inter-GPU transport is the
+    code `bench.py --gpus 8` runs (main.py:53-64,82's DDP); no scaling is measured or claimed.  Compared with the plain
+    single-GPU trainer on the same batches: same losses step by step (the first bitwise-level, later ones to the
+    amplification of Adam's sign-like first updates), replicas' self-check divergence exactly 0."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_rccl_world1_worker, args=(port, str(tmp_path)), nprocs=1, join=True)
+    r = torch.load(tmp_path / "world1.pt")
+    assert r["backend"] == "nccl" and r["world"] == 1
+    assert r["graph"], r["err"]
+    assert r["flat_equals_graph_grads"] and r["grads_are_views"] and r["views_bound_once"] and r["rebound_after_partial_clear"]
+    assert r["self_check"].get("max_parameter_divergence") == 0.0 and "self_check_error" not in r["self_check"], r["self_check"]
+    assert "all_reduce" in r["self_check"]["gradient_exchange"] and "nccl" in r["self_check"]["gradient_exchange"]
+    assert r["finite"] and all(np.isfinite(v) for v in r["losses"])
+    assert abs(r["losses"][0] - r["plain_losses"][0]) <= 1e-5 * (1 + abs(r["plain_losses"][0])), (r["losses"], r["plain_losses"])
+    for a, b in zip(r["losses"], r["plain_losses"]):
+        assert abs(a - b) <= 2e-2 * (1 + abs(b)), (r["losses"], r["plain_losses"])
+    print("world-size-1 RCCL step: losses %s | plain %s | parameter gap to the plain trainer %.2e" % (
+        ["%.5f" % v for v in r["losses"]], ["%.5f" % v for v in r["plain_losses"]], r["param_gap"]))
 
 
 def test_bat_nuscenes_yaml_batch100():

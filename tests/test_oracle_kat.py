@@ -37,6 +37,37 @@ def test_fps_skips_near_origin_and_all_zero_cloud():
     assert (ops.furthest_point_sampling(zero, 8) == 0).all()
 
 
+def near_origin_literal_case():
+    """A cloud whose point 1 has |p|^2 == (float)1e-3 == 0x3A83126F EXACTLY under the canonical chain
+    fmaf(z,z, fmaf(y,y, x*x)), point 3 one float below; -> (xyz, expected indices under upstream's double literal)."""
+    from fractions import Fraction
+    x = np.uint32(0x3cab68e6).view(f32)
+    y = np.uint32(0x3cc23c60).view(f32)
+    t = np.uint32(0x3A83126F).view(f32)
+    xx = f32(x * x)                                          # one rounding, as __fmul_rn
+    exact = Fraction(float(y)) * Fraction(float(y)) + Fraction(float(xx))     # what the fma rounds ONCE
+    ulp = Fraction(2) ** (-10 - 23)                          # t is in [2^-10, 2^-9)
+    assert abs(exact - Fraction(float(t))) < ulp / 2, "the constructed point does not hit 0x3A83126F"
+    assert t == f32(1e-3) and float(t) > 1e-3               # above the double literal: upstream KEEPS the point
+    # a point one float BELOW the threshold float is <= 0.001 in double as well: skipped under either literal
+    lo = np.array([0.0316227, 0, 0], f32)                    # 0.0316227^2 = 9.99995e-4
+    assert float(f32(lo[0] * lo[0])) <= 1e-3
+    xyz = np.array([[[1, 0, 0], [x, y, 0], [0.5, 0, 0], lo]], f32)
+    # from point 0: point 1 is at d2 = 0.959 (kept -> farthest), point 2 at 0.25, point 3 never a candidate;
+    # then point 2 (min(0.25, 0.23) = 0.23 > 0 of the taken ones).  With `mag <= 1e-3f` it would be [0, 2, 0].
+    return xyz, [[0, 1, 2]]
+
+
+def test_fps_near_origin_literal_is_double():
+    """upstream: `if (mag <= 1e-3) continue;` -- float against the DOUBLE literal (round-4 review, fidelity nit)"""
+    xyz, want = near_origin_literal_case()
+    assert ops.furthest_point_sampling(xyz, 3).tolist() == want
+    # the same decision at a size where the product's register kernel holds several points per lane
+    big = np.concatenate([xyz, np.tile(np.array([[[0.75, 0, 0]]], f32), (1, 296, 1))], 1)
+    got = ops.furthest_point_sampling(big, 3)[0].tolist()
+    assert got[:2] == [0, 1], got
+
+
 def test_fps_tie_follows_upstream_tree_order():
     # N=4 -> block of 4 threads; points 1,2,3 are all at distance 1 from point 0 (a tie).
     # Tree: stride 2 merges (0,2),(1,3) keeping the lower slot on ties; stride 1 merges (0,1).
