@@ -279,8 +279,8 @@ def _batch48_gradients_vs_fp64(model_name, host, tag, seed=4):
         assert err <= max(2e-2, 3.0 * yard), (k, err, "fp32 CPU oracle vs fp64 on this key:", yard)
     whole, whole32 = (num / den) ** 0.5, (num32 / den) ** 0.5
     cos, ratio = flat_cos(g, g64)
-    print("%s " + tag + " gradient vs fp64: whole-gradient L2 error %.2e (fp32 CPU oracle: %.2e), cos %.6f, norm ratio %.4f; worst "
-          "key %s %.2e (fp32 CPU oracle on it: %.2e)" % (model_name, whole, whole32, cos, ratio, *worst))
+    print("%s %s gradient vs fp64: whole-gradient L2 error %.2e (fp32 CPU oracle: %.2e), cos %.6f, norm ratio %.4f; worst "
+          "key %s %.2e (fp32 CPU oracle on it: %.2e)" % (model_name, tag, whole, whole32, cos, ratio, *worst))
     assert whole <= max(2e-2, 1.5 * whole32), (whole, whole32)
     assert cos > 0.995 and abs(ratio - 1) < 0.03, (cos, ratio)
 
