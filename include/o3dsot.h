@@ -65,12 +65,27 @@ int o3d_gather_points_grad(const float* grad_out, const int32_t* idx, int B, int
  * without the two transposed copies. */
 int o3d_gather_rows(const float* src, const int32_t* idx, int B, int N, int D, int npoint, float* out, void* stream);
 
+/* o3d_gather_rows for one or two point-major tensors (a (B,N,Da), b (B,N,Db) | NULL with Db = 0) through the same index, whose
+ * rows may be a prefix of a longer index (idx[b * ld_idx + j], ld_idx >= npoint): the seed labels / BoxCloud rows of the
+ * trackers (models/bat.py:96-97,132-133: `.long()` + expand + torch.gather per tensor). */
+int o3d_gather_rows2(const float* a, int Da, const float* b, int Db, const int32_t* idx, long ld_idx, int B, int N, int npoint,
+                     float* outa, float* outb, void* stream);
+
 /* ---- ball query -----------------------------------------------------------------------
  * replaces _ext.ball_query(new_xyz, xyz, radius, nsample) pointnet2_utils.py:268
  * new_xyz (B,npoint,3), xyz (B,N,3) -> idx (B,npoint,nsample) i32: first `nsample`
  * indices k (ascending) with d^2 < radius^2, padded with the first hit, zeros if none. */
 int o3d_ball_query(const float* new_xyz, const float* xyz, int B, int N, int npoint, float radius,
                    int nsample, int32_t* idx, void* stream);
+
+/* Sampling gather + ball query of one or two sets of clouds in one launch: centres = xyz[b, sidx[b, j]] (sidx (B, npoint)
+ * int32, or NULL: the first npoint points, pointnet2_modules.py:56) written to `centers` ((B*npoint0 + B*npoint1 + 1, 3):
+ * set 0's, set 1's, then an origin row), idx_s (B, npoint_s, nsample) = ball_query around them (bit-identical to
+ * o3d_ball_query on the gathered centres).  npoint1 = 0: one set.  Replaces gather_operation + ball_query of
+ * pointnet2_modules.py:52-64 / pointnet2_utils.py:92,268 for both clouds of a backbone level. */
+int o3d_sample_query(const float* xyz0, const int32_t* sidx0, int N0, int npoint0, int32_t* idx0, const float* xyz1,
+                     const int32_t* sidx1, int N1, int npoint1, int32_t* idx1, int B, float radius, int nsample,
+                     float* centers, void* stream);
 
 /* ---- grouping -------------------------------------------------------------------------
  * replaces _ext.group_points(features, idx)               pointnet2_utils.py:217
@@ -282,6 +297,18 @@ int o3d_pool_fwd_ct(const float* Y, long ldp, const float* scale, const float* s
 int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t* argq, const float* yarg,
                    const float* mean, int B, int C, int npoint0, int npoint1, const int32_t* meta, long start1,
                    long ldp, float* D, float* part, void* stream);
+
+/* o3d_pool_bwd_c in ONE pass (round 5): D's live columns are written once, column by column (gradient at the ball's arg-max
+ * column, zero elsewhere), no zero fill.  cball / ball_off / meta from o3d_compact_build; C % 8 == 0, ldp % 512 == 0,
+ * start1 % 512 == 0, else O3D_EINVAL (use o3d_pool_bwd_c).  part [ldp/512][2][C]: one partial row per 512-column chunk
+ * (segment 1's rows after segment 0's Pmax0/512), only the live ones written: finalize with meta and tile = 512.
+ * dOut0 / dOut1: the pooled-output gradient of segment 0 / 1 as (B, C, npoint_s) with batch / channel strides sb / sc in
+ * floats, innermost stride 1; NULL = no gradient (zeros).
+ * Replaces max_pool2d's backward of pointnet2_modules.py:70-73 together with o3d_pool_bwd_c. */
+int o3d_pool_bwd_dense(const float* dOut0, long sb0, long sc0, const float* dOut1, long sb1, long sc1, const float* out,
+                       const int32_t* argq, const float* yarg, const float* mean,
+                       const int32_t* cball, const int32_t* ball_off, const int32_t* meta, long start1, long ldp, int B,
+                       int C, int npoint0, int npoint1, float* D, float* part, void* stream);
 
 /* The same sums as o3d_group_reduce_c without float atomics: the cloud's columns are sorted by (column chunk,
  * point) once per call (perm: ldp ints; poff: o3d_group_reduce_gather_scratch(...) ints, -1 = shape not covered,

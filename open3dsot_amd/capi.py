@@ -26,6 +26,7 @@ SIGNATURES = {
     "o3d_gather_points": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "o3d_gather_points_grad": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
     "o3d_gather_rows": [_vp, _vp, _i, _i, _i, _i, _vp, _vp],
+    "o3d_gather_rows2": [_vp, _i, _vp, _i, _vp, ctypes.c_long, _i, _i, _i, _vp, _vp, _vp],
     "o3d_ball_query": [_vp, _vp, _i, _i, _i, _f, _i, _vp, _vp],
     "o3d_group_points": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],
     "o3d_group_points_grad": [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp],

@@ -469,6 +469,119 @@ __global__ __launch_bounds__(256) void pool_bwd_partials_c_kernel(const float* _
     }
 }
 
+// Backward of the pool in ONE pass (round 5): the dense gradient D (C, ldp) of the pooled layer is written column by column --
+// D[c, q] = dOut[c, ball(q)] where q is the ball's arg-max column and out > 0, else 0 -- instead of a zero fill of the
+// live columns (0.52 GB of zeros per BAT step) followed by a scatter.  Workgroup = 512 columns x 8 channels: the {gradient,
+// arg-max column} pairs of the chunk's balls (<= 512: every ball has at least one column) are staged in LDS with loads that
+// run along the ball index of the (B, C, npoint) tensors, then every lane writes float4 runs of four channel rows and looks
+// its columns' balls up in LDS (round 2's single pass gathered dOut / out / argq from global memory per column: 12 gathers
+// per float4 store, 0.41 ms).  The BatchNorm-backward sums ride along: a ball counts in the chunk that holds its first
+// column, one partial row {sum g, sum g (yarg - mean)} per chunk (live rows only, like the GEMM epilogues').
+constexpr int PBD_COLS = 512, PBD_CH = 8, PBD_BALLS = 128;
+
+struct PoolGrad { const float* p; long sb, sc; };     // a segment's pooled-output gradient (B, C, npoint), strides in floats
+                                                       // (innermost 1); p == NULL: no gradient arrived (zeros)
+
+__global__ __launch_bounds__(256) void pool_bwd_dense_kernel(PoolGrad g0, PoolGrad g1, const float* __restrict__ out,
+                                                             const int32_t* __restrict__ argq, const float* __restrict__ yarg,
+                                                             const float* __restrict__ mean, const int32_t* __restrict__ cball,
+                                                             const int32_t* __restrict__ ball_off,
+                                                             const int32_t* __restrict__ meta, long start1, long ldp, int C,
+                                                             int dummy_ball, int seg1_ball, int np0, int np1,
+                                                             float* __restrict__ D, float* __restrict__ part) {
+    // staged per pass: PBD_BALLS balls (a 512-column chunk of the KITTI-like crops holds ~50, of the k-NN level 128, of
+    // full balls 16; more -> more passes), so that 8 workgroups fit a CU: the kernel is a latency chain per workgroup
+    // (index loads -> gathers along the balls -> LDS -> stores) and lives on the bytes in flight per CU
+    __shared__ float2 stg[PBD_CH][PBD_BALLS];       // {g, bits(arg-max column) | -1}
+    __shared__ int sh_hi;
+    const long q0 = (long)blockIdx.x * PBD_COLS;
+    const int c0 = blockIdx.y * PBD_CH;
+    const int seg = (start1 > 0 && q0 >= start1) ? 1 : 0;
+    const long local0 = q0 - (seg ? start1 : 0);
+    // every index load of the prologue is issued at once (none depends on another): the live count, the chunk's first
+    // ball, this lane's four column -> ball entries (allocated up to ldp; only used when the columns are live)
+    const int qi = threadIdx.x & 127, half = threadIdx.x >> 7;
+    const long q = q0 + 4 * qi;
+    const int live = meta[4 * seg];                  // columns of the segment rounded up to 256
+    const int b_lo = cball[q0];
+    const int4 cb = *reinterpret_cast<const int4*>(&cball[q]);
+    if (threadIdx.x == 0) sh_hi = -1;
+    if (local0 >= live) return;                      // (uniform)
+    const int ncols = (int)min((long)PBD_COLS, live - local0);     // 256 or 512
+    const bool mine = 4 * qi < ncols;
+    __syncthreads();
+    if (half == 0) {               // (wave-uniform) last real ball of the chunk: padding columns carry the dummy ball, the
+        int hi = cb.x;             // largest id, and follow every real column
+        hi = cb.y != dummy_ball ? cb.y : hi;
+        hi = cb.z != dummy_ball ? cb.z : hi;
+        hi = cb.w != dummy_ball ? cb.w : hi;
+        if (!mine || cb.x == dummy_ball) hi = -1;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) hi = max(hi, __shfl_xor(hi, m, 64));
+        if ((threadIdx.x & 63) == 0) atomicMax(&sh_hi, hi);
+    }
+    __syncthreads();
+    const int nb = sh_hi - b_lo + 1;                 // >= 1: a live chunk starts with a real column
+    const int cl = threadIdx.x >> 5, bl = threadIdx.x & 31;
+    const float mu = mean[seg * C + c0 + cl];
+    const PoolGrad gs = seg ? g1 : g0;
+    float s = 0.f, sq = 0.f;
+    float4 v[PBD_CH / 2];
+#pragma unroll
+    for (int cc = 0; cc < PBD_CH / 2; ++cc) v[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int qq = (int)q;
+    for (int base = 0; base < nb; base += PBD_BALLS) {
+        if (base) __syncthreads();
+        {   // ---- stage PBD_BALLS balls: thread = (channel, ball lane); the loads run along the ball index
+            const int c = c0 + cl;
+            float ov[PBD_BALLS / 32], gv[PBD_BALLS / 32], yv[PBD_BALLS / 32];
+            int av[PBD_BALLS / 32], fo[PBD_BALLS / 32];
+#pragma unroll
+            for (int k = 0; k < PBD_BALLS / 32; ++k) {
+                const int i = base + bl + 32 * k;
+                const int ball = b_lo + (i < nb ? i : nb - 1);           // clamped, not predicated: loads stay in flight
+                const int local = seg ? ball - seg1_ball : ball, np = seg ? np1 : np0;      // (a chunk lies in one segment)
+                const int b = local / np, j = local - b * np;
+                const long o = (seg ? (long)seg1_ball * C : 0) + ((long)b * C + c) * np + j;     // = pool_index(c, ball, ...)
+                ov[k] = out[o]; yv[k] = yarg[o]; av[k] = argq[o]; fo[k] = ball_off[ball];
+                gv[k] = gs.p ? gs.p[b * gs.sb + c * gs.sc + j] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < PBD_BALLS / 32; ++k) {
+                const int i = base + bl + 32 * k;
+                const bool pos = ov[k] > 0.f;
+                const float g = pos ? gv[k] : 0.f;
+                stg[cl][bl + 32 * k] = make_float2(g, __int_as_float(pos ? av[k] : -1));
+                if (i < nb && fo[k] >= q0) { s += g; sq += g * (yv[k] - mu); }   // the ball's first column lies in this chunk
+            }
+        }
+        __syncthreads();
+        if (mine) {   // ---- this lane's four columns of four channel rows: look the balls up
+            const int i0 = cb.x - b_lo - base, i1 = cb.y - b_lo - base, i2 = cb.z - b_lo - base, i3 = cb.w - b_lo - base;
+            const int lim = min(PBD_BALLS, nb - base);          // (padding columns: dummy ball -> beyond nb)
+#pragma unroll
+            for (int cc = 0; cc < PBD_CH / 2; ++cc) {
+                const int ch = half * (PBD_CH / 2) + cc;
+                if (i0 >= 0 && i0 < lim) { const float2 e = stg[ch][i0]; if (__float_as_int(e.y) == qq + 0) v[cc].x = e.x; }
+                if (i1 >= 0 && i1 < lim) { const float2 e = stg[ch][i1]; if (__float_as_int(e.y) == qq + 1) v[cc].y = e.x; }
+                if (i2 >= 0 && i2 < lim) { const float2 e = stg[ch][i2]; if (__float_as_int(e.y) == qq + 2) v[cc].z = e.x; }
+                if (i3 >= 0 && i3 < lim) { const float2 e = stg[ch][i3]; if (__float_as_int(e.y) == qq + 3) v[cc].w = e.x; }
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) { s += __shfl_xor(s, m, 64); sq += __shfl_xor(sq, m, 64); }
+    if (bl == 0) {
+        part[((long)blockIdx.x * 2 + 0) * C + c0 + cl] = s;
+        part[((long)blockIdx.x * 2 + 1) * C + c0 + cl] = sq;
+    }
+    if (mine) {
+#pragma unroll
+        for (int cc = 0; cc < PBD_CH / 2; ++cc)
+            *reinterpret_cast<float4*>(&D[(long)(c0 + half * (PBD_CH / 2) + cc) * ldp + q]) = v[cc];
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // layer-0 backward reduce: dY = A1*dN + w*(A2*Y0 + A3);  S[c, b*ld+n] = sum of dY over the columns that
 // reference point n, T[c, ball] = sum of dY over the ball.  Workgroup = (cloud, CS channels), LDS fp32
@@ -1161,6 +1274,28 @@ extern "C" int o3d_pool_bwd_c(const float* dOut, const float* out, const int32_t
     hipLaunchKernelGGL(zero_cols_kernel, dim3((unsigned)o3d_cdiv(ldp, 1024), C), dim3(256), 0, s, D, ldp, meta, start1);
     hipLaunchKernelGGL(pool_bwd_partials_c_kernel, dim3(C, nseg, POOL_BWD_SPLIT), dim3(256), 0, s, dOut, out, yarg, mean, C,
                        nballs, seg1_ball, npoint0, np1, part, argq, D, ldp);
+    return o3d_launch_status();
+}
+
+// o3d_pool_bwd_c in one pass (pool_bwd_dense_kernel): no zero fill.  The pooled-output gradient comes per segment as a
+// (B, C, npoint_s) tensor with arbitrary batch / channel strides (sb, sc in floats; NULL = zeros): the template and the
+// search gradient of a paired level, or a (C, B * npoint) flat view, are read where they lie (were: 6 strided torch copies
+// per step into one buffer).  Needs the column -> ball map and the ball offsets of o3d_compact_build; C % 8 == 0, ldp % 512 == 0, start1 % 512 == 0 (else O3D_EINVAL: use o3d_pool_bwd_c).  part: one row
+// {sum g, sum g (yarg - mean)} per 512-column chunk, [ldp / 512][2][C], live rows only (finalize with tile = 512).
+extern "C" int o3d_pool_bwd_dense(const float* dOut0, long sb0, long sc0, const float* dOut1, long sb1, long sc1,
+                                  const float* out, const int32_t* argq, const float* yarg,
+                                  const float* mean, const int32_t* cball, const int32_t* ball_off, const int32_t* meta,
+                                  long start1, long ldp, int B, int C, int npoint0, int npoint1, float* D, float* part,
+                                  void* stream) {
+    if (!out || !argq || !yarg || !mean || !cball || !ball_off || !meta || !D || !part || B <= 0 || C <= 0 ||
+        C % PBD_CH != 0 || npoint0 <= 0 || npoint1 < 0 || ldp <= 0 || ldp % PBD_COLS != 0 || start1 < 0 ||
+        start1 % PBD_COLS != 0 || ldp > 0x7fffffffL)
+        return O3D_EINVAL;
+    const int seg1_ball = B * npoint0, np1 = npoint1 > 0 ? npoint1 : npoint0;
+    const PoolGrad g0 = {dOut0, sb0, sc0}, g1 = {dOut1, sb1, sc1};
+    hipLaunchKernelGGL(pool_bwd_dense_kernel, dim3((unsigned)(ldp / PBD_COLS), C / PBD_CH), dim3(256), 0, o3d_stream(stream),
+                       g0, g1, out, argq, yarg, mean, cball, ball_off, meta, npoint1 > 0 ? start1 : 0, ldp, C,
+                       B * (npoint0 + npoint1), seg1_ball, npoint0, np1, D, part);
     return o3d_launch_status();
 }
 

@@ -50,6 +50,54 @@ __global__ __launch_bounds__(256) void ball_query_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------
+// Sampling gather + ball query of one or two sets of clouds in ONE launch (round 5).  A set-abstraction level starts with
+// new_xyz = xyz[sample_idx] (farthest-point indices, or the arange(npoint) prefix: pointnet2_modules.py:52-62) followed by
+// ball_query(new_xyz, xyz) (:64, pointnet2_utils.py:268), for the template and for the search cloud: 2 gathers (or strided
+// copies) + 2 ball queries + the concatenation of the centres for the fused path = 5 launches per level.  Here a wave takes
+// a centre of either set: fetches it through the sampling index, writes it to `centers` ((nballs + 1, 3): set 0's centres,
+// set 1's, then the origin row of the padding columns' dummy ball -- new_xyz of both sets are views of it) and runs the sweep of
+// ball_query_kernel on it (same arithmetic, same order: bit-identical indices).
+struct SampleQuerySet { const float* xyz; const int32_t* sidx; int N, npoint; int32_t* idx; };   // sidx NULL: prefix
+
+__global__ __launch_bounds__(256) void sample_query_kernel(SampleQuerySet s0, SampleQuerySet s1, long total0, long total,
+                                                           float r2, int nsample, float* __restrict__ centers) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    if (blockIdx.x == 0 && threadIdx.x < 3) centers[total * 3 + threadIdx.x] = 0.f;      // the dummy ball's centre
+    for (long c = (long)blockIdx.x * 4 + wave; c < total; c += (long)gridDim.x * 4) {
+        const bool second = c >= total0;
+        const SampleQuerySet& st = second ? s1 : s0;
+        const long cl = second ? c - total0 : c;
+        const int N = st.N;
+        const long b = cl / st.npoint;
+        const int j = (int)(cl - b * st.npoint);
+        const float* p = st.xyz + b * N * 3;
+        const int src = st.sidx ? st.sidx[cl] : j;
+        const float cx = p[3 * src + 0], cy = p[3 * src + 1], cz = p[3 * src + 2];
+        if (lane < 3) centers[c * 3 + lane] = lane == 0 ? cx : lane == 1 ? cy : cz;
+        int32_t* out = st.idx + cl * nsample;
+        int cnt = 0, first = 0;
+        for (int base = 0; base < N && cnt < nsample; base += 64) {
+            const int k = base + lane;
+            bool hit = false;
+            if (k < N) {
+                const float d2 = o3d_sqdist3(cx, cy, cz, p[3 * k], p[3 * k + 1], p[3 * k + 2]);
+                hit = d2 < r2;
+            }
+            const unsigned long long m = __ballot(hit);
+            if (m) {
+                if (cnt == 0) first = base + (__ffsll((long long)m) - 1);
+                const int pos = cnt + __popcll(m & ((1ull << lane) - 1ull));
+                if (hit && pos < nsample) out[pos] = k;
+                cnt += __popcll(m);
+            }
+        }
+        if (cnt > nsample) cnt = nsample;
+        for (int l = cnt + lane; l < nsample; l += 64) out[l] = first;  // pad (0 when empty)
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // group / gather: out[b,c,q] = feats[b,c,idx[b,q]], q over npoint*nsample (contiguous writes)
 constexpr int GCT = 16;  // channels per workgroup
 __global__ __launch_bounds__(256) void group_points_kernel(const float* __restrict__ feats,
@@ -241,6 +289,21 @@ extern "C" int o3d_ball_query(const float* new_xyz, const float* xyz, int B, int
     return o3d_launch_status();
 }
 
+extern "C" int o3d_sample_query(const float* xyz0, const int32_t* sidx0, int N0, int npoint0, int32_t* idx0,
+                                const float* xyz1, const int32_t* sidx1, int N1, int npoint1, int32_t* idx1, int B,
+                                float radius, int nsample, float* centers, void* stream) {
+    if (B <= 0 || N0 <= 0 || npoint0 <= 0 || nsample <= 0 || !xyz0 || !idx0 || !centers || npoint1 < 0 ||
+        (npoint1 > 0 && (!xyz1 || !idx1 || N1 <= 0)) || (!sidx0 && npoint0 > N0) || (npoint1 > 0 && !sidx1 && npoint1 > N1))
+        return O3D_EINVAL;
+    const long total0 = (long)B * npoint0, total = total0 + (long)B * npoint1;
+    SampleQuerySet s0 = {xyz0, sidx0, N0, npoint0, idx0}, s1 = {xyz1, sidx1, N1, npoint1 > 0 ? npoint1 : 1, idx1};
+    long blocks = (total + 3) / 4;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(sample_query_kernel, dim3((unsigned)blocks), dim3(256), 0, o3d_stream(stream), s0, s1, total0, total,
+                       radius * radius, nsample, centers);
+    return o3d_launch_status();
+}
+
 extern "C" int o3d_group_points(const float* feats, const int32_t* idx, int B, int C, int N,
                                 int npoint, int nsample, float* out, void* stream) {
     if (B < 0 || C < 0 || N < 0 || npoint < 0 || nsample < 0 || B > 65535) return O3D_EINVAL;
@@ -280,7 +343,35 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
     const long b = bj / npoint;
     out[t] = src[(b * N + idx[bj]) * D + d];
 }
+// the same for two tensors over the same points through one index whose rows may be a prefix of a longer index
+// (ld_idx >= npoint: idx[b * ld_idx + j]): the seed labels of the trackers (models/bat.py:96-97,132-133)
+__global__ __launch_bounds__(256) void gather_rows2_kernel(const float* __restrict__ a, int Da, const float* __restrict__ b_,
+                                                           int Db, const int32_t* __restrict__ idx, long ld_idx, int N,
+                                                           int npoint, long total, float* __restrict__ outa,
+                                                           float* __restrict__ outb) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;      // (b, j, d), d fastest over Da + Db
+    if (t >= total) return;
+    const int D = Da + Db;
+    const long bj = t / D;
+    const int d = (int)(t - bj * D);
+    const long b = bj / npoint;
+    const int j = (int)(bj - b * npoint);
+    const long row = b * N + idx[b * ld_idx + j];
+    if (d < Da) outa[bj * Da + d] = a[row * Da + d];
+    else outb[bj * Db + (d - Da)] = b_[row * Db + (d - Da)];
+}
 }  // namespace
+
+extern "C" int o3d_gather_rows2(const float* a, int Da, const float* b, int Db, const int32_t* idx, long ld_idx, int B, int N,
+                                int npoint, float* outa, float* outb, void* stream) {
+    if (B < 0 || N <= 0 || Da <= 0 || Db < 0 || npoint < 0 || ld_idx < npoint || !a || !outa || !idx || (Db > 0 && (!b || !outb)))
+        return O3D_EINVAL;
+    const long total = (long)B * npoint * (Da + Db);
+    if (total == 0) return O3D_OK;
+    hipLaunchKernelGGL(gather_rows2_kernel, dim3((unsigned)o3d_cdiv(total, 256)), dim3(256), 0, o3d_stream(stream), a, Da, b, Db,
+                       idx, ld_idx, N, npoint, total, outa, outb);
+    return o3d_launch_status();
+}
 
 extern "C" int o3d_gather_rows(const float* src, const int32_t* idx, int B, int N, int D, int npoint, float* out,
                                void* stream) {

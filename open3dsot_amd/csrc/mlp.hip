@@ -279,7 +279,7 @@ __device__ __forceinline__ void bn_finalize_body(const BnFinArgs& a, const int b
         const int off = seg * a.C;
         double s = 0.0, q = 0.0;
         int nparts = seg ? a.nparts1 : a.nparts;
-        if (a.meta) { const int live = a.meta[4 * seg] / a.tile; nparts = live < nparts ? live : nparts; }
+        if (a.meta) { const int live = (a.meta[4 * seg] + a.tile - 1) / a.tile; nparts = live < nparts ? live : nparts; }   // (ceil: a 512-column row of o3d_pool_bwd_dense may be half live)
         if (c < a.C) {
 #pragma unroll 8
             for (int t = sl; t < nparts; t += FIN_SL) {
@@ -465,7 +465,7 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const BnBwdFinArgs& a, cons
         const int off = seg * a.C;
         double s = 0.0, q = 0.0;
         int nparts = seg ? a.nparts1 : a.nparts;
-        if (a.meta) { const int live = a.meta[4 * seg] / a.tile; nparts = live < nparts ? live : nparts; }
+        if (a.meta) { const int live = (a.meta[4 * seg] + a.tile - 1) / a.tile; nparts = live < nparts ? live : nparts; }   // (ceil: a 512-column row of o3d_pool_bwd_dense may be half live)
         if (c < a.C) {
 #pragma unroll 8
             for (int t = sl; t < nparts; t += FIN_SL) {

@@ -97,6 +97,26 @@ def gather_rows(src, idx):
     return out
 
 
+def gather_rows2(a, b, idx, npoint):
+    """a (B,N,Da), b (B,N,Db) | None, idx (B, >= npoint) int32 (row stride free) -> a[b, idx[b, :npoint]] (B,npoint,Da)
+    [, the same of b]: the trackers' label re-indexing by the sampling indices in one launch (no gradient: labels)"""
+    _chk_f(a, "a")
+    if not (idx.dtype == torch.int32 and idx.dim() == 2 and idx.stride(1) == 1 and idx.shape[1] >= npoint and idx.is_cuda):
+        raise RuntimeError("gather_rows2: idx must be a CUDA int32 (B, >= npoint) tensor with unit inner stride")
+    B, N, Da = a.shape
+    Db = 0
+    if b is not None:
+        _chk_f(b, "b")
+        Db = b.shape[2]
+    outa = torch.empty((B, npoint, Da), dtype=torch.float32, device=a.device)
+    outb = torch.empty((B, npoint, Db), dtype=torch.float32, device=a.device) if b is not None else None
+    with torch.cuda.device(a.device):
+        capi.check(capi.load().o3d_gather_rows2(a.data_ptr(), Da, b.data_ptr() if b is not None else None, Db, idx.data_ptr(),
+                                                idx.stride(0), B, N, npoint, outa.data_ptr(),
+                                                outb.data_ptr() if outb is not None else None, _stream()), "gather_rows2")
+    return outa, outb
+
+
 def gather_points_grad(grad_out, idx, n):
     """grad_out (B,C,npoint), idx (B,npoint) -> (B,C,n)   [pointnet2_utils.py:98]"""
     _chk_f(grad_out, "grad_out")

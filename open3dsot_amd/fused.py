@@ -60,6 +60,7 @@ capi.register("o3d_center_term_out", [_vp, _vp, _i, _i, _i, _vp, _i, _vp, _vp])
 capi.register("o3d_pool_fwd_c", [_vp, _l, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_fwd_ct", [_vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _l, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp])
 capi.register("o3d_pool_bwd_c", [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _l, _l, _vp, _vp, _vp])
+capi.register("o3d_pool_bwd_dense", [_vp, _l, _l, _vp, _l, _l] + [_vp] * 7 + [_l, _l, _i, _i, _i, _i, _vp, _vp, _vp])
 capi.register("o3d_sa_eval_fused", [_vp, _l, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _l, _vp, _vp])
 capi.register("o3d_group_reduce_c", [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp,
                                      _vp, _vp])
@@ -341,7 +342,7 @@ _CONST = {}
 
 # ---- the autograd function ---------------------------------------------------------------
 class _Cfg:
-    __slots__ = ("nxyz", "inv_radius", "training", "bns", "eps", "momentum")
+    __slots__ = ("nxyz", "inv_radius", "training", "bns", "eps", "momentum", "centers")
 
 
 def _direct_tile(lib, pmax, m):
@@ -421,8 +422,10 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
               _ptr(xs[-1]) if nseg == 2 else None, _ptr(fs[-1]) if nseg == 2 else None, Ns[-1] if nseg == 2 else 0,
               Npads[-1] if nseg == 2 else 0, B, nxyz, C, float(cfg.inv_radius), Cin0m, X0n.data_ptr(), st)
         centers = None
-        if nxyz:       # ball centres of every segment + the dummy ball (origin) of the padding columns: one launch
-            centers = torch.cat([sg[1].detach().reshape(-1, 3) for sg in segs] + [_const_vec(dev, 3, 0.0).view(1, 3)])
+        if nxyz:       # ball centres of every segment + the dummy ball (origin) of the padding columns
+            centers = getattr(cfg, "centers", None)         # laid out like that by o3d_sample_query (sa_pair_sampled)
+            if centers is None:
+                centers = torch.cat([sg[1].detach().reshape(-1, 3) for sg in segs] + [_const_vec(dev, 3, 0.0).view(1, 3)])
             if not unit:
                 centers = centers * cfg.inv_radius
         # zero-padded / transposed weight copies come from the device's WeightPrep table (open3dsot_amd/fused_heads.py):
@@ -442,12 +445,11 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             if nseg == 1:
                 statcs = [bn.running_mean.detach().unsqueeze(0) for bn in cfg.bns]
             else:
-                allc = torch.cat([bn.running_mean.detach() for bn in cfg.bns for _ in range(nseg)])
-                statcs, o = [], 0
-                for bn in cfg.bns:
-                    n = bn.running_mean.numel()
-                    statcs.append(allc[o:o + nseg * n].view(nseg, n))
-                    o += nseg * n
+                # one row per segment, through the device's WeightPrep table (refreshed by the ONE launch at the start of a
+                # tracker forward; was a torch.cat per level).  The shift only has to be the SAME vector in the producer's
+                # epilogue and in the finalize -- any value near the mean conditions the second moment -- so a snapshot taken
+                # at the start of the forward serves both segments
+                statcs = [prep.snapshot(bn.running_mean, nseg) for bn in cfg.bns]
         for l in range(L):
             Cout, Cin = Ws[l].shape
             bn = cfg.bns[l]
@@ -534,31 +536,48 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         want_xyz = nxyz > 0 and any(needs[4 * s_] or needs[4 * s_ + 1] for s_ in range(nseg))
         want_feats = C > 0 and any(needs[4 * s_ + 2] for s_ in range(nseg))
         Cl = Ws[-1].shape[0]
-        # pooled-layer gradient: the segments' (B, Cl, npoint) blocks back to back, like `out`
-        if nseg == 1:
-            dOut = dOuts[0].contiguous()
-        else:
-            dOut = torch.empty((nballs * Cl,), device=dev, dtype=f32)
-            for s_ in range(nseg):
-                dst = dOut[ball_bases[s_] * Cl:(ball_bases[s_] + nballs_s[s_]) * Cl].view(B, Cl, npoints[s_])
-                if dOuts[s_] is None:
-                    dst.zero_()
-                else:
-                    dst.copy_(dOuts[s_])
-        part = torch.empty((nseg, POOL_BWD_SPLIT, 2, Cl), device=dev, dtype=f32)
         np1 = npoints[1] if nseg == 2 else 0
         dN = torch.empty((Cl, ldp), device=dev, dtype=f32)          # dense class-sum gradient of the pooled layer
-        _call("pool_bwd", 0.0, lib.o3d_pool_bwd_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
-              means[-1].data_ptr(), B, Cl, npoints[0], np1, meta.data_ptr(), start1, ldp, dN.data_ptr(),
-              part.data_ptr(), st)
-        dtile = 0
+        # one pass over the live columns (no zero fill; csrc/compact.hip::pool_bwd_dense_kernel), partial rows per 512 columns;
+        # the segments' gradients are read where they lie (any batch / channel strides)
+        pool_dense = _POOL_BWD_DENSE["on"] and Cl % 8 == 0 and ldp % POOL_DENSE_COLS == 0 and start1 % POOL_DENSE_COLS == 0
+        if pool_dense:
+            gsrc = []
+            for s_ in range(nseg):
+                g = dOuts[s_]
+                if g is not None and g.stride(2) != 1:
+                    g = g.contiguous()
+                gsrc += [_ptr(g), g.stride(0) if g is not None else 0, g.stride(1) if g is not None else 0]
+            if nseg == 1:
+                gsrc += [None, 0, 0]
+            part = torch.empty((ldp // POOL_DENSE_COLS, 2, Cl), device=dev, dtype=f32)
+            _call("pool_bwd", 0.0, lib.o3d_pool_bwd_dense, *gsrc, out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
+                  means[-1].data_ptr(), cball.data_ptr(), ball_off.data_ptr(), meta.data_ptr(), start1, ldp, B, Cl, npoints[0],
+                  np1, dN.data_ptr(), part.data_ptr(), st)
+        else:
+            # pooled-layer gradient: the segments' (B, Cl, npoint) blocks back to back, like `out`
+            if nseg == 1:
+                dOut = dOuts[0].contiguous()
+            else:
+                dOut = torch.empty((nballs * Cl,), device=dev, dtype=f32)
+                for s_ in range(nseg):
+                    dst = dOut[ball_bases[s_] * Cl:(ball_bases[s_] + nballs_s[s_]) * Cl].view(B, Cl, npoints[s_])
+                    if dOuts[s_] is None:
+                        dst.zero_()
+                    else:
+                        dst.copy_(dOuts[s_])
+            part = torch.empty((nseg, POOL_BWD_SPLIT, 2, Cl), device=dev, dtype=f32)
+            _call("pool_bwd", 0.0, lib.o3d_pool_bwd_c, dOut.data_ptr(), out.data_ptr(), argq.data_ptr(), yarg.data_ptr(),
+                  means[-1].data_ptr(), B, Cl, npoints[0], np1, meta.data_ptr(), start1, ldp, dN.data_ptr(),
+                  part.data_ptr(), st)
+        dtile = POOL_DENSE_COLS if pool_dense else 0
         part_rows = 0    # > 0: `part` comes from the fused data + weight gradient kernel (rows per segment block)
         seg_grads = [[None, None, None] for _ in range(nseg)]
         for l in range(L - 1, -1, -1):
             Cout, Cin = Ws[l].shape
             coef = torch.empty((5, nseg, Cout), device=dev, dtype=f32)  # dgamma dbeta (row 0: all segments) A1 A2 A3
             cp = [coef[k].data_ptr() for k in range(5)]
-            if l == L - 1:       # partials of the pool backward: POOL_BWD_SPLIT rows per segment, all live
+            if l == L - 1 and not pool_dense:       # partials of the pool backward: POOL_BWD_SPLIT rows per segment, all live
                 if nseg == 1:
                     _call("bn_bwd_finalize", 0.0, lib.o3d_bn_bwd_finalize, part.data_ptr(), POOL_BWD_SPLIT, Cout, counts[0],
                           gammas[l].data_ptr(), means[l].data_ptr(), invstds[l].data_ptr(), *cp, None, st)
@@ -705,6 +724,16 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             gin += [seg_grads[s_][0] if needs[4 * s_] else None, seg_grads[s_][1] if needs[4 * s_ + 1] else None,
                     seg_grads[s_][2] if needs[4 * s_ + 2] else None, None]
         return (None, None, *gin, *gw)
+
+
+# pool backward in one pass (no zero fill of the dense gradient; csrc/compact.hip::pool_bwd_dense_kernel); `set_pool_bwd_dense(False)`
+# = the zero fill + scatter pair it replaces: a TEST hook (both must give the same gradients), not a tuning switch
+POOL_DENSE_COLS = 512
+_POOL_BWD_DENSE = {"on": True}
+
+
+def set_pool_bwd_dense(enabled):
+    _POOL_BWD_DENSE["on"] = bool(enabled)
 
 
 # data + weight gradient of a 64-input-channel inner layer in ONE kernel (csrc/mlp_wgrad.hip::fused_bwd_kernel: SA level 0's
@@ -868,6 +897,67 @@ def sa_group_mlp_pool_pair(grouper, mlp, a, b):
     for conv, bn in layers:
         params += [conv.weight, bn.weight, bn.bias]
     return FusedGroupedMLPCompact.apply(cfg, 2, a[0], a[1], a[2], idx_a, b[0], b[1], b[2], idx_b, *params)
+
+
+capi.register("o3d_sample_query", [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _f, _i, _vp, _vp])
+
+
+def sa_pair_sampled(grouper, mlp, a, b):
+    """sa_group_mlp_pool_pair with the sampling folded in: a, b = (xyz (B,N,3), features | None, npoint, sample_idx (B,npoint)
+    int32 | None = the arange(npoint) prefix).  ONE launch gathers the centres of both sets, writes them in the layout the
+    fused path wants and runs both ball queries (csrc/index_ops.hip::sample_query_kernel; were 2 gathers or strided copies
+    + 2 ball queries + 1 concatenation per level).  -> (new_xyz_a, pooled_a, new_xyz_b, pooled_b) or None when the joint
+    layout does not apply or a coordinate tensor carries a gradient (the caller then takes the operator-by-operator route)."""
+    (xyz_a, f_a, np_a, si_a), (xyz_b, f_b, np_b, si_b) = a, b
+    if not (_SAMPLE_QUERY["on"] and xyz_a.is_cuda) or xyz_a.shape[0] != xyz_b.shape[0] or (f_a is None) != (f_b is None):
+        return None
+    if f_a is not None and f_a.shape[1] != f_b.shape[1]:
+        return None
+    if torch.is_grad_enabled() and (xyz_a.requires_grad or xyz_b.requires_grad):
+        return None
+    B, ns = xyz_a.shape[0], grouper.nsample
+    layers = _layers(mlp)
+    if not (_shape_ok(np_a, ns) and _shape_ok(np_b, ns) and _compact_ok(layers, np_a, ns, B) and
+            _compact_ok(layers, np_b, ns, B) and (B * np_a * ns) % 256 == 0):
+        return None
+    if (si_a is None and np_a > xyz_a.shape[1]) or (si_b is None and np_b > xyz_b.shape[1]):
+        return None
+    dev, f32, i32 = xyz_a.device, torch.float32, torch.int32
+    xa, xb = xyz_a.detach().contiguous(), xyz_b.detach().contiguous()
+    for si in (si_a, si_b):
+        if si is not None and not (si.dtype == i32 and si.is_contiguous()):
+            return None
+    nb_a, nb_b = B * np_a, B * np_b
+    centers = torch.empty((nb_a + nb_b + 1, 3), device=dev, dtype=f32)
+    idx_a = torch.empty((B, np_a, ns), device=dev, dtype=i32)
+    idx_b = torch.empty((B, np_b, ns), device=dev, dtype=i32)
+    with torch.cuda.device(dev):
+        _call("sample_query", 0.0, capi.load().o3d_sample_query, xa.data_ptr(), _ptr(si_a), xa.shape[1], np_a, idx_a.data_ptr(),
+              xb.data_ptr(), _ptr(si_b), xb.shape[1], np_b, idx_b.data_ptr(), B, float(grouper.radius), ns,
+              centers.data_ptr(), _stream())
+    new_a, new_b = centers[:nb_a].view(B, np_a, 3), centers[nb_a:nb_a + nb_b].view(B, np_b, 3)
+    inv_r = float(1.0 / grouper.radius if grouper.normalize_xyz else 1.0)
+    if _eval_fused_ok(mlp, layers, [(xa, new_a, f_a, idx_a), (xb, new_b, f_b, idx_b)], 3):
+        outs = _run_eval(mlp, layers, [(xa, new_a, f_a, idx_a), (xb, new_b, f_b, idx_b)], 3, inv_r)
+        return new_a, outs[0], new_b, outs[1]
+    cfg = _Cfg()
+    cfg.nxyz, cfg.training = 3, bool(mlp.training)
+    cfg.inv_radius = inv_r
+    cfg.bns = [bn for _, bn in layers]
+    cfg.centers = centers
+    params = []
+    for conv, bn in layers:
+        params += [conv.weight, bn.weight, bn.bias]
+    outs = FusedGroupedMLPCompact.apply(cfg, 2, xa, new_a, f_a, idx_a, xb, new_b, f_b, idx_b, *params)
+    return new_a, outs[0], new_b, outs[1]
+
+
+# (TEST hook: False = gather / ball query / concatenation as separate launches, the route sa_pair_sampled is tested against)
+_SAMPLE_QUERY = {"on": True}
+
+
+def set_sample_query(enabled):
+    _SAMPLE_QUERY["on"] = bool(enabled)
 
 
 def group_mlp_pool(mlp, bundle, idx):

@@ -171,7 +171,7 @@ def _as_flat(t):
 
 # ---- weight preparation ------------------------------------------------------------------------------------
 class _Job:
-    __slots__ = ("ref", "dst", "rows", "cols", "transpose", "src_ptr")
+    __slots__ = ("ref", "dst", "rows", "cols", "transpose", "src_ptr", "snap")
 
 
 class WeightPrep:
@@ -212,6 +212,30 @@ class WeightPrep:
         elif not (self.active and key in self.fresh) or job.src_ptr != param.data_ptr():
             self._copy_now(job, param)
         return job.dst
+
+    def snapshot(self, buf, nrows):
+        """(nrows, C) tensor whose every row is a copy of the 1-D `buf` taken by the table's launch at the start of the
+        forward (or on the spot outside a prep scope): the BatchNorm running means as they were before the forward's
+        own updates, one row per segment of a paired set abstraction (fused.py; was a torch.cat per level)"""
+        n = buf.numel()
+        key0 = (id(buf), "snap", nrows, 0)
+        job0 = self.jobs.get(key0)
+        if job0 is None or job0.ref() is not buf:
+            snap = torch.zeros((nrows, n), device=buf.device, dtype=torch.float32)
+            for r in range(nrows):
+                job = _Job()
+                job.ref = weakref.ref(buf)
+                job.rows, job.cols, job.transpose = 1, n, False
+                job.dst = snap[r:r + 1]
+                job.snap = snap
+                job.src_ptr = buf.data_ptr()
+                self.jobs[(id(buf), "snap", nrows, r)] = job
+            self.dirty = True
+            job0 = self.jobs[key0]
+            job0.snap.copy_(buf.detach().reshape(1, n).expand(nrows, n))
+        elif not (self.active and key0 in self.fresh) or job0.src_ptr != buf.data_ptr():
+            job0.snap.copy_(buf.detach().reshape(1, n).expand(nrows, n))
+        return job0.snap
 
     def refresh(self):
         """all registered copies in one launch"""

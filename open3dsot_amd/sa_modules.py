@@ -122,6 +122,25 @@ class _PointnetSAModuleBase(nn.Module):
         if (_FUSED["enabled"] and _FUSED["paired"] and xyz_a.is_cuda and len(self.groupers) == 1):
             from . import fused
             if fused.supports(self.groupers[0], self.mlps[0], features_a):
+                # sampling gather + both ball queries + the centres' layout in one launch (fused.sa_pair_sampled); the
+                # sampling indices: given (prefetched beside the previous step), farthest-point sampling of both clouds in
+                # one launch, or the reference's arange(npoint) prefix (then the kernel needs no index at all)
+                if sample_idxs is not None:
+                    si_a, si_b = sample_idxs
+                elif self.use_fps:
+                    si_a, si_b = pointnet2_utils.furthest_point_sample_pair(xyz_a, npoint_a, xyz_b, npoint_b)
+                else:
+                    si_a = si_b = None
+                got = fused.sa_pair_sampled(self.groupers[0], self.mlps[0], (xyz_a, features_a, npoint_a, si_a),
+                                            (xyz_b, features_b, npoint_b, si_b))
+                if got is not None:
+                    self.npoint = npoint_b
+                    if si_a is None:
+                        si_a = _prefix_idx(xyz_a.size(0), npoint_a, xyz_a.device)
+                        si_b = _prefix_idx(xyz_b.size(0), npoint_b, xyz_b.device)
+                    return (got[0], got[1], si_a), (got[2], got[3], si_b)
+                if si_a is not None and sample_idxs is None:
+                    sample_idxs = (si_a, si_b)          # (do not sample twice on the fallback route)
                 if sample_idxs is not None:
                     idx_a, idx_b = sample_idxs
                     new_a = pointnet2_utils.gather_xyz(xyz_a, idx_a)

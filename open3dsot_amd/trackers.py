@@ -62,6 +62,22 @@ def best_proposal(boxes):
     return out, idx
 
 
+def _seed_rows(a, b, sample_idxs, n):
+    """a[:, idx] (, b[:, idx]) with idx = sample_idxs[:, :n]: the labels / BoxCloud rows of the points the backbone kept
+    (models/bat.py:96-97,132-133, models/p2b.py:62-63: `.long()`, expand and one torch.gather per tensor).  On the GPU one
+    launch for both tensors, straight from the int32 sampling indices (ext.gather_rows2); labels carry no gradient."""
+    if a.is_cuda and a.dtype == torch.float32 and sample_idxs.dtype == torch.int32 and not a.requires_grad \
+            and (b is None or (b.dtype == torch.float32 and not b.requires_grad)):
+        from . import ext
+        a3 = a.contiguous().unsqueeze(-1) if a.dim() == 2 else a.contiguous()
+        ra, rb = ext.gather_rows2(a3, b.contiguous() if b is not None else None, sample_idxs, n)
+        return (ra.squeeze(-1) if a.dim() == 2 else ra), rb
+    idx = sample_idxs[:, :n].long()
+    ra = a.gather(1, idx if a.dim() == 2 else idx[:, :, None].expand(-1, -1, a.shape[2]))
+    rb = b.gather(1, idx[:, :, None].expand(-1, -1, b.shape[2])) if b is not None else None
+    return ra, rb
+
+
 class MatchingBaseModel(nn.Module):
     def __init__(self, config=None, **kwargs):
         super().__init__()
@@ -164,7 +180,7 @@ class P2B(MatchingBaseModel):
         end_points = self(batch)
         n_seed = end_points["estimation_cla"].shape[1]
         data = dict(batch)
-        data["seg_label"] = batch["seg_label"].gather(1, end_points["sample_idxs"][:, :n_seed].long())
+        data["seg_label"] = _seed_rows(batch["seg_label"], None, end_points["sample_idxs"], n_seed)[0]
         if end_points["estimation_cla"].is_cuda and fused_loss.enabled():
             return fused_loss.track_loss(self.config, data, end_points, with_bc=False)     # one launch (csrc/loss.hip)
         ld = self.compute_loss(data, end_points)
@@ -227,8 +243,7 @@ class BAT(MatchingBaseModel):
             # its two consumers on the device (the kNN kernel and the fused loss) both want it point-major and dense: one
             # copy here instead of one in each
             pred_search_bc = pred_search_bc.contiguous()
-        t_idx = sample_idxs_t[:, :M // 8, None].long().expand(-1, -1, self.config.bc_channel)
-        template_bc = template_bc.gather(dim=1, index=t_idx)                               # (B,M/8,9)
+        template_bc = _seed_rows(template_bc, None, sample_idxs_t, M // 8)[0]               # (B,M/8,9)
         fusion = self.xcorr(template_feature, search_feature, template_xyz, search_xyz, template_bc,
                             pred_search_bc)
         boxes, cla, vote_xyz, centers = self.rpn(search_xyz, fusion)
@@ -240,11 +255,9 @@ class BAT(MatchingBaseModel):
         """forward + label re-indexing + weighted loss (bat.py:114-143); returns (loss, loss_dict)."""
         end_points = self(batch)
         n_seed = end_points["estimation_cla"].shape[1]
-        sidx = end_points["sample_idxs"][:, :n_seed].long()
         data = dict(batch)
-        data["seg_label"] = batch["seg_label"].gather(1, sidx)
-        data["points2cc_dist_s"] = batch["points2cc_dist_s"].gather(
-            1, sidx[:, :, None].expand(-1, -1, self.config.bc_channel))
+        data["seg_label"], data["points2cc_dist_s"] = _seed_rows(batch["seg_label"], batch["points2cc_dist_s"],
+                                                                 end_points["sample_idxs"], n_seed)
         if end_points["estimation_cla"].is_cuda and fused_loss.enabled():
             return fused_loss.track_loss(self.config, data, end_points, with_bc=True)      # one launch (csrc/loss.hip)
         ld = self.compute_loss(data, end_points)

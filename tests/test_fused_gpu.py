@@ -537,6 +537,41 @@ def test_paired_backbone_matches_sequential():
         assert rel(b1.float(), b2.float()) < 1e-5, n1
 
 
+@pytest.mark.parametrize("use_fps", [True, False])
+@pytest.mark.parametrize("train", [True, False])
+def test_sample_query_launch_matches_gather_ball_query_cat(use_fps, train):
+    """fused.sa_pair_sampled (round 5: sampling gather + both ball queries + the centres' layout in ONE launch,
+    csrc/index_ops.hip::sample_query_kernel) against the route it replaces (gather_xyz / prefix copy, two ball queries, a
+    concatenation): sampling indices, centres and every pooled feature of the paired backbone BIT-identical (the same
+    kernels downstream on the same indices), running statistics and parameter gradients equal to run-to-run rounding"""
+    import copy
+    from open3dsot_amd import backbone, fused, synth
+    torch.manual_seed(0)
+    net = backbone.Pointnet_Backbone(use_fps=use_fps, normalize_xyz=False).cuda().train(train)
+    ref = copy.deepcopy(net)
+    b = synth.to_torch(synth.make_batch(77, 6, 512, 1024), torch.device("cuda"))
+    t, s = b["template_points"], b["search_points"]
+    with torch.set_grad_enabled(train):
+        ra, rb = net.forward_pair(t, [256, 128, 64], s, [512, 256, 128])
+        fused.set_sample_query(False)
+        try:
+            qa, qb = ref.forward_pair(t, [256, 128, 64], s, [512, 256, 128])
+        finally:
+            fused.set_sample_query(True)
+    for x, y in zip(ra + rb, qa + qb):
+        assert x.shape == y.shape and x.dtype == y.dtype
+        assert torch.equal(x, y), float((x.float() - y.float()).abs().max())
+    for (n1, b1), (_, b2) in zip(net.named_buffers(), ref.named_buffers()):
+        assert rel(b1.float(), b2.float()) < 1e-6, n1
+    if train:
+        gen = torch.Generator(device="cuda").manual_seed(5)
+        go = [torch.randn(x.shape, device="cuda", generator=gen) for x in (ra[1], rb[1])]
+        torch.autograd.backward([ra[1], rb[1]], go)
+        torch.autograd.backward([qa[1], qb[1]], go)
+        for (n1, p1), (_, p2) in zip(net.named_parameters(), ref.named_parameters()):
+            assert l2rel(p1.grad, p2.grad) < 1e-5, n1
+
+
 @pytest.mark.parametrize("kind", ["sa1", "sa2", "sa3", "rpn"])
 def test_reduce_gather_matches_atomic_reduce(kind):
     """o3d_group_reduce_gather (transposed index + LDS gather) against o3d_group_reduce_c (LDS atomics): same S / T,
@@ -587,6 +622,59 @@ def test_reduce_gather_matches_atomic_reduce_paired(kind, B, full):
         finally:
             fused.set_reduce_gather(was)
     for a, b in zip(*grads):      # two fp32 summation orders of the same terms: grows with the number of terms
+        assert l2rel(a, b) < (1e-5 if B <= 4 else 5e-5), l2rel(a, b)
+
+
+@pytest.mark.parametrize("kind", ["sa1", "sa2", "sa3", "rpn"])
+def test_pool_bwd_one_pass_matches_zero_fill_and_scatter(kind):
+    """o3d_pool_bwd_dense (round 5: the pooled layer's dense gradient written once, column by column, statistics rows per
+    512 columns) against o3d_pool_bwd_c (zero fill of the live columns + scatter, 8 statistics rows per segment): the same
+    dense gradient, so every parameter / input gradient agrees to the order of two fp32 sums of the statistics"""
+    import copy
+    from open3dsot_amd import fused
+    grouper, mlp, xyz, new_xyz, feats = make_case(kind)
+    grads = []
+    for dense in (False, True):
+        fused.set_pool_bwd_dense(dense)
+        try:
+            m = copy.deepcopy(mlp)
+            leaves = [t.clone().requires_grad_(True) if t is not None else None for t in (xyz, new_xyz, feats)]
+            out = fused.sa_group_mlp_pool(grouper, m, *leaves)
+            go = torch.randn(out.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(2))
+            out.backward(go)
+            grads.append([p.grad for p in m.parameters()] + [t.grad for t in leaves if t is not None])
+        finally:
+            fused.set_pool_bwd_dense(True)
+    for a, b in zip(*grads):
+        assert l2rel(a, b) < 1e-5, l2rel(a, b)
+
+
+@pytest.mark.parametrize("kind,B,full", [("sa1", 3, False), ("sa2", 3, False), ("sa3", 3, False), ("sa1", 48, True),
+                                         ("sa2", 48, True), ("sa3", 48, True)])
+def test_pool_bwd_one_pass_matches_zero_fill_and_scatter_paired(kind, B, full):
+    """the same comparison through the two-segment (template + search) call, also at BASELINE config 2's sizes (segment 1
+    at a non-zero `start1`, chunks whose last 256 columns are dead, padding columns of the dummy ball)"""
+    import copy
+    from open3dsot_amd import fused
+    grouper, mlp, xyz_s, new_s, feats_s = make_case(kind, B=B, full=full)
+    N, npoint = xyz_s.shape[1], new_s.shape[1]
+    xyz_t = (xyz_s[:, :N // 2, :] * 0.9 + 0.05).contiguous()
+    new_t = xyz_t[:, :npoint // 2, :].contiguous()
+    feats_t = torch.randn(feats_s.shape[0], feats_s.shape[1], N // 2, device="cuda") if feats_s is not None else None
+    grads = []
+    for dense in (False, True):
+        fused.set_pool_bwd_dense(dense)
+        try:
+            m = copy.deepcopy(mlp)
+            segs = [[t.clone().requires_grad_(True) if t is not None else None for t in sg]
+                    for sg in ((xyz_t, new_t, feats_t), (xyz_s, new_s, feats_s))]
+            outs = fused.sa_group_mlp_pool_pair(grouper, m, tuple(segs[0]), tuple(segs[1]))
+            gen = torch.Generator(device="cuda").manual_seed(4)
+            torch.autograd.backward(list(outs), [torch.randn(o.shape, device="cuda", generator=gen) for o in outs])
+            grads.append([p.grad for p in m.parameters()] + [t.grad for sg in segs for t in sg if t is not None])
+        finally:
+            fused.set_pool_bwd_dense(True)
+    for a, b in zip(*grads):
         assert l2rel(a, b) < (1e-5 if B <= 4 else 5e-5), l2rel(a, b)
 
 
