@@ -453,20 +453,6 @@ typedef struct {
 int o3d_pw_fwd_pair(const o3d_pw_fwd_args* a, const o3d_pw_fwd_args* b, void* stream);
 int o3d_pw_dgrad_pair(const o3d_pw_dgrad_args* a, const o3d_pw_dgrad_args* b, void* stream);
 
-/* GEMM + BatchNorm finalize of a 1-D conv layer as ONE call (round 5): o3d_pw_fwd(g) then o3d_bn_finalize(f), resp.
- * o3d_pw_dgrad(g) then o3d_bn_bwd_finalize(f) -- ONE launch when the GEMM takes the split-K tile (every launch of the
- * trackers' heads: the last workgroup to finish a 32-row slab folds the slab's partial rows in row order, fp64, and writes the
- * layer's constants; csrc/mlp_direct.hip::splitk_finalize), else the two launches.  f.part / f.C / f.nparts / f.stat_c must
- * describe g's own partial rows.  counters: >= 128 device words that are zero before the first call (every launch leaves them
- * zero; calls that share them must be stream-ordered); fold: scratch of o3d_bn_finalize for the two-launch route or NULL.
- * Replaces Conv1d + BatchNorm1d of pytorch_utils.py:124-155 in the heads (models/head/rpn.py:16-39, models/bat.py:22-26). */
-int o3d_pw_fwd_fin(const o3d_pw_fwd_args* g, const o3d_bn_fin_args* f, unsigned* counters, float* fold, void* stream);
-int o3d_pw_dgrad_fin(const o3d_pw_dgrad_args* g, const o3d_bn_bwd_fin_args* f, unsigned* counters, float* fold, void* stream);
-int o3d_pw_fwd_fin_pair(const o3d_pw_fwd_args* ga, const o3d_bn_fin_args* fa, const o3d_pw_fwd_args* gb,
-                        const o3d_bn_fin_args* fb, unsigned* counters, void* stream);
-int o3d_pw_dgrad_fin_pair(const o3d_pw_dgrad_args* ga, const o3d_bn_bwd_fin_args* fa, const o3d_pw_dgrad_args* gb,
-                          const o3d_bn_bwd_fin_args* fb, unsigned* counters, void* stream);
-
 /* Several independent weight gradients of the flat (C, P) layout in one launch (+ one reduction launch): the 1-D conv
  * stacks of the heads (models/head/rpn.py:16-39, models/head/xcorr.py:14-17, models/bat.py:22-26).  Job i computes what
  * o3d_mlp_conv_wgrad2(dN, NULL, 4, Y, A1, A2, A3, X, in_scale, in_shift, 1, Cin, Cout, P, scratch, dW, stream) computes

@@ -29,38 +29,3 @@ __device__ __forceinline__ void reduce_scatter32(float (&x)[32], int l31) {
         }
     }
 }
-
-// ---- BatchNorm finalize arithmetic of one channel, shared by the finalize kernels (mlp.hip) and the split-K tile's in-kernel
-// finalize (mlp_direct.hip): from the fp64 sums {sum y, sum (y-c)^2} resp. {sum g, sum g (y - mean)}.
-// No fp64 division / square root: v_rsq_f32 + one fp64 Newton step (relative error ~1e-14), the reciprocal of the count once.
-struct BnFwdOut { float mean, invstd, scale, shift, run_mean, run_var; };
-__device__ __forceinline__ BnFwdOut bn_fwd_math(double s, double q, double count, double cs, float g, float bt, float eps,
-                                                float momentum, float run_mean, float run_var) {
-    const double ic = 1.0 / count;
-    const double mean = s * ic;
-    double var = q * ic - (mean - cs) * (mean - cs);
-    if (var < 0.0) var = 0.0;
-    const double v = var + (double)eps;
-    double rd = (double)rsqrtf((float)v);
-    rd = rd * (1.5 - 0.5 * v * rd * rd);
-    BnFwdOut o;
-    o.mean = (float)mean;
-    o.invstd = (float)rd;
-    o.scale = g * o.invstd;
-    o.shift = bt - o.mean * o.scale;
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    o.run_mean = (1.f - momentum) * run_mean + momentum * o.mean;
-    o.run_var = (1.f - momentum) * run_var + momentum * (float)unbiased;
-    return o;
-}
-struct BnBwdOut { float dgamma, dbeta, a1, a2, a3; };
-__device__ __forceinline__ BnBwdOut bn_bwd_math(double s, double q, double count, double g, double is, double mu) {
-    const double a1 = g * is;
-    const double ic = 1.0 / count;
-    const double a2 = -a1 * is * is * q * ic;
-    const double a3 = -a1 * s * ic - a2 * mu;
-    BnBwdOut o;
-    o.dbeta = (float)s; o.dgamma = (float)(q * is);
-    o.a1 = (float)a1; o.a2 = (float)a2; o.a3 = (float)a3;
-    return o;
-}

@@ -85,16 +85,6 @@ struct DirectArgs {
     // CONSTANT input channel block (the pooled feature SegPointNet broadcasts to every point, models/backbone/
     // pointnet.py:188-190) contributes W_b . pooled[b] to every column of cloud b: a bias, not 1024 GEMM rows
     const float* cbias; int cb_N, cb_B;
-    // split-K tile only: the BatchNorm finalize of this launch's statistics folded into the launch (round 5, see splitk_finalize)
-    struct FusedFin {
-        int kind;                 // 0: none; 1: forward statistics; 2: backward statistics
-        unsigned* cnt;            // one word per 32-row slab: zero between launches (the last workgroup of a slab resets it)
-        double count;             // positions normalised over
-        const float* gamma; const float* beta; float* running_mean; float* running_var; float momentum, eps;   // kind 1
-        float* mean; float* invstd; float* scale; float* shift;                                                  // kind 1 outputs
-        const float* bmean; const float* binvstd;                                                                 // kind 2: the layer's
-        float* dgamma; float* dbeta; float* A1; float* A2; float* A3;                                             // forward statistics; outputs
-    } fin;
 };
 
 template <int MODE, int NT>
@@ -391,78 +381,6 @@ __device__ __forceinline__ float reduce_scatter8(float (&x)[8], int l31) {
     return r;
 }
 
-// The BatchNorm finalize of a split-K launch INSIDE the launch (round 5).  The heads' conv stacks and the small set-abstraction
-// levels are chains of ~15 us launches each followed by a 7-8 us finalize launch whose only work is a dependent read of <= 200
-// partial rows.  Here the workgroups of a 32-row slab count themselves on a device word; the LAST one to arrive folds the
-// slab's partial rows -- in row order, in fp64: deterministic -- and writes the layer's constants for those 32 channels.
-// Nothing but the finalize arithmetic runs after the count, and only in 1 of ~100 workgroups.
-// Visibility without a device-scope release fence (which on a multi-XCD part writes back the whole L2: the "seam" of
-// MI355X_MICROARCH.md, 5-13 us): the partial rows are written with agent-scope (written-through, sc1) stores, the wave waits
-// for them (vmcnt) before the workgroup's relaxed agent-scope increment, and the last workgroup reads the rows with
-// agent-scope loads that bypass the non-coherent L2.  Everything else the launch writes is consumed after the kernel boundary.
-template <int EPI>
-__device__ __forceinline__ void splitk_finalize(const DirectArgs& a, const int by, const int m0, float* __restrict__ red) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partial-row stores have been performed
-    __syncthreads();                                      // ... all four waves'; and `red` is free
-    int* flag = reinterpret_cast<int*>(red);
-    const unsigned expected = a.meta ? (unsigned)(a.meta[0] / SK_COLS) : (unsigned)(a.B * (a.P / SK_COLS));
-    if (threadIdx.x == 0) {
-        const unsigned old = __hip_atomic_fetch_add(a.fin.cnt + by, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const int last = old + 1 == expected;
-        if (last) __hip_atomic_store(a.fin.cnt + by, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch / replay
-        *flag = last;
-    }
-    __syncthreads();
-    const bool last = *flag != 0;
-    __syncthreads();
-    if (!last) return;
-    // thread = (4 consecutive values of the slab's 2 x 32 = 64, as one 16-byte load) x a sixteenth of the rows
-    // (agent-scope loads spelled as inline asm: the compiler puts a full s_waitcnt behind every __hip_atomic_load, i.e. one
-    // exposed memory round trip per row; here eight rows are in flight per wait, rows clamped instead of predicated)
-    double* dsh = reinterpret_cast<double*>(red);         // [16][64]
-    const int v4 = threadIdx.x & 15, sl = threadIdx.x >> 4;
-    const float* src = a.part + (long)(v4 >> 3) * a.M + m0 + 4 * (v4 & 7);
-    double acc[4] = {0.0, 0.0, 0.0, 0.0};
-    const long rstep = 2L * a.M;
-    for (unsigned r0 = sl; r0 < expected; r0 += 128) {
-        typedef float f32x4 __attribute__((ext_vector_type(4)));
-        f32x4 x[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const unsigned r = r0 + 16 * i;
-            const float* p = src + (long)(r < expected ? r : expected - 1) * rstep;
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(x[i]) : "v"(p) : "memory");
-        }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]), "+v"(x[3]), "+v"(x[4]), "+v"(x[5]), "+v"(x[6]), "+v"(x[7])
-                     :: "memory");
-#pragma unroll
-        for (int i = 0; i < 8; ++i)
-            if (r0 + 16 * i < expected) {
-                acc[0] += (double)x[i].x; acc[1] += (double)x[i].y; acc[2] += (double)x[i].z; acc[3] += (double)x[i].w;
-            }
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) dsh[sl * 64 + 4 * v4 + k] = acc[k];
-    __syncthreads();
-    if (threadIdx.x >= 32) return;
-    const int t = threadIdx.x, c = m0 + t;
-    double s = 0.0, q = 0.0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { s += dsh[k * 64 + t]; q += dsh[k * 64 + 32 + t]; }
-    const DirectArgs::FusedFin& f = a.fin;
-    if constexpr (EPI == 0) {
-        const double cs = a.stat_c ? (double)a.stat_c[c] : 0.0;
-        const bool run = f.running_mean && f.momentum >= 0.f;
-        const BnFwdOut o = bn_fwd_math(s, q, f.count, cs, f.gamma ? f.gamma[c] : 1.f, f.beta ? f.beta[c] : 0.f, f.eps, f.momentum,
-                                       run ? f.running_mean[c] : 0.f, run ? f.running_var[c] : 0.f);
-        f.mean[c] = o.mean; f.invstd[c] = o.invstd; f.scale[c] = o.scale; f.shift[c] = o.shift;
-        if (run) { f.running_mean[c] = o.run_mean; f.running_var[c] = o.run_var; }
-    } else if constexpr (EPI == 1) {
-        const BnBwdOut o = bn_bwd_math(s, q, f.count, f.gamma ? (double)f.gamma[c] : 1.0, (double)f.binvstd[c], (double)f.bmean[c]);
-        f.dgamma[c] = o.dgamma; f.dbeta[c] = o.dbeta; f.A1[c] = o.a1; f.A2[c] = o.a2; f.A3[c] = o.a3;
-    }
-}
-
 template <int MODE, int EPI>
 __device__ __forceinline__ void splitk_body(DirectArgs& a, const int bx, const int by, float* __restrict__ red) {
     static_assert(MODE <= B_DY && EPI <= 2, "split-K tile: plain / transformed / BatchNorm-backward operands only");
@@ -592,14 +510,7 @@ __device__ __forceinline__ void splitk_body(DirectArgs& a, const int bx, const i
     }
     if (stats) {       // lane l31 < 8 of half h: statistic l31 >> 2 of row mrow + (l31 & 3)
         const float r = reduce_scatter8(x8, l31);
-        if (l31 < 8) {
-            float* dst = a.part + (long)tile * 2 * a.M + (long)(l31 >> 2) * a.M + mrow + (l31 & 3);
-            if (a.fin.kind) __hip_atomic_store(dst, r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // written through: see splitk_finalize
-            else *dst = r;
-        }
-        if constexpr (EPI <= 1) {
-            if (a.fin.kind) splitk_finalize<EPI>(a, by, m0, red);
-        }
+        if (l31 < 8) a.part[(long)tile * 2 * a.M + (long)(l31 >> 2) * a.M + mrow + (l31 & 3)] = r;
     }
 }
 
@@ -869,104 +780,6 @@ extern "C" int o3d_pw_dgrad_pair(const o3d_pw_dgrad_args* pa, const o3d_pw_dgrad
     }
     if (x.Yprev) return x.Y ? launch_pair<B_DY, 1>(a, b, ca, st) : launch_pair<B_PLAIN, 1>(a, b, ca, st);
     return x.Y ? launch_pair<B_DY, 2>(a, b, ca, st) : launch_pair<B_PLAIN, 2>(a, b, ca, st);
-}
-
-// ---- GEMM + BatchNorm finalize as ONE call (round 5) ----------------------------------------------------------------------
-// o3d_pw_fwd(g) followed by o3d_bn_finalize(f) resp. o3d_pw_dgrad(g) followed by o3d_bn_bwd_finalize(f): one LAUNCH when the
-// GEMM takes the split-K tile (the finalize then runs in the last workgroup of every 32-row slab, splitk_finalize), else the
-// two launches.  counters: >= 128 device words, zero before the first call (each launch leaves them zero).
-namespace {
-static bool fin_ok(const DirectArgs& a, int tile, const unsigned* counters) {
-    return counters && a.part && a.start1 == 0 && splitk_ok(a, tile) && a.M / SK_ROWS <= 64;
-}
-static void fin_fwd(DirectArgs& a, const o3d_bn_fin_args& f, unsigned* cnt) {
-    a.fin.kind = 1; a.fin.cnt = cnt; a.fin.count = f.count; a.fin.gamma = f.gamma; a.fin.beta = f.beta;
-    a.fin.running_mean = f.running_mean; a.fin.running_var = f.running_var; a.fin.momentum = f.momentum; a.fin.eps = f.eps;
-    a.fin.mean = f.mean; a.fin.invstd = f.invstd; a.fin.scale = f.scale; a.fin.shift = f.shift;
-}
-static void fin_bwd(DirectArgs& a, const o3d_bn_bwd_fin_args& f, unsigned* cnt) {
-    a.fin.kind = 2; a.fin.cnt = cnt; a.fin.count = f.count; a.fin.gamma = f.gamma; a.fin.bmean = f.mean; a.fin.binvstd = f.invstd;
-    a.fin.dgamma = f.dgamma; a.fin.dbeta = f.dbeta; a.fin.A1 = f.A1; a.fin.A2 = f.A2; a.fin.A3 = f.A3;
-}
-static bool fwd_fin_args_ok(const o3d_pw_fwd_args& g, const o3d_bn_fin_args& f) {
-    return pw_fwd_args_ok(g) && g.part && f.part == g.part && f.C == g.Cout && f.stat_c == g.stat_c && f.mean && f.invstd &&
-           f.scale && f.shift && f.nparts == (int)(g.P / pw_tile(g.P, g.Cout));
-}
-static bool dgrad_fin_args_ok(const o3d_pw_dgrad_args& g, const o3d_bn_bwd_fin_args& f) {
-    return pw_dgrad_args_ok(g) && g.Yprev && g.part && f.part == g.part && f.C == g.Cin && f.mean && f.invstd && f.dgamma &&
-           f.dbeta && f.A1 && f.A2 && f.A3 && f.nparts == (int)(g.P / pw_tile(g.P, g.Cin));
-}
-}  // namespace
-
-extern "C" int o3d_pw_fwd_fin(const o3d_pw_fwd_args* pg, const o3d_bn_fin_args* pf, unsigned* counters, float* fold,
-                              void* stream) {
-    if (!pg || !pf || !fwd_fin_args_ok(*pg, *pf)) return O3D_EINVAL;
-    const o3d_pw_fwd_args& g = *pg;
-    const int tile = pw_tile(g.P, g.Cout);
-    if (tile == 128 && g.P % 128 != 0) return O3D_EINVAL;
-    DirectArgs a = pw_fwd_direct(g);
-    if (fin_ok(a, tile, counters)) {
-        fin_fwd(a, *pf, counters);
-        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-        return g.in_scale ? launch_splitk<B_XFORM, 0>(a, st) : launch_splitk<B_PLAIN, 0>(a, st);
-    }
-    const int rc = o3d_pw_fwd(g.X, g.W, g.in_scale, g.in_shift, g.bias, g.resid, g.Cin, g.Cout, g.P, g.Y, g.part, g.stat_c, stream);
-    if (rc != O3D_OK) return rc;
-    return o3d_bn_finalize(pf->part, pf->nparts, pf->C, pf->count, pf->stat_c, pf->gamma, pf->beta, pf->running_mean,
-                           pf->running_var, pf->momentum, pf->eps, pf->mean, pf->invstd, pf->scale, pf->shift, fold, stream);
-}
-
-extern "C" int o3d_pw_dgrad_fin(const o3d_pw_dgrad_args* pg, const o3d_bn_bwd_fin_args* pf, unsigned* counters, float* fold,
-                                void* stream) {
-    if (!pg || !pf || !dgrad_fin_args_ok(*pg, *pf)) return O3D_EINVAL;
-    const o3d_pw_dgrad_args& g = *pg;
-    const int tile = pw_tile(g.P, g.Cin);
-    if (tile == 128 && g.P % 128 != 0) return O3D_EINVAL;
-    DirectArgs a = pw_dgrad_direct(g);
-    if (fin_ok(a, tile, counters)) {
-        fin_bwd(a, *pf, counters);
-        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-        return g.Y ? launch_splitk<B_DY, 1>(a, st) : launch_splitk<B_PLAIN, 1>(a, st);
-    }
-    const int rc = o3d_pw_dgrad(g.dN, g.Y, g.A1, g.A2, g.A3, g.Wt, g.Cin, g.Cout, g.P, g.Yprev, g.scale_p, g.shift_p, g.mean_p,
-                                g.resid, g.dNprev, g.part, stream);
-    if (rc != O3D_OK) return rc;
-    return o3d_bn_bwd_finalize(pf->part, pf->nparts, pf->C, pf->count, pf->gamma, pf->mean, pf->invstd, pf->dgamma, pf->dbeta,
-                               pf->A1, pf->A2, pf->A3, fold, stream);
-}
-
-// the same for two independent problems over the same columns (o3d_pw_fwd_pair + o3d_bn_finalize_pair): one launch when both
-// take the split-K tile with the same operand mode, else the pair GEMM launch followed by the pair finalize launch
-extern "C" int o3d_pw_fwd_fin_pair(const o3d_pw_fwd_args* ga, const o3d_bn_fin_args* fa, const o3d_pw_fwd_args* gb,
-                                   const o3d_bn_fin_args* fb, unsigned* counters, void* stream) {
-    if (!ga || !fa || !gb || !fb || !fwd_fin_args_ok(*ga, *fa) || !fwd_fin_args_ok(*gb, *fb)) return O3D_EINVAL;
-    const int ta = pw_tile(ga->P, ga->Cout), tb = pw_tile(gb->P, gb->Cout);
-    DirectArgs a = pw_fwd_direct(*ga), b = pw_fwd_direct(*gb);
-    if (ga->P == gb->P && fin_ok(a, ta, counters) && fin_ok(b, tb, counters) && (ga->in_scale == nullptr) == (gb->in_scale == nullptr)) {
-        fin_fwd(a, *fa, counters);
-        fin_fwd(b, *fb, counters + 64);
-        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-        return ga->in_scale ? launch_pair<B_XFORM, 0>(a, b, 4, st) : launch_pair<B_PLAIN, 0>(a, b, 4, st);
-    }
-    const int rc = o3d_pw_fwd_pair(ga, gb, stream);
-    if (rc != O3D_OK) return rc;
-    return o3d_bn_finalize_pair(fa, fb, stream);
-}
-
-extern "C" int o3d_pw_dgrad_fin_pair(const o3d_pw_dgrad_args* ga, const o3d_bn_bwd_fin_args* fa, const o3d_pw_dgrad_args* gb,
-                                     const o3d_bn_bwd_fin_args* fb, unsigned* counters, void* stream) {
-    if (!ga || !fa || !gb || !fb || !dgrad_fin_args_ok(*ga, *fa) || !dgrad_fin_args_ok(*gb, *fb)) return O3D_EINVAL;
-    const int ta = pw_tile(ga->P, ga->Cin), tb = pw_tile(gb->P, gb->Cin);
-    DirectArgs a = pw_dgrad_direct(*ga), b = pw_dgrad_direct(*gb);
-    if (ga->P == gb->P && fin_ok(a, ta, counters) && fin_ok(b, tb, counters) && (ga->Y == nullptr) == (gb->Y == nullptr)) {
-        fin_bwd(a, *fa, counters);
-        fin_bwd(b, *fb, counters + 64);
-        hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-        return ga->Y ? launch_pair<B_DY, 1>(a, b, 4, st) : launch_pair<B_PLAIN, 1>(a, b, 4, st);
-    }
-    const int rc = o3d_pw_dgrad_pair(ga, gb, stream);
-    if (rc != O3D_OK) return rc;
-    return o3d_bn_bwd_finalize_pair(fa, fb, stream);
 }
 
 // Layer 0 of a per-point stack whose input is [X (Cin rows) ; a per-cloud constant block]: Y (Cout, P) = W_a . X +

@@ -357,35 +357,6 @@ class _BnBwdFinArgs(ctypes.Structure):    # o3d_bn_bwd_fin_args
 
 for _n in ("o3d_pw_fwd_pair", "o3d_pw_dgrad_pair", "o3d_bn_finalize_pair", "o3d_bn_bwd_finalize_pair"):
     capi.register(_n, [_vp, _vp, _vp])
-capi.register("o3d_pw_fwd_fin", [_vp, _vp, _vp, _vp, _vp])
-capi.register("o3d_pw_dgrad_fin", [_vp, _vp, _vp, _vp, _vp])
-capi.register("o3d_pw_fwd_fin_pair", [_vp, _vp, _vp, _vp, _vp, _vp])
-capi.register("o3d_pw_dgrad_fin_pair", [_vp, _vp, _vp, _vp, _vp, _vp])
-# GEMM + BatchNorm finalize as one entry (round 5: one LAUNCH on the split-K tile, csrc/mlp_direct.hip::splitk_finalize).  Its
-# argument list is [GEMM arguments (without the stream), finalize arguments (without fold / stream), fold, stream];
-# entry -> (pair entry, GEMM struct, finalize struct)
-_FIN = {"o3d_pw_fwd_fin": ("o3d_pw_fwd_fin_pair", _PwFwdArgs, _BnFinArgs),
-        "o3d_pw_dgrad_fin": ("o3d_pw_dgrad_fin_pair", _PwDgradArgs, _BnBwdFinArgs)}
-_FIN_ON = {"on": True}        # TEST hook: False = the GEMM and the finalize as two launches (what the fused launch is tested against)
-_FIN_CNT = {}
-
-
-def set_fused_finalize(enabled):
-    _FIN_ON["on"] = bool(enabled)
-
-
-def fin_counters(dev):
-    """the device words the workgroups of a fused GEMM + finalize launch count themselves on: 128 per (device, stream), zero
-    between launches (the kernel resets what it used).  Created outside a graph capture: the eager warm-up steps do."""
-    key = (dev.index if dev.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(dev).cuda_stream)
-    t = _FIN_CNT.get(key)
-    if t is None:
-        t = torch.zeros(128, device=dev, dtype=torch.int32)
-        if not torch.cuda.is_current_stream_capturing():
-            _FIN_CNT[key] = t
-    return t
-
-
 # single entry -> (pair entry, argument struct, trailing arguments of the single call that the struct does not carry)
 _PAIRABLE = {"o3d_pw_fwd": ("o3d_pw_fwd_pair", _PwFwdArgs, 1), "o3d_pw_dgrad": ("o3d_pw_dgrad_pair", _PwDgradArgs, 1),
              "o3d_bn_finalize": ("o3d_bn_finalize_pair", _BnFinArgs, 2),
@@ -407,30 +378,13 @@ def _drive(gens):
 
     def single(k):
         name, flops, entry, args, dims = pend[k]
-        if entry in _FIN:
-            _, gs, fs = _FIN[entry]
-            g, f = gs(*args[0]), fs(*args[1])
-            _call(name, flops, getattr(lib, entry), ctypes.addressof(g), ctypes.addressof(f), _fin_cnt_ptr(), args[2], args[3],
-                  dims=dims)
-        else:
-            _call(name, flops, getattr(lib, entry), *args, dims=dims)
+        _call(name, flops, getattr(lib, entry), *args, dims=dims)
         advance(k)
-
-    def _fin_cnt_ptr():
-        return fin_counters(torch.device("cuda", torch.cuda.current_device())).data_ptr()
     for k in range(n):
         advance(k)
     while not all(done):
         live = [k for k in range(n) if not done[k]]
-        if len(live) == 2 and pend[0][2] == pend[1][2] and pend[0][2] in _FIN and pend[0][3][-1] == pend[1][3][-1]:
-            pair_entry, gs, fs = _FIN[pend[0][2]]
-            ga, fa = gs(*pend[0][3][0]), fs(*pend[0][3][1])
-            gb, fb = gs(*pend[1][3][0]), fs(*pend[1][3][1])
-            _call(pend[0][0], pend[0][1] + pend[1][1], getattr(lib, pair_entry), ctypes.addressof(ga), ctypes.addressof(fa),
-                  ctypes.addressof(gb), ctypes.addressof(fb), _fin_cnt_ptr(), pend[0][3][-1])
-            advance(0)
-            advance(1)
-        elif len(live) == 2 and pend[0][2] == pend[1][2] and pend[0][2] in _PAIRABLE and pend[0][3][-1] == pend[1][3][-1]:
+        if len(live) == 2 and pend[0][2] == pend[1][2] and pend[0][2] in _PAIRABLE and pend[0][3][-1] == pend[1][3][-1]:
             pair_entry, struct, tail = _PAIRABLE[pend[0][2]]
             sa, sb = struct(*pend[0][3][:-tail]), struct(*pend[1][3][:-tail])
             _call(pend[0][0], pend[0][1] + pend[1][1], getattr(lib, pair_entry), ctypes.addressof(sa), ctypes.addressof(sb),
@@ -439,7 +393,7 @@ def _drive(gens):
             advance(1)
         elif len(live) == 2:
             # not aligned: issue the launch that has no partner (a pack, a row sum ...) or, failing that, the first one
-            k = next((k for k in live if pend[k][2] not in _PAIRABLE and pend[k][2] not in _FIN), live[0])
+            k = next((k for k in live if pend[k][2] not in _PAIRABLE), live[0])
             single(k)
         else:
             single(live[0])
@@ -484,17 +438,15 @@ def _chain_forward(cfg, tensors, need_bwd):
             if cfg.training:
                 nparts = P // lib.o3d_pw_tile(P, Mp)
                 part = torch.empty((nparts, 2, Mp), device=dev, dtype=f32)
-                gargs = [src.data_ptr(), Wp.data_ptr(), sc, sh, None, None, Kp, Mp, P, Y.data_ptr(), part.data_ptr(),
-                         bn.running_mean.data_ptr()]
-                fargs = [part.data_ptr(), nparts, Mp, float(P), bn.running_mean.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
-                         bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
-                         vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr()]
+                yield ("pw_conv_fwd", 2.0 * Kp * Mp * P, "o3d_pw_fwd", [src.data_ptr(), Wp.data_ptr(), sc, sh, None, None, Kp, Mp,
+                                                                       P, Y.data_ptr(), part.data_ptr(),
+                                                                       bn.running_mean.data_ptr(), st], (Kp, Mp))
                 fold = torch.empty((64, Mp), device=dev, dtype=f32)
-                if _FIN_ON["on"]:     # the layer's GEMM and its BatchNorm finalize as one entry (one launch on the split-K tile)
-                    yield ("pw_conv_fwd", 2.0 * Kp * Mp * P, "o3d_pw_fwd_fin", [gargs, fargs, fold.data_ptr(), st], (Kp, Mp))
-                else:
-                    yield ("pw_conv_fwd", 2.0 * Kp * Mp * P, "o3d_pw_fwd", gargs + [st], (Kp, Mp))
-                    yield ("bn_finalize", 0.0, "o3d_bn_finalize", fargs + [fold.data_ptr(), st], None)
+                yield ("bn_finalize", 0.0, "o3d_bn_finalize", [part.data_ptr(), nparts, Mp, float(P), bn.running_mean.data_ptr(),
+                                                               gamma.data_ptr(), beta.data_ptr(), bn.running_mean.data_ptr(),
+                                                               bn.running_var.data_ptr(), float(bn.momentum), float(bn.eps),
+                                                               vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(),
+                                                               vec[3].data_ptr(), fold.data_ptr(), st], None)
             else:
                 yield ("pw_conv_fwd", 2.0 * Kp * Mp * P, "o3d_pw_fwd", [src.data_ptr(), Wp.data_ptr(), sc, sh, None, None, Kp, Mp,
                                                                        P, Y.data_ptr(), None, None, st], (Kp, Mp))
@@ -571,21 +523,6 @@ def _chain_backward(state, dOut, needs):
         keep.extend((dN, Y, scratch, dW, coef, Xs, vecs[l - 1] if l > 0 else None))
         return dW.view(Wl.shape)
 
-    coef_pre = None      # the coefficients of the layer the loop below turns to next, when the data-gradient launch in front of
-                         # it has already finalized them (GEMM + finalize as one entry)
-
-    def dgrad_fin(gargs, flops, dims, lq, part_q, nparts_q):
-        """the data-gradient launch that writes `part_q` and the BatchNorm-backward finalize of layer lq as ONE entry
-        -> (coef (5, C): dgamma dbeta A1 A2 A3, launch tuple)"""
-        Cq_ = Ys[lq].shape[0]
-        vq = vecs[lq]
-        coef_q = torch.empty((5, Cq_), device=dev, dtype=f32)
-        fold_q = torch.empty((64, Cq_), device=dev, dtype=f32)
-        fargs = [part_q.data_ptr(), nparts_q, Cq_, float(P), gammas[lq].data_ptr(), vq[0].data_ptr(), vq[1].data_ptr(),
-                 coef_q[0].data_ptr(), coef_q[1].data_ptr(), coef_q[2].data_ptr(), coef_q[3].data_ptr(), coef_q[4].data_ptr()]
-        keep.append(fold_q)
-        return coef_q, ("pw_conv_dgrad", flops, "o3d_pw_dgrad_fin", [gargs, fargs, fold_q.data_ptr(), st], dims)
-
     # ---- last layer: plain conv (+ bias, + residual)
     l = L - 1
     if needs[cfg.nsrc + 4 * l + 1]:
@@ -601,13 +538,10 @@ def _chain_backward(state, dOut, needs):
         nparts = P // lib.o3d_pw_tile(P, Cp)
         part = torch.empty((nparts, 2, Cp), device=dev, dtype=f32)
         v = vecs[l - 1]
-        gargs = [G.data_ptr(), None, None, None, None, Wts[l].data_ptr(), Cp, Mp, P, Ys[l - 1].data_ptr(), v[2].data_ptr(),
-                 v[3].data_ptr(), v[0].data_ptr(), None, dN.data_ptr(), part.data_ptr()]
-        if _FIN_ON["on"]:
-            coef_pre, launch = dgrad_fin(gargs, 2.0 * Cp * Mp * P, (Cp, Mp, True), l - 1, part, nparts)
-            yield launch
-        else:
-            yield ("pw_conv_dgrad", 2.0 * Cp * Mp * P, "o3d_pw_dgrad", gargs + [st], (Cp, Mp, True))
+        yield ("pw_conv_dgrad", 2.0 * Cp * Mp * P, "o3d_pw_dgrad", [G.data_ptr(), None, None, None, None, Wts[l].data_ptr(), Cp,
+                                                                   Mp, P, Ys[l - 1].data_ptr(), v[2].data_ptr(), v[3].data_ptr(),
+                                                                   v[0].data_ptr(), None, dN.data_ptr(), part.data_ptr(), st],
+               (Cp, Mp, True))
     elif want_x:
         dX0 = torch.empty((K0p, P), device=dev, dtype=f32)
         yield ("pw_conv_dgrad", 2.0 * K0p * Mp * P, "o3d_pw_dgrad", [G.data_ptr(), None, None, None, None, Wts[0].data_ptr(), K0p,
@@ -618,15 +552,12 @@ def _chain_backward(state, dOut, needs):
     for l in range(L - 2, -1, -1):
         Cp = Ys[l].shape[0]
         v = vecs[l]
-        if coef_pre is not None:       # finalized by the launch that wrote `part`
-            coef, coef_pre = coef_pre, None
-        else:
-            coef = torch.empty((5, Cp), device=dev, dtype=f32)          # dgamma dbeta A1 A2 A3
-            fold = torch.empty((64, Cp), device=dev, dtype=f32)
-            yield ("bn_bwd_finalize", 0.0, "o3d_bn_bwd_finalize", [part.data_ptr(), nparts, Cp, float(P), gammas[l].data_ptr(),
-                                                                   v[0].data_ptr(), v[1].data_ptr(), coef[0].data_ptr(),
-                                                                   coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(),
-                                                                   coef[4].data_ptr(), fold.data_ptr(), st], None)
+        coef = torch.empty((5, Cp), device=dev, dtype=f32)          # dgamma dbeta A1 A2 A3
+        fold = torch.empty((64, Cp), device=dev, dtype=f32)
+        yield ("bn_bwd_finalize", 0.0, "o3d_bn_bwd_finalize", [part.data_ptr(), nparts, Cp, float(P), gammas[l].data_ptr(),
+                                                               v[0].data_ptr(), v[1].data_ptr(), coef[0].data_ptr(),
+                                                               coef[1].data_ptr(), coef[2].data_ptr(), coef[3].data_ptr(),
+                                                               coef[4].data_ptr(), fold.data_ptr(), st], None)
         if not cfg.training:
             coef[3].zero_()
             coef[4].zero_()
@@ -639,13 +570,10 @@ def _chain_backward(state, dOut, needs):
             nparts_next = P // lib.o3d_pw_tile(P, Cq)
             part_next = torch.empty((nparts_next, 2, Cq), device=dev, dtype=f32)
             vp = vecs[l - 1]
-            gargs = [dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2], Wts[l].data_ptr(), Cq, Cp, P, Ys[l - 1].data_ptr(),
-                     vp[2].data_ptr(), vp[3].data_ptr(), vp[0].data_ptr(), None, dNp.data_ptr(), part_next.data_ptr()]
-            if _FIN_ON["on"]:
-                coef_pre, launch = dgrad_fin(gargs, 2.0 * Cq * Cp * P, (Cq, Cp), l - 1, part_next, nparts_next)
-                yield launch
-            else:
-                yield ("pw_conv_dgrad", 2.0 * Cq * Cp * P, "o3d_pw_dgrad", gargs + [st], (Cq, Cp))
+            yield ("pw_conv_dgrad", 2.0 * Cq * Cp * P, "o3d_pw_dgrad", [dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
+                                                                       Wts[l].data_ptr(), Cq, Cp, P, Ys[l - 1].data_ptr(),
+                                                                       vp[2].data_ptr(), vp[3].data_ptr(), vp[0].data_ptr(), None,
+                                                                       dNp.data_ptr(), part_next.data_ptr(), st], (Cq, Cp))
             keep.append(dN)
             dN, part, nparts = dNp, part_next, nparts_next
         elif want_x:

@@ -307,52 +307,6 @@ def test_chain_pair_equals_two_single_chains(train, B, N):
     assert f3.grad is not None and torch.isfinite(f3.grad).all()
 
 
-@pytest.mark.parametrize("pair", [False, True])
-@pytest.mark.parametrize("B,N", [(4, 64), (48, 128), (48, 64)])
-def test_finalize_inside_the_gemm_launch_equals_the_two_launches(pair, B, N):
-    """Round 5: a hidden layer's GEMM and its BatchNorm finalize as ONE launch (o3d_pw_fwd_fin / o3d_pw_dgrad_fin: the last
-    workgroup of a 32-row slab of the split-K tile folds the slab's partial rows and writes the layer's constants) against
-    the GEMM launch + finalize launch it replaces: the same partial rows folded in another fixed order in fp64 -> outputs,
-    gradients and running statistics equal to fp32 rounding; and DETERMINISTIC -- thirty repetitions are bitwise identical
-    (a lost or early count, a stale partial row read through a non-coherent cache would show here)."""
-    from open3dsot_amd import fused_heads, nn_blocks
-    cla = build_seq(CASES["cla"][1], 256, 21).train()
-    vote = build_seq(CASES["vote"][1], 259, 22).train()
-    g = torch.Generator(device="cuda").manual_seed(9)
-    feat = torch.randn(B, 256, N, device="cuda", generator=g)
-    xyz = torch.randn(B, N, 3, device="cuda", generator=g)
-    ca, cb = torch.randn(B, 1, N, device="cuda", generator=g), torch.randn(B, 259, N, device="cuda", generator=g)
-
-    def run(fused_fin):
-        fused_heads.set_fused_finalize(fused_fin)
-        try:
-            m1, m2 = copy.deepcopy(cla), copy.deepcopy(vote)
-            f, x = feat.clone().requires_grad_(True), xyz.clone().requires_grad_(True)
-            if pair:
-                oa, ob = nn_blocks.seq_apply_pair((m1, [f], False), (m2, [x.transpose(1, 2), f], True))
-            else:
-                oa = nn_blocks.seq_apply(m1, [f])
-                ob = nn_blocks.seq_apply(m2, [x.transpose(1, 2), f], residual=True)
-            ((oa * ca).sum() + (ob * cb).sum()).backward()
-            torch.cuda.synchronize()
-            return [oa.detach(), ob.detach(), f.grad, x.grad] + [p.grad for m in (m1, m2) for p in m.parameters()] + \
-                [b.clone() for m in (m1, m2) for b in m.buffers() if b.dtype.is_floating_point]
-        finally:
-            fused_heads.set_fused_finalize(True)
-
-    two = run(False)
-    one = run(True)
-    for i, (a, b) in enumerate(zip(one, two)):
-        assert a.shape == b.shape and torch.isfinite(a).all(), i
-        assert l2rel(a, b) < 2e-6, (i, l2rel(a, b))
-    for rep in range(30):
-        again = run(True)
-        for i, (a, b) in enumerate(zip(again, one)):
-            assert torch.equal(a, b), (rep, i, float((a - b).abs().max()))
-    cnt = fused_heads.fin_counters(torch.device("cuda", torch.cuda.current_device()))
-    assert int(cnt.abs().sum()) == 0          # every launch left its counters at zero
-
-
 @pytest.mark.parametrize("B,Na,Nb", [(4, 64, 128), (48, 64, 128), (2, 32, 96)])
 def test_shared_conv_pair_equals_two_convs(B, Na, Nb):
     """conv_final on the template and on the search feature (models/bat.py:91-92) as ONE GEMM over the columns of both
