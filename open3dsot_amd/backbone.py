@@ -93,7 +93,7 @@ def _pointwise_chain(x, layers, pool=False):
         from . import fused_pointwise
         pairs = [(conv, bn) for conv, bn, _ in layers]
         if fused_pointwise.supported(x, pairs):
-            return fused_pointwise.chain(x.contiguous(), pairs, "gmax" if pool else "act")
+            return fused_pointwise.chain(x, pairs, "gmax" if pool else "act")       # (any strides: a stack's output is a (B,C,N) view of its flat (C, B*N) buffer and goes into the next stack as it is)
     h = _pointwise_chain_torch(x, layers)
     return h.amax(dim=2) if pool else h
 
@@ -105,7 +105,7 @@ def _cloud_chain(second, pooled, layers):
         from . import fused_pointwise
         pairs = [(conv, bn) for conv, bn, _ in layers]
         if fused_pointwise.cloud_supported(second, pooled, pairs):
-            return fused_pointwise.chain_cloud(second.contiguous(), pooled, pairs)
+            return fused_pointwise.chain_cloud(second, pooled, pairs)
     x = torch.cat([second, pooled.unsqueeze(-1).expand(-1, -1, second.shape[2])], dim=1)
     return _pointwise_chain(x, layers)
 
@@ -200,7 +200,7 @@ class SegPointNet(nn.Module):
             pooled = _pointwise_chain(second, first[2:], pool=True).unsqueeze(-1)      # (B,C1,1)
             x = _cloud_chain(second, pooled.squeeze(-1), [tuple(m) for m in self.seq_per_point2])
             if self.output_size > 0:
-                x = nn_blocks.pointwise_conv1d(self.fc, x.contiguous())
+                x = nn_blocks.pointwise_conv1d(self.fc, x)          # (x: a view of the stack's flat buffer, consumed in place)
         else:
             second = None
             for i, m in enumerate(self.seq_per_point):

@@ -65,7 +65,10 @@ class FusedPointwiseChain(torch.autograd.Function):
         P = B * N
         dev, f32 = x.device, torch.float32
         st = _stream()
-        X0 = x.detach().permute(1, 0, 2).reshape(Cin0, P).contiguous()
+        # flat (Cin, B*N) operand: a (B,C,N) view of another stack's flat buffer (the usual case between M2-Track's stacks) is
+        # that buffer, no copy -- round 4 made it (B,C,N)-contiguous first and flat again here: two 25 MB copies per hand-over
+        xp = x.detach().permute(1, 0, 2)
+        X0 = (xp if xp.is_contiguous() else xp.contiguous()).view(Cin0, P)
         ntiles = P // TILE
         Ys, means, invstds, scales, shifts = [], [], [], [], []
         bias_fix = {}
