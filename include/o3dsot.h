@@ -400,6 +400,19 @@ int o3d_pack_rows(const o3d_rows_src* srcs, int nsrc, int B, int N, int rows, fl
  * models/bat.py:91-92 */
 int o3d_pack_rows_ld(const o3d_rows_src* srcs, int nsrc, int B, int N, int rows, float* X, long ld, void* stream);
 
+/* The element-wise glue of the vote head, models/head/rpn.py:47-56 (round 5; strides in floats, sources (B, C, N) views):
+ * score (B,N) = sigmoid(cla), vote_xyz (B,N,3) = vote[:, :3]^T, vote_feature (B,1+f,N) = cat(score, vote[:, 3:]) in one
+ * launch (were sigmoid + a transposing copy + torch.cat); and its backward: dvote (3+f, B*N) = [d vote_xyz^T ; d vote_feature
+ * [:, 1:]] in the flat layout of the conv stacks, dcla (B,N) = d vote_feature[:, 0] * s (1 - s); a NULL gradient is zeros. */
+int o3d_rpn_votes_fwd(const float* cla, long cla_sb, long cla_sn, const float* vote, long v_sb, long v_sc, long v_sn, int B, int N,
+                      int f, float* score, float* vote_xyz, float* vote_feature, void* stream);
+int o3d_rpn_votes_bwd(const float* score, const float* dvf, long f_sb, long f_sc, long f_sn, const float* dvx, long x_sb, long x_sc,
+                      long x_sn, int B, int N, int f, float* dcla, float* dvote, void* stream);
+/* boxes (B,P,5) = transpose(cat(offsets[:, :3] + centers^T, offsets[:, 3:])) of models/head/rpn.py:62-66 (offsets (B,5,P) with
+ * any strides, centers (B,P,3) contiguous): one launch (were add + cat + a transposing copy; the backward is two views). */
+int o3d_box_assemble(const float* offsets, long o_sb, long o_sc, long o_sn, const float* centers, int B, int P, float* boxes,
+                     void* stream);
+
 /* Every padded / transposed weight copy of a step in one launch.  jobs: DEVICE array of njobs x 6 longs
  * {src ptr, dst ptr, rows, cols, dst_ld, transpose}: src (rows, cols) row-major -> dst[r*ld + c], or
  * dst[c*ld + r] when transpose != 0; the padding of dst is not written. */

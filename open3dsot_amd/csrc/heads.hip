@@ -233,3 +233,93 @@ extern "C" int o3d_best_proposal(const float* boxes, int B, int P, float* out, i
     hipLaunchKernelGGL(best_proposal_kernel, dim3(B), dim3(64), 0, o3d_stream(stream), boxes, P, out, out_idx);
     return o3d_launch_status();
 }
+
+// ---- the element-wise glue of the vote head (models/head/rpn.py:44-66) as three launches (round 5) ------------------------
+//   rpn_votes_fwd   sigmoid of the seed scores, the votes' coordinates point-major, cat(score, vote features) (:47-56):
+//                   were sigmoid + a transposing copy + a concatenation
+//   rpn_votes_bwd   their backward: the packed gradient of `vote` (rows: d xyz, d features) and d scores * s (1 - s):
+//                   were a concatenation + sigmoid_backward (+ the views autograd made contiguous)
+//   box_assemble    boxes (B,P,5) = [offsets[:, :3] + centres ; offsets[:, 3:]] transposed (:62-66): were add + cat + copy;
+//                   its backward is two VIEWS of the incoming gradient (no launch)
+namespace {
+struct Src3 { const float* p; long sb, sc, sn; };     // a (B, C, N) tensor with arbitrary strides (floats)
+
+__global__ __launch_bounds__(256) void rpn_votes_fwd_kernel(Src3 cla /* (B,1,N) */, Src3 vote /* (B,3+f,N) */, int B, int N, int f,
+                                                            float* __restrict__ score, float* __restrict__ vxyz,
+                                                            float* __restrict__ vfeat) {
+    const long col = (long)blockIdx.x * 256 + threadIdx.x;
+    if (col >= (long)B * N) return;
+    const int b = (int)(col / N), n = (int)(col - (long)b * N);
+    const int r = blockIdx.y;                 // 0: the score row; 1..f: feature rows; f + 1: the three coordinates
+    if (r == 0) {
+        const float x = cla.p[b * cla.sb + n * cla.sn];
+        const float s = 1.f / (1.f + expf(-x));
+        score[col] = s;
+        vfeat[((long)b * (1 + f)) * N + n] = s;
+    } else if (r <= f) {
+        vfeat[((long)b * (1 + f) + r) * N + n] = vote.p[b * vote.sb + (long)(2 + r) * vote.sc + n * vote.sn];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) vxyz[col * 3 + k] = vote.p[b * vote.sb + k * vote.sc + n * vote.sn];
+    }
+}
+
+__global__ __launch_bounds__(256) void rpn_votes_bwd_kernel(const float* __restrict__ score, Src3 dvf /* (B,1+f,N) | NULL */,
+                                                            Src3 dvx /* (B,3,N) view of d vote_xyz | NULL */, int B, int N, int f,
+                                                            float* __restrict__ dcla /* (B,N) */,
+                                                            float* __restrict__ dvote /* (3+f, B*N) */) {
+    const long col = (long)blockIdx.x * 256 + threadIdx.x;
+    const long P = (long)B * N;
+    if (col >= P) return;
+    const int b = (int)(col / N), n = (int)(col - (long)b * N);
+    const int r = blockIdx.y;                 // 0..2+f: rows of dvote; 3 + f: d scores
+    if (r < 3) {
+        dvote[(long)r * P + col] = dvx.p ? dvx.p[b * dvx.sb + r * dvx.sc + n * dvx.sn] : 0.f;
+    } else if (r < 3 + f) {
+        dvote[(long)r * P + col] = dvf.p ? dvf.p[b * dvf.sb + (long)(r - 2) * dvf.sc + n * dvf.sn] : 0.f;
+    } else {
+        const float s = score[col];
+        dcla[col] = dvf.p ? dvf.p[b * dvf.sb + n * dvf.sn] * s * (1.f - s) : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void box_assemble_kernel(Src3 off /* (B,5,P) */, const float* __restrict__ centers /* (B,P,3) */,
+                                                           long total, int P, float* __restrict__ boxes /* (B,P,5) */) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;       // (b, p, k), k fastest
+    if (t >= total) return;
+    const long bp = t / 5;
+    const int k = (int)(t - bp * 5);
+    const int b = (int)(bp / P), p = (int)(bp - (long)b * P);
+    float v = off.p[b * off.sb + k * off.sc + p * off.sn];
+    if (k < 3) v += centers[bp * 3 + k];
+    boxes[t] = v;
+}
+}  // namespace
+
+extern "C" int o3d_rpn_votes_fwd(const float* cla, long cla_sb, long cla_sn, const float* vote, long v_sb, long v_sc, long v_sn,
+                                 int B, int N, int f, float* score, float* vote_xyz, float* vote_feature, void* stream) {
+    if (!cla || !vote || !score || !vote_xyz || !vote_feature || B <= 0 || N <= 0 || f <= 0) return O3D_EINVAL;
+    const Src3 c = {cla, cla_sb, 0, cla_sn}, v = {vote, v_sb, v_sc, v_sn};
+    hipLaunchKernelGGL(rpn_votes_fwd_kernel, dim3((unsigned)o3d_cdiv((long)B * N, 256), f + 2), dim3(256), 0, o3d_stream(stream),
+                       c, v, B, N, f, score, vote_xyz, vote_feature);
+    return o3d_launch_status();
+}
+
+extern "C" int o3d_rpn_votes_bwd(const float* score, const float* dvf, long f_sb, long f_sc, long f_sn, const float* dvx,
+                                 long x_sb, long x_sc, long x_sn, int B, int N, int f, float* dcla, float* dvote, void* stream) {
+    if (!score || !dcla || !dvote || B <= 0 || N <= 0 || f <= 0) return O3D_EINVAL;
+    const Src3 a = {dvf, f_sb, f_sc, f_sn}, x = {dvx, x_sb, x_sc, x_sn};
+    hipLaunchKernelGGL(rpn_votes_bwd_kernel, dim3((unsigned)o3d_cdiv((long)B * N, 256), f + 4), dim3(256), 0, o3d_stream(stream),
+                       score, a, x, B, N, f, dcla, dvote);
+    return o3d_launch_status();
+}
+
+extern "C" int o3d_box_assemble(const float* offsets, long o_sb, long o_sc, long o_sn, const float* centers, int B, int P,
+                                float* boxes, void* stream) {
+    if (!offsets || !centers || !boxes || B <= 0 || P <= 0) return O3D_EINVAL;
+    const Src3 o = {offsets, o_sb, o_sc, o_sn};
+    const long total = (long)B * P * 5;
+    hipLaunchKernelGGL(box_assemble_kernel, dim3((unsigned)o3d_cdiv(total, 256)), dim3(256), 0, o3d_stream(stream), o, centers, total,
+                       P, boxes);
+    return o3d_launch_status();
+}

@@ -307,6 +307,41 @@ def test_chain_pair_equals_two_single_chains(train, B, N):
     assert f3.grad is not None and torch.isfinite(f3.grad).all()
 
 
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("B,N", [(3, 64), (48, 128)])
+def test_rpn_glue_kernels_equal_the_reference_torch_ops(train, B, N):
+    """The element-wise glue of P2BVoteNetRPN.forward (models/head/rpn.py:47-56,62-66: sigmoid, transposed vote
+    coordinates, cat(score, vote features); offsets + centres, cat, transpose) as RpnVotes / BoxAssemble (round 5, one launch
+    each way) against the torch-op form: every output and every gradient of the whole head"""
+    from open3dsot_amd import rpn
+    torch.manual_seed(4)
+    head = rpn.P2BVoteNetRPN(256, vote_channel=256, num_proposal=N // 2).cuda().train(train)
+    ref = copy.deepcopy(head)
+    g = torch.Generator(device="cuda").manual_seed(6)
+    xyz = torch.randn(B, N, 3, device="cuda", generator=g) * 0.5
+    feat = torch.randn(B, 256, N, device="cuda", generator=g)
+    outs, grads = [], []
+    for m, on in ((head, True), (ref, False)):
+        rpn.set_fused_glue(on)
+        try:
+            x, f = xyz.clone().requires_grad_(True), feat.clone().requires_grad_(True)
+            boxes, cla, vote_xyz, centers = m(x, f)
+            assert boxes.shape == (B, N // 2, 5) and boxes.is_contiguous() and vote_xyz.is_contiguous()
+            cts = [torch.randn(t.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(30 + i))
+                   for i, t in enumerate((boxes, cla, vote_xyz, centers))]
+            sum((t * c).sum() for t, c in zip((boxes, cla, vote_xyz, centers), cts)).backward()
+            outs.append([boxes, cla, vote_xyz, centers])
+            grads.append([x.grad, f.grad] + [p.grad for p in m.parameters()])
+        finally:
+            rpn.set_fused_glue(True)
+    for a, b in zip(outs[0], outs[1]):
+        assert rel(a, b) < 2e-6, rel(a, b)
+    for i, (a, b) in enumerate(zip(grads[0], grads[1])):
+        assert (a is None) == (b is None), i
+        if a is not None:
+            assert l2rel(a, b) < 2e-5, (i, l2rel(a, b))      # (the list sums of the vote aggregation use LDS float atomics)
+
+
 @pytest.mark.parametrize("B,Na,Nb", [(4, 64, 128), (48, 64, 128), (2, 32, 96)])
 def test_shared_conv_pair_equals_two_convs(B, Na, Nb):
     """conv_final on the template and on the search feature (models/bat.py:91-92) as ONE GEMM over the columns of both
