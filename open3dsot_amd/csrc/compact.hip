@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void pool_bwd_dense_kernel(PoolGrad g0, PoolGr
                                                              const float* __restrict__ mean, const int32_t* __restrict__ cball,
                                                              const int32_t* __restrict__ ball_off,
                                                              const int32_t* __restrict__ meta, long start1, long ldp, int C,
-                                                             int dummy_ball, int seg1_ball, int np0, int np1,
+                                                             int dummy_ball, int seg1_ball, int np0, int np1, int ngroups,
                                                              float* __restrict__ D, float* __restrict__ part) {
     // staged per pass: PBD_BALLS balls (a 512-column chunk of the KITTI-like crops holds ~50, of the k-NN level 128, of
     // full balls 16; more -> more passes), so that 8 workgroups fit a CU: the kernel is a latency chain per workgroup
@@ -495,7 +495,9 @@ __global__ __launch_bounds__(256) void pool_bwd_dense_kernel(PoolGrad g0, PoolGr
     __shared__ float2 stg[PBD_CH][PBD_BALLS];       // {g, bits(arg-max column) | -1}
     __shared__ int sh_hi;
     const long q0 = (long)blockIdx.x * PBD_COLS;
-    const int c0 = blockIdx.y * PBD_CH;
+    const int cbase = blockIdx.y * PBD_CH * ngroups;  // `ngroups` groups of PBD_CH channels, one after the other: the chunk's
+                                                      // index prologue is paid once, and 2/3 of the worst-case grid are dead
+                                                      // workgroups whose dispatch costs as much as they are many
     const int seg = (start1 > 0 && q0 >= start1) ? 1 : 0;
     const long local0 = q0 - (seg ? start1 : 0);
     // every index load of the prologue is issued at once (none depends on another): the live count, the chunk's first
@@ -523,13 +525,16 @@ __global__ __launch_bounds__(256) void pool_bwd_dense_kernel(PoolGrad g0, PoolGr
     __syncthreads();
     const int nb = sh_hi - b_lo + 1;                 // >= 1: a live chunk starts with a real column
     const int cl = threadIdx.x >> 5, bl = threadIdx.x & 31;
-    const float mu = mean[seg * C + c0 + cl];
     const PoolGrad gs = seg ? g1 : g0;
+    const int qq = (int)q;
+  for (int cg = 0; cg < ngroups; ++cg) {
+    const int c0 = cbase + cg * PBD_CH;
+    if (cg) __syncthreads();                         // the previous group's lookups are done with `stg`
+    const float mu = mean[seg * C + c0 + cl];
     float s = 0.f, sq = 0.f;
     float4 v[PBD_CH / 2];
 #pragma unroll
     for (int cc = 0; cc < PBD_CH / 2; ++cc) v[cc] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int qq = (int)q;
     for (int base = 0; base < nb; base += PBD_BALLS) {
         if (base) __syncthreads();
         {   // ---- stage PBD_BALLS balls: thread = (channel, ball lane); the loads run along the ball index
@@ -559,13 +564,18 @@ __global__ __launch_bounds__(256) void pool_bwd_dense_kernel(PoolGrad g0, PoolGr
         if (mine) {   // ---- this lane's four columns of four channel rows: look the balls up
             const int i0 = cb.x - b_lo - base, i1 = cb.y - b_lo - base, i2 = cb.z - b_lo - base, i3 = cb.w - b_lo - base;
             const int lim = min(PBD_BALLS, nb - base);          // (padding columns: dummy ball -> beyond nb)
+            // branch-free: clamped indices, the arg-max test carries the validity (a staged arg is a real column of ITS ball,
+            // so a clamped look-up of another ball can never equal this lane's column)
+            const int j0 = min(max(i0, 0), lim - 1), j1 = min(max(i1, 0), lim - 1);
+            const int j2 = min(max(i2, 0), lim - 1), j3 = min(max(i3, 0), lim - 1);
 #pragma unroll
             for (int cc = 0; cc < PBD_CH / 2; ++cc) {
                 const int ch = half * (PBD_CH / 2) + cc;
-                if (i0 >= 0 && i0 < lim) { const float2 e = stg[ch][i0]; if (__float_as_int(e.y) == qq + 0) v[cc].x = e.x; }
-                if (i1 >= 0 && i1 < lim) { const float2 e = stg[ch][i1]; if (__float_as_int(e.y) == qq + 1) v[cc].y = e.x; }
-                if (i2 >= 0 && i2 < lim) { const float2 e = stg[ch][i2]; if (__float_as_int(e.y) == qq + 2) v[cc].z = e.x; }
-                if (i3 >= 0 && i3 < lim) { const float2 e = stg[ch][i3]; if (__float_as_int(e.y) == qq + 3) v[cc].w = e.x; }
+                const float2 e0 = stg[ch][j0], e1 = stg[ch][j1], e2 = stg[ch][j2], e3 = stg[ch][j3];
+                v[cc].x = __float_as_int(e0.y) == qq + 0 ? e0.x : v[cc].x;
+                v[cc].y = __float_as_int(e1.y) == qq + 1 ? e1.x : v[cc].y;
+                v[cc].z = __float_as_int(e2.y) == qq + 2 ? e2.x : v[cc].z;
+                v[cc].w = __float_as_int(e3.y) == qq + 3 ? e3.x : v[cc].w;
             }
         }
     }
@@ -580,6 +590,7 @@ __global__ __launch_bounds__(256) void pool_bwd_dense_kernel(PoolGrad g0, PoolGr
         for (int cc = 0; cc < PBD_CH / 2; ++cc)
             *reinterpret_cast<float4*>(&D[(long)(c0 + half * (PBD_CH / 2) + cc) * ldp + q]) = v[cc];
     }
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1293,9 +1304,12 @@ extern "C" int o3d_pool_bwd_dense(const float* dOut0, long sb0, long sc0, const 
         return O3D_EINVAL;
     const int seg1_ball = B * npoint0, np1 = npoint1 > 0 ? npoint1 : npoint0;
     const PoolGrad g0 = {dOut0, sb0, sc0}, g1 = {dOut1, sb1, sc1};
-    hipLaunchKernelGGL(pool_bwd_dense_kernel, dim3((unsigned)(ldp / PBD_COLS), C / PBD_CH), dim3(256), 0, o3d_stream(stream),
-                       g0, g1, out, argq, yarg, mean, cball, ball_off, meta, npoint1 > 0 ? start1 : 0, ldp, C,
-                       B * (npoint0 + npoint1), seg1_ball, npoint0, np1, D, part);
+    // (measured, round 5: 4 groups per workgroup -- a quarter of the workgroups, the index prologue paid once -- takes 0.31 ms per
+    // step against 0.23 for one: the groups of a workgroup run one after the other, each a full gather -> LDS -> store chain)
+    const int ngroups = 1;
+    hipLaunchKernelGGL(pool_bwd_dense_kernel, dim3((unsigned)(ldp / PBD_COLS), C / (PBD_CH * ngroups)), dim3(256), 0,
+                       o3d_stream(stream), g0, g1, out, argq, yarg, mean, cball, ball_off, meta, npoint1 > 0 ? start1 : 0, ldp, C,
+                       B * (npoint0 + npoint1), seg1_ball, npoint0, np1, ngroups, D, part);
     return o3d_launch_status();
 }
 
