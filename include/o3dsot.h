@@ -254,6 +254,14 @@ int o3d_group_expand_c3(const float* X3, long ldz, const int32_t* gp, const int3
  * data gradient (dY = A1*dN + w*(A2*Y + A3), ReLU mask, statistics; Wt = W^T), weight gradient.
  * tile = columns per wave tile = columns per statistics partial row: o3d_direct_tile(ldp, M, 1). */
 int o3d_direct_tile(long P, int M, int compact);
+/* Round 5: a 128-column direct GEMM launch over the compact layout (o3d_mlp_conv_fwd_c / o3d_mlp_conv_dgrad_c with tile = 128)
+ * cuts the remainder tiles of its last resident round (T mod S live tiles, S = o3d_direct_tail_slots(output rows) resident
+ * column-tile slots) into 2 or 4 column blocks that run as workgroups of the same launch, decided on the device from the live
+ * count.  Their statistics go to EXTRA rows behind the regular ones: `part` must hold ldp/128 + nseg * S rows; the
+ * o3d_bn_finalize_c[2] / o3d_bn_bwd_finalize_c[2] calls with tile = 128 follow the same plan (C = the launch's output rows). */
+int o3d_direct_tail_slots(int M);
+/* test hook: -1 automatic (default), 0 no remainder split, S > 0 pretend S slots for every shape */
+int o3d_direct_tail_override(int slots);
 int o3d_mlp_conv_fwd_c(const float* X, const float* W, const float* in_scale, const float* in_shift, int Cin,
                        int Cout, long ldp, const float* w, const int32_t* meta, long start1, int tile, float* Y,
                        float* part, const float* stat_c, void* stream);

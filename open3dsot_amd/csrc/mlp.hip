@@ -264,6 +264,9 @@ struct BnFinArgs {
     // second segment (nparts1 > 0): its partial rows follow segment 0's `nparts`, its outputs / stat_c sit at
     // +C, its live count at meta[4]; the running statistics see segment 0's update first
     int nparts1; double count1;
+    // statistics rows of a direct GEMM launch whose remainder tiles were cut into column blocks (mlp_common.hpp::tail_plan):
+    // the same plan, from the same live count, tells how many extra rows follow the regular ones
+    int tail_slots; long extra_row0;
 };
 
 __device__ __forceinline__ void bn_finalize_body(const BnFinArgs& a, const int bx) {
@@ -279,12 +282,23 @@ __device__ __forceinline__ void bn_finalize_body(const BnFinArgs& a, const int b
         const int off = seg * a.C;
         double s = 0.0, q = 0.0;
         int nparts = seg ? a.nparts1 : a.nparts;
-        if (a.meta) { const int live = (a.meta[4 * seg] + a.tile - 1) / a.tile; nparts = live < nparts ? live : nparts; }   // (ceil: a 512-column row of o3d_pool_bwd_dense may be half live)
+        int nextra = 0;
+        if (a.meta) {
+            const int cap = nparts;
+            const int live = (a.meta[4 * seg] + a.tile - 1) / a.tile;    // (ceil: a 512-column row of o3d_pool_bwd_dense may be half live)
+            nparts = live < nparts ? live : nparts;
+            if (a.tail_slots > 0) { const TailPlan pl = tail_plan(nparts, a.tail_slots, cap); nextra = pl.R * (pl.f - 1); }
+        }
         if (c < a.C) {
 #pragma unroll 8
             for (int t = sl; t < nparts; t += FIN_SL) {
                 s += (double)part[((long)t * 2 + 0) * a.C + c];
                 q += (double)part[((long)t * 2 + 1) * a.C + c];
+            }
+            const float* extra = a.part + (a.extra_row0 + (long)seg * a.tail_slots) * 2 * a.C;
+            for (int t = sl; t < nextra; t += FIN_SL) {
+                s += (double)extra[((long)t * 2 + 0) * a.C + c];
+                q += (double)extra[((long)t * 2 + 1) * a.C + c];
             }
         }
         if (seg) __syncthreads();
@@ -451,6 +465,7 @@ struct BnBwdFinArgs {
     // second segment (nparts1 > 0): partial rows after segment 0's, mean / invstd / A1..A3 at +C, live count at
     // meta[4]; dgamma / dbeta (C each) are the SUM over the segments (the affine parameters are shared)
     int nparts1; double count1;
+    int tail_slots; long extra_row0;      // as BnFinArgs
 };
 
 __device__ __forceinline__ void bn_bwd_finalize_body(const BnBwdFinArgs& a, const int bx) {
@@ -465,12 +480,23 @@ __device__ __forceinline__ void bn_bwd_finalize_body(const BnBwdFinArgs& a, cons
         const int off = seg * a.C;
         double s = 0.0, q = 0.0;
         int nparts = seg ? a.nparts1 : a.nparts;
-        if (a.meta) { const int live = (a.meta[4 * seg] + a.tile - 1) / a.tile; nparts = live < nparts ? live : nparts; }   // (ceil: a 512-column row of o3d_pool_bwd_dense may be half live)
+        int nextra = 0;
+        if (a.meta) {
+            const int cap = nparts;
+            const int live = (a.meta[4 * seg] + a.tile - 1) / a.tile;    // (ceil: a 512-column row of o3d_pool_bwd_dense may be half live)
+            nparts = live < nparts ? live : nparts;
+            if (a.tail_slots > 0) { const TailPlan pl = tail_plan(nparts, a.tail_slots, cap); nextra = pl.R * (pl.f - 1); }
+        }
         if (c < a.C) {
 #pragma unroll 8
             for (int t = sl; t < nparts; t += FIN_SL) {
                 s += (double)part[((long)t * 2 + 0) * a.C + c];
                 q += (double)part[((long)t * 2 + 1) * a.C + c];
+            }
+            const float* extra = a.part + (a.extra_row0 + (long)seg * a.tail_slots) * 2 * a.C;
+            for (int t = sl; t < nextra; t += FIN_SL) {
+                s += (double)extra[((long)t * 2 + 0) * a.C + c];
+                q += (double)extra[((long)t * 2 + 1) * a.C + c];
             }
         }
         if (seg) __syncthreads();
@@ -1044,6 +1070,7 @@ extern "C" int o3d_bn_finalize_c(const float* part, int nparts, int C, double co
     if (!part || nparts <= 0 || C <= 0 || !mean || !invstd || !scale || !shift || !meta || tile <= 0) return O3D_EINVAL;
     BnFinArgs a = {part, nparts, C, meta, tile, count, stat_c, gamma, beta, running_mean, running_var, momentum, eps,
                    mean, invstd, scale, shift};
+    if (tile == 128) { a.tail_slots = o3d_direct_tail_slots(C); a.extra_row0 = nparts; }     // rows of a direct GEMM launch
     return launch(bn_finalize_kernel, dim3(o3d_cdiv(C, FIN_CH)), dim3(256), 0, o3d_stream(stream), a);
 }
 
@@ -1054,6 +1081,7 @@ extern "C" int o3d_bn_bwd_finalize_c(const float* part, int nparts, int C, doubl
         tile <= 0)
         return O3D_EINVAL;
     BnBwdFinArgs a = {part, nparts, C, count, meta, tile, gamma, mean, invstd, dgamma, dbeta, A1, A2, A3};
+    if (tile == 128) { a.tail_slots = o3d_direct_tail_slots(C); a.extra_row0 = nparts; }
     return launch(bn_bwd_finalize_kernel, dim3(o3d_cdiv(C, FIN_CH)), dim3(256), 0, o3d_stream(stream), a);
 }
 
@@ -1067,6 +1095,7 @@ extern "C" int o3d_bn_finalize_c2(const float* part, int nparts0, int nparts1, i
         return O3D_EINVAL;
     BnFinArgs a = {part, nparts0, C, meta, tile, count0, stat_c, gamma, beta, running_mean, running_var, momentum, eps,
                    mean, invstd, scale, shift, nparts1, count1};
+    if (tile == 128) { a.tail_slots = o3d_direct_tail_slots(C); a.extra_row0 = (long)nparts0 + nparts1; }
     return launch(bn_finalize_kernel, dim3(o3d_cdiv(C, FIN_CH)), dim3(256), 0, o3d_stream(stream), a);
 }
 
@@ -1080,6 +1109,7 @@ extern "C" int o3d_bn_bwd_finalize_c2(const float* part, int nparts0, int nparts
         return O3D_EINVAL;
     BnBwdFinArgs a = {part, nparts0, C, count0, meta, tile, gamma, mean, invstd, dgamma, dbeta, A1, A2, A3, nparts1,
                       count1};
+    if (tile == 128 && meta) { a.tail_slots = o3d_direct_tail_slots(C); a.extra_row0 = (long)nparts0 + nparts1; }
     return launch(bn_bwd_finalize_kernel, dim3(o3d_cdiv(C, FIN_CH)), dim3(256), 0, o3d_stream(stream), a);
 }
 

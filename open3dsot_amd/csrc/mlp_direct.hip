@@ -85,6 +85,9 @@ struct DirectArgs {
     // CONSTANT input channel block (the pooled feature SegPointNet broadcasts to every point, models/backbone/
     // pointnet.py:188-190) contributes W_b . pooled[b] to every column of cloud b: a bias, not 1024 GEMM rows
     const float* cbias; int cb_N, cb_B;
+    // remainder tiles in finer units (mlp_common.hpp::tail_plan): resident column-tile slots of this launch (0: off) and the
+    // first statistics row behind the launch's regular rows
+    int tail_slots; long extra_row0;
 };
 
 template <int MODE, int NT>
@@ -150,7 +153,7 @@ __device__ __forceinline__ void compute_group(const RawB<NT>& f, const float4& a
 // of half the length for launches that do not fill the chip (everything after compaction at batch 48).
 // MT = 2: 64 output rows per wave (MT = 1, 32 rows, is only used by the split-K tile further down).
 template <int WAVES, int MODE, int EPI, int NT, int MT = 2>
-__device__ __forceinline__ void direct_gemm_body(DirectArgs& a, const int bx, const int by) {
+__device__ __forceinline__ void direct_gemm_body(DirectArgs& a, const int bx, const int by, const long part_row = -1) {
     constexpr int POS = 32 * NT;
     constexpr int DT_MW = 32 * MT;      // output rows per wave
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -324,7 +327,7 @@ __device__ __forceinline__ void direct_gemm_body(DirectArgs& a, const int bx, co
         }
         if (stats) {       // lane l31 of half h ends up owning value index l31 -> (statistic l31>>4, row r = l31&15)
             reduce_scatter32(red, l31);
-            a.part[(long)tile * 2 * a.M + (long)(l31 >> 4) * a.M + m0 + 32 * i + acc_row(l31 & 15, h)] = red[0];
+            a.part[(part_row >= 0 ? part_row : (long)tile) * 2 * a.M + (long)(l31 >> 4) * a.M + m0 + 32 * i + acc_row(l31 & 15, h)] = red[0];
         }
     }
 }
@@ -334,6 +337,29 @@ template <int WAVES, int MODE, int EPI, int NT, int MT = 2>
 __global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, (NT == 4 && MT == 2) ? 2 : 4)))
 void direct_gemm_kernel(DirectArgs a) {
     direct_gemm_body<WAVES, MODE, EPI, NT, MT>(a, blockIdx.x, blockIdx.y);
+}
+
+// direct_gemm_kernel<WAVES, MODE, EPI, 4, 2> with the remainder tiles of every segment cut into 64- or 32-column blocks
+// (mlp_common.hpp::tail_plan): workgroup index -> (tile, block) from the device-side live count; a block is the same body
+// instantiated for 2 or 1 n-tiles on contiguous columns (NT = 1: lane l <-> column p0 + l).  Compact layout only (meta != NULL).
+template <int WAVES, int MODE, int EPI>
+__global__ __launch_bounds__(WAVES * 64) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void direct_gemm_tail_kernel(DirectArgs a) {
+    const int tile = blockIdx.x;                                     // 128-column tile index over the whole operand
+    const int seg = (a.start1 > 0 && (long)tile * 128 >= a.start1) ? 1 : 0;
+    const int t0 = seg ? (int)(a.start1 / 128) : 0;                  // first tile of the segment
+    const int cap = a.start1 > 0 ? (seg ? (int)((a.P - a.start1) / 128) : (int)(a.start1 / 128)) : a.P / 128;   // worst-case tiles of the segment
+    const int T = a.meta[4 * seg] / 128;
+    const TailPlan pl = tail_plan(T, a.tail_slots, cap);
+    const int tl = tile - t0;
+    if (tl < pl.full) { direct_gemm_body<WAVES, MODE, EPI, 4, 2>(a, tile, blockIdx.y); return; }
+    const int u = tl - pl.full;
+    if (u >= pl.R * pl.f) return;                                    // dead workgroup (pl.f == 1: R = 0)
+    const int j = u / pl.f, blk = u - j * pl.f;
+    const int tt = t0 + pl.full + j;                                 // the tail tile
+    const long row = blk == 0 ? (long)tt : a.extra_row0 + (long)seg * a.tail_slots + (long)j * (pl.f - 1) + (blk - 1);
+    if (pl.f == 4) direct_gemm_body<WAVES, MODE, EPI, 1, 2>(a, tt * 4 + blk, blockIdx.y, row);
+    else           direct_gemm_body<WAVES, MODE, EPI, 2, 2>(a, tt * 2 + blk, blockIdx.y, row);
 }
 
 // Two independent GEMMs of the same shape class (same columns, same operand / epilogue mode, same wave tile) in one
@@ -558,6 +584,14 @@ template <int MODE, int EPI, int NT, int MT = 2>
 int launch_direct_nt(const DirectArgs& a, hipStream_t st) {
     const int tiles = a.B * (a.P / (32 * NT));
     const int slabs = a.M / (32 * MT);
+    if constexpr (NT == 4 && MT == 2 && MODE != B_DYPOOL && EPI <= 1) {
+        if (a.tail_slots > 0 && a.meta && a.B == 1) {      // remainder tiles in finer units (direct_gemm_tail_kernel)
+            if (slabs % 4 == 0)      hipLaunchKernelGGL((direct_gemm_tail_kernel<4, MODE, EPI>), dim3(tiles, slabs / 4), dim3(256), 0, st, a);
+            else if (slabs % 2 == 0) hipLaunchKernelGGL((direct_gemm_tail_kernel<2, MODE, EPI>), dim3(tiles, slabs / 2), dim3(128), 0, st, a);
+            else                     hipLaunchKernelGGL((direct_gemm_tail_kernel<1, MODE, EPI>), dim3(tiles, slabs), dim3(64), 0, st, a);
+            return o3d_launch_status();
+        }
+    }
     if (slabs % 4 == 0) {
         hipLaunchKernelGGL((direct_gemm_kernel<4, MODE, EPI, NT, MT>), dim3(tiles, slabs / 4), dim3(256), 0, st, a);
     } else if (slabs % 2 == 0) {
@@ -597,6 +631,28 @@ int launch_direct(const DirectArgs& a, int tile, hipStream_t st) {
 
 bool o3d_direct_ok(int M, int K, int P) { return M % DT_M == 0 && K % 16 == 0 && P % 128 == 0; }
 
+static int g_tail_override = -1;
+// TEST hook: -1 = the resident-slot count of the device (default), 0 = no remainder split at all (what the split is tested and
+// A/B-ed against), S > 0 = pretend S slots whatever the shape (small problems then meet every branch of tail_plan)
+extern "C" int o3d_direct_tail_override(int slots) { g_tail_override = slots; return O3D_OK; }
+
+extern "C" int o3d_direct_tail_slots(int M) {
+    if (g_tail_override >= 0) return (M > 0 && M % DT_M == 0) ? g_tail_override : 0;
+    static int cus = 0;
+    if (cus == 0) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n;
+    }
+    if (M <= 0 || M % DT_M != 0) return 0;
+    const int slabs = M / DT_M;
+    const int waves = slabs % 4 == 0 ? 4 : (slabs % 2 == 0 ? 2 : 1);
+    const int per_tile = slabs / waves;                      // workgroups per column tile (grid.y)
+    const int slots = (8 / waves) * cus / per_tile;
+    return slots >= 64 ? slots : 0;
+}
+
 // Columns per wave tile (= columns per statistics partial row) for a problem of P worst-case columns and
 // M output rows: 64 while the expected number of waves (a quarter of the worst case is live after
 // compaction) does not fill the 256 CUs a few times over, else 128.
@@ -621,6 +677,7 @@ int o3d_direct_fwd(const float* X, const float* W, const float* in_scale, const 
     a.w = w; a.meta = meta; a.start1 = start1;
     a.A = W; a.X = X; a.c1 = in_scale; a.c2 = in_shift; a.Out = Y; a.M = Cout; a.K = Cin; a.P = P; a.B = B;
     a.part = part; a.stat_c = stat_c; a.ns = 4;
+    if (meta && tile == 128 && B == 1 && in_scale) { a.tail_slots = o3d_direct_tail_slots(Cout); a.extra_row0 = P / 128; }
     return in_scale ? launch_direct<B_XFORM, 0>(a, tile, st) : launch_direct<B_PLAIN, 0>(a, tile, st);
 }
 
@@ -635,6 +692,7 @@ int o3d_direct_dgrad(const float* dN, const float* pk, int ns,
     a.A = Wt; a.X = dN; a.Y = Y; a.c1 = A1; a.c2 = A2; a.c3 = A3; a.pk = reinterpret_cast<const float2*>(pk); a.ns = ns;
     a.Out = dNprev; a.M = Cin; a.K = Cout; a.P = P; a.B = B; a.part = part;
     a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p;
+    if (meta && tile == 128 && B == 1 && dN) { a.tail_slots = o3d_direct_tail_slots(Cin); a.extra_row0 = P / 128; }
     return dN ? launch_direct<B_DY, 1>(a, tile, st) : launch_direct<B_DYPOOL, 1>(a, tile, st);
 }
 

@@ -350,6 +350,27 @@ def _direct_tile(lib, pmax, m):
     return lib.o3d_direct_tile(pmax, m, 1)
 
 
+capi.register("o3d_direct_tail_slots", [_i])
+capi.register("o3d_direct_tail_override", [_i])
+_TAIL = {"on": True, "applied": -1}       # "on": False = no split (tools/ab_hook.py fused._TAIL.on flips it for the same-box A/B)
+
+
+def set_tail_split(slots):
+    """TEST hook for the remainder-tile split of the large GEMM launches: -1 automatic (default), 0 off, S > 0 pretend S
+    resident slots (small problems then meet every branch of csrc/mlp_common.hpp::tail_plan)"""
+    capi.load().o3d_direct_tail_override(int(slots))
+    _TAIL["on"], _TAIL["applied"] = int(slots) != 0, int(slots)
+
+
+def _tail_rows(lib, tile, rows, nseg, layer):
+    """extra statistics rows behind the regular ones of a 128-column direct GEMM launch over the compact layout with `rows`
+    output rows (layers >= 1; layer 0's rows come from the expand kernel): one block of resident-slot size per segment"""
+    if not _TAIL["on"] and _TAIL["applied"] != 0:          # switched off through the dict (A/B tool): tell the library
+        lib.o3d_direct_tail_override(0)
+        _TAIL["applied"] = 0
+    return nseg * lib.o3d_direct_tail_slots(rows) if (tile == 128 and layer >= 1) else 0
+
+
 class FusedGroupedMLPCompact(torch.autograd.Function):
     """QueryAndGroup + SharedMLP + max-pool (+ the whole backward) on the compact layout of csrc/compact.hip: one column per
     DISTINCT neighbour of a ball (ball_query pads with copies of the first hit; copies are folded into
@@ -455,7 +476,9 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             bn = cfg.bns[l]
             tile = ETILE if l == 0 else _direct_tile(lib, ldp, Cout)
             Y = torch.empty((Cout, ldp), device=dev, dtype=f32)
-            part = torch.empty((ldp // tile, 2, Cout), device=dev, dtype=f32) if cfg.training else None
+            # (+ the rows of a direct GEMM launch's remainder tiles cut into column blocks: csrc/mlp_common.hpp::tail_plan)
+            part = torch.empty((ldp // tile + _tail_rows(lib, tile, Cout, nseg, l), 2, Cout), device=dev, dtype=f32) \
+                if cfg.training else None
             statc = statcs[l] if cfg.training else None
             if l == 0 and direct3:
                 _call("group_expand", 0.0, lib.o3d_group_expand_c3, X0n.data_ptr(), ldz, gp.data_ptr(), cball.data_ptr(),
@@ -709,7 +732,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             Wt = ctx.Wts[l]
             dNp = torch.empty((Cin, ldp), device=dev, dtype=f32)
             dtile = _direct_tile(lib, ldp, Cin)
-            part = torch.empty((ldp // dtile, 2, Cin), device=dev, dtype=f32)
+            part = torch.empty((ldp // dtile + _tail_rows(lib, dtile, Cin, nseg, 1), 2, Cin), device=dev, dtype=f32)
             _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
                   Wt.data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1, dtile, Ys[l - 1].data_ptr(),
                   scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),

@@ -678,6 +678,42 @@ def test_pool_bwd_one_pass_matches_zero_fill_and_scatter_paired(kind, B, full):
         assert l2rel(a, b) < (1e-5 if B <= 4 else 5e-5), l2rel(a, b)
 
 
+@pytest.mark.parametrize("slots", [8, 16, 24, 40, 64])
+@pytest.mark.parametrize("kind,B", [("sa2", 8), ("sa3", 12)])
+def test_remainder_tiles_in_column_blocks_match_the_plain_launch(kind, B, slots):
+    """Round 5: the last T mod S live tiles of a 128-column GEMM launch cut into 2 or 4 column blocks that run as workgroups
+    of the same launch (csrc/mlp_direct.hip::direct_gemm_tail_kernel, csrc/mlp_common.hpp::tail_plan; their statistics in
+    extra rows the finalize kernels follow).  With the slot count forced small, problems of a few dozen tiles meet every
+    branch of the plan (no remainder, quarter blocks, half blocks, too large a remainder, both segments of a paired call):
+    pooled features, running statistics and every gradient against the unsplit launch -- the same MFMA chains on the same
+    operands, only the statistics are summed in another order."""
+    import copy
+    from open3dsot_amd import fused
+    grouper, mlp, xyz_s, new_s, feats_s = make_case(kind, B=B, full=True)
+    N, npoint = xyz_s.shape[1], new_s.shape[1]
+    xyz_t = (xyz_s[:, :N // 2, :] * 0.9 + 0.05).contiguous()
+    new_t = xyz_t[:, :npoint // 2, :].contiguous()
+    feats_t = torch.randn(feats_s.shape[0], feats_s.shape[1], N // 2, device="cuda") if feats_s is not None else None
+    res = []
+    for s in (0, slots):
+        fused.set_tail_split(s)
+        try:
+            m = copy.deepcopy(mlp)
+            segs = [[t.clone().requires_grad_(True) if t is not None else None for t in sg]
+                    for sg in ((xyz_t, new_t, feats_t), (xyz_s, new_s, feats_s))]
+            outs = fused.sa_group_mlp_pool_pair(grouper, m, tuple(segs[0]), tuple(segs[1]))
+            gen = torch.Generator(device="cuda").manual_seed(4)
+            torch.autograd.backward(list(outs), [torch.randn(o.shape, device="cuda", generator=gen) for o in outs])
+            res.append(([o.detach() for o in outs] + [b.clone() for b in m.buffers() if b.dtype.is_floating_point],
+                        [p.grad for p in m.parameters()] + [t.grad for sg in segs for t in sg if t is not None]))
+        finally:
+            fused.set_tail_split(-1)
+    for a, b in zip(res[0][0], res[1][0]):
+        assert rel(a, b) < 2e-6, rel(a, b)
+    for a, b in zip(res[0][1], res[1][1]):
+        assert l2rel(a, b) < 2e-5, l2rel(a, b)
+
+
 def test_shapes_outside_the_compact_layout_run_operator_by_operator():
     """what the distinct-neighbour layout does not take (here nsample = 128 > 64; likewise channel counts that are no
     multiple of 64) runs the reference's own sequence -- ball query, grouping_operation, SharedMLP, max-pool -- on the
