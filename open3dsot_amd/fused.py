@@ -179,7 +179,7 @@ GEMM_KERNELS = ("conv_fwd", "conv_fwd_points", "conv_dgrad", "conv_dgrad_points"
 # "<name>(" or "<name><" against the demangled kernel name, so `direct_gemm_kernel` does not swallow (or, as in round 3,
 # silently miss) `direct_gemm_pair_kernel`.  GEMM_REDUCE_SYMBOLS: the slice reductions of the weight gradients -- their
 # bytes belong to the family, they are not counted as launches.
-GEMM_KERNEL_SYMBOLS = ("direct_gemm_kernel", "direct_gemm_pair_kernel", "splitk_gemm_kernel", "splitk_gemm_pair_kernel", "wgrad2_kernel", "wgrad2_group_kernel", "fused_bwd_kernel",
+GEMM_KERNEL_SYMBOLS = ("direct_gemm_kernel", "direct_gemm_tail_kernel", "direct_gemm_pair_kernel", "splitk_gemm_kernel", "splitk_gemm_pair_kernel", "wgrad2_kernel", "wgrad2_group_kernel", "fused_bwd_kernel",
                        "conv_fwd_kernel", "conv_dgrad_kernel", "conv_wgrad_kernel")
 GEMM_REDUCE_SYMBOLS = ("wgrad_reduce_kernel", "wgrad_reduce1_kernel", "wgrad_reduce_group_kernel")
 
