@@ -373,7 +373,14 @@ constexpr int FOLD_G = 32;
 
 // folds a long partial list into FOLD_G parts in caller scratch (FOLD_G*2*C floats); no-op when short
 static const float* fold_partials(const float* part, int& nparts, int C, float* fold, hipStream_t s) {
-    if (!fold || nparts <= 4 * FOLD_G) return part;
+    // Round 5: only lists beyond O3D_FOLD_ABOVE rows are folded first.  The finalize kernels walk a list with 64 lanes per
+    // channel group and handle the compact layout's 6 000-row lists in ~8 us without a fold; the fold launch in front of every
+    // finalize of a 768-row (M2-Track, 98 304 columns) or 3 072-row (P2B's xcorr) list was a 4.6 us launch each, 31 per M2-Track
+    // step (threshold was 128 rows; same-box A/B in profiles/r05_ab_partials_fold.txt)
+#ifndef O3D_FOLD_ABOVE
+#define O3D_FOLD_ABOVE 16384
+#endif
+    if (!fold || nparts <= O3D_FOLD_ABOVE) return part;
     hipLaunchKernelGGL(partials_fold_kernel, dim3(FOLD_G, o3d_cdiv(2 * C, 256)), dim3(256), 0, s, part, nparts, 2 * C,
                        FOLD_G, fold);
     nparts = FOLD_G;
