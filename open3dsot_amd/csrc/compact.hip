@@ -303,28 +303,26 @@ __global__ __launch_bounds__(256) void pool_c_kernel(const float* __restrict__ Y
 constexpr int PT_CH = 32, PT_COLS = 128, PT_OVER = 32, PT_LD = PT_COLS + PT_OVER + 3;     // odd stride: conflict-free; +3: the 4-wide reads
 constexpr int PT_RB = 32, PT_RLD = PT_CH + 1;         // balls per output batch; padded row of the result staging
 
-__global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y, long ldp,
-                                                     const float* __restrict__ scale, const float* __restrict__ shift,
-                                                     const int32_t* __restrict__ ball_off,
-                                                     const int32_t* __restrict__ ball_cnt,
-                                                     const int32_t* __restrict__ cball,
-                                                     const int32_t* __restrict__ meta, long start1, int C,
-                                                     int seg1_ball, int np0, int np1, int nballs,
-                                                     float* __restrict__ out, int32_t* __restrict__ argq,
-                                                     float* __restrict__ yarg) {
+// one work item of pool_t_kernel: the PT_COLS-column chunk at q0 x the PT_CH channels from c0
+__device__ __forceinline__ void pool_t_item(const float* __restrict__ Y, long ldp,
+                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                            const int32_t* __restrict__ ball_off,
+                                            const int32_t* __restrict__ ball_cnt,
+                                            const int32_t* __restrict__ cball,
+                                            const int32_t* __restrict__ meta, long start1, int C,
+                                            int seg1_ball, int np0, int np1, int nballs,
+                                            float* __restrict__ out, int32_t* __restrict__ argq,
+                                            float* __restrict__ yarg, const long q0, const int c0, float* pt_tile) {
     // LDS: tile [PT_CH][PT_LD] | ball table off / cnt / output base [PT_COLS] each | results [3][PT_RB][PT_RLD]
-    extern __shared__ float pt_tile[];
     int* pt_off = reinterpret_cast<int*>(pt_tile + PT_CH * PT_LD);
     int* pt_cnt = pt_off + PT_COLS;
     int* pt_ob = pt_cnt + PT_COLS;
     float* pt_res = reinterpret_cast<float*>(pt_ob + PT_COLS);
-    const long q0 = (long)blockIdx.x * PT_COLS;
     const int seg = (start1 > 0 && q0 >= start1) ? 1 : 0;
     const long sbase = seg ? start1 : 0;
     if (q0 - sbase >= meta[4 * seg]) return;            // dead chunk
     const long qend = sbase + meta[4 * seg + 1];        // one past the segment's last real column
     if (q0 >= qend) return;                             // only padding columns: no ball starts here
-    const int c0 = blockIdx.y * PT_CH;
     // balls that START in this chunk: [bfirst, blast] (at most PT_COLS: one per column)
     int bfirst = cball[q0];
     if (ball_off[bfirst] < q0) ++bfirst;
@@ -420,6 +418,33 @@ __global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y
     }
 }
 
+// PERSISTENT grid (round 5, as pool_bwd_dense_kernel): a fixed number of workgroups walks the LIVE (chunk, channel group) items
+// -- chunks that hold at least one real column, from the device-side meta -- instead of a worst-case grid two thirds of which
+// are workgroups that read the live count and return
+constexpr int PT_GRID = 4096;
+__global__ __launch_bounds__(256) void pool_t_kernel(const float* __restrict__ Y, long ldp,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     const int32_t* __restrict__ ball_off,
+                                                     const int32_t* __restrict__ ball_cnt,
+                                                     const int32_t* __restrict__ cball,
+                                                     const int32_t* __restrict__ meta, long start1, int C,
+                                                     int seg1_ball, int np0, int np1, int nballs,
+                                                     float* __restrict__ out, int32_t* __restrict__ argq,
+                                                     float* __restrict__ yarg) {
+    extern __shared__ float pt_tile[];
+    const int ngrp = C / PT_CH;
+    const int n0 = (meta[1] + PT_COLS - 1) / PT_COLS;
+    const int n1 = start1 > 0 ? (meta[5] + PT_COLS - 1) / PT_COLS : 0;
+    const long items = (long)(n0 + n1) * ngrp;
+    for (long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int ch = (int)(it / ngrp), cg = (int)(it - (long)ch * ngrp);
+        const long q0 = ch < n0 ? (long)ch * PT_COLS : start1 + (long)(ch - n0) * PT_COLS;
+        pool_t_item(Y, ldp, scale, shift, ball_off, ball_cnt, cball, meta, start1, C, seg1_ball, np0, np1, nballs, out, argq, yarg, q0,
+                    cg * PT_CH, pt_tile);
+        __syncthreads();
+    }
+}
+
 // dense gradient of the pooled layer: zero the live columns, then one value per (c, ball)
 __global__ __launch_bounds__(256) void zero_cols_kernel(float* __restrict__ D, long ldp,
                                                         const int32_t* __restrict__ meta, long start1) {
@@ -477,27 +502,32 @@ __global__ __launch_bounds__(256) void pool_bwd_partials_c_kernel(const float* _
 // its columns' balls up in LDS (round 2's single pass gathered dOut / out / argq from global memory per column: 12 gathers
 // per float4 store, 0.41 ms).  The BatchNorm-backward sums ride along: a ball counts in the chunk that holds its first
 // column, one partial row {sum g, sum g (yarg - mean)} per chunk (live rows only, like the GEMM epilogues').
-constexpr int PBD_COLS = 512, PBD_CH = 8, PBD_BALLS = 128;
+constexpr int PBD_COLS = 512, PBD_CH = 8, PBD_BALLS = 128, PBD_GRID = 4096;
 
 struct PoolGrad { const float* p; long sb, sc; };     // a segment's pooled-output gradient (B, C, npoint), strides in floats
                                                        // (innermost 1); p == NULL: no gradient arrived (zeros)
 
-__global__ __launch_bounds__(256) void pool_bwd_dense_kernel(PoolGrad g0, PoolGrad g1, const float* __restrict__ out,
-                                                             const int32_t* __restrict__ argq, const float* __restrict__ yarg,
-                                                             const float* __restrict__ mean, const int32_t* __restrict__ cball,
-                                                             const int32_t* __restrict__ ball_off,
-                                                             const int32_t* __restrict__ meta, long start1, long ldp, int C,
-                                                             int dummy_ball, int seg1_ball, int np0, int np1, int ngroups,
-                                                             float* __restrict__ D, float* __restrict__ part) {
+struct PoolBwdDense {
+    PoolGrad g0, g1;
+    const float* out; const int32_t* argq; const float* yarg; const float* mean; const int32_t* cball; const int32_t* ball_off;
+    const int32_t* meta; long start1, ldp; int C, dummy_ball, seg1_ball, np0, np1;
+    float* D; float* part;
+};
+
+// one work item: the 512-column chunk at q0 x the PBD_CH channels from c0
+__device__ __forceinline__ void pool_bwd_dense_item(const PoolBwdDense& a, const long q0, const int c0, float2 (&stg)[PBD_CH][PBD_BALLS],
+                                                    int& sh_hi) {
+    const PoolGrad g0 = a.g0, g1 = a.g1;
+    const float* __restrict__ out = a.out; const int32_t* __restrict__ argq = a.argq; const float* __restrict__ yarg = a.yarg;
+    const float* __restrict__ mean = a.mean; const int32_t* __restrict__ cball = a.cball;
+    const int32_t* __restrict__ ball_off = a.ball_off; const int32_t* __restrict__ meta = a.meta;
+    const long start1 = a.start1, ldp = a.ldp;
+    const int C = a.C, dummy_ball = a.dummy_ball, seg1_ball = a.seg1_ball, np0 = a.np0, np1 = a.np1;
+    float* __restrict__ D = a.D; float* __restrict__ part = a.part;
     // staged per pass: PBD_BALLS balls (a 512-column chunk of the KITTI-like crops holds ~50, of the k-NN level 128, of
     // full balls 16; more -> more passes), so that 8 workgroups fit a CU: the kernel is a latency chain per workgroup
     // (index loads -> gathers along the balls -> LDS -> stores) and lives on the bytes in flight per CU
-    __shared__ float2 stg[PBD_CH][PBD_BALLS];       // {g, bits(arg-max column) | -1}
-    __shared__ int sh_hi;
-    const long q0 = (long)blockIdx.x * PBD_COLS;
-    const int cbase = blockIdx.y * PBD_CH * ngroups;  // `ngroups` groups of PBD_CH channels, one after the other: the chunk's
-                                                      // index prologue is paid once, and 2/3 of the worst-case grid are dead
-                                                      // workgroups whose dispatch costs as much as they are many
+    const long chunk = q0 / PBD_COLS;              // the chunk's statistics row
     const int seg = (start1 > 0 && q0 >= start1) ? 1 : 0;
     const long local0 = q0 - (seg ? start1 : 0);
     // every index load of the prologue is issued at once (none depends on another): the live count, the chunk's first
@@ -527,9 +557,7 @@ __global__ __launch_bounds__(256) void pool_bwd_dense_kernel(PoolGrad g0, PoolGr
     const int cl = threadIdx.x >> 5, bl = threadIdx.x & 31;
     const PoolGrad gs = seg ? g1 : g0;
     const int qq = (int)q;
-  for (int cg = 0; cg < ngroups; ++cg) {
-    const int c0 = cbase + cg * PBD_CH;
-    if (cg) __syncthreads();                         // the previous group's lookups are done with `stg`
+  {
     const float mu = mean[seg * C + c0 + cl];
     float s = 0.f, sq = 0.f;
     float4 v[PBD_CH / 2];
@@ -582,8 +610,8 @@ __global__ __launch_bounds__(256) void pool_bwd_dense_kernel(PoolGrad g0, PoolGr
 #pragma unroll
     for (int m = 16; m >= 1; m >>= 1) { s += __shfl_xor(s, m, 64); sq += __shfl_xor(sq, m, 64); }
     if (bl == 0) {
-        part[((long)blockIdx.x * 2 + 0) * C + c0 + cl] = s;
-        part[((long)blockIdx.x * 2 + 1) * C + c0 + cl] = sq;
+        part[(chunk * 2 + 0) * C + c0 + cl] = s;
+        part[(chunk * 2 + 1) * C + c0 + cl] = sq;
     }
     if (mine) {
 #pragma unroll
@@ -591,6 +619,25 @@ __global__ __launch_bounds__(256) void pool_bwd_dense_kernel(PoolGrad g0, PoolGr
             *reinterpret_cast<float4*>(&D[(long)(c0 + half * (PBD_CH / 2) + cc) * ldp + q]) = v[cc];
     }
   }
+}
+
+// PERSISTENT grid (round 5): two thirds of a worst-case grid over (chunks x channel groups) are workgroups whose chunk is dead on
+// real crops -- up to 49 000 per launch here, and a dead workgroup still costs its dispatch (section 7d of DESIGN.md).  A fixed
+// number of workgroups walks the LIVE items instead (counts from the device-side meta), channel group fastest so that
+// neighbouring workgroups share a chunk's index lines.
+__global__ __launch_bounds__(256) void pool_bwd_dense_kernel(PoolBwdDense a) {
+    __shared__ float2 stg[PBD_CH][PBD_BALLS];       // {g, bits(arg-max column) | -1}
+    __shared__ int sh_hi;
+    const int ngrp = a.C / PBD_CH;
+    const int n0 = (a.meta[0] + PBD_COLS - 1) / PBD_COLS;
+    const int n1 = a.start1 > 0 ? (a.meta[4] + PBD_COLS - 1) / PBD_COLS : 0;
+    const long items = (long)(n0 + n1) * ngrp;
+    for (long it = blockIdx.x; it < items; it += gridDim.x) {
+        const int ch = (int)(it / ngrp), cg = (int)(it - (long)ch * ngrp);
+        const long q0 = ch < n0 ? (long)ch * PBD_COLS : a.start1 + (long)(ch - n0) * PBD_COLS;
+        pool_bwd_dense_item(a, q0, cg * PBD_CH, stg, sh_hi);
+        __syncthreads();                                // the item's look-ups are done with `stg` / `sh_hi`
+    }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1264,7 +1311,8 @@ extern "C" int o3d_pool_fwd_ct(const float* Y, long ldp, const float* scale, con
     static const bool attr_ok = hipFuncSetAttribute(reinterpret_cast<const void*>(pool_t_kernel),
                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
     if (!attr_ok) return O3D_ELAUNCH;
-    hipLaunchKernelGGL(pool_t_kernel, dim3((unsigned)(ldp / PT_COLS), C / PT_CH), dim3(256), lds, o3d_stream(stream), Y, ldp,
+    const long worst = (ldp / PT_COLS) * (C / PT_CH);
+    hipLaunchKernelGGL(pool_t_kernel, dim3((unsigned)(worst < PT_GRID ? worst : PT_GRID)), dim3(256), lds, o3d_stream(stream), Y, ldp,
                        scale, shift, ball_off, ball_cnt, cball, meta, start1, C, seg1_ball, npoint0,
                        npoint1 > 0 ? npoint1 : npoint0, nballs, out, argq, yarg);
     return o3d_launch_status();
@@ -1304,12 +1352,14 @@ extern "C" int o3d_pool_bwd_dense(const float* dOut0, long sb0, long sc0, const 
         return O3D_EINVAL;
     const int seg1_ball = B * npoint0, np1 = npoint1 > 0 ? npoint1 : npoint0;
     const PoolGrad g0 = {dOut0, sb0, sc0}, g1 = {dOut1, sb1, sc1};
-    // (measured, round 5: 4 groups per workgroup -- a quarter of the workgroups, the index prologue paid once -- takes 0.31 ms per
-    // step against 0.23 for one: the groups of a workgroup run one after the other, each a full gather -> LDS -> store chain)
-    const int ngroups = 1;
-    hipLaunchKernelGGL(pool_bwd_dense_kernel, dim3((unsigned)(ldp / PBD_COLS), C / (PBD_CH * ngroups)), dim3(256), 0,
-                       o3d_stream(stream), g0, g1, out, argq, yarg, mean, cball, ball_off, meta, npoint1 > 0 ? start1 : 0, ldp, C,
-                       B * (npoint0 + npoint1), seg1_ball, npoint0, np1, ngroups, D, part);
+    // (measured, round 5: 4 channel groups per workgroup of a worst-case grid -- a quarter of the workgroups, the index prologue
+    // paid once -- took 0.31 ms per step against 0.23: 1.5 rounds of long workgroups instead of 6 of short ones; the persistent
+    // grid below has neither the dead workgroups nor that quantisation)
+    PoolBwdDense a = {g0, g1, out, argq, yarg, mean, cball, ball_off, meta, npoint1 > 0 ? start1 : 0, ldp, C,
+                      B * (npoint0 + npoint1), seg1_ball, npoint0, np1, D, part};
+    const long worst = (ldp / PBD_COLS) * (C / PBD_CH);
+    const unsigned grid = (unsigned)(worst < PBD_GRID ? worst : PBD_GRID);
+    hipLaunchKernelGGL(pool_bwd_dense_kernel, dim3(grid), dim3(256), 0, o3d_stream(stream), a);
     return o3d_launch_status();
 }
 
