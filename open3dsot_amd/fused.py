@@ -111,6 +111,21 @@ def _eval_consts(lib, bn, gamma, beta, vec, nrep, st, conv_bias=None):
 # BatchNorm `num_batches_tracked` increments: inside a tracker forward (fused_heads.prep_scope) they are collected and
 # applied by ONE multi-tensor launch at the end of the forward instead of one launch per fused operator
 _COUNTERS = {"pending": None}
+# running-mean corrections `running_mean += momentum * conv_bias` of the per-point stacks (their statistics are taken without the
+# bias): collected the same way, one multi-tensor launch per forward (round 5; was one per stack)
+_BIASFIX = {"pending": None}
+
+
+def bias_fix(momentum, running_means, biases):
+    """running_mean_i += momentum * bias_i, now or -- inside a tracker forward -- with every other stack's at its end"""
+    if not running_means:
+        return
+    if _BIASFIX["pending"] is None:
+        torch._foreach_add_(running_means, biases, alpha=momentum)
+        return
+    ent = _BIASFIX["pending"].setdefault(float(momentum), ([], []))
+    ent[0].extend(running_means)
+    ent[1].extend(biases)
 
 
 def touch(tensors):
@@ -142,10 +157,14 @@ def counters_begin():
     if _COUNTERS["pending"] is not None:
         return False
     _COUNTERS["pending"] = {}
+    _BIASFIX["pending"] = {}
     return True
 
 
 def counters_end():
+    fixes, _BIASFIX["pending"] = _BIASFIX["pending"], None
+    for mom, (rms, bs) in (fixes or {}).items():
+        torch._foreach_add_(rms, bs, alpha=mom)
     pending, _COUNTERS["pending"] = _COUNTERS["pending"], None
     if not pending:
         return

@@ -14,6 +14,7 @@ import torch
 
 from . import capi
 from .fused import _call, _check_versions, _const_vec, _eval_consts, _ptr, _stream, _versions, count_batches, POOL_BWD_SPLIT, TILE
+from .fused import bias_fix as _fused_bias_fix
 
 _vp, _i, _l = ctypes.c_void_p, ctypes.c_int, ctypes.c_long
 capi.register("o3d_pw_tile", [_l, _i])
@@ -109,8 +110,8 @@ class FusedPointwiseChain(torch.autograd.Function):
                 _eval_consts(lib, bn, gammas[l], betas[l], vec, 1, st, conv_bias=b)
             Ys.append(Y)
             means.append(vec[0]); invstds.append(vec[1]); scales.append(vec[2]); shifts.append(vec[3])
-        for mom, (rms, bs) in bias_fix.items():      # one multi-tensor launch per stack instead of one per layer
-            torch._foreach_add_(rms, bs, alpha=mom)
+        for mom, (rms, bs) in bias_fix.items():      # one multi-tensor launch per FORWARD inside a tracker scope, else per stack
+            _fused_bias_fix(mom, rms, bs)
         if cfg.training:
             count_batches(cfg.bns, 1)
         Cl = Ws[-1].shape[0]

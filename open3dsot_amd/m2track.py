@@ -44,6 +44,35 @@ def _head(out):
                          nn.Linear(128, 128), RowBatchNorm1d(128), nn.ReLU(), nn.Linear(128, out))
 
 
+
+class _PackParts(torch.autograd.Function):
+    """torch.cat(parts, dim=1) of (B, C_i, N) tensors with any strides, written straight into the flat (sum C_i, B*N) layout the
+    per-point stacks consume (csrc/heads.hip::pack_rows_kernel) and handed out as its (B, C, N) view: the stack takes that view
+    as its operand without a copy (were a concatenation + a layout copy per stack input).  The backward is views of the
+    incoming gradient."""
+
+    @staticmethod
+    def forward(ctx, *parts):
+        from .fused_heads import pack_rows
+        B, _, N = parts[0].shape
+        ctx.sizes = [t.shape[1] for t in parts]
+        rows = sum(ctx.sizes)
+        with torch.cuda.device(parts[0].device):
+            flat = pack_rows([t.detach() for t in parts], rows)
+        return flat.view(rows, B, N).permute(1, 0, 2)
+
+    @staticmethod
+    def backward(ctx, g):
+        return tuple(g.split(ctx.sizes, dim=1))
+
+
+def _cat_channels(parts):
+    """torch.cat(parts, dim=1); on the GPU one launch into the stacks' flat layout (see _PackParts)"""
+    if parts[0].is_cuda and all(t.dtype == torch.float32 and t.dim() == 3 for t in parts) and len(parts) <= 4:
+        return _PackParts.apply(*parts)
+    return torch.cat(parts, dim=1)
+
+
 class M2TRACK(nn.Module):
     def __init__(self, config=None, **kwargs):
         super().__init__()
@@ -82,7 +111,7 @@ class M2TRACK(nn.Module):
         out = {}
         x = input_dict["points"].transpose(1, 2)
         if self.box_aware:
-            x = torch.cat([x, input_dict["candidate_bc"].transpose(1, 2)], dim=1)
+            x = _cat_channels([x, input_dict["candidate_bc"].transpose(1, 2)])
         seg_out = self.seg_pointnet(x)
         if self.box_aware:       # one split node instead of two slices (whose backward is 2 x (fill + copy) + an add)
             seg_logits, pred_bc = seg_out.split([2, seg_out.shape[1] - 2], dim=1)
@@ -122,7 +151,7 @@ class M2TRACK(nn.Module):
                 merged = box_utils.motion_merge_reference(mask_xyz, prev_boxes, motion_pred_masked)[0]
         if self.use_second_stage:
             if self.box_aware:
-                merged = torch.cat([merged, mask_pred_bc], dim=1)
+                merged = _cat_channels([merged, mask_pred_bc])
             offset = seq_rows(self.box_mlp, self.mini_pointnet2(merged))
             out["estimation_boxes"] = box_utils.get_offset_box_tensor(aux_box, offset)
         else:
