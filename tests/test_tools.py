@@ -147,3 +147,20 @@ def test_hbm_traffic_family_covers_every_gemm_kernel_of_the_round3_table():
     assert abs(tot / 8 / 1e9 - 8.84) < 0.01
     assert any(k.startswith("fused_bwd_kernel") for k in per) and any(k.startswith("direct_gemm_pair_kernel") for k in per)
     assert abs((tot + other) / 8 / 1e9 - 12.8) < 0.05
+
+
+def test_every_gemm_kernel_of_the_round5_trace_has_a_family_and_a_symbol():
+    """round 5 added direct_gemm_tail_kernel: the first artefact run filed it under "other" in the family table and dropped it
+    from the traffic / SQ accounting because the symbol lists did not know it.  Every kernel of the committed round-5 trace
+    that computes with MFMA must be in fused.GEMM_KERNEL_SYMBOLS (or the reduce list) and land in a named family."""
+    sys.path.insert(0, ROOT)
+    from open3dsot_amd.fused import GEMM_KERNEL_SYMBOLS, GEMM_REDUCE_SYMBOLS, kernel_symbol
+    per_step = os.path.join(ROOT, "profiles", "r05_steady_state_per_step.txt")
+    names = [ln.split(" x ", 1)[1].strip() for ln in open(per_step).read().splitlines()[1:] if " x " in ln]
+    gemm_like = [n for n in names if any(t in n for t in ("gemm", "wgrad", "fused_bwd", "conv_fwd_kernel", "conv_dgrad_kernel"))]
+    assert any("direct_gemm_tail_kernel" in n for n in gemm_like)
+    for n in gemm_like:
+        assert kernel_symbol(n) in GEMM_KERNEL_SYMBOLS + GEMM_REDUCE_SYMBOLS, n
+    fam = run("trace_families.py", per_step)
+    other = [ln for ln in fam.splitlines() if ln.strip().endswith("other")]
+    assert other and float(other[0].split()[0]) < 0.2, other      # nothing big is filed under "other"
