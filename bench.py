@@ -60,6 +60,9 @@ def parse():
                     "(live_fraction 1.0) instead of the KITTI-like crops")
     ap.add_argument("--per-launch", default=None, metavar="FILE", help="write the per-launch roofline table of the GEMM "
                     "launches (algorithmic FLOPs / bytes, HIP-event time, share of max(MFMA, HBM) roofline) to FILE")
+    ap.add_argument("--exchange", action="store_true", help="run the MULTI-GPU code path at --gpus 1: a one-rank RCCL process "
+                    "group, gradient pack inside the captured graph, all_reduce(AVG) on the flat buffer, FlatAdam on its views "
+                    "(DataParallelStep(exchange=True)); prices the exchange path's per-step overhead on a one-GPU box")
     ap.add_argument("--composed", action="store_true", help="disable the fused kernels (debug A/B only)")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying one HIP graph")
     return ap.parse_args()
@@ -351,6 +354,8 @@ def secondary_lines(args):
     def one(tag, **over):
         a = copy.copy(args)
         a.steps, a.warmup, a.no_cpu_baseline, a.per_launch = args.secondary_steps, 5, True, None
+        over = dict(over)
+        a.full = over.pop("full", False)
         for k, v in over.items():
             setattr(a, k, v)
         try:
@@ -358,11 +363,22 @@ def secondary_lines(args):
                 a.steps, a.warmup = 200, 20
                 r = run_infer(a)
             else:
-                r = measure(a, 0, 0, 1, full=False)
+                r = measure(a, 0, 0, 1, full=a.full)
             out[tag] = {"value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"], "steps": r["steps"],
                         "workload": r["config"]["workload"], "hip_graph": bool(r["config"].get("hip_graph"))}
+            for k in ("rccl_world_size", "max_parameter_divergence", "gradient_exchange", "exchange_path", "self_check_error"):
+                if over.get("exchange") and k in r["config"]:
+                    out[tag][k] = r["config"][k]
+            if a.full and r.get("roofline"):       # the worst-case line carries its own roofline fractions
+                out[tag]["roofline"] = {k: r["roofline"].get(k) for k in ("bound", "achieved", "peak", "unit", "frac",
+                                                                           "whole_step_frac", "live_fraction")}
         except Exception as e:  # a secondary line must never take the main line down
             out[tag] = {"error": "%s: %s" % (type(e).__name__, e)}
+        if over.get("exchange") and dist.is_initialized():
+            try:
+                dist.destroy_process_group()
+            except Exception:
+                pass
         torch.cuda.empty_cache()
     one("p2b_batch48", model="P2B")
     one("p2b_batch1", model="P2B", batch=1)
@@ -370,7 +386,10 @@ def secondary_lines(args):
     one("bat_nuscenes_search2048_batch48", search_size=2048)
     one("bat_nuscenes_yaml_batch100", batch=100)
     one("bat_nuscenes_search2048_batch100", search_size=2048, batch=100)       # config 5 as one workload
-    one("bat_dense_worst_case", dense=True)
+    one("bat_dense_worst_case", dense=True, full=True)
+    # the multi-GPU step at world size 1: what the exchange path (pack in the graph + all_reduce(AVG) + FlatAdam on views of
+    # the exchange buffer) costs per step beside the headline; NOT a scaling measurement
+    one("bat_rccl_world1_exchange", exchange=True)
     one("bat_infer_batch1", infer=True)
     one("p2b_infer_batch1", infer=True, model="P2B")
     one("m2track_infer_batch1", infer=True, model="M2TRACK")     # (last: a fault while capturing it cannot touch the lines above)
@@ -396,7 +415,17 @@ def measure(args, rank, local_rank, world, full=True):
         base_make = synth.make_dense_batch if args.dense else synth.make_batch
         make = lambda first, n: base_make(first, n, 512, args.search_size)
     sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
-    trainer = D.DataParallelStep(model, world=world, graph=not args.no_graph, graph_warmup=2)
+    exchange = bool(getattr(args, "exchange", False))
+    if exchange and world == 1 and not dist.is_initialized():
+        import socket
+        sock = socket.socket()
+        sock.bind(("127.0.0.1", 0))
+        os.environ.update(RANK="0", LOCAL_RANK=str(local_rank), WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(sock.getsockname()[1]))
+        sock.close()
+        D.init_distributed(force=True)          # a one-rank RCCL communicator
+    trainer = D.DataParallelStep(model, world=world, graph=not args.no_graph, graph_warmup=2,
+                                 exchange=True if exchange else None)
 
     # resident synthetic batches (distinct per rank and per pool slot)
     pool = []
@@ -447,6 +476,9 @@ def measure(args, rank, local_rank, world, full=True):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         own_elapsed, elapsed = elapsed, float(t.item())
         multi = D.replica_self_check(model, trainer, own_elapsed, args.batch * args.steps)
+    elif exchange:
+        multi = D.replica_self_check(model, trainer, elapsed, args.batch * args.steps)
+        multi["exchange_path"] = bool(trainer.exchange and all(p.grad is v for p, v in zip(trainer.grads.params, trainer.grads.views)))
 
     # ---- roofline of the dominant kernel family, measured live with HIP events ------------
     roofline = None
@@ -506,6 +538,15 @@ def measure(args, rank, local_rank, world, full=True):
                 gbs = roofline["traffic"] / (roofline["avg_launch_ms"] * 1e-3) / 1e9
                 roofline["fabric_gbs"] = round(gbs, 1)
                 roofline["fabric_frac_of_hbm_peak"] = round(gbs / PEAK_HBM_GBS, 4)
+    if roofline is not None and roofline.get("gemm_gflop_per_step"):
+        # the same executed FLOPs over the WHOLE timed step (every kernel, launch gaps included): what the step as a unit
+        # reaches of the matrix peak, beside `frac` (the GEMM launches' own time)
+        step_ms = 1e3 * elapsed / args.steps
+        roofline["whole_step_frac"] = round(roofline["gemm_gflop_per_step"] / step_ms / PEAK_FP32_MFMA_TFLOPS, 4)
+        if roofline.get("reference_formula_gflop_per_step"):
+            # SURVEY 8(d)'s gather-first formula over the FLOPs the kernels execute (distinct-neighbour compaction, layer 0
+            # on points): > 1 means the formula's work is NOT what runs; credit is on executed FLOPs only
+            roofline["formula_over_executed"] = round(roofline["reference_formula_gflop_per_step"] / roofline["gemm_gflop_per_step"], 3)
     if roofline is None and full:  # no instrumented kernels yet: whole-step algorithmic rate (labelled as such)
         flops = 3.0 * mlp_flops_per_pair(args.model) * args.batch
         ach = flops / (elapsed / args.steps) / 1e12
@@ -539,7 +580,9 @@ def measure(args, rank, local_rank, world, full=True):
         }
         if full and not args.no_cpu_baseline and world == 1 and args.search_size == 1024:
             line["cpu_baseline"] = cpu_baseline(args.model, sd_cpu, args.batch, args.cpu_budget)
-        line["config"]["rccl_world_size"] = dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1
+        line["config"]["rccl_world_size"] = dist.get_world_size() if ((world > 1 or exchange) and dist.is_initialized()) else 1
+        if exchange:
+            line["config"]["rccl_backend"] = dist.get_backend() if dist.is_initialized() else None
         if multi is not None:
             line["config"].update(multi)
         return line

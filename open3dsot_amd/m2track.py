@@ -68,7 +68,11 @@ class _PackParts(torch.autograd.Function):
 
 def _cat_channels(parts):
     """torch.cat(parts, dim=1); on the GPU one launch into the stacks' flat layout (see _PackParts)"""
-    if parts[0].is_cuda and all(t.dtype == torch.float32 and t.dim() == 3 for t in parts) and len(parts) <= 4:
+    p0 = parts[0]
+    # pack_rows takes B and N from the first part: a mismatched part must reach torch.cat, which raises
+    if p0.is_cuda and len(parts) <= 4 and all(
+            t.dtype == torch.float32 and t.dim() == 3 and t.device == p0.device and t.shape[0] == p0.shape[0]
+            and t.shape[2] == p0.shape[2] for t in parts):
         return _PackParts.apply(*parts)
     return torch.cat(parts, dim=1)
 

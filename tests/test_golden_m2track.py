@@ -176,6 +176,74 @@ def test_m2track_flat_path_within_the_references_fp64_yardstick(gold, gold48, go
     print("%s %s worst: %s err %.2e (reference fp32: %.2e, bound %.2e)" % ((tag, mode) + worst))
 
 
+def assert_grads_within_fp64_yardstick(named_grads, goldg, tag, report=None):
+    """tests/golden/ref_m2track_grad.npz (generator: tests/golden/make_golden_m2track_grad.py): the gradient of the reference's
+    own M2TRACK loss (models/m2track.py:73-231) evaluated in DOUBLE precision, hard masks replayed, with the reference's own
+    fp32 gradient's distance to it stored per key.  Every parameter's gradient of the run under test must be within
+    max(2e-2, 3 x that yardstick) of the truth in relative L2 -- the rule tests/test_golden_trackers_b8.py holds BAT / P2B
+    to -- and so must the whole vector.  Keys whose true gradient is below 1e-6 of the whole norm (biases in front of a
+    BatchNorm: true gradient 0) only enter the whole-vector bound.  Tensors above 40 000 elements are stored as the
+    deterministic sample flat[::stride]; the whole-vector error weighs a sampled key's squared error by its stride."""
+    gn = float(goldg[tag + ".gradnorm64"])
+    keys = sorted(k[len(tag) + 8:] for k in goldg.files if k.startswith(tag + ".grad64."))
+    assert set(keys) == set(named_grads), sorted(set(keys) ^ set(named_grads))
+    rows, whole = [], 0.0
+    for k in keys:
+        stride = int(goldg["%s.stride.%s" % (tag, k)])
+        truth = goldg["%s.grad64.%s" % (tag, k)].astype(np.float64)
+        got = named_grads[k].detach().cpu().double().flatten()[::stride].numpy()
+        assert got.shape == truth.shape, (k, got.shape, truth.shape)
+        d2 = float(((got - truth) ** 2).sum())
+        whole += stride * d2
+        if float(goldg["%s.norm64.%s" % (tag, k)]) <= 1e-6 * gn:
+            continue
+        yard = float(goldg["%s.ref32err.%s" % (tag, k)])
+        rows.append((k, d2 ** 0.5 / float(np.linalg.norm(truth)), yard, max(2e-2, 3 * yard)))
+    yard = float(goldg[tag + ".ref32err_whole"])
+    rows.append(("WHOLE", whole ** 0.5 / gn, yard, max(2e-2, 3 * yard)))
+    if report is not None:
+        report.extend(rows)
+    bad = [r for r in rows if not r[1] <= r[3]]
+    assert not bad, ["%s: err %.2e, reference fp32 vs fp64 %.2e, bound %.2e" % r for r in bad]
+    return rows
+
+
+@pytest.fixture(scope="module")
+def goldg():
+    return np.load(os.path.join(ROOT, "tests", "golden", "ref_m2track_grad.npz"))
+
+
+def grad_fixture_batch(tag, gold, gold48, goldg):
+    """inputs of a tag of ref_m2track_grad.npz: the stored ones of the two older fixtures, or (benchmarked batch, 48 x 2 048
+    points: not stored) regenerated from open3dsot_amd/synth.py and checked against the digest the generator stored"""
+    if tag != "b48x2048":
+        return batch(gold if tag == "b8" else gold48)
+    import hashlib
+    from open3dsot_amd import synth
+    bt = synth.make_motion_batch(211, 48, point_sample_size=1024)
+    h = hashlib.sha256()
+    for k in sorted(bt):
+        h.update(k.encode())
+        h.update(np.ascontiguousarray(bt[k]).tobytes())
+    assert h.digest() == goldg[tag + ".in_sha256"].tobytes(), "synth.make_motion_batch(211, 48, 1024) is not the generator's batch"
+    return synth.to_torch(bt)
+
+
+@pytest.mark.parametrize("tag", ["b8", "b48", "b48x2048"])
+def test_m2track_flat_path_gradients_within_the_references_fp64_yardstick(gold, gold48, goldg, tag):
+    """CPU twin of tests/test_golden_m2track_gpu.py::test_gpu_m2track_gradients_...: the host mirror's autograd gradient of
+    loss_total against the reference model's own fp64 gradient, per parameter"""
+    net = build(gold, True)
+    b = grad_fixture_batch(tag, gold, gold48, goldg)
+    ld = net.compute_loss(b, net(b))
+    assert abs(float(ld["loss_total"].detach()) - float(goldg[tag + ".loss64"])) <= 1e-4 * (1 + float(goldg[tag + ".loss64"]))
+    ld["loss_total"].backward()
+    rows = assert_grads_within_fp64_yardstick({k: p.grad for k, p in net.named_parameters()}, goldg, tag)
+    worst = max(rows, key=lambda r: r[1] / r[3])
+    print("%s gradients, %d keys, worst: %s err %.2e (reference fp32: %.2e, bound %.2e); whole %.2e"
+          % ((tag, len(rows)) + worst + (rows[-1][1],)))
+
+
 @pytest.fixture(scope="module")
 def gold48():
     return np.load(os.path.join(ROOT, "tests", "golden", "ref_m2track_b48.npz"))

@@ -285,6 +285,105 @@ def _batch48_gradients_vs_fp64(model_name, host, tag, seed=4):
     assert cos > 0.995 and abs(ratio - 1) < 0.03, (cos, ratio)
 
 
+def oracle_forward(model_name, sd, host, dtype, train=True):
+    """CPU oracle forward in `dtype` (the index operators see the float32 coordinates either way) -> (end points, loss dict
+    incl. 'total', state dict after)"""
+    from open3dsot_amd import synth, trackers
+    sdx = {k: (v.detach().clone().to(dtype) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    b = {k: (v.to(dtype) if v.dtype.is_floating_point else v) for k, v in synth.to_torch(host).items()}
+    with torch.no_grad():
+        out = (torch_ref.bat_forward if model_name == "BAT" else torch_ref.p2b_forward)(sdx, b, train)
+        cfg = trackers.BAT_CAR if model_name == "BAT" else trackers.P2B_CAR
+        loss, ld = torch_ref.matching_loss(b, out, {k: v for k, v in cfg.items() if k.endswith("_weight")},
+                                           bat=model_name == "BAT")
+    return out, {k: float(v) for k, v in dict(ld, total=loss).items()}, sdx
+
+
+@pytest.mark.parametrize("model_name", ["P2B", "BAT"])
+def test_batch1_training_step_forward_losses_stats_gradients(model_name):
+    """BASELINE config 1's shape -- ONE template / search pair, 512 / 1 024 points, training mode (cfgs/P2B_Car.yaml with
+    batch 1; the `p2b_batch1` bench line times exactly this step): the split-K / 32-row tile plans, BatchNorm partial
+    lists of a single cloud and 128-column heads that no other training parity test reaches.  Sampling indices exact; every
+    end point, loss term and running statistic within max(1e-4, 3 x the fp32 CPU oracle's own distance to its fp64
+    evaluation) of the fp64 value (a BatchNorm over the 128 seeds of ONE pair amplifies rounding: the yardstick says how
+    much of the bound is used), and within 1e-3 of the fp32 oracle outright; every parameter gradient under the rule of
+    test_full_size_batch48_gradients_vs_fp64."""
+    from open3dsot_amd import fused_loss, synth
+    dev = torch.device("cuda", 0)
+    host = synth.make_batch(171, 1)
+    model = make_model(model_name, 6)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    batch = synth.to_torch(host, dev)
+    assert batch["template_points"].shape == (1, 512, 3) and batch["search_points"].shape == (1, 1024, 3)
+    out = model(batch)
+    data = dict(batch)
+    sidx = out["sample_idxs"][:, :out["estimation_cla"].shape[1]].long()
+    data["seg_label"] = batch["seg_label"].gather(1, sidx)
+    if model_name == "BAT":
+        data["points2cc_dist_s"] = batch["points2cc_dist_s"].gather(1, sidx[:, :, None].expand(-1, -1, 9))
+    total, ld = fused_loss.track_loss(model.config, data, out, with_bc=model_name == "BAT")
+    torch.cuda.synchronize()
+    ref32, ld32, sd32 = oracle_forward(model_name, sd, host, torch.float32)
+    ref64, ld64, sd64 = oracle_forward(model_name, sd, host, torch.float64)
+    assert np.array_equal(out["sample_idxs"].cpu().numpy(), ref32["sample_idxs"].numpy())
+    rows = []
+    for k in OUT_KEYS:
+        if k in ref64:
+            rows.append((k, rel(out[k], ref64[k]), rel(ref32[k], ref64[k]), rel(out[k], ref32[k])))
+    for k, v in ld64.items():
+        got = float(total) if k == "total" else float(ld[k])
+        rows.append(("loss." + k, abs(got - v) / (1 + abs(v)), abs(ld32[k] - v) / (1 + abs(v)), abs(got - ld32[k]) / (1 + abs(v))))
+    for k, v in model.state_dict().items():
+        if "running" in k:
+            rows.append((k, rel(v, sd64[k]), rel(sd32[k], sd64[k]), rel(v, sd32[k])))
+        elif "num_batches" in k:
+            assert int(v) == int(sd32[k]), k
+    worst = max(rows, key=lambda r: r[1] / max(1e-4, 3 * r[2]))
+    print("%s batch 1: %d quantities, worst vs fp64: %s err %.2e (fp32 oracle: %.2e; vs the fp32 oracle %.2e)"
+          % ((model_name, len(rows)) + worst))
+    bad = [r for r in rows if not (r[1] <= max(1e-4, 3 * r[2]) and r[3] <= 1e-3)]
+    assert not bad, bad
+    _batch48_gradients_vs_fp64(model_name, host, "B=1", seed=6)
+
+
+@pytest.mark.parametrize("model_name", ["P2B", "BAT"])
+def test_batch1_graph_replay_equals_eager_step(model_name):
+    """the captured batch-1 training step (what `bench.py --model p2b --batch 1` replays) on a NEW pair against an eager
+    forward + backward of a twin with the same weights and running statistics: loss and every parameter gradient"""
+    import copy
+    from open3dsot_amd import dist as D, synth, trackers
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(7)
+    model = trackers.get_model(model_name)().to(dev).train()
+    twin = copy.deepcopy(model)
+    b0, b1 = [synth.to_torch(synth.make_batch(960 + i, 1), dev) for i in range(2)]
+    step = D.DataParallelStep(model, optimizer=torch.optim.SGD(model.parameters(), lr=0.0), world=1, graph=True,
+                              graph_warmup=0, require_graph=True)
+    step.step(b0)
+    assert step.graph is not None, step.graph_error
+    loss_g = float(step.step(b1))
+    torch.cuda.synchronize()
+    grads_g = {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+    twin.training_loss(b0)
+    loss_e, _ = twin.training_loss(b1)
+    loss_e.backward()
+    assert abs(loss_g - float(loss_e)) <= 1e-5 * (1 + abs(float(loss_e))), (loss_g, float(loss_e))
+    top = max(float(p.grad.abs().max()) for p in twin.parameters() if p.grad is not None)
+    worst = 0.0
+    for k, p in twin.named_parameters():
+        if p.grad is None:
+            assert k not in grads_g
+            continue
+        scale = float(p.grad.abs().max())
+        if scale < 1e-4 * top:
+            assert float(grads_g[k].abs().max()) < 1e-3 * top, k
+            continue
+        err = float((grads_g[k] - p.grad).abs().max()) / scale
+        worst = max(worst, err)
+        assert err < 5e-3, (k, err)
+    print("%s batch 1, graph replay vs eager: worst per-parameter max-norm gradient difference %.1e" % (model_name, worst))
+
+
 def test_bat_dense_worst_case_batch48():
     """The worst case of the data-dependent work -- `synth.make_dense_batch`, the clouds `bench.py --dense` and the
     `bat_dense_worst_case` secondary line time: every ball of every set-abstraction level full of DISTINCT neighbours,
