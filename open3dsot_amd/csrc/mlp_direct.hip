@@ -638,13 +638,16 @@ extern "C" int o3d_direct_tail_override(int slots) { g_tail_override = slots; re
 
 extern "C" int o3d_direct_tail_slots(int M) {
     if (g_tail_override >= 0) return (M > 0 && M % DT_M == 0) ? g_tail_override : 0;
-    static int cus = 0;
-    if (cus == 0) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
-            n = 256;
-        cus = n;
+    // compute units of the CURRENT device, cached per device (round-5 advisor: one static cached the first caller's device)
+    static int cus_of[64] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (cus_of[dev] == 0) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus_of[dev] = n;
     }
+    const int cus = cus_of[dev];
     if (M <= 0 || M % DT_M != 0) return 0;
     const int slabs = M / DT_M;
     const int waves = slabs % 4 == 0 ? 4 : (slabs % 2 == 0 ? 2 : 1);

@@ -47,11 +47,17 @@ def shard_indices(step, rank, world, per_rank_batch):
 
 
 def _defer_wgrads():
-    if torch.cuda.is_available():
-        from . import fused_heads
-        return fused_heads.defer_wgrads()
+    """the backward's scope: the heads' weight gradients in grouped launches (fused_heads.defer_wgrads) and the weight-gradient
+    side branch (fused.wgrad_branch: the set-abstraction levels' wgrad launches on a second stream / graph branch, joined when
+    the scope ends, i.e. before anything reads a gradient)"""
     import contextlib
-    return contextlib.nullcontext()
+    if not torch.cuda.is_available():
+        return contextlib.nullcontext()
+    from . import fused, fused_heads
+    stack = contextlib.ExitStack()
+    stack.enter_context(fused.wgrad_branch())          # exits LAST: joins after the heads' final flush
+    stack.enter_context(fused_heads.defer_wgrads())
+    return stack
 
 
 class FlatBatch(dict):

@@ -16,6 +16,7 @@ statistics exactly like torch.nn.BatchNorm2d (biased variance to normalise, unbi
 running_var, momentum 0.1); the NEXT kernel applies BN+ReLU while loading.  Saved for
 backward: Y_l and four per-channel vectors per layer, plus arg-max of the pool.
 """
+import contextlib
 import ctypes
 
 import torch
@@ -359,6 +360,86 @@ def _const_vec(dev, n, value):
 _CONST = {}
 
 
+# ---- weight gradients on a second branch of the step (round 6) ---------------------------------------------------------
+# The weight gradient of a layer is a LEAF of the backward: nothing in the step reads dW_l before the optimizer, while the
+# data gradient of the same layer heads the critical chain  dgrad_l -> bn_bwd_finalize_{l-1} -> dgrad_{l-1} -> ...  (a chain of
+# launches with wave-quantised tails and ~7 us dependent finalizes during which most of the chip idles).  Inside
+# `wgrad_branch()` -- DataParallelStep wraps loss.backward() in it -- the wgrad launches (+ their slice reductions, the layer-0
+# per-point weight gradient and its centre term) go to a SIDE stream forked from the launch stream behind the layer's
+# bn_bwd_finalize; the scope's end joins it.  Captured into the step's HIP graph the fork/join are graph edges: the wgrad
+# nodes form a second branch that the hardware schedules into the main chain's idle slots.
+# Soundness = the contract of fused_heads.defer_wgrads (the gradient tensors autograd is handed are FILLED LATER): a parameter
+# that already holds a gradient or carries hooks is never branched (`_deferrable`), a parameter met twice in one scope joins
+# first, and everything a side launch reads is kept alive in the scope until the join (a tensor freed on the launch stream
+# could be handed out again while the side launch still reads it).
+_WGRAD_BRANCH = {"on": True}       # tools/ab_hook.py fused._WGRAD_BRANCH.on flips it for the same-box A/B; tests run both
+_BRANCH = {"scope": None, "last_launches": 0}      # last_launches: side-branch forks of the scope that closed last (tests)
+_SIDE_STREAMS = {}
+
+
+def set_wgrad_branch(enabled):
+    _WGRAD_BRANCH["on"] = bool(enabled)
+
+
+def _branch_join(sc):
+    if sc["side"] is not None and sc["forked"]:
+        sc["main"].wait_stream(sc["side"])
+    sc["forked"] = False
+    sc["keep"] = []
+    sc["keys"] = set()
+
+
+@contextlib.contextmanager
+def wgrad_branch():
+    if not _WGRAD_BRANCH["on"] or _BRANCH["scope"] is not None or not torch.cuda.is_available():
+        yield
+        return
+    sc = _BRANCH["scope"] = {"main": None, "side": None, "keep": [], "keys": set(), "forked": False, "launches": 0}
+    try:
+        yield
+    finally:
+        _BRANCH["scope"] = None
+        _BRANCH["last_launches"] = sc["launches"]
+        _branch_join(sc)
+
+
+def branch_join():
+    """the launch stream waits for everything the open scope has put on the side branch (no-op without one)"""
+    if _BRANCH["scope"] is not None:
+        _branch_join(_BRANCH["scope"])
+
+
+def _branch_side(params, keep):
+    """-> the side stream the weight-gradient launches of `params` may go to (forked behind everything the launch stream
+    has been given so far), or None: launch inline.  keep: every tensor those launches read or use as scratch."""
+    sc = _BRANCH["scope"]
+    if sc is None:
+        return None
+    from .fused_heads import _deferrable
+    params = [p for p in params if p is not None]
+    if not _deferrable(params):
+        return None
+    main = torch.cuda.current_stream()
+    if sc["main"] is None:
+        key = (main.device.index, main.cuda_stream)
+        side = _SIDE_STREAMS.get(key)
+        if side is None:
+            side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=main.device)
+        sc["main"], sc["side"] = main, side
+    elif main != sc["main"]:
+        return None
+    keys = {id(p) for p in params}
+    if sc["keys"] & keys:      # second use of a parameter: autograd ADDS this gradient to the first as soon as the backward
+        _branch_join(sc)       # returns -- the first must be complete, and this one is launched inline
+        return None
+    sc["keys"] |= keys
+    sc["side"].wait_stream(main)
+    sc["keep"].append(keep)
+    sc["forked"] = True
+    sc["launches"] += 1
+    return sc["side"]
+
+
 # ---- the autograd function ---------------------------------------------------------------
 class _Cfg:
     __slots__ = ("nxyz", "inv_radius", "training", "bns", "eps", "momentum", "centers")
@@ -545,6 +626,7 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         if need_bwd:
             ctx.cfg = cfg
             ctx.versions = _versions(params)
+            ctx.wparams = [params[3 * l] for l in range(L)]       # (identity only: which parameter a weight gradient belongs to)
             # weights as the backward's GEMMs want them: W_l^T for the data gradients, W0^T padded to 64 rows
             ctx.Wts = [None] + [prep.get(params[3 * l], Ws[l].shape[1], Ws[l].shape[0], transpose=True) for l in range(1, L)]
             want_in = any(ctx.needs_input_grad[2:2 + 4 * nseg])
@@ -676,33 +758,42 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
                           npoints[0], Npads[0], npoints[-1], Npads[-1], Cout, S.data_ptr(), _ptr(T), st)
                 one, zero = _const_vec(dev, Cout, 1.0), _const_vec(dev, Cout, 0.0)
                 Cinm = X0n.shape[0]                  # rows of the padded per-point operand
-                if Cinm % 64 == 0:       # aligned: the tile-matched MFMA weight-gradient kernel, X as stored
+                aligned = Cinm % 64 == 0
+                if aligned:       # the tile-matched MFMA weight-gradient kernel, X as stored
                     wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cinm, Cout, ldz),), device=dev, dtype=f32)
                     dWm = torch.empty((Cout, Cinm), device=dev, dtype=f32)
-                    _call("conv_wgrad_points", 2.0 * Cinm * Cout * ldz, lib.o3d_mlp_conv_wgrad2, S.data_ptr(), None, 4,
-                          S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(), None, None, 1,
-                          Cinm, Cout, ldz, wpart.data_ptr(), dWm.data_ptr(), st, dims=(Cinm, Cout, True))
                 else:
                     tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
                     total_chunks = ldz // 32
                     nsl = max(1, min(total_chunks // 4 if total_chunks >= 4 else 1, 768 // tiles))
                     wpart = torch.empty((nsl + 16, Cout, Cin), device=dev, dtype=f32)
                     dWm = torch.empty((Cout, Cin), device=dev, dtype=f32)
-                    _call("conv_wgrad_points", 2.0 * Cin * Cout * ldz, lib.o3d_mlp_conv_wgrad, S.data_ptr(), None, None,
-                          None, 4, S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(), None,
-                          None, None, None, None, None, 0, 0, 0, 1.0, 1, Cin, Cout, ldz, nsl, wpart.data_ptr(),
-                          dWm.data_ptr(), st)
-                if nxyz and dWm.shape[1] != Cin:
-                    # the centre term of grouped_xyz = xyz[idx] - new_xyz and the compaction of the padded rows in one
-                    # launch (was: the term in place, then a strided torch copy of dWm[:, :Cin])
-                    dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
-                    _call("center_term", 0.0, lib.o3d_center_term_out, T.data_ptr(), centers.data_ptr(), Cout, nballs,
-                          dWm.shape[1], dWm.data_ptr(), Cin, dW.data_ptr(), st)
-                else:
-                    if nxyz:      # the centre term of grouped_xyz = xyz[idx] - new_xyz
-                        _call("center_term", 0.0, lib.o3d_center_term, T.data_ptr(), centers.data_ptr(), Cout, nballs,
-                              dWm.shape[1], dWm.data_ptr(), st)
-                    dW = dWm if dWm.shape[1] == Cin else dWm[:, :Cin].contiguous()
+                fold = bool(nxyz) and dWm.shape[1] != Cin
+                dW = torch.empty((Cout, Cin), device=dev, dtype=f32) if fold else None
+                # dW0 is a leaf: the per-point weight gradient and its centre term on the side branch (the data gradient
+                # W0^T . S below, which the next level's backward waits for, stays on the launch stream)
+                side = _branch_side([ctx.wparams[0]], (S, T, wpart, dWm, dW, one, zero, ctx.saved))
+                st0 = side.cuda_stream if side is not None else st
+                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                    if aligned:
+                        _call("conv_wgrad_points", 2.0 * Cinm * Cout * ldz, lib.o3d_mlp_conv_wgrad2, S.data_ptr(), None, 4,
+                              S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(), None, None, 1,
+                              Cinm, Cout, ldz, wpart.data_ptr(), dWm.data_ptr(), st0, dims=(Cinm, Cout, True))
+                    else:
+                        _call("conv_wgrad_points", 2.0 * Cin * Cout * ldz, lib.o3d_mlp_conv_wgrad, S.data_ptr(), None, None,
+                              None, 4, S.data_ptr(), one.data_ptr(), zero.data_ptr(), zero.data_ptr(), X0n.data_ptr(), None,
+                              None, None, None, None, None, 0, 0, 0, 1.0, 1, Cin, Cout, ldz, nsl, wpart.data_ptr(),
+                              dWm.data_ptr(), st0)
+                    if fold:
+                        # the centre term of grouped_xyz = xyz[idx] - new_xyz and the compaction of the padded rows in one
+                        # launch (was: the term in place, then a strided torch copy of dWm[:, :Cin])
+                        _call("center_term", 0.0, lib.o3d_center_term_out, T.data_ptr(), centers.data_ptr(), Cout, nballs,
+                              dWm.shape[1], dWm.data_ptr(), Cin, dW.data_ptr(), st0)
+                    else:
+                        if nxyz:      # the centre term of grouped_xyz = xyz[idx] - new_xyz
+                            _call("center_term", 0.0, lib.o3d_center_term, T.data_ptr(), centers.data_ptr(), Cout, nballs,
+                                  dWm.shape[1], dWm.data_ptr(), st0)
+                        dW = dWm if dWm.shape[1] == Cin else dWm[:, :Cin].contiguous()
                 grads[0] = dW
                 if want_xyz or want_feats:
                     # dX = W0^T . S as a plain forward GEMM on the direct MFMA kernel: rows padded to a multiple of 64
@@ -744,9 +835,12 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             flops = (2.0 * Cin * Cout, meta, ldp)      # executed FLOPs = per live column (count read back when profiling)
             dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
             wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, ldp),), device=dev, dtype=f32)
-            _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
-                  Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Cin, Cout, ldp,
-                  cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(), dW.data_ptr(), st, dims=(Cin, Cout))
+            side = _branch_side([ctx.wparams[l]], (dN, coef, wpart, ctx.saved))
+            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
+                      Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Cin, Cout, ldp,
+                      cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(), dW.data_ptr(),
+                      side.cuda_stream if side is not None else st, dims=(Cin, Cout))
             grads[3 * l] = dW
             Wt = ctx.Wts[l]
             dNp = torch.empty((Cin, ldp), device=dev, dtype=f32)
@@ -966,8 +1060,11 @@ def sa_pair_sampled(grouper, mlp, a, b):
         return None
     dev, f32, i32 = xyz_a.device, torch.float32, torch.int32
     xa, xb = xyz_a.detach().contiguous(), xyz_b.detach().contiguous()
-    for si in (si_a, si_b):
-        if si is not None and not (si.dtype == i32 and si.is_contiguous()):
+    # sample_query_kernel reads sidx[b * npoint + j]: exactly a contiguous (B, npoint) int32 tensor on the clouds' device (a
+    # prefetched or caller-supplied index of another width, batch or device takes the operator-by-operator route, which
+    # follows idx.shape)
+    for si, npt in ((si_a, np_a), (si_b, np_b)):
+        if si is not None and not (si.dtype == i32 and si.is_contiguous() and tuple(si.shape) == (B, npt) and si.device == dev):
             return None
     nb_a, nb_b = B * np_a, B * np_b
     centers = torch.empty((nb_a + nb_b + 1, 3), device=dev, dtype=f32)

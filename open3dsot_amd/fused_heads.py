@@ -61,14 +61,27 @@ def _flush_jobs(jobs, st):
         _call("pw_conv_wgrad", sum(j[0] for j in chunk), lib.o3d_mlp_conv_wgrad2_group, ctypes.addressof(arr), len(chunk), st)
 
 
-def _flush_queue():
+def _flush_queue(early=False):
+    """early: a full group of jobs while the scope is still open -- launched on the weight-gradient side branch when one is
+    open (open3dsot_amd/fused.py::wgrad_branch), beside the rest of the backward instead of behind it; the parameter keys stay
+    recorded, so that a later second use of one of these parameters still finds it"""
     q = _DEFER["queue"]
-    _DEFER["queue"], _DEFER["keys"] = [], set()
+    _DEFER["queue"] = []
+    if not early:
+        _DEFER["keys"] = set()
     by_stream = {}
     for jobs, keep, st in q:
         by_stream.setdefault(st, []).extend(jobs)
     for st, jobs in by_stream.items():
-        _flush_jobs(jobs, st)
+        side = None
+        if early and st == _stream():
+            from . import fused
+            side = fused._branch_side([], q)       # (the scope keeps `q` -- the operands -- alive until the join)
+        if side is not None:
+            with torch.cuda.stream(side):
+                _flush_jobs(jobs, side.cuda_stream)
+        else:
+            _flush_jobs(jobs, st)
     del q
 
 
@@ -103,8 +116,12 @@ def _submit_jobs(jobs, keep, st, params):
     _DEFER["queue"].append((jobs, keep, st))      # (the queue keeps the operands alive until the flush)
     if (_DEFER["keys"] & keys) or not _deferrable(params):
         _flush_queue()
+        from . import fused
+        fused.branch_join()         # an earlier group with this parameter may be running on the side branch
     else:
         _DEFER["keys"] |= keys
+        if sum(len(e[0]) for e in _DEFER["queue"]) >= _MAXJOBS:
+            _flush_queue(early=True)
 
 
 @contextlib.contextmanager

@@ -138,6 +138,10 @@ class FusedPointwiseChain(torch.autograd.Function):
                 ctx.Wts = [None] + [prep.get(params[4 * l], Ws[l].shape[1], Ws[l].shape[0], transpose=True) for l in range(1, L)]
             ctx.cfg = cfg
             ctx.versions = _versions(params)
+            if X0.data_ptr() == x.data_ptr():
+                # X0 ALIASES the caller's storage (a view of the producing stack's flat buffer, no copy): an in-place write to
+                # that tensor between forward and backward would silently corrupt dW0 and dX -- tracked like the parameters
+                ctx.versions.append((x, x._version))
             ctx.dims = (B, N, L)
             ctx.has_bias = [b is not None for b in biases]
             ctx.has_cbias = cbias is not None

