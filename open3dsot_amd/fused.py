@@ -372,7 +372,13 @@ _CONST = {}
 # that already holds a gradient or carries hooks is never branched (`_deferrable`), a parameter met twice in one scope joins
 # first, and everything a side launch reads is kept alive in the scope until the join (a tensor freed on the launch stream
 # could be handed out again while the side launch still reads it).
-_WGRAD_BRANCH = {"on": True}       # tools/ab_hook.py fused._WGRAD_BRANCH.on flips it for the same-box A/B; tests run both
+# MEASURED AND NOT KEPT AS THE DEFAULT (profiles/r06_ab_wgrad_branch.txt, same-box alternating A/B on the final kernels): the
+# branch overlaps 1.07 ms of kernel time per BAT step (sum of kernel durations 6.57 ms against a busy union of 5.11; without
+# it 5.50 / 5.20) and the busy time does shrink by 0.09 ms -- the tails are filled -- but every fork / join is a cross-queue
+# dependency of the replayed graph (~7-10 us each, 14 forks per step) and the overlapped kernels stretch (the 14 slice
+# reductions 0.11 -> 0.36 ms): BAT 5.31 -> 5.39 ms, P2B 8.71 -> 8.79, M2-Track 6.30 -> 6.52.  The mechanism stays as a tested
+# switch (tests/test_model_gpu.py::test_wgrad_side_branch_equals_inline_launches), off.
+_WGRAD_BRANCH = {"on": False}      # tools/ab_hook.py fused._WGRAD_BRANCH.on flips it for the same-box A/B; tests run both
 _BRANCH = {"scope": None, "last_launches": 0}      # last_launches: side-branch forks of the scope that closed last (tests)
 _SIDE_STREAMS = {}
 

@@ -8,6 +8,7 @@ each cloud ("gmax", AdaptiveMaxPool1d(1)).  Parameters stay in the caller's nn.C
 modules.  A Conv1d bias in front of a training-mode BatchNorm cancels in the output and has zero
 gradient; it only shifts the running mean, which is updated accordingly.
 """
+import contextlib
 import ctypes
 
 import torch
@@ -143,6 +144,9 @@ class FusedPointwiseChain(torch.autograd.Function):
                 # that tensor between forward and backward would silently corrupt dW0 and dX -- tracked like the parameters
                 ctx.versions.append((x, x._version))
             ctx.dims = (B, N, L)
+            # (identity only: which parameter a weight gradient belongs to; a sliced weight -- chain_cloud's W[:, :C] -- is not
+            # a leaf autograd merely stores, so it is never branched)
+            ctx.wparams = [params[4 * l] if isinstance(params[4 * l], torch.nn.Parameter) else None for l in range(L)]
             ctx.has_bias = [b is not None for b in biases]
             ctx.has_cbias = cbias is not None
             ctx.saved = (X0, Ws, gammas, Ys, means, invstds, scales, shifts, out.detach() if cfg.mode != "act" else None,
@@ -233,9 +237,14 @@ class FusedPointwiseChain(torch.autograd.Function):
                 wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, P),), device=dev, dtype=f32)
                 xs = (X0.data_ptr(), None, None) if l == 0 else \
                      (Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr())
-                _call("pw_conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2, _ptr(dN), _ptr(pk) if dN is None else None,
-                      N if dN is None else 4, Ys[l].data_ptr(), A[0], A[1],
-                      A[2], xs[0], xs[1], xs[2], 1, Cin, Cout, P, wpart.data_ptr(), dW.data_ptr(), st, dims=(Cin, Cout))
+                # the weight gradient is a leaf of the backward: on the side branch when one is open (fused.wgrad_branch)
+                from .fused import _branch_side
+                side = _branch_side([ctx.wparams[l]], (dN, pk, coef, wpart, ctx.saved)) if ctx.wparams[l] is not None else None
+                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                    _call("pw_conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2, _ptr(dN), _ptr(pk) if dN is None else None,
+                          N if dN is None else 4, Ys[l].data_ptr(), A[0], A[1],
+                          A[2], xs[0], xs[1], xs[2], 1, Cin, Cout, P, wpart.data_ptr(), dW.data_ptr(),
+                          side.cuda_stream if side is not None else st, dims=(Cin, Cout))
             else:
                 tiles = ((Cin + 127) // 128) * ((Cout + 127) // 128)
                 nsl = max(1, min(P // 32 // 4, 768 // tiles))
