@@ -882,6 +882,7 @@ def test_wgrad_side_branch_equals_inline_launches(model_name, graph):
     twin = copy.deepcopy(model)
     b0, b1 = [synth.to_torch(synth.make_batch(970 + 6 * i, 6, 256, 512), dev) for i in range(2)]
     res = {}
+    was = fused._WGRAD_BRANCH["on"]
     for on, m in ((True, model), (False, twin)):
         fused.set_wgrad_branch(on)
         fused._BRANCH["last_launches"] = 0
@@ -894,7 +895,7 @@ def test_wgrad_side_branch_equals_inline_launches(model_name, graph):
             torch.cuda.synchronize()
             assert (step.graph is not None) == graph, step.graph_error
         finally:
-            fused.set_wgrad_branch(True)
+            fused.set_wgrad_branch(was)
         assert (forks > 0) == on, (on, forks)
         res[on] = (loss, {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
     (la, ga), (lb, gb) = res[True], res[False]
