@@ -622,7 +622,7 @@ __device__ __forceinline__ void pool_bwd_dense_item(const PoolBwdDense& a, const
 }
 
 // PERSISTENT grid (round 5): two thirds of a worst-case grid over (chunks x channel groups) are workgroups whose chunk is dead on
-// real crops -- up to 49 000 per launch here, and a dead workgroup still costs its dispatch (section 7d of DESIGN.md).  A fixed
+// real crops -- up to 49 000 per launch here, and a dead workgroup still costs its dispatch (section 7d of HISTORY.md).  A fixed
 // number of workgroups walks the LIVE items instead (counts from the device-side meta), channel group fastest so that
 // neighbouring workgroups share a chunk's index lines.
 __global__ __launch_bounds__(256) void pool_bwd_dense_kernel(PoolBwdDense a) {

@@ -45,7 +45,7 @@ namespace {
 
 constexpr int BN_POS = 128;  // positions per workgroup tile (forward / dgrad)
 constexpr int BK = 16;       // channel chunk (forward / dgrad)
-constexpr int LDMK = BK + 4; // [row][k] LDS stride (conflict-free ds_read_b128)
+constexpr int LDMK = BK + 4; // [row][k] LDS stride (conflict-free ds_read_b128, see HISTORY.md section 5b)
 constexpr int WBK = 32;      // position chunk of the weight-gradient kernel
 constexpr int WLD = WBK + 4;
 

@@ -560,7 +560,7 @@ void splitk_gemm_pair_kernel(DirectArgs a0, DirectArgs a1) {
 
 // which problems take the split-K tile: 64-column partial rows (the caller's `tile`), K in whole pairs of 8-k groups with
 // at least one pair per wave, and at most splitk_max() output elements in the worst case (beyond that the 8 row slabs of a
-// column tile re-reading their B panel from L2 costs more than the shorter chains gain: DESIGN.md section 7c)
+// column tile re-reading their B panel from L2 costs more than the shorter chains gain: HISTORY.md section 7c)
 // (measured, same-box A/B of a BAT step: 0 -> 5.73 / 5.76 ms, 4 M (the heads only) -> 5.60, 16 M -> 5.50 / 5.54)
 static long splitk_max() { return 16L << 20; }
 static bool splitk_ok(const DirectArgs& a, int tile) {

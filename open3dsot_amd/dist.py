@@ -166,7 +166,7 @@ class DataParallelStep:
         self._static_grads = None      # the gradient tensors the captured backward writes (graph pool)
         self._eager_steps = 0
         self._buffers = [b for b in model.buffers()]
-        # sampling prefetch: the farthest-point-sampling indices of batch t+1 are computed on a second
+        # sampling prefetch (HISTORY.md section 7): the farthest-point-sampling indices of batch t+1 are computed on a second
         # stream while the graph of step t replays -- 766 strictly serial rounds on 96 of 1024 SIMDs otherwise head every
         # step with the rest of the chip idle.  prefetch_sampling=False keeps the sampling inside the captured step (what
         # tests/test_model_gpu.py::test_sampling_prefetch_* compares against).
@@ -332,7 +332,7 @@ class DataParallelStep:
                     if self.require_graph:
                         raise RuntimeError("HIP-graph capture of the training step failed: " + self.graph_error) from e
                     # loudly: an eager step is several times slower on the launch-bound models, and a failed capture went
-                    # unnoticed for two rounds on M2-Track
+                    # unnoticed for two rounds on M2-Track (HISTORY.md 8b)
                     import warnings
                     warnings.warn("open3dsot_amd: HIP-graph capture of the training step failed, running eagerly (%s)"
                                   % self.graph_error.splitlines()[0][:300], RuntimeWarning, stacklevel=2)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """tools/asm_waits.py file.s [...]: per kernel the static count of global loads / stores, `s_waitcnt vmcnt(0)` and
 scratch (spill) instructions -- many full waits next to as many loads is the signature of a serialised
-load -> wait -> use chain (what the direct GEMM epilogue had: DESIGN.md section 7)."""
+load -> wait -> use chain (what the direct GEMM epilogue had: HISTORY.md section 7)."""
 import re
 import sys
 

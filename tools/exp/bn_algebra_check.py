@@ -1,4 +1,4 @@
-"""CPU check of DESIGN.md section 9.1: the data gradient of an inner layer WITHOUT reading the layer's own output Y.
+"""CPU check of HISTORY.md (round 1-2) section 9.1: the data gradient of an inner layer WITHOUT reading the layer's own output Y.
 
     layer:   Y = W X            X = relu(bn(Y_prev)) >= 0, (Cin, L) columns with class weights w (first hit of a ball
                                 carries its padding copies)

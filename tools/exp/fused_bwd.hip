@@ -1,6 +1,6 @@
 // tools/exp/fused_bwd.hip -- EXPERIMENT (not built into the library): data gradient + weight gradient of one
 // aligned inner layer of the grouped MLP in ONE kernel, for the HBM-bound 64-channel layers of SA1
-// (DESIGN.md section 9.2).
+// (HISTORY.md (round 1-2) section 9.2).
 //
 // Today (csrc/mlp_direct.hip + csrc/mlp_wgrad.hip) the two gradients are two launches that each read dN and Y
 // (2*Cout rows) plus Yprev (Cin rows): (4*Cout + 2*Cin + Cin) * 4 B per column.  Here one staging of

@@ -1,4 +1,4 @@
-// Probe for DESIGN.md section 9.2: the layer-0 backward reduce (S[c,n] = sum of dY0 over the columns that reference
+// Probe for HISTORY.md (round 1-2) section 9.2: the layer-0 backward reduce (S[c,n] = sum of dY0 over the columns that reference
 // point n, T[c,ball] = sum over the ball's columns) WITHOUT LDS float atomics.
 //
 //   variant A (what csrc/compact.hip::reduce_c_kernel does today): per column one ds_add_f32 into S, in-lane folded

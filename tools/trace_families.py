@@ -1,4 +1,4 @@
-"""The per-step breakdown of tools/trace_steps.py summed by kernel FAMILY (the rows DESIGN.md section 7b quotes).
+"""The per-step breakdown of tools/trace_steps.py summed by kernel FAMILY (the rows HISTORY.md section 7b quotes).
 usage: trace_families.py <steady_state_per_step.txt>"""
 import re
 import sys
