@@ -273,6 +273,13 @@ int o3d_mlp_conv_wgrad2_c(const float* dN, const float* Y, const float* A1, cons
                           const float* X, const float* in_scale, const float* in_shift, int Cin, int Cout,
                           long ldp, const float* w, const int32_t* meta, long start1, float* scratch, float* dW,
                           void* stream);
+/* Round 6 (experiment of the round-5 review's item 2-ii, kept as a tested switch): the same weight-gradient launch, which also
+ * WRITES the operand it stages -- dY = A1*dN + w*(A2*Y + A3), (Cout, ldp), live columns only -- so that the data gradient
+ * o3d_mlp_conv_dgrad_c can be given that one tensor (dN = dY, Y = NULL: A1..A3 ignored) instead of rebuilding dY from dN and Y. */
+int o3d_mlp_conv_wgrad2_c_dy(const float* dN, const float* Y, const float* A1, const float* A2, const float* A3,
+                             const float* X, const float* in_scale, const float* in_shift, int Cin, int Cout,
+                             long ldp, const float* w, const int32_t* meta, long start1, float* scratch, float* dW,
+                             float* dY, void* stream);
 
 /* BatchNorm finalize kernels reading only the live partial rows (meta[0] / tile); per segment: pass the
  * segment's first partial row and its meta block. */

@@ -1179,7 +1179,8 @@ extern "C" int o3d_mlp_conv_dgrad_c(const float* dN, const float* Y, const float
                                     const float* scale_p,
                                     const float* shift_p, const float* mean_p, float* dNprev, float* part,
                                     void* stream) {
-    if (!dN || !Y || !A1 || !A2 || !A3 || !Wt || !w || !meta || !Yprev || !scale_p || !shift_p || !mean_p ||
+    // Y == NULL (then A1..A3 are ignored): dN is the finished dY of o3d_mlp_conv_wgrad2_c_dy
+    if (!dN || (Y && (!A1 || !A2 || !A3)) || !Wt || !w || !meta || !Yprev || !scale_p || !shift_p || !mean_p ||
         !dNprev || !part || ldp <= 0 || ldp > 0x7fffffff || !o3d_direct_ok(Cin, Cout, (int)ldp) ||
         (tile != 64 && tile != 128))
         return O3D_EINVAL;

@@ -696,6 +696,8 @@ int o3d_direct_dgrad(const float* dN, const float* pk, int ns,
     a.Out = dNprev; a.M = Cin; a.K = Cout; a.P = P; a.B = B; a.part = part;
     a.Yprev = Yprev; a.scale_p = scale_p; a.shift_p = shift_p; a.mean_p = mean_p;
     if (meta && tile == 128 && B == 1 && dN) { a.tail_slots = o3d_direct_tail_slots(Cin); a.extra_row0 = P / 128; }
+    // Y == NULL: `dN` already IS dY (written once by o3d_mlp_conv_wgrad2_c_dy): one operand tensor, no constants
+    if (dN && !Y) { a.c1 = a.c2 = a.c3 = nullptr; return launch_direct<B_PLAIN, 1>(a, tile, st); }
     return dN ? launch_direct<B_DY, 1>(a, tile, st) : launch_direct<B_DYPOOL, 1>(a, tile, st);
 }
 

@@ -32,6 +32,8 @@ struct Wgrad2Args {
     const int32_t* meta;   // compact layout: 4 device ints per segment, meta[4*s] = live columns of segment s
     long start1;           // first column of segment 1 (0 = one segment); its per-channel constants follow
                            // segment 0's (A1..A3 after Cout floats, in_scale/in_shift after Cin floats)
+    float* dY_out;         // (Cout, P) or NULL: the staged operand dY = A1*dN + w*(A2*Y + A3) of the live columns written out
+                           // ONCE (by the workgroups of input tile 0), so that the data gradient can load one tensor
 };
 
 template <int TM, int TN, int POOLED>
@@ -110,10 +112,13 @@ __device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, const int bid, 
     float4 rg[PA], ry[PA], rx[PB];
     float4 rw = make_float4(1.f, 1.f, 1.f, 1.f);
     int rk = 0;
+    float* const dyo = (!POOLED && ci0 == 0) ? a.dY_out : nullptr;
+    long dy_ofs = 0;                                 // element (first staging row of this thread, its 4 columns) of the loaded chunk
     auto load_chunk = [&](int chl) {
         const long chg = col0 / CP + chl;            // chunk index in the whole column space
         const long b = chg / chunks_per_b;
         const int p = (int)(chg - b * chunks_per_b) * CP + 4 * c4;
+        dy_ofs = (b * a.Cout + co0 + r0) * (long)a.P + p;
         if (a.w) rw = *reinterpret_cast<const float4*>(&a.w[b * a.P + p]);
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
@@ -148,6 +153,7 @@ __device__ __forceinline__ void wgrad2_body(const Wgrad2Args& a, const int bid, 
             o.x = fmaf(ka1[i], g.x, rw.x * fmaf(ka2[i], ry[i].x, ka3[i])); o.y = fmaf(ka1[i], g.y, rw.y * fmaf(ka2[i], ry[i].y, ka3[i]));
             o.z = fmaf(ka1[i], g.z, rw.z * fmaf(ka2[i], ry[i].z, ka3[i])); o.w = fmaf(ka1[i], g.w, rw.w * fmaf(ka2[i], ry[i].w, ka3[i]));
             *reinterpret_cast<float4*>(&As(buf)[(r0 + RPP * i) * LD + 4 * c4]) = o;
+            if (dyo) *reinterpret_cast<float4*>(&dyo[dy_ofs + (long)(RPP * i) * a.P]) = o;
         }
 #pragma unroll
         for (int i = 0; i < PB; ++i) {
@@ -595,7 +601,7 @@ extern "C" long o3d_mlp_conv_wgrad2_scratch(int B, int Cin, int Cout, int P) {
 static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y, const float* A1, const float* A2,
                        const float* A3, const float* X, const float* in_scale, const float* in_shift, int B, int Cin,
                        int Cout, int P, const float* w, const int32_t* meta, long start1, float* scratch, float* dW,
-                       void* stream);
+                       void* stream, float* dY_out = nullptr);
 
 extern "C" int o3d_mlp_conv_wgrad2(const float* dN, const float* pk, int ns, const float* Y, const float* A1,
                                    const float* A2, const float* A3, const float* X, const float* in_scale,
@@ -615,10 +621,21 @@ extern "C" int o3d_mlp_conv_wgrad2_c(const float* dN, const float* Y, const floa
                        scratch, dW, stream);
 }
 
+// the same launch, which also writes the operand it stages -- dY = A1*dN + w*(A2*Y + A3), (Cout, ldp), live columns only --
+// so that o3d_mlp_conv_dgrad_c can be given ONE tensor (dN = dY, Y = NULL) instead of rebuilding dY from two
+extern "C" int o3d_mlp_conv_wgrad2_c_dy(const float* dN, const float* Y, const float* A1, const float* A2,
+                                        const float* A3, const float* X, const float* in_scale, const float* in_shift,
+                                        int Cin, int Cout, long ldp, const float* w, const int32_t* meta, long start1,
+                                        float* scratch, float* dW, float* dY, void* stream) {
+    if (!dN || !w || !meta || !dY || ldp <= 0 || ldp > 0x7fffffff || start1 < 0 || start1 % 256 != 0) return O3D_EINVAL;
+    return wgrad2_impl(dN, nullptr, 4, Y, A1, A2, A3, X, in_scale, in_shift, 1, Cin, Cout, (int)ldp, w, meta, start1,
+                       scratch, dW, stream, dY);
+}
+
 static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y, const float* A1, const float* A2,
                        const float* A3, const float* X, const float* in_scale, const float* in_shift, int B, int Cin,
                        int Cout, int P, const float* w, const int32_t* meta, long start1, float* scratch, float* dW,
-                       void* stream) {
+                       void* stream, float* dY_out) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || Cin % 64 || Cout % 64 || P <= 0 || P % 64 || !Y || !A1 || !A2 || !A3 ||
         !X || (in_scale == nullptr) != (in_shift == nullptr) || !scratch || !dW || (!dN && (!pk || ns < 4 || ns % 4)))
         return O3D_EINVAL;
@@ -632,7 +649,7 @@ static int wgrad2_impl(const float* dN, const float* pk, int ns, const float* Y,
     a.chunks_per_block = (a.total_chunks + nsl - 1) / nsl;
     a.nslices = nsl;
     a.part = scratch;
-    a.w = w; a.meta = meta; a.start1 = start1;
+    a.w = w; a.meta = meta; a.start1 = start1; a.dY_out = dY_out;
     hipStream_t s = o3d_stream(stream);
     int rc;
     if (TM == 128 && TN == 128) rc = launch_wgrad2<128, 128>(a, s);

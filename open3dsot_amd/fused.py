@@ -71,6 +71,7 @@ capi.register("o3d_mlp_conv_fwd_c", [_vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _
 capi.register("o3d_mlp_conv_dgrad_c", [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _l, _i, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp])
 capi.register("o3d_mlp_conv_wgrad2_c", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _l, _vp, _vp, _vp])
+capi.register("o3d_mlp_conv_wgrad2_c_dy", [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _l, _vp, _vp, _l, _vp, _vp, _vp, _vp])
 capi.register("o3d_bn_finalize_c", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp])
 capi.register("o3d_bn_bwd_finalize_c", [_vp, _i, _i, _d, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp])
 
@@ -841,18 +842,29 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             flops = (2.0 * Cin * Cout, meta, ldp)      # executed FLOPs = per live column (count read back when profiling)
             dW = torch.empty((Cout, Cin), device=dev, dtype=f32)
             wpart = torch.empty((lib.o3d_mlp_conv_wgrad2_scratch(1, Cin, Cout, ldp),), device=dev, dtype=f32)
-            side = _branch_side([ctx.wparams[l]], (dN, coef, wpart, ctx.saved))
-            with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
-                _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
+            dYm = None
+            if _DY_ONCE["on"]:
+                # (experiment, review item 2-ii) the weight gradient writes the operand it stages, dY, once; the data gradient
+                # below then loads that ONE tensor instead of rebuilding dY from dN and Y
+                dYm = torch.empty((Cout, ldp), device=dev, dtype=f32)
+                _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_c_dy, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
                       Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Cin, Cout, ldp,
-                      cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(), dW.data_ptr(),
-                      side.cuda_stream if side is not None else st, dims=(Cin, Cout))
+                      cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(), dW.data_ptr(), dYm.data_ptr(), st,
+                      dims=(Cin, Cout))
+            else:
+                side = _branch_side([ctx.wparams[l]], (dN, coef, wpart, ctx.saved))
+                with (torch.cuda.stream(side) if side is not None else contextlib.nullcontext()):
+                    _call("conv_wgrad", flops, lib.o3d_mlp_conv_wgrad2_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
+                          Ys[l - 1].data_ptr(), scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), Cin, Cout, ldp,
+                          cw.data_ptr(), meta.data_ptr(), start1, wpart.data_ptr(), dW.data_ptr(),
+                          side.cuda_stream if side is not None else st, dims=(Cin, Cout))
             grads[3 * l] = dW
             Wt = ctx.Wts[l]
             dNp = torch.empty((Cin, ldp), device=dev, dtype=f32)
             dtile = _direct_tile(lib, ldp, Cin)
             part = torch.empty((ldp // dtile + _tail_rows(lib, dtile, Cin, nseg, 1), 2, Cin), device=dev, dtype=f32)
-            _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_c, dN.data_ptr(), Ys[l].data_ptr(), A[0], A[1], A[2],
+            _call("conv_dgrad", flops, lib.o3d_mlp_conv_dgrad_c, (dYm if dYm is not None else dN).data_ptr(),
+                  None if dYm is not None else Ys[l].data_ptr(), A[0], A[1], A[2],
                   Wt.data_ptr(), Cin, Cout, ldp, cw.data_ptr(), meta.data_ptr(), start1, dtile, Ys[l - 1].data_ptr(),
                   scales[l - 1].data_ptr(), shifts[l - 1].data_ptr(), means[l - 1].data_ptr(), dNp.data_ptr(),
                   part.data_ptr(), st, dims=(Cin, Cout))
@@ -876,6 +888,11 @@ _POOL_BWD_DENSE = {"on": True}
 
 def set_pool_bwd_dense(enabled):
     _POOL_BWD_DENSE["on"] = bool(enabled)
+
+
+# (experiment, round 6) dY written once by the weight gradient, the data gradient loads one operand tensor: see
+# profiles/r06_ab_dy_once.txt.  tools/ab_hook.py fused._DY_ONCE.on flips it; tests run both.
+_DY_ONCE = {"on": False}
 
 
 # data + weight gradient of a 64-input-channel inner layer in ONE kernel (csrc/mlp_wgrad.hip::fused_bwd_kernel: SA level 0's

@@ -914,6 +914,43 @@ def test_wgrad_side_branch_equals_inline_launches(model_name, graph):
     print("%s graph=%s: side branch vs inline, worst per-parameter max-norm gradient difference %.1e" % (model_name, graph, worst))
 
 
+def test_dy_written_once_equals_the_two_operand_data_gradient():
+    """fused._DY_ONCE (round-6 experiment, off by default): the weight-gradient launch writes the operand it stages,
+    dY = A1*dN + w*(A2*Y + A3), and the data gradient loads that one tensor (o3d_mlp_conv_wgrad2_c_dy +
+    o3d_mlp_conv_dgrad_c with Y = NULL) instead of rebuilding it from dN and Y: same loss, same gradients (the summation
+    order inside the kernels is unchanged; what differs run to run is the LDS-atomic noise of the list sums)"""
+    import copy
+    from open3dsot_amd import fused, synth, trackers
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(13)
+    model = trackers.BAT().to(dev).train()
+    twin = copy.deepcopy(model)
+    batch = synth.to_torch(synth.make_batch(990, 6, 256, 512), dev)
+    res = {}
+    for on, m in ((True, model), (False, twin)):
+        fused._DY_ONCE["on"] = on
+        try:
+            loss, _ = m.training_loss(batch)
+            loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            fused._DY_ONCE["on"] = False
+        res[on] = (float(loss.detach()), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None})
+    (la, ga), (lb, gb) = res[True], res[False]
+    assert la == lb, (la, lb)
+    top = max(float(v.abs().max()) for v in gb.values())
+    worst = 0.0
+    for k, want in gb.items():
+        scale = float(want.abs().max())
+        if scale < 1e-4 * top:
+            assert float(ga[k].abs().max()) < 1e-3 * top, k
+            continue
+        err = float((ga[k] - want).abs().max()) / scale
+        worst = max(worst, err)
+        assert err < 5e-3, (k, err)
+    print("dY written once vs two-operand data gradient: worst per-parameter max-norm gradient difference %.1e" % worst)
+
+
 @pytest.mark.parametrize("train", [True, False])
 def test_segpointnet_cloud_bias_matches_broadcast_concat(train):
     """SegPointNet (models/backbone/pointnet.py:144-204): the pooled feature broadcast to every point and concatenated
