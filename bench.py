@@ -200,6 +200,17 @@ def cpu_baseline(model_name, sd, batch_size, budget_s=150.0):
     return res
 
 
+def _flush_c_stdio():
+    """RCCL prints a start-up banner through C stdio; into a pipe that is fully buffered and would come out at process
+    exit, AFTER the JSON line.  Flushed on every rank once the communicator exists, and again before the line is printed."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def _spawned_rank(rank, args, port):
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
@@ -338,9 +349,11 @@ def run(args):
                 line["secondary"] = json.loads(rows[-1]) if rows else {"error": "exit %d: %s" % (cp.returncode, cp.stderr[-300:])}
             except Exception as e:
                 line["secondary"] = {"error": "%s: %s" % (type(e).__name__, e)}
-        print(json.dumps(line))
-    if world > 1:
+    if dist.is_initialized():       # (before the line: whatever the communicator's teardown prints must not follow it)
         dist.destroy_process_group()
+    _flush_c_stdio()
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 def secondary_lines(args):
@@ -454,6 +467,7 @@ def measure(args, rank, local_rank, world, full=True):
             pool, flat = [trainer.make_batch(b) for b in pool], True
         trainer.step(pool[i % len(pool)], next_batch=pool[(i + 1) % len(pool)] if i + 1 < nwarm else pool[0])
     torch.cuda.synchronize()
+    _flush_c_stdio()
     log("warm-up: %.2f s; hip graph: %s %s" % (time.perf_counter() - tw, trainer.graph is not None,
                                               trainer.graph_error or ""))
     barrier()
