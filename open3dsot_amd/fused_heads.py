@@ -120,7 +120,10 @@ def _submit_jobs(jobs, keep, st, params):
         fused.branch_join()         # an earlier group with this parameter may be running on the side branch
     else:
         _DEFER["keys"] |= keys
-        if sum(len(e[0]) for e in _DEFER["queue"]) >= _MAXJOBS:
+        from . import fused
+        if fused._BRANCH["scope"] is not None and sum(len(e[0]) for e in _DEFER["queue"]) >= _MAXJOBS:
+            # only with the weight-gradient side branch open (off by default): full groups go out beside the rest of the
+            # backward.  Without it an early flush only splits the step's 23 jobs into more launches than the 3 of the final one
             _flush_queue(early=True)
 
 

@@ -59,6 +59,13 @@ esac; done
 for p in $PARTS; do case "$p" in ab:*)
   bash tools/ab.sh "$(echo "${p#ab:}" | tr '+' ' ')" 2 > $OUT/ab_$(echo "${p#ab:}" | tr -c 'A-Za-z0-9_=' '_').txt 2>&1; cat $OUT/ab_$(echo "${p#ab:}" | tr -c 'A-Za-z0-9_=' '_').txt | tail -3 ;;
 esac; done
+if has stats; then     # the native rocprofv3 --kernel-trace --stats table of the bench command (40 timed steps + warm-up + capture)
+  cd /tmp
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_run -o bench -- python $REPO/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/rocprof_stats.log 2>&1; echo "stats exit $?"
+  cd $REPO
+  K=$(find $OUT/stats_run -name "*kernel_stats.csv" | head -1); [ -n "$K" ] && cp "$K" $OUT/rocprof_kernel_stats.csv && head -6 $OUT/rocprof_kernel_stats.csv | cut -c1-160
+  rm -rf $OUT/stats_run
+fi
 if has trace; then
   cd /tmp
   timeout 600 rocprofv3 --kernel-trace --output-format csv -d $OUT/trace_graph -o bench -- python $REPO/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-secondary > $OUT/rocprof_graph.log 2>&1; echo "trace graph exit $?"
