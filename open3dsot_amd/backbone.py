@@ -47,17 +47,18 @@ class Pointnet_Backbone(nn.Module):
         return l_xyz[-1], l_features[-1], idx0
 
 
-def _backbone_forward_pair(self, pc_a, numpoints_a, pc_b, numpoints_b, sample_idxs=None):
+def _backbone_forward_pair(self, pc_a, numpoints_a, pc_b, numpoints_b, sample_idxs=None, geometry=None):
     """self(pc_a, numpoints_a), self(pc_b, numpoints_b) with every level's two module calls issued as one
     (sa_modules.forward_pair): same numbers as the two calls in that order.  sample_idxs = (idx_a, idx_b): level 0's
-    farthest-point-sampling indices when they were computed ahead of the step (`sampling_indices`)."""
+    farthest-point-sampling indices when they were computed ahead of the step (`sampling_indices`).  geometry: one dict per
+    level (`pair_geometry`) when the levels' coordinate-only parts were computed ahead of the step as well."""
     xyz_a, feat_a = self._break_up_pc(pc_a)
     xyz_b, feat_b = self._break_up_pc(pc_b)
     la, lb = ([xyz_a], [feat_a]), ([xyz_b], [feat_b])
     idx0 = [None, None]
     for i, sa in enumerate(self.SA_modules):
         ra, rb = sa.forward_pair(la[0][i], la[1][i], numpoints_a[i], lb[0][i], lb[1][i], numpoints_b[i],
-                                 sample_idxs if i == 0 else None)
+                                 sample_idxs if i == 0 else None, geo=geometry[i] if geometry is not None else None)
         for k, (lst, r) in enumerate(((la, ra), (lb, rb))):
             lst[0].append(r[0])
             lst[1].append(r[1])
@@ -81,6 +82,27 @@ def sampling_indices(self, pc_a, npoint_a, pc_b, npoint_b):
 
 
 Pointnet_Backbone.sampling_indices = sampling_indices
+
+
+def pair_geometry(self, pc_a, numpoints_a, pc_b, numpoints_b, sample_idxs=None):
+    """[dict per level] -- for every level of forward_pair the part that depends on the input COORDINATES only: level 0's
+    centres are the (farthest-point or prefix) samples of the clouds, the next level's clouds are those centres, and so on
+    (models/backbone/pointnet.py:66-88 with pointnet2_modules.py:52-62): no feature enters.  None when some level would
+    not take the fused paired path (the step then computes everything inline)."""
+    xyz_a, xyz_b = pc_a[..., 0:3].contiguous(), pc_b[..., 0:3].contiguous()
+    out = []
+    for i, sa in enumerate(self.SA_modules):
+        geo = sa.pair_geometry(xyz_a, numpoints_a[i], xyz_b, numpoints_b[i], sample_idxs if i == 0 else None)
+        if geo is None:
+            return None
+        out.append(geo)
+        B, na, nb = xyz_a.shape[0], numpoints_a[i], numpoints_b[i]
+        xyz_a = geo["centers"][:B * na].view(B, na, 3)
+        xyz_b = geo["centers"][B * na:B * (na + nb)].view(B, nb, 3)
+    return out
+
+
+Pointnet_Backbone.pair_geometry = pair_geometry
 
 
 def _pointwise_chain(x, layers, pool=False):

@@ -325,6 +325,12 @@ class DataParallelStep:
             flat = isinstance(batch, FlatBatch) and batch.layout == self._static.layout
             if self._sampling is not None and self._static.extra_keys:
                 extra = self._sampling_for(batch)
+                if set(extra) != set(self._static.extra_keys):
+                    # (e.g. trackers.set_geometry_prefetch flipped after the capture: a missing key would leave the PREVIOUS
+                    # batch's value in the captured step's input buffers)
+                    raise RuntimeError("DataParallelStep: the model's sampling_inputs() returns other keys than the captured "
+                                       "step was built with (%s vs %s); build a new trainer" % (
+                                           sorted(extra)[:4], sorted(self._static.extra_keys)[:4]))
                 if not (flat and all(extra[k] is batch[k] for k in extra)):
                     flat = False
                     src = dict(batch)

@@ -449,7 +449,7 @@ def _branch_side(params, keep):
 
 # ---- the autograd function ---------------------------------------------------------------
 class _Cfg:
-    __slots__ = ("nxyz", "inv_radius", "training", "bns", "eps", "momentum", "centers")
+    __slots__ = ("nxyz", "inv_radius", "training", "bns", "eps", "momentum", "centers", "geo", "geo_dims")
 
 
 def _direct_tile(lib, pmax, m):
@@ -499,13 +499,17 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         gammas = [params[3 * l + 1].detach().contiguous() for l in range(L)]
         betas = [params[3 * l + 2].detach().contiguous() for l in range(L)]
         nxyz = cfg.nxyz
-        dev = segs[0][3].device
+        geo = getattr(cfg, "geo", None)       # the level's coordinate-only part computed ahead of the step (pair_geometry)
+        dev = segs[0][3].device if geo is None else geo["gp"].device
         f32, i32 = torch.float32, torch.int32
         st = _stream()
-        B, _, ns = segs[0][3].shape
+        if geo is None:
+            B, _, ns = segs[0][3].shape
+            npoints = [sg[3].shape[1] for sg in segs]
+        else:
+            B, ns, npoints = cfg.geo_dims[0], cfg.geo_dims[1], list(cfg.geo_dims[2])
         C = segs[0][2].shape[1] if segs[0][2] is not None else 0
         Cin0, C0 = nxyz + C, Ws[0].shape[0]
-        npoints = [sg[3].shape[1] for sg in segs]
         Ns = [sg[2].shape[2] if sg[2] is not None else sg[0].shape[1] for sg in segs]
         Npads = [-(-n // TILE) * TILE for n in Ns]
         Pmaxs = [B * npt * ns for npt in npoints]
@@ -520,13 +524,19 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad)
         unit = cfg.inv_radius == 1.0          # normalize_xyz False in every tracker config: no scaling launches
         # ---- compaction of the grouping indices (per segment, into joint arrays)
-        ball_cnt = torch.empty((nballs,), device=dev, dtype=i32)
-        ball_off = torch.empty((nballs + 1,), device=dev, dtype=i32)
-        gp = torch.empty((ldp,), device=dev, dtype=i32)
-        cball = torch.empty((ldp,), device=dev, dtype=i32)
-        cw = torch.empty((ldp,), device=dev, dtype=f32)
-        meta = torch.empty((nseg, 4), device=dev, dtype=i32)
-        if nseg == 2:      # both segments: three launches instead of six
+        if geo is not None:
+            ball_cnt, ball_off, gp, cball, cw, meta = (geo[k] for k in ("ball_cnt", "ball_off", "gp", "cball", "cw", "meta"))
+            assert nseg == 2 and gp.numel() == ldp and ball_cnt.numel() == nballs and meta.numel() == 8
+        else:
+            ball_cnt = torch.empty((nballs,), device=dev, dtype=i32)
+            ball_off = torch.empty((nballs + 1,), device=dev, dtype=i32)
+            gp = torch.empty((ldp,), device=dev, dtype=i32)
+            cball = torch.empty((ldp,), device=dev, dtype=i32)
+            cw = torch.empty((ldp,), device=dev, dtype=f32)
+            meta = torch.empty((nseg, 4), device=dev, dtype=i32)
+        if geo is not None:
+            pass
+        elif nseg == 2:      # both segments: three launches instead of six
             _call("compact_build", 0.0, lib.o3d_compact_build2, segs[0][3].data_ptr(), npoints[0], Npads[0],
                   segs[1][3].data_ptr(), npoints[1], Npads[1], B, ns, starts[1], pt_bases[1], nballs, ball_cnt.data_ptr(),
                   ball_off.data_ptr(), gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), meta.data_ptr(), st)
@@ -1061,7 +1071,55 @@ def sa_group_mlp_pool_pair(grouper, mlp, a, b):
 capi.register("o3d_sample_query", [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _i, _f, _i, _vp, _vp])
 
 
-def sa_pair_sampled(grouper, mlp, a, b):
+GEO_KEYS = ("centers", "ball_cnt", "ball_off", "gp", "cball", "cw", "meta")
+
+
+def _pair_shapes_ok(layers, B, np_a, np_b, ns):
+    return (_shape_ok(np_a, ns) and _shape_ok(np_b, ns) and _compact_ok(layers, np_a, ns, B) and
+            _compact_ok(layers, np_b, ns, B) and (B * np_a * ns) % 256 == 0)
+
+
+def pair_geometry(grouper, mlp, xyz_a, np_a, si_a, xyz_b, np_b, si_b):
+    """Everything of a paired set-abstraction level that depends on the COORDINATES only (pointnet2_modules.py:52-62 and
+    pointnet2_utils.py:299-320 up to the grouping indices): the centres (sampling gather), both ball queries and the
+    distinct-neighbour layout of csrc/compact.hip -- sample_query + the three compaction launches -- as a dict of tensors
+    (GEO_KEYS) that `sa_pair_sampled(..., geo=...)` takes instead of computing them.  A training loop computes it for batch
+    t+1 beside step t, like the farthest-point sampling (round 6: 12 launches, 0.14 ms per BAT step, off the step's serial
+    chain).  -> None when the joint layout does not apply (the caller then lets the step compute it inline)."""
+    if not (_SAMPLE_QUERY["on"] and xyz_a.is_cuda) or xyz_a.shape[0] != xyz_b.shape[0]:
+        return None
+    B, ns = xyz_a.shape[0], grouper.nsample
+    if not _pair_shapes_ok(_layers(mlp), B, np_a, np_b, ns):
+        return None
+    if (si_a is None and np_a > xyz_a.shape[1]) or (si_b is None and np_b > xyz_b.shape[1]):
+        return None
+    dev, f32, i32 = xyz_a.device, torch.float32, torch.int32
+    for si, npt in ((si_a, np_a), (si_b, np_b)):
+        if si is not None and not (si.dtype == i32 and si.is_contiguous() and tuple(si.shape) == (B, npt) and si.device == dev):
+            return None
+    lib = capi.load()
+    xa, xb = xyz_a.detach().contiguous(), xyz_b.detach().contiguous()
+    nb_a, nb_b = B * np_a, B * np_b
+    nballs, ldp = nb_a + nb_b, (nb_a + nb_b) * ns
+    Npad_a, Npad_b = -(-xa.shape[1] // TILE) * TILE, -(-xb.shape[1] // TILE) * TILE
+    geo = {"centers": torch.empty((nballs + 1, 3), device=dev, dtype=f32),
+           "ball_cnt": torch.empty((nballs,), device=dev, dtype=i32), "ball_off": torch.empty((nballs + 1,), device=dev, dtype=i32),
+           "gp": torch.empty((ldp,), device=dev, dtype=i32), "cball": torch.empty((ldp,), device=dev, dtype=i32),
+           "cw": torch.empty((ldp,), device=dev, dtype=f32), "meta": torch.empty((2, 4), device=dev, dtype=i32)}
+    idx_a = torch.empty((B, np_a, ns), device=dev, dtype=i32)
+    idx_b = torch.empty((B, np_b, ns), device=dev, dtype=i32)
+    with torch.cuda.device(dev):
+        st = _stream()
+        _call("sample_query", 0.0, lib.o3d_sample_query, xa.data_ptr(), _ptr(si_a), xa.shape[1], np_a, idx_a.data_ptr(),
+              xb.data_ptr(), _ptr(si_b), xb.shape[1], np_b, idx_b.data_ptr(), B, float(grouper.radius), ns,
+              geo["centers"].data_ptr(), st)
+        _call("compact_build", 0.0, lib.o3d_compact_build2, idx_a.data_ptr(), np_a, Npad_a, idx_b.data_ptr(), np_b, Npad_b, B,
+              ns, nb_a * ns, B * Npad_a, nballs, geo["ball_cnt"].data_ptr(), geo["ball_off"].data_ptr(), geo["gp"].data_ptr(),
+              geo["cball"].data_ptr(), geo["cw"].data_ptr(), geo["meta"].data_ptr(), st)
+    return geo
+
+
+def sa_pair_sampled(grouper, mlp, a, b, geo=None):
     """sa_group_mlp_pool_pair with the sampling folded in: a, b = (xyz (B,N,3), features | None, npoint, sample_idx (B,npoint)
     int32 | None = the arange(npoint) prefix).  ONE launch gathers the centres of both sets, writes them in the layout the
     fused path wants and runs both ball queries (csrc/index_ops.hip::sample_query_kernel; were 2 gathers or strided copies
@@ -1090,16 +1148,22 @@ def sa_pair_sampled(grouper, mlp, a, b):
         if si is not None and not (si.dtype == i32 and si.is_contiguous() and tuple(si.shape) == (B, npt) and si.device == dev):
             return None
     nb_a, nb_b = B * np_a, B * np_b
-    centers = torch.empty((nb_a + nb_b + 1, 3), device=dev, dtype=f32)
-    idx_a = torch.empty((B, np_a, ns), device=dev, dtype=i32)
-    idx_b = torch.empty((B, np_b, ns), device=dev, dtype=i32)
-    with torch.cuda.device(dev):
-        _call("sample_query", 0.0, capi.load().o3d_sample_query, xa.data_ptr(), _ptr(si_a), xa.shape[1], np_a, idx_a.data_ptr(),
-              xb.data_ptr(), _ptr(si_b), xb.shape[1], np_b, idx_b.data_ptr(), B, float(grouper.radius), ns,
-              centers.data_ptr(), _stream())
+    if geo is not None and not (mlp.training and tuple(geo["centers"].shape) == (nb_a + nb_b + 1, 3) and
+                                geo["gp"].numel() == (nb_a + nb_b) * ns and geo["gp"].device == dev):
+        geo = None          # (eval mode takes the one-kernel set abstraction, which wants the grouping indices themselves)
+    if geo is not None:     # the coordinate-only part came with the batch (pair_geometry, computed beside the previous step)
+        centers, idx_a, idx_b = geo["centers"], None, None
+    else:
+        centers = torch.empty((nb_a + nb_b + 1, 3), device=dev, dtype=f32)
+        idx_a = torch.empty((B, np_a, ns), device=dev, dtype=i32)
+        idx_b = torch.empty((B, np_b, ns), device=dev, dtype=i32)
+        with torch.cuda.device(dev):
+            _call("sample_query", 0.0, capi.load().o3d_sample_query, xa.data_ptr(), _ptr(si_a), xa.shape[1], np_a,
+                  idx_a.data_ptr(), xb.data_ptr(), _ptr(si_b), xb.shape[1], np_b, idx_b.data_ptr(), B, float(grouper.radius), ns,
+                  centers.data_ptr(), _stream())
     new_a, new_b = centers[:nb_a].view(B, np_a, 3), centers[nb_a:nb_a + nb_b].view(B, np_b, 3)
     inv_r = float(1.0 / grouper.radius if grouper.normalize_xyz else 1.0)
-    if _eval_fused_ok(mlp, layers, [(xa, new_a, f_a, idx_a), (xb, new_b, f_b, idx_b)], 3):
+    if geo is None and _eval_fused_ok(mlp, layers, [(xa, new_a, f_a, idx_a), (xb, new_b, f_b, idx_b)], 3):
         outs = _run_eval(mlp, layers, [(xa, new_a, f_a, idx_a), (xb, new_b, f_b, idx_b)], 3, inv_r)
         return new_a, outs[0], new_b, outs[1]
     cfg = _Cfg()
@@ -1107,6 +1171,7 @@ def sa_pair_sampled(grouper, mlp, a, b):
     cfg.inv_radius = inv_r
     cfg.bns = [bn for _, bn in layers]
     cfg.centers = centers
+    cfg.geo, cfg.geo_dims = geo, (B, ns, (np_a, np_b))
     params = []
     for conv, bn in layers:
         params += [conv.weight, bn.weight, bn.bias]

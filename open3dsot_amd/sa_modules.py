@@ -113,12 +113,14 @@ class _PointnetSAModuleBase(nn.Module):
             new_xyz = xyz[:, :npoint, :].contiguous()
         return sample_idxs, new_xyz
 
-    def forward_pair(self, xyz_a, features_a, npoint_a, xyz_b, features_b, npoint_b, sample_idxs=None):
+    def forward_pair(self, xyz_a, features_a, npoint_a, xyz_b, features_b, npoint_b, sample_idxs=None, geo=None):
         """forward(xyz_a, ...) followed by forward(xyz_b, ...) -- the template and the search cloud through the
         shared module (models/bat.py:89-90) -- as one set of launches on the fused path: the weights are
         read once, the BatchNorm batch statistics stay separate and the running statistics see a's update
         before b's.  Returns ((new_xyz, feats, sample_idxs)_a, (...)_b).
-        sample_idxs = (idx_a, idx_b): sampling indices computed ahead of the step (see `forward`)."""
+        sample_idxs = (idx_a, idx_b): sampling indices computed ahead of the step (see `forward`).
+        geo: the level's coordinate-only part (centres, ball queries, distinct-neighbour layout) computed ahead of the step
+        (`pair_geometry`); only the fused training path takes it, everything else ignores it."""
         if (_FUSED["enabled"] and _FUSED["paired"] and xyz_a.is_cuda and len(self.groupers) == 1):
             from . import fused
             if fused.supports(self.groupers[0], self.mlps[0], features_a):
@@ -132,7 +134,7 @@ class _PointnetSAModuleBase(nn.Module):
                 else:
                     si_a = si_b = None
                 got = fused.sa_pair_sampled(self.groupers[0], self.mlps[0], (xyz_a, features_a, npoint_a, si_a),
-                                            (xyz_b, features_b, npoint_b, si_b))
+                                            (xyz_b, features_b, npoint_b, si_b), geo=geo)
                 if got is not None:
                     self.npoint = npoint_b
                     if si_a is None:
@@ -159,6 +161,21 @@ class _PointnetSAModuleBase(nn.Module):
                     return (new_a, outs[0], idx_a), (new_b, outs[1], idx_b)
         ia, ib = sample_idxs if sample_idxs is not None else (None, None)
         return self.forward(xyz_a, features_a, npoint_a, True, ia), self.forward(xyz_b, features_b, npoint_b, True, ib)
+
+
+def _sa_pair_geometry(self, xyz_a, npoint_a, xyz_b, npoint_b, sample_idxs=None):
+    """the coordinate-only part of forward_pair (fused.pair_geometry) or None when the fused paired path would not run;
+    sample_idxs = (idx_a, idx_b) for a level that samples with FPS, None for the arange(npoint) prefix"""
+    if not (_FUSED["enabled"] and _FUSED["paired"] and xyz_a.is_cuda and len(self.groupers) == 1):
+        return None
+    if self.use_fps and sample_idxs is None:
+        return None
+    from . import fused
+    si_a, si_b = sample_idxs if sample_idxs is not None else (None, None)
+    return fused.pair_geometry(self.groupers[0], self.mlps[0], xyz_a, npoint_a, si_a, xyz_b, npoint_b, si_b)
+
+
+_PointnetSAModuleBase.pair_geometry = _sa_pair_geometry
 
 
 class PointnetSAModuleMSG(_PointnetSAModuleBase):

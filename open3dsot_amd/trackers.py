@@ -78,6 +78,15 @@ def _seed_rows(a, b, sample_idxs, n):
     return ra, rb
 
 
+# the coordinate-only part of the backbone (centres, ball queries, distinct-neighbour layouts of all three levels) computed with
+# the sampling indices ahead of the step (`sampling_inputs`); False = inside the step, the route it is tested against
+_GEOMETRY_PREFETCH = {"on": True}
+
+
+def set_geometry_prefetch(enabled):
+    _GEOMETRY_PREFETCH["on"] = bool(enabled)
+
+
 class MatchingBaseModel(nn.Module):
     def __init__(self, config=None, **kwargs):
         super().__init__()
@@ -101,11 +110,28 @@ class MatchingBaseModel(nn.Module):
         input dict instead of launching the 766 serial FPS rounds at the head of the step."""
         t, s = batch["template_points"], batch["search_points"]
         idx = self.backbone.sampling_indices(t, t.shape[1] // 2, s, s.shape[1] // 2)
-        return {} if idx is None else {"fps_idx_t": idx[0], "fps_idx_s": idx[1]}
+        out = {} if idx is None else {"fps_idx_t": idx[0], "fps_idx_s": idx[1]}
+        # round 6: the rest of the backbone that depends on the coordinates only -- every level's centres, ball queries and
+        # distinct-neighbour layout ("geo<level>.<name>", open3dsot_amd/fused.py::pair_geometry): 12 launches off the step's chain
+        if _GEOMETRY_PREFETCH["on"] and self.training and t.is_cuda:
+            M, N = t.shape[1], s.shape[1]
+            geo = self.backbone.pair_geometry(t, [M // 2, M // 4, M // 8], s, [N // 2, N // 4, N // 8], idx)
+            if geo is not None:
+                for i, g in enumerate(geo):
+                    for k, v in g.items():
+                        out["geo%d.%s" % (i, k)] = v
+        return out
 
     @staticmethod
     def _given_sampling(input_dict):
         return (input_dict["fps_idx_t"], input_dict["fps_idx_s"]) if "fps_idx_t" in input_dict else None
+
+    @staticmethod
+    def _given_geometry(input_dict):
+        if "geo0.gp" not in input_dict:
+            return None
+        from .fused import GEO_KEYS
+        return [{k: input_dict["geo%d.%s" % (i, k)] for k in GEO_KEYS} for i in range(3)]
 
     def evaluate_one_sample(self, data_dict):
         """The network half of MatchingBaseModel.evaluate_one_sample (models/base_model.py:44-57) without its host round
@@ -167,7 +193,8 @@ class P2B(MatchingBaseModel):
         template, search = input_dict["template_points"], input_dict["search_points"]
         M, N = template.shape[1], search.shape[1]
         (template_xyz, template_feature, _), (search_xyz, search_feature, sample_idxs) = self.backbone.forward_pair(
-            template, [M // 2, M // 4, M // 8], search, [N // 2, N // 4, N // 8], self._given_sampling(input_dict))
+            template, [M // 2, M // 4, M // 8], search, [N // 2, N // 4, N // 8], self._given_sampling(input_dict),
+            self._given_geometry(input_dict))
         template_feature, search_feature = pt_utils.pointwise_conv1d_pair(self.conv_final, template_feature, search_feature)
         fusion = self.xcorr(template_feature, search_feature, template_xyz)
         boxes, cla, vote_xyz, centers = self.rpn(search_xyz, fusion)
@@ -235,7 +262,7 @@ class BAT(MatchingBaseModel):
         M, N = template.shape[1], search.shape[1]
         (template_xyz, template_feature, sample_idxs_t), (search_xyz, search_feature, sample_idxs) = \
             self.backbone.forward_pair(template, [M // 2, M // 4, M // 8], search, [N // 2, N // 4, N // 8],
-                                       self._given_sampling(input_dict))
+                                       self._given_sampling(input_dict), self._given_geometry(input_dict))
         template_feature, search_feature = pt_utils.pointwise_conv1d_pair(self.conv_final, template_feature, search_feature)
         pred_search_bc = pt_utils.seq_apply(self.mlp_bc, [search_xyz.transpose(1, 2), search_feature])
         pred_search_bc = pred_search_bc.transpose(1, 2)                                    # (B,N/8,9)

@@ -1391,6 +1391,71 @@ def test_bat_nuscenes_2048_batch100():
     assert np.array_equal(out["sample_idxs"].cpu().numpy(), ref["sample_idxs"].numpy())
 
 
+@pytest.mark.parametrize("model_name", ["BAT", "P2B"])
+def test_geometry_prefetch_equals_the_inline_step(model_name):
+    """Round 6: beside the farthest-point sampling, EVERYTHING of the backbone that depends on the input coordinates only
+    -- per level the centres, both ball queries and the distinct-neighbour layout (fused.pair_geometry) -- is computed for
+    the next batch beside the current step and enters the captured step as inputs ("geo<level>.<name>").  Against a trainer
+    whose step computes it inline (trackers.set_geometry_prefetch(False)): the same layout arrays bit for bit, the same
+    losses step by step, the same gradients (to the LDS-atomic noise of the backward); a batch that was not announced is
+    handled on the spot."""
+    import copy
+    from open3dsot_amd import dist as D, fused, synth, trackers
+    dev = torch.device("cuda", 0)
+    model_a = make_model(model_name, 9)
+    model_b = copy.deepcopy(model_a)
+    pool = [synth.to_torch(synth.make_batch(310 + 4 * i, 4, 512, 1024), dev) for i in range(3)]
+    trackers.set_geometry_prefetch(False)
+    try:
+        ta = D.DataParallelStep(model_a, optimizer=torch.optim.SGD(model_a.parameters(), lr=0.0), world=1, graph=True,
+                                graph_warmup=1, require_graph=True)
+        la = [float(ta.step(pool[i % 3], next_batch=pool[(i + 1) % 3])) for i in range(5)]
+        torch.cuda.synchronize()
+        ga = {k: p.grad.detach().clone() for k, p in model_a.named_parameters() if p.grad is not None}
+    finally:
+        trackers.set_geometry_prefetch(True)
+    assert not any(k.startswith("geo") for k in ta._static)
+    tb = D.DataParallelStep(model_b, optimizer=torch.optim.SGD(model_b.parameters(), lr=0.0), world=1, graph=True,
+                            graph_warmup=1, require_graph=True)
+    lb = []
+    for i in range(5):
+        cur, nxt = pool[i % 3], pool[(i + 1) % 3]
+        lb.append(float(tb.step(cur, next_batch=nxt)))
+        if tb.graph is not None:          # the layout the replay consumed == the layout computed from `cur` on the spot
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                want = model_b.sampling_inputs(cur)
+            assert sum(k.startswith("geo") for k in want) == 3 * len(fused.GEO_KEYS)
+            for k, v in want.items():
+                if k.endswith((".gp", ".cball", ".cw")):          # (worst-case buffers: only the live columns are defined)
+                    live = int(want[k.rsplit(".", 1)[0] + ".meta"].view(-1)[0])
+                    assert torch.equal(tb._static[k][:live], v[:live]), (i, k)
+                elif k.endswith(".ball_off"):                       # (nballs + 1 slots; the kernels define the first nballs)
+                    assert torch.equal(tb._static[k][:-1], v[:-1]), (i, k)
+                else:
+                    assert torch.equal(tb._static[k], v), (i, k)
+    torch.cuda.synchronize()
+    gb = {k: p.grad.detach().clone() for k, p in model_b.named_parameters() if p.grad is not None}
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 1e-5 * (1 + abs(a)), (la, lb)
+    top = max(float(v.abs().max()) for v in ga.values())
+    for k, want in ga.items():
+        scale = float(want.abs().max())
+        if scale < 1e-4 * top:
+            continue
+        assert float((gb[k] - want).abs().max()) / scale < 5e-3, k
+    other = synth.to_torch(synth.make_batch(910, 4, 512, 1024), dev)      # not announced: computed on the spot
+    l_other = float(tb.step(other))
+    if ta._static.extra_keys:      # (BAT: the inline trainer's captured step takes the sampling indices but no geometry inputs;
+        with pytest.raises(RuntimeError, match="sampling_inputs"):      # P2B's takes nothing and never asks the model)
+            ta.step(other)
+    trackers.set_geometry_prefetch(False)
+    try:
+        assert abs(l_other - float(ta.step(other))) <= 1e-5 * (1 + abs(l_other))
+    finally:
+        trackers.set_geometry_prefetch(True)
+
+
 def test_sampling_prefetch_feeds_the_same_indices_as_the_inline_step():
     """DataParallelStep.step(batch, next_batch=...): the farthest-point sampling of the NEXT batch runs on a second
     stream beside the replayed graph of this step and enters the next replay as an input.  The indices the captured step
