@@ -379,7 +379,8 @@ _CONST = {}
 # dependency of the replayed graph (~7-10 us each, 14 forks per step) and the overlapped kernels stretch (the 14 slice
 # reductions 0.11 -> 0.36 ms): BAT 5.31 -> 5.39 ms, P2B 8.71 -> 8.79, M2-Track 6.30 -> 6.52.  The mechanism stays as a tested
 # switch (tests/test_model_gpu.py::test_wgrad_side_branch_equals_inline_launches), off.
-_WGRAD_BRANCH = {"on": False}      # tools/ab_hook.py fused._WGRAD_BRANCH.on flips it for the same-box A/B; tests run both
+_WGRAD_BRANCH = {"on": False,      # tools/ab_hook.py fused._WGRAD_BRANCH.on flips it for the same-box A/B; tests run both
+                 "heads_only": False}   # True (with "on"): only the heads' grouped launches branch (ONE fork per full group)
 _BRANCH = {"scope": None, "last_launches": 0}      # last_launches: side-branch forks of the scope that closed last (tests)
 _SIDE_STREAMS = {}
 
@@ -424,6 +425,8 @@ def _branch_side(params, keep):
         return None
     from .fused_heads import _deferrable
     params = [p for p in params if p is not None]
+    if params and _WGRAD_BRANCH["heads_only"]:      # a set-abstraction level's own weight gradient: inline in this mode
+        return None
     if not _deferrable(params):
         return None
     main = torch.cuda.current_stream()

@@ -62,9 +62,10 @@ def _flush_jobs(jobs, st):
 
 
 def _flush_queue(early=False):
-    """early: a full group of jobs while the scope is still open -- launched on the weight-gradient side branch when one is
-    open (open3dsot_amd/fused.py::wgrad_branch), beside the rest of the backward instead of behind it; the parameter keys stay
-    recorded, so that a later second use of one of these parameters still finds it"""
+    """early: FULL groups of jobs (multiples of _MAXJOBS) while the scope is still open -- launched on the weight-gradient side
+    branch when one is open (open3dsot_amd/fused.py::wgrad_branch), beside the rest of the backward instead of behind it; what
+    does not fill a group stays queued; the parameter keys stay recorded, so that a later second use of one of these
+    parameters still finds it"""
     q = _DEFER["queue"]
     _DEFER["queue"] = []
     if not early:
@@ -74,9 +75,16 @@ def _flush_queue(early=False):
         by_stream.setdefault(st, []).extend(jobs)
     for st, jobs in by_stream.items():
         side = None
-        if early and st == _stream():
-            from . import fused
-            side = fused._branch_side([], q)       # (the scope keeps `q` -- the operands -- alive until the join)
+        if early:
+            n = (len(jobs) // _MAXJOBS) * _MAXJOBS
+            if n < len(jobs):        # the remainder waits for the next full group / the end of the scope (operands: held by
+                _DEFER["queue"].append((jobs[n:], q, st))      # `q`, which the re-queued entry keeps alive)
+                jobs = jobs[:n]
+            if jobs and st == _stream():
+                from . import fused
+                side = fused._branch_side([], q)       # (the scope keeps `q` -- the operands -- alive until the join)
+        if not jobs:
+            continue
         if side is not None:
             with torch.cuda.stream(side):
                 _flush_jobs(jobs, side.cuda_stream)
@@ -199,8 +207,9 @@ class WeightPrep:
         self.dev = dev
         self.jobs = {}
         self.table = None
-        self.dirty = False
-        self.active = False
+        self.tables = []      # every table a launch has ever been given: a captured HIP graph replays that launch with THAT
+        self.dirty = False    # address, so a table is never freed while this object lives (round 6: a second model on the
+        self.active = False   # device used to rebuild -- and free -- the one table a captured step of the first still read)
         self.fresh = set()
 
     @staticmethod
@@ -276,6 +285,7 @@ class WeightPrep:
                 return
             rows = [[j.src_ptr, j.dst.data_ptr(), j.rows, j.cols, j.dst.shape[1], int(j.transpose)] for j in self.jobs.values()]
             self.table = torch.tensor(rows, dtype=torch.int64, device=self.dev)       # only while the job set changes
+            self.tables.append(self.table)
             self.dirty = False
         with torch.cuda.device(self.dev):
             _call("prep_weights", 0.0, capi.load().o3d_prep_weights, self.table.data_ptr(), self.table.shape[0],
@@ -283,34 +293,55 @@ class WeightPrep:
         self.fresh = set(self.jobs)
 
 
-_PREP = {}
+_PREP = {}           # device -> the default table (used outside any scope: copies on the spot, never launches a table)
+_OWNED = weakref.WeakKeyDictionary()      # owner module -> {device: WeightPrep}
+_ACTIVE = {}         # device -> the WeightPrep of the scope that is open on it
+
+
+def _dev_key(dev):
+    return (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
 
 
 def prep_for(dev):
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    """the weight-preparation table in force on `dev`: the open scope's (its owner's own table), else the device's default"""
+    key = _dev_key(dev)
+    if key in _ACTIVE:
+        return _ACTIVE[key]
     if key not in _PREP:
         _PREP[key] = WeightPrep(torch.device(*key))
     return _PREP[key]
 
 
 @contextlib.contextmanager
-def prep_scope(dev):
-    """Between entry and exit the weights do not change (one forward of a tracker): every prepared copy of the
-    device is refreshed by one launch now and `get` hands the buffers out without further copies."""
+def prep_scope(dev, owner=None):
+    """Between entry and exit the weights do not change (one forward of a tracker): every prepared copy is refreshed by
+    one launch now and `get` hands the buffers out without further copies.  owner: the module whose forward this is -- it
+    gets a table of ITS OWN (round 6).  One table per device served every model on it: a second model's first forward
+    rebuilt (and freed) the table a captured step of the first model still launched with, and a model that died left
+    rows pointing at freed buffers in the table of the one that lived on (memory fault in a test with two live trainers)."""
     if dev.type != "cuda" or not _ON["on"]:
         yield
         return
-    prep = prep_for(dev)
-    if prep.active:          # nested scopes: the outer one did the work
+    key = _dev_key(dev)
+    if key in _ACTIVE:          # nested scopes: the outer one did the work
         yield
         return
+    if owner is not None:
+        per_dev = _OWNED.setdefault(owner, {})
+        if key not in per_dev:
+            per_dev[key] = WeightPrep(torch.device(*key))
+        prep = per_dev[key]
+    else:
+        prep = prep_for(dev)
     prep.refresh()
     prep.active = True
+    _ACTIVE[key] = prep
     own_counters = counters_begin()
     try:
         yield
     finally:
         prep.active = False
+        _ACTIVE.pop(key, None)
         if own_counters:
             counters_end()
 

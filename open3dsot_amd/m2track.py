@@ -108,7 +108,7 @@ class M2TRACK(nn.Module):
         from . import fused_heads
         # one forward = one scope: the prepared weight copies refreshed by one launch, every BatchNorm counter of the
         # forward (five stacks, twelve row BatchNorms) updated by one launch at the end
-        with fused_heads.prep_scope(input_dict["points"].device):
+        with fused_heads.prep_scope(input_dict["points"].device, owner=self):
             return self._forward(input_dict)
 
     def _forward(self, input_dict):

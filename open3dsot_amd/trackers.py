@@ -186,7 +186,7 @@ class P2B(MatchingBaseModel):
                                  num_proposal=c.num_proposal, normalize_xyz=c.normalize_xyz)
 
     def forward(self, input_dict):
-        with fused_heads.prep_scope(input_dict["search_points"].device):
+        with fused_heads.prep_scope(input_dict["search_points"].device, owner=self):
             return self._forward(input_dict)
 
     def _forward(self, input_dict):
@@ -253,7 +253,7 @@ class BAT(MatchingBaseModel):
         return out
 
     def forward(self, input_dict):
-        with fused_heads.prep_scope(input_dict["search_points"].device):
+        with fused_heads.prep_scope(input_dict["search_points"].device, owner=self):
             return self._forward(input_dict)
 
     def _forward(self, input_dict):

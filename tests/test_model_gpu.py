@@ -1391,6 +1391,44 @@ def test_bat_nuscenes_2048_batch100():
     assert np.array_equal(out["sample_idxs"].cpu().numpy(), ref["sample_idxs"].numpy())
 
 
+def test_captured_step_survives_other_models_on_the_device():
+    """Round 6 regression: the weight-preparation table (fused_heads.WeightPrep: every padded / transposed weight copy of a
+    forward in one launch from a DEVICE job table) was one per device.  A second model's first forward rebuilt and freed the
+    table that the first model's captured step still launched with, and a model that died left rows pointing at freed
+    buffers in the survivor's table -- a replay then read a dangling table (memory access fault in a test that kept two
+    trainers alive).  Now every tracker owns its table and tables are never freed while their owner lives.  Here: capture A;
+    build, capture and step B; drop a third model that existed while A captured; replay A on a new batch == an eager twin."""
+    import copy
+    import gc
+    from open3dsot_amd import dist as D, synth, trackers
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(17)
+    bystander = trackers.BAT().to(dev).train()
+    b0, b1, b2 = [synth.to_torch(synth.make_batch(1200 + 4 * i, 4, 256, 512), dev) for i in range(3)]
+    bystander.training_loss(b0)[0].backward()                 # registered its weight copies on the device
+    model_a = trackers.BAT().to(dev).train()
+    twin = copy.deepcopy(model_a)
+    ta = D.DataParallelStep(model_a, optimizer=torch.optim.SGD(model_a.parameters(), lr=0.0), world=1, graph=True,
+                            graph_warmup=0, require_graph=True)
+    ta.step(b0)
+    assert ta.graph is not None
+    model_b = trackers.P2B().to(dev).train()
+    tb = D.DataParallelStep(model_b, optimizer=torch.optim.SGD(model_b.parameters(), lr=1e-3), world=1, graph=True,
+                            graph_warmup=0, require_graph=True)
+    for b in (b0, b1, b2):
+        tb.step(b)
+    del bystander
+    gc.collect()
+    junk = [torch.full((1 << 20,), float("nan"), device=dev) for _ in range(8)]      # whatever was freed gets overwritten
+    torch.cuda.synchronize()
+    loss_a = float(ta.step(b1))
+    torch.cuda.synchronize()
+    twin.training_loss(b0)
+    loss_e = float(twin.training_loss(b1)[0].detach())
+    assert abs(loss_a - loss_e) <= 1e-5 * (1 + abs(loss_e)), (loss_a, loss_e)
+    del junk
+
+
 @pytest.mark.parametrize("model_name", ["BAT", "P2B"])
 def test_geometry_prefetch_equals_the_inline_step(model_name):
     """Round 6: beside the farthest-point sampling, EVERYTHING of the backbone that depends on the input coordinates only
