@@ -1369,8 +1369,8 @@ def test_bat_nuscenes_2048_batch100():
     seen = []
     orig = fused.sa_pair_sampled        # (round 5: the paired levels enter through the sampling + ball query launch)
 
-    def spy(grouper, mlp, a, b):
-        outs = orig(grouper, mlp, a, b)
+    def spy(grouper, mlp, a, b, geo=None):
+        outs = orig(grouper, mlp, a, b, geo=geo)
         seen.append((a[2], b[2], outs is not None and "FusedGroupedMLPCompact" in outs[1].grad_fn.name()))
         return outs
     fused.sa_pair_sampled = spy
