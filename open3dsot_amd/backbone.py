@@ -84,15 +84,16 @@ def sampling_indices(self, pc_a, npoint_a, pc_b, npoint_b):
 Pointnet_Backbone.sampling_indices = sampling_indices
 
 
-def pair_geometry(self, pc_a, numpoints_a, pc_b, numpoints_b, sample_idxs=None):
+def pair_geometry(self, pc_a, numpoints_a, pc_b, numpoints_b, sample_idxs=None, dst=None):
     """[dict per level] -- for every level of forward_pair the part that depends on the input COORDINATES only: level 0's
     centres are the (farthest-point or prefix) samples of the clouds, the next level's clouds are those centres, and so on
     (models/backbone/pointnet.py:66-88 with pointnet2_modules.py:52-62): no feature enters.  None when some level would
-    not take the fused paired path (the step then computes everything inline)."""
+    not take the fused paired path (the step then computes everything inline).  dst: one dict of destination tensors per level."""
     xyz_a, xyz_b = pc_a[..., 0:3].contiguous(), pc_b[..., 0:3].contiguous()
     out = []
     for i, sa in enumerate(self.SA_modules):
-        geo = sa.pair_geometry(xyz_a, numpoints_a[i], xyz_b, numpoints_b[i], sample_idxs if i == 0 else None)
+        geo = sa.pair_geometry(xyz_a, numpoints_a[i], xyz_b, numpoints_b[i], sample_idxs if i == 0 else None,
+                               out=dst[i] if dst is not None else None)
         if geo is None:
             return None
         out.append(geo)

@@ -60,6 +60,11 @@ def _defer_wgrads():
     return stack
 
 
+# prefetch variants (round 6; gpurun_out/prefetch_matrix2.txt: in place / by copy and default / high stream priority all within
+# 0.03 ms of each other on the BAT step): extras written straight into the next FlatBatch's own fields; default stream priority
+_PREFETCH = {"inplace": True, "high_priority": False}
+
+
 class FlatBatch(dict):
     """A batch whose tensors are views of ONE flat device buffer (fields 256-byte aligned).  A captured step reads its
     inputs from static buffers; handing it a new batch is then one device copy of `flat` instead of one copy node per
@@ -198,6 +203,10 @@ class DataParallelStep:
         # step with the rest of the chip idle.  prefetch_sampling=False keeps the sampling inside the captured step (what
         # tests/test_model_gpu.py::test_sampling_prefetch_* compares against).
         self._sampling = getattr(model, "sampling_inputs", None) if prefetch_sampling else None
+        self._sampling_takes_out = False
+        if self._sampling is not None:
+            import inspect
+            self._sampling_takes_out = "out" in inspect.signature(self._sampling).parameters
         self._side = None
         self._prefetched = None        # (batch object, {key: tensor}, event)
         # the constant 1 that seeds `loss.backward`: allocated here, outside any capture (open3dsot_amd/fused_loss.py::one)
@@ -293,16 +302,21 @@ class DataParallelStep:
 
     def _prefetch(self, next_batch):
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            self._side = torch.cuda.Stream(priority=-1 if _PREFETCH["high_priority"] else 0)
         own = getattr(next_batch, "extra_keys", ()) if next_batch is not self._static else ()
         # behind everything the main stream has been given so far (the input copy of THIS step; not its graph, which is
         # replayed after this call): nothing on the main stream still reads the buffers written here
         self._side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._side), torch.no_grad():
-            extra = self._sampling({k: v for k, v in next_batch.items() if k not in own})
+            src = {k: v for k, v in next_batch.items() if k not in own}
+            if own and self._sampling_takes_out and _PREFETCH["inplace"]:      # straight into the FlatBatch's own fields
+                extra = self._sampling(src, out={k: next_batch[k] for k in own})
+            else:
+                extra = self._sampling(src)
             if own:                    # a FlatBatch with room for them: they travel with its one flat copy
                 for k in own:
-                    next_batch[k].copy_(extra[k])
+                    if extra[k] is not next_batch[k]:
+                        next_batch[k].copy_(extra[k])
                 extra = {k: next_batch[k] for k in own}
             ev = torch.cuda.Event()
             ev.record(self._side)

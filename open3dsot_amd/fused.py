@@ -1082,11 +1082,11 @@ def _pair_shapes_ok(layers, B, np_a, np_b, ns):
             _compact_ok(layers, np_b, ns, B) and (B * np_a * ns) % 256 == 0)
 
 
-def pair_geometry(grouper, mlp, xyz_a, np_a, si_a, xyz_b, np_b, si_b):
+def pair_geometry(grouper, mlp, xyz_a, np_a, si_a, xyz_b, np_b, si_b, out=None):
     """Everything of a paired set-abstraction level that depends on the COORDINATES only (pointnet2_modules.py:52-62 and
     pointnet2_utils.py:299-320 up to the grouping indices): the centres (sampling gather), both ball queries and the
     distinct-neighbour layout of csrc/compact.hip -- sample_query + the three compaction launches -- as a dict of tensors
-    (GEO_KEYS) that `sa_pair_sampled(..., geo=...)` takes instead of computing them.  A training loop computes it for batch
+    (GEO_KEYS; written into `out`'s tensors when given) that `sa_pair_sampled(..., geo=...)` takes instead of computing them.  A training loop computes it for batch
     t+1 beside step t, like the farthest-point sampling (round 6: 12 launches, 0.14 ms per BAT step, off the step's serial
     chain).  -> None when the joint layout does not apply (the caller then lets the step compute it inline)."""
     if not (_SAMPLE_QUERY["on"] and xyz_a.is_cuda) or xyz_a.shape[0] != xyz_b.shape[0]:
@@ -1105,10 +1105,13 @@ def pair_geometry(grouper, mlp, xyz_a, np_a, si_a, xyz_b, np_b, si_b):
     nb_a, nb_b = B * np_a, B * np_b
     nballs, ldp = nb_a + nb_b, (nb_a + nb_b) * ns
     Npad_a, Npad_b = -(-xa.shape[1] // TILE) * TILE, -(-xb.shape[1] // TILE) * TILE
-    geo = {"centers": torch.empty((nballs + 1, 3), device=dev, dtype=f32),
-           "ball_cnt": torch.empty((nballs,), device=dev, dtype=i32), "ball_off": torch.empty((nballs + 1,), device=dev, dtype=i32),
-           "gp": torch.empty((ldp,), device=dev, dtype=i32), "cball": torch.empty((ldp,), device=dev, dtype=i32),
-           "cw": torch.empty((ldp,), device=dev, dtype=f32), "meta": torch.empty((2, 4), device=dev, dtype=i32)}
+    shapes = {"centers": ((nballs + 1, 3), f32), "ball_cnt": ((nballs,), i32), "ball_off": ((nballs + 1,), i32),
+              "gp": ((ldp,), i32), "cball": ((ldp,), i32), "cw": ((ldp,), f32), "meta": ((2, 4), i32)}
+    if out is not None and all(k in out and tuple(out[k].shape) == sh and out[k].dtype == dt and out[k].device == dev and
+                               out[k].is_contiguous() for k, (sh, dt) in shapes.items()):
+        geo = {k: out[k] for k in shapes}        # written in place: the caller's buffers (a FlatBatch's own fields)
+    else:
+        geo = {k: torch.empty(sh, device=dev, dtype=dt) for k, (sh, dt) in shapes.items()}
     idx_a = torch.empty((B, np_a, ns), device=dev, dtype=i32)
     idx_b = torch.empty((B, np_b, ns), device=dev, dtype=i32)
     with torch.cuda.device(dev):

@@ -163,7 +163,7 @@ class _PointnetSAModuleBase(nn.Module):
         return self.forward(xyz_a, features_a, npoint_a, True, ia), self.forward(xyz_b, features_b, npoint_b, True, ib)
 
 
-def _sa_pair_geometry(self, xyz_a, npoint_a, xyz_b, npoint_b, sample_idxs=None):
+def _sa_pair_geometry(self, xyz_a, npoint_a, xyz_b, npoint_b, sample_idxs=None, out=None):
     """the coordinate-only part of forward_pair (fused.pair_geometry) or None when the fused paired path would not run;
     sample_idxs = (idx_a, idx_b) for a level that samples with FPS, None for the arange(npoint) prefix"""
     if not (_FUSED["enabled"] and _FUSED["paired"] and xyz_a.is_cuda and len(self.groupers) == 1):
@@ -172,7 +172,7 @@ def _sa_pair_geometry(self, xyz_a, npoint_a, xyz_b, npoint_b, sample_idxs=None):
         return None
     from . import fused
     si_a, si_b = sample_idxs if sample_idxs is not None else (None, None)
-    return fused.pair_geometry(self.groupers[0], self.mlps[0], xyz_a, npoint_a, si_a, xyz_b, npoint_b, si_b)
+    return fused.pair_geometry(self.groupers[0], self.mlps[0], xyz_a, npoint_a, si_a, xyz_b, npoint_b, si_b, out=out)
 
 
 _PointnetSAModuleBase.pair_geometry = _sa_pair_geometry

@@ -80,7 +80,7 @@ def _seed_rows(a, b, sample_idxs, n):
 
 # the coordinate-only part of the backbone (centres, ball queries, distinct-neighbour layouts of all three levels) computed with
 # the sampling indices ahead of the step (`sampling_inputs`); False = inside the step, the route it is tested against
-_GEOMETRY_PREFETCH = {"on": True}
+_GEOMETRY_PREFETCH = {"on": True, "min_batch": 8, "without_fps": False}
 
 
 def set_geometry_prefetch(enabled):
@@ -103,9 +103,10 @@ class MatchingBaseModel(nn.Module):
         sched = torch.optim.lr_scheduler.StepLR(opt, step_size=c.lr_decay_step, gamma=c.lr_decay_rate)
         return {"optimizer": opt, "lr_scheduler": sched}
 
-    def sampling_inputs(self, batch):
+    def sampling_inputs(self, batch, out=None):
         """{"fps_idx_t", "fps_idx_s"}: the level-0 farthest-point-sampling indices of a batch, or {} when the backbone
-        does not sample (P2B).  They depend on the input clouds only, so a training loop may compute them for batch t+1
+        does not sample (P2B); `out`: {key: tensor} destinations the larger ones are written into in place.  They depend
+        on the input clouds only, so a training loop may compute them for batch t+1
         while step t runs (open3dsot_amd/dist.py::DataParallelStep.step(next_batch=...)): forward takes them from the
         input dict instead of launching the 766 serial FPS rounds at the head of the step."""
         t, s = batch["template_points"], batch["search_points"]
@@ -113,9 +114,19 @@ class MatchingBaseModel(nn.Module):
         out = {} if idx is None else {"fps_idx_t": idx[0], "fps_idx_s": idx[1]}
         # round 6: the rest of the backbone that depends on the coordinates only -- every level's centres, ball queries and
         # distinct-neighbour layout ("geo<level>.<name>", open3dsot_amd/fused.py::pair_geometry): 12 launches off the step's chain
-        if _GEOMETRY_PREFETCH["on"] and self.training and t.is_cuda:
+        # (not for tiny batches: at batch 1 the step is 1.4 ms and HOST-bound, the ~35 extra eager launches of the prefetch
+        # cost more than the 12 launches they take out of the graph -- p2b_batch1 1.39 -> 1.55 ms, profiles/r06_ab_geometry_prefetch.txt)
+        # (and only beside a farthest-point sampling that is prefetched anyway: P2B, whose backbone does not sample, has no
+        # prefetch stream at all without it, and gaining 12 launches cost it +0.1 ms of a larger input copy and a second
+        # stream: 8.76 against 8.65 ms per step, gpurun_out/secondary_ab.txt)
+        if (_GEOMETRY_PREFETCH["on"] and self.training and t.is_cuda and t.shape[0] >= _GEOMETRY_PREFETCH["min_batch"]
+                and (idx is not None or _GEOMETRY_PREFETCH["without_fps"])):
             M, N = t.shape[1], s.shape[1]
-            geo = self.backbone.pair_geometry(t, [M // 2, M // 4, M // 8], s, [N // 2, N // 4, N // 8], idx)
+            dst = None
+            if out is not None and "geo0.gp" in out:      # destination buffers (a FlatBatch's own fields): written in place
+                from .fused import GEO_KEYS
+                dst = [{k: out["geo%d.%s" % (i, k)] for k in GEO_KEYS if "geo%d.%s" % (i, k) in out} for i in range(3)]
+            geo = self.backbone.pair_geometry(t, [M // 2, M // 4, M // 8], s, [N // 2, N // 4, N // 8], idx, dst=dst)
             if geo is not None:
                 for i, g in enumerate(geo):
                     for k, v in g.items():

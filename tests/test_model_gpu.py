@@ -1430,7 +1430,7 @@ def test_captured_step_survives_other_models_on_the_device():
 
 
 @pytest.mark.parametrize("model_name", ["BAT", "P2B"])
-def test_geometry_prefetch_equals_the_inline_step(model_name):
+def test_geometry_prefetch_equals_the_inline_step(model_name, request):
     """Round 6: beside the farthest-point sampling, EVERYTHING of the backbone that depends on the input coordinates only
     -- per level the centres, both ball queries and the distinct-neighbour layout (fused.pair_geometry) -- is computed for
     the next batch beside the current step and enters the captured step as inputs ("geo<level>.<name>").  Against a trainer
@@ -1443,6 +1443,10 @@ def test_geometry_prefetch_equals_the_inline_step(model_name):
     model_a = make_model(model_name, 9)
     model_b = copy.deepcopy(model_a)
     pool = [synth.to_torch(synth.make_batch(310 + 4 * i, 4, 512, 1024), dev) for i in range(3)]
+    monkey_min = trackers._GEOMETRY_PREFETCH["min_batch"]
+    trackers._GEOMETRY_PREFETCH["min_batch"] = 1          # (the default leaves batches below 8 alone: host-bound steps,
+    trackers._GEOMETRY_PREFETCH["without_fps"] = True     # and a backbone that does not sample: P2B)
+    request.addfinalizer(lambda: trackers._GEOMETRY_PREFETCH.update(min_batch=monkey_min, without_fps=False))
     trackers.set_geometry_prefetch(False)
     try:
         ta = D.DataParallelStep(model_a, optimizer=torch.optim.SGD(model_a.parameters(), lr=0.0), world=1, graph=True,
