@@ -589,11 +589,13 @@ def measure(args, rank, local_rank, world, full=True):
                            " (the per-GPU batch of cfgs/BAT_CAR_NUSCENES.yaml:56)" if args.batch == 100 else ""),
                        "global_batch": world * args.batch, "parallelism": "dp%d" % world,
                        "fused_kernels": bool(sa_modules.fused_enabled()),
-                       "hip_graph": trainer.graph is not None},
+                       "hip_graph": trainer.graph is not None},      # (false = the capture failed and the step ran eagerly: see graph_error)
             "roofline": roofline,
         }
         if full and not args.no_cpu_baseline and world == 1 and args.search_size == 1024:
             line["cpu_baseline"] = cpu_baseline(args.model, sd_cpu, args.batch, args.cpu_budget)
+        if trainer.graph is None and not args.no_graph:
+            line["config"]["graph_error"] = (trainer.graph_error or "no capture attempted")[:300]
         line["config"]["rccl_world_size"] = dist.get_world_size() if ((world > 1 or exchange) and dist.is_initialized()) else 1
         if exchange:
             line["config"]["rccl_backend"] = dist.get_backend() if dist.is_initialized() else None
