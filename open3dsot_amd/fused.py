@@ -1075,6 +1075,7 @@ capi.register("o3d_sample_query", [_vp, _vp, _i, _i, _vp, _vp, _vp, _i, _i, _vp,
 
 
 GEO_KEYS = ("centers", "ball_cnt", "ball_off", "gp", "cball", "cw", "meta")
+_GEO_STATS = {"in_place": 0, "allocated": 0}      # (tests / diagnostics: how pair_geometry's outputs were provided)
 
 
 def _pair_shapes_ok(layers, B, np_a, np_b, ns):
@@ -1110,8 +1111,10 @@ def pair_geometry(grouper, mlp, xyz_a, np_a, si_a, xyz_b, np_b, si_b, out=None):
     if out is not None and all(k in out and tuple(out[k].shape) == sh and out[k].dtype == dt and out[k].device == dev and
                                out[k].is_contiguous() for k, (sh, dt) in shapes.items()):
         geo = {k: out[k] for k in shapes}        # written in place: the caller's buffers (a FlatBatch's own fields)
+        _GEO_STATS["in_place"] += 1
     else:
         geo = {k: torch.empty(sh, device=dev, dtype=dt) for k, (sh, dt) in shapes.items()}
+        _GEO_STATS["allocated"] += 1
     idx_a = torch.empty((B, np_a, ns), device=dev, dtype=i32)
     idx_b = torch.empty((B, np_b, ns), device=dev, dtype=i32)
     with torch.cuda.device(dev):

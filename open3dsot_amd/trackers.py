@@ -111,7 +111,7 @@ class MatchingBaseModel(nn.Module):
         input dict instead of launching the 766 serial FPS rounds at the head of the step."""
         t, s = batch["template_points"], batch["search_points"]
         idx = self.backbone.sampling_indices(t, t.shape[1] // 2, s, s.shape[1] // 2)
-        out = {} if idx is None else {"fps_idx_t": idx[0], "fps_idx_s": idx[1]}
+        given, out = out, ({} if idx is None else {"fps_idx_t": idx[0], "fps_idx_s": idx[1]})     # (`out` from here on: the result)
         # round 6: the rest of the backbone that depends on the coordinates only -- every level's centres, ball queries and
         # distinct-neighbour layout ("geo<level>.<name>", open3dsot_amd/fused.py::pair_geometry): 12 launches off the step's chain
         # (not for tiny batches: at batch 1 the step is 1.4 ms and HOST-bound, the ~35 extra eager launches of the prefetch
@@ -123,9 +123,9 @@ class MatchingBaseModel(nn.Module):
                 and (idx is not None or _GEOMETRY_PREFETCH["without_fps"])):
             M, N = t.shape[1], s.shape[1]
             dst = None
-            if out is not None and "geo0.gp" in out:      # destination buffers (a FlatBatch's own fields): written in place
+            if given is not None and "geo0.gp" in given:      # destination buffers (a FlatBatch's own fields): written in place
                 from .fused import GEO_KEYS
-                dst = [{k: out["geo%d.%s" % (i, k)] for k in GEO_KEYS if "geo%d.%s" % (i, k) in out} for i in range(3)]
+                dst = [{k: given["geo%d.%s" % (i, k)] for k in GEO_KEYS if "geo%d.%s" % (i, k) in given} for i in range(3)]
             geo = self.backbone.pair_geometry(t, [M // 2, M // 4, M // 8], s, [N // 2, N // 4, N // 8], idx, dst=dst)
             if geo is not None:
                 for i, g in enumerate(geo):

@@ -1459,6 +1459,7 @@ def test_geometry_prefetch_equals_the_inline_step(model_name, request):
     assert not any(k.startswith("geo") for k in ta._static)
     tb = D.DataParallelStep(model_b, optimizer=torch.optim.SGD(model_b.parameters(), lr=0.0), world=1, graph=True,
                             graph_warmup=1, require_graph=True)
+    idx_prefetch = True
     lb = []
     for i in range(5):
         cur, nxt = pool[i % 3], pool[(i + 1) % 3]
@@ -1486,6 +1487,18 @@ def test_geometry_prefetch_equals_the_inline_step(model_name, request):
         if scale < 1e-4 * top:
             continue
         assert float((gb[k] - want).abs().max()) / scale < 5e-3, k
+    if idx_prefetch:
+        # batches laid out like the captured step's inputs (DataParallelStep.make_batch, what bench.py's loop hands over): the
+        # prefetch then writes the geometry straight INTO the next batch's own fields -- no allocation, no copy launch -- and
+        # the batch travels into the step as one flat copy: same losses as the per-field route above
+        flat_pool = [tb.make_batch(b) for b in pool]
+        assert all(isinstance(b, D.FlatBatch) and "geo0.gp" in b.extra_keys for b in flat_pool)
+        before = dict(fused._GEO_STATS)
+        lf = [float(tb.step(flat_pool[i % 3], next_batch=flat_pool[(i + 1) % 3])) for i in range(5)]
+        torch.cuda.synchronize()
+        assert fused._GEO_STATS["in_place"] - before["in_place"] >= 3 * 4, (before, fused._GEO_STATS)
+        for a, b in zip(la, lf):
+            assert abs(a - b) <= 1e-5 * (1 + abs(a)), (la, lf)
     other = synth.to_torch(synth.make_batch(910, 4, 512, 1024), dev)      # not announced: computed on the spot
     l_other = float(tb.step(other))
     if ta._static.extra_keys:      # (BAT: the inline trainer's captured step takes the sampling indices but no geometry inputs;

@@ -45,6 +45,8 @@ for i in range(60):
 t_all1 = torch.cuda.Event(enable_timing=True); t_all1.record()
 torch.cuda.synchronize()
 import statistics as st
+from open3dsot_amd import fused
+print("pair_geometry outputs:", fused._GEO_STATS, "| pool[1] is FlatBatch:", isinstance(pool[1], D.FlatBatch), "own keys:", len(getattr(pool[1], "extra_keys", ())), "takes out:", tr._sampling_takes_out)
 gd = [r["g0"].elapsed_time(r["g1"]) for r in rec]
 pe = [r["g0"].elapsed_time(r["p_end"]) for r in rec]          # prefetch end relative to the graph's start
 gap = [rec[i]["g1"].elapsed_time(rec[i + 1]["g0"]) for i in range(len(rec) - 1)]   # end of graph t -> start of graph t+1
