@@ -349,11 +349,11 @@ def run(args):
                 line["secondary"] = json.loads(rows[-1]) if rows else {"error": "exit %d: %s" % (cp.returncode, cp.stderr[-300:])}
             except Exception as e:
                 line["secondary"] = {"error": "%s: %s" % (type(e).__name__, e)}
-    if dist.is_initialized():       # (before the line: whatever the communicator's teardown prints must not follow it)
-        dist.destroy_process_group()
-    _flush_c_stdio()
+    _flush_c_stdio()                # (RCCL's start-up banner, if it is still buffered, goes out BEFORE the line)
     if rank == 0:
         print(json.dumps(line), flush=True)
+    if dist.is_initialized():       # after the line: a teardown that hangs or aborts must not cost the measurement
+        dist.destroy_process_group()
 
 
 def secondary_lines(args):
