@@ -1,5 +1,5 @@
 #!/bin/bash
-# One GPU call (gpurun).  usage: gpu_round5.sh <tag> [parts]   parts = any of: smoke tests ref bench qbench trace pmc sq probe:<name> ab:<env> hook:<module.dict.key>[:MODEL] k:<name+name+...> m:<MODEL>
+# One GPU call (gpurun).  usage: gpu_round6.sh <tag> [parts]   parts = any of: smoke tests ref bench qbench stats trace pmc sq probe:<name> ab:<env> hook:<module.dict.key>[:MODEL] k:<name+name+...> m:<MODEL>
 # (default: smoke tests ref bench trace).  Everything lands in gpurun_out/<tag>/.
 TAG=${1:-r4}; shift
 PARTS="${*:-smoke tests ref bench trace}"
