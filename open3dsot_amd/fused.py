@@ -537,18 +537,16 @@ class FusedGroupedMLPCompact(torch.autograd.Function):
             cball = torch.empty((ldp,), device=dev, dtype=i32)
             cw = torch.empty((ldp,), device=dev, dtype=f32)
             meta = torch.empty((nseg, 4), device=dev, dtype=i32)
-        if geo is not None:
-            pass
-        elif nseg == 2:      # both segments: three launches instead of six
-            _call("compact_build", 0.0, lib.o3d_compact_build2, segs[0][3].data_ptr(), npoints[0], Npads[0],
-                  segs[1][3].data_ptr(), npoints[1], Npads[1], B, ns, starts[1], pt_bases[1], nballs, ball_cnt.data_ptr(),
-                  ball_off.data_ptr(), gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), meta.data_ptr(), st)
-        else:
-            for s_, sg in enumerate(segs):
-                _call("compact_build", 0.0, lib.o3d_compact_build, sg[3].data_ptr(), B, npoints[s_], ns, Npads[s_],
-                      starts[s_], pt_bases[s_], ball_bases[s_], nballs, ball_cnt[ball_bases[s_]:].data_ptr(),
-                      ball_off[ball_bases[s_]:].data_ptr(), gp.data_ptr(), cball.data_ptr(), cw.data_ptr(),
-                      meta[s_].data_ptr(), st)
+            if nseg == 2:      # both segments: three launches instead of six
+                _call("compact_build", 0.0, lib.o3d_compact_build2, segs[0][3].data_ptr(), npoints[0], Npads[0],
+                      segs[1][3].data_ptr(), npoints[1], Npads[1], B, ns, starts[1], pt_bases[1], nballs, ball_cnt.data_ptr(),
+                      ball_off.data_ptr(), gp.data_ptr(), cball.data_ptr(), cw.data_ptr(), meta.data_ptr(), st)
+            else:
+                for s_, sg in enumerate(segs):
+                    _call("compact_build", 0.0, lib.o3d_compact_build, sg[3].data_ptr(), B, npoints[s_], ns, Npads[s_],
+                          starts[s_], pt_bases[s_], ball_bases[s_], nballs, ball_cnt[ball_bases[s_]:].data_ptr(),
+                          ball_off[ball_bases[s_]:].data_ptr(), gp.data_ptr(), cball.data_ptr(), cw.data_ptr(),
+                          meta[s_].data_ptr(), st)
         # ---- layer 0 on the points: Z = W0 . [xyz * inv_radius ; feats], flat (C0, ldz)
         padded = any(n != npd for n, npd in zip(Ns, Npads))
         # rows padded to a multiple of 16 (zero rows, zero weight columns): the per-point GEMM then runs on the
